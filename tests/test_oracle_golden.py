@@ -1,0 +1,133 @@
+"""Pin the CPU oracle (oracle/surf_oracle.py) to outputs of the reference's own modules.
+
+The fixtures in tests/golden/ were produced by tests/golden/make_golden.py, which imports the
+reference in the build container.  Tolerance: 1e-5 abs/rel unless a row says otherwise (the
+oracle re-orders fp32 sums: explicit taps instead of F.grid_sample, analytic gradient instead
+of autograd)."""
+import numpy as np
+import torch
+
+from oracle import surf_oracle as O
+from tests.golden_cfg import CFG, pipeline_views, stub_regnet
+
+
+def close(a, b, atol=1e-5, rtol=1e-5):
+    a, b = torch.as_tensor(a).float(), torch.as_tensor(b).float()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e} (max tol {tol.max().item():.3e})"
+
+
+def test_a1_fpn(scene, weights, golden_fpn):
+    outs = O.fpn_forward(weights, scene["imgs"])
+    assert [tuple(o.shape[-2:]) for o in outs] == [(4, 6), (8, 12), (16, 24), (32, 48)]
+    for i, o in enumerate(outs):
+        close(o, golden_fpn[f"out{i}"], atol=2e-5, rtol=1e-4)
+
+
+def test_a2_a3_a4_a6_a7_pipeline(scene, weights, golden_fpn, golden_pipe):
+    feats = [golden_fpn[f"out{i}"] for i in range(4)]
+    gp = golden_pipe
+    intrs, c2ws = scene["intrs"], scene["c2ws"]
+    base_range = (scene["far"] - scene["near"]).squeeze()
+    D = CFG["base_volume_dim"]
+    depths, mvol, mid, coords = None, None, None, None
+    for s in range(4):
+        if s == 0:
+            coords = O.init_coords(D)
+            up_feats = None
+        else:
+            coords, up_feats = O.up_sample(coords, mid)
+            D *= 2
+            assert torch.equal(coords.to(torch.int16), gp[f"s{s}_up_coords"])
+            keep = O.depth_filtering(depths, coords, D, intrs, c2ws, base_range * CFG["range_ratios"][s])
+            coords, up_feats = coords[keep], up_feats[keep]
+            assert torch.equal(coords.to(torch.int16), gp[f"s{s}_filt_coords"])
+        cv, keep = O.back_proj_multiscale(weights, feats, coords, D, intrs, c2ws, s)
+        assert torch.equal(keep, gp[f"s{s}_keep"])
+        close(cv, gp[f"s{s}_costvol"], atol=1e-5, rtol=1e-4)
+        cv, coords = cv[keep], coords[keep]
+        if s > 0:
+            cv = torch.cat([cv, up_feats[keep]], dim=1)
+        close(cv, gp[f"s{s}_reg_in"], atol=1e-5, rtol=1e-4)
+        # continue from the golden regulariser outputs so later stages are compared on equal inputs
+        out, mid = gp[f"s{s}_reg_out"], gp[f"s{s}_reg_mid"]
+        o2, m2 = stub_regnet(gp[f"s{s}_reg_in"], coords, D, s)
+        close(o2, out, atol=1e-5)
+        mvol, mask = O.sparse2dense(out[:, 0], coords, D, mvol)
+        close(mvol, gp[f"s{s}_mvol"], atol=1e-5, rtol=1e-5)
+        assert float(mask.sum()) == float(gp[f"s{s}_mask_sum"])
+        table = O.get_index(coords, D)
+        assert torch.equal(table.to(torch.int32), gp[f"s{s}_table"])
+        depths = O.matching_field(scene["imgs"].shape[-2:], intrs, c2ws, scene["near_fars"], mvol, s,
+                                  CFG["range_ratios"], CFG["n_samples_depths"], CFG["depth_res_levels"], depths)
+        close(torch.stack(depths), gp[f"s{s}_depths"], atol=2e-5, rtol=1e-5)
+        depths = list(gp[f"s{s}_depths"])
+
+
+def test_a9_a10_lookups(golden_pipe, golden_render):
+    vols, tabs, masks, mvol = pipeline_views(golden_pipe)
+    gr = golden_render
+    pts = gr["pts"]
+    close(O.lookup_sparse_volume(pts, vols, tabs), gr["phi"], atol=1e-5, rtol=1e-5)
+    m = torch.stack([O.lookup_volume_nearest(pts, mk) for mk in masks], dim=-1)
+    assert torch.equal(m, gr["mask_nearest"])
+    close(O.lookup_volume_trilinear(pts, mvol), gr["mvol_trilinear"][:, 0], atol=1e-5)
+
+
+def test_a11_sdf_mlp_and_gradient(weights, golden_pipe, golden_render):
+    vols, tabs, _, _ = pipeline_views(golden_pipe)
+    gr = golden_render
+    pts = gr["pts"]
+    layers = O.sdf_weights(weights)
+    phi, jphi = O.lookup_sparse_volume(pts, vols, tabs, with_jac=True)
+    sdf, grad, y = O.sdf_mlp(layers, pts, phi, jphi)
+    close(y, gr["sdf_out"], atol=2e-6, rtol=1e-5)
+    close(sdf, gr["sdf_out"][:, 0], atol=2e-6, rtol=1e-5)
+    close(grad, gr["sdf_grad"], atol=2e-5, rtol=1e-4)
+
+
+def test_a12_a13_feature_lookup_and_blending(scene, weights, golden_fpn, golden_render):
+    feats = [golden_fpn[f"out{i}"] for i in range(4)][::-1]
+    gr = golden_render
+    rf, rd, mv = O.lookup_feature(gr["pts"], scene["imgs"], scene["intrs"], scene["c2ws"], feats)
+    assert torch.equal(mv, gr["mask_valid"])
+    close(rf, gr["rgb_feat"], atol=1e-5, rtol=1e-5)
+    close(rd, gr["ray_diff"], atol=1e-5, rtol=1e-5)
+    rgb = O.blending(weights, gr["rgb_feat"], gr["ray_diff"], gr["mask_valid"])
+    close(rgb, gr["blend_rgb"], atol=1e-5, rtol=1e-5)
+
+
+def test_a8_a14_render(scene, weights, golden_fpn, golden_pipe, golden_render):
+    vols, tabs, masks, mvol = pipeline_views(golden_pipe)
+    feats = [golden_fpn[f"out{i}"] for i in range(4)][::-1]
+    R = scene["rays_o"].shape[0]
+    near, far = scene["near"].repeat(R, 1), scene["far"].repeat(R, 1)
+    for ratio in (1.0, 0.3):
+        tag = "r%02d_" % int(ratio * 10)
+        out = O.render(weights, scene["rays_o"], scene["rays_d"], near, far, mvol, vols, tabs, masks, feats,
+                       scene["imgs"], scene["intrs"], scene["c2ws"], CFG["n_samples"], CFG["sample_ranges"],
+                       CFG["n_depth"], ratio)
+        g = {k[len(tag):]: v for k, v in golden_render.items() if k.startswith(tag)}
+        close(out["mid_z_vals"], g["mid_z_vals"], atol=2e-6)
+        close(out["sdf"], g["sdf"], atol=1e-5, rtol=1e-5)
+        close(out["gradients"], g["gradients"], atol=5e-5, rtol=1e-4)
+        close(out["weights"], g["weights"], atol=2e-5, rtol=1e-3)
+        close(out["color_fine"], g["color_fine"], atol=2e-5, rtol=1e-4)
+        close(out["render_depth"], g["render_depth"], atol=5e-5, rtol=1e-4)
+        close(out["sdf_depth"], g["sdf_depth"], atol=5e-5, rtol=1e-4)
+        close(out["normal"], g["normal"], atol=5e-5, rtol=1e-3)
+        close(out["inside_sphere"], g["inside_sphere"])
+        assert torch.equal(out["valid_mask"], g["valid_mask"])
+        close(out["mid_inside_sphere"], g["mid_inside_sphere"])
+        close(out["gradient_error"], g["gradient_error"], atol=1e-5, rtol=1e-4)
+        # the fixture is only meaningful if the rays actually hit the surface
+        assert float((g["weight_sum"] > 0.5).float().mean()) > 0.15
+        assert float(g["mid_inside_sphere"].sum()) >= 5
+
+
+def test_a16_sdf_grid(weights, golden_pipe, golden_grid):
+    vols, tabs, _, _ = pipeline_views(golden_pipe)
+    u = O.sdf_grid(weights, vols, tabs, golden_grid["bound_min"], golden_grid["bound_max"], 24)
+    close(u, golden_grid["u"], atol=5e-6, rtol=1e-5)
