@@ -1,0 +1,131 @@
+/*
+ * surf_hip.h -- C ABI of the MI355X (gfx950) kernels behind the SuRF volume-rendering hot path.
+ *
+ * The reference (prstrive/SuRF) has no FFI: its "operator API" is the Python class
+ * models/surf.py:15 `SuRF(nn.Module)`.  These entry points are what a binding for that path
+ * would call instead of the PyTorch ops listed beside each one (file:line into the reference).
+ * INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every `d_` / unprefixed data pointer is a DEVICE pointer owned by the caller; the library
+ *     never allocates, frees or synchronises.  `h_` pointers are small HOST arrays read at launch.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).
+ *   - return value: 0 ok, <0 invalid argument (SURF_E_*), >0 a hipError_t from the launch.
+ *   - all floating point is fp32; index tables are int32 (the reference's int64 tables are
+ *     converted by the host wrapper), -1 = empty voxel.
+ *
+ * Layouts
+ *   - dense volumes (matching logits, index tables): [x][y][z], z fastest (volume.py:99-132).
+ *   - sparse feature volumes: rows of 8 floats = 7 channels + 1 pad (surf.py:119 `out_feats[:,1:]`).
+ *   - image / feature maps: NHWC with 4 floats per texel ("texel4"): (nv, H, W, 4).
+ *   - per-sample arrays are ray-major: index = ray * S + sample.
+ */
+#ifndef SURF_HIP_H
+#define SURF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SURF_MAX_VIEWS 8
+#define SURF_MAX_STAGES 4
+#define SURF_MAX_SAMPLES 256
+
+#define SURF_E_ARG (-1)      /* null pointer / bad size */
+#define SURF_E_LIMIT (-2)    /* exceeds SURF_MAX_* */
+
+/* ABI version, bumped whenever a signature below changes. */
+int surf_abi_version(void);
+
+/* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
+int surf_pack_texel4(const float* src, int n, int C, int H, int W, float* dst, void* stream);
+
+/*
+ * Ray set-up: z-sampling guided by the matching volume + section mid-points + voxel mask.
+ * Replaces ImplicitSurface.render's sampling block (implicit_surface.py:268-311, perturb = 0),
+ * the head of render_core (implicit_surface.py:72-86) and lookup_volume (projector.py:392-420).
+ *   rays_o, rays_d (R,3); near, far (R)
+ *   mvol        dense matching volume (Dm^3)
+ *   lin_depth   device copy of torch.linspace(0,1,n_depth); lin_samples: the n_stage linspaces
+ *               torch.linspace(0,1,n_samples[s]) concatenated (S floats)
+ *   h_n_samples[n_stage], h_sample_ranges[n_stage]   (confs/surf.conf:118-119)
+ *   tables[n_stage] (fine -> coarse, as surf.py:159 passes them), h_dims[n_stage]
+ * outputs (any of z_vals may be NULL): z_vals, mid_z, dists (R,S); pts (R*S,3); vmask (R*S) uint8
+ */
+int surf_ray_setup(const float* rays_o, const float* rays_d, const float* near, const float* far, int n_rays,
+                   const float* mvol, int Dm, const float* lin_depth, int n_depth, const float* lin_samples,
+                   const int* h_n_samples, const float* h_sample_ranges, int n_stage, float sample_dist,
+                   const int32_t* const* h_tables, const int* h_dims, int n_vol,
+                   float* z_vals, float* mid_z, float* dists, float* pts, uint8_t* vmask, void* stream);
+
+/*
+ * Size in floats of the packed SDF-MLP weight buffer, and the packer.
+ * Replaces the weight_norm re-parameterisation + layer loop of SDFNetworkSparse
+ * (sdf_network.py:28-121) for the shipped architecture (d_hidden 128, 6 hidden layers,
+ * skip_in [3], multires 4, 28 feature channels, scale 1).  `h_W[l]`/`h_b[l]` are HOST pointers to
+ * the EFFECTIVE (weight-normed) row-major matrices lin0..lin6 and biases.
+ */
+int64_t surf_sdf_packed_floats(void);
+int surf_sdf_pack_weights(const float* const* h_W, const float* const* h_b, float* h_packed);
+
+/* Bytes of scratch the SDF kernel needs for a launch of n points (gradient variant only). */
+int64_t surf_sdf_scratch_bytes(int64_t n_points);
+
+/*
+ * SDF MLP forward (+ analytic gradient) at n points with sparse trilinear feature gather.
+ * Replaces lookup_sparse_volume/grid_sample_3d_sparse (projector.py:217-390),
+ * SDFNetworkSparse.forward/sdf (sdf_network.py:95-124) and the first-order part of
+ * SDFNetworkSparse.gradient (sdf_network.py:129-141).
+ *   pts (n,3); mask (n) uint8 or NULL (NULL = all points active)
+ *   h_vols[n_vol]: (N_s,8) rows; h_tables[n_vol]: (D_s^3) int32; fine -> coarse
+ *   packed: device copy of surf_sdf_pack_weights output
+ *   sdf (n); grad (n,3) or NULL (forward only); scratch: >= surf_sdf_scratch_bytes(n) or NULL if grad NULL
+ * Points with mask 0 are not written.
+ */
+int surf_sdf_mlp(const float* pts, const uint8_t* mask, int64_t n, const float* const* h_vols,
+                 const int32_t* const* h_tables, const int* h_dims, int n_vol, const float* packed,
+                 float* sdf, float* grad, void* scratch, void* stream);
+
+/*
+ * Multi-view feature fetch + blending MLP.
+ * Replaces lookup_feature/compute_angle (projector.py:485-556) and BlendingNetwork.forward
+ * (blending_network.py:69-118).
+ *   h_feats[n_level]: texel4 maps (nv,H_i,W_i,4) fine -> coarse, h_hw[2*n_level] their sizes
+ *   imgs: texel4 (nv,H,W,4) rgb
+ *   h_intrs (nv,4,4), h_w2c (nv,4,4) = inverse(c2w), h_c2w (nv,4,4): HOST row-major
+ *   blend_w: device copy of surf_blend_pack_weights output
+ *   color (n,3); n_valid (n) uint8 = number of source views the point projects into
+ * Only the shipped colour network (d_feature 16 = 4 pyramid levels x 4 channels) is supported.
+ */
+int surf_blend_raw_floats(void);     /* floats of the concatenated state_dict tensors, order below   */
+int surf_blend_packed_floats(void);  /* floats of the MFMA-ordered buffer the kernel reads            */
+/* h_raw: HOST concatenation of color_network.{s, ray_dir_fc.0.weight, ray_dir_fc.0.bias, ray_dir_fc.2.*,
+ * base_fc.0.*, base_fc.2.*, vis_fc.0.*, vis_fc.2.*, vis_fc2.0.*, vis_fc2.2.*, rgb_fc.0.*, rgb_fc.2.*,
+ * rgb_fc.4.*} (weight then bias, row-major), i.e. blending_network.py:34-64 in declaration order. */
+int surf_blend_pack_weights(const float* h_raw, float* h_packed);
+int surf_blend(const float* pts, const uint8_t* mask, int64_t n, const float* const* h_feats, const int* h_hw,
+               int n_level, const float* imgs, int nv, const float* h_intrs, const float* h_w2c,
+               const float* h_c2w, const float* blend_w, float* color, uint8_t* n_valid, void* stream);
+
+/*
+ * NeuS SDF -> alpha compositing, zero-crossing depth and per-ray reductions.
+ * Replaces render_core's tail (implicit_surface.py:126-166,181-216) and validate's normal sum (:380-382).
+ *   per-sample inputs (R,S): sdf, grad(3), color(3), n_valid, mid_z, dists, pts(3), vmask
+ *   h_rot_ref: inverse(c2w[0][:3,:3]) row-major (9 floats, HOST)
+ * outputs (R rows each; any may be NULL): color(3), render_depth, sdf_depth, normal(3) (camera frame),
+ *   normal_val(3) = sum_k grad*w*inside (world frame, for validate), valid_mask u8, mid_inside u8,
+ *   weights (R,S), inside (R,S), eik (R,2) = per-ray [sum relax*(|g|-1)^2, sum relax]
+ */
+int surf_composite(const float* sdf, const float* grad, const float* color, const uint8_t* n_valid,
+                   const float* mid_z, const float* dists, const float* pts, const uint8_t* vmask,
+                   const float* rays_d, int n_rays, int S, float inv_s, float cos_anneal_ratio,
+                   const float* h_rot_ref, float* out_color, float* out_depth, float* out_sdf_depth,
+                   float* out_normal, float* out_normal_val, uint8_t* out_valid, uint8_t* out_mid_inside,
+                   float* out_weights, float* out_inside, float* out_eik, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SURF_HIP_H */

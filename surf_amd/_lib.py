@@ -1,0 +1,73 @@
+"""ctypes binding of the C-ABI kernel library (include/surf_hip.h -> surf_amd/libsurf_hip.so).
+
+The library is the product path: there is no CPU fallback.  Importing this module without the
+built library raises; calling a kernel without a GPU fails inside HIP.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsurf_hip.so")
+
+c_f32p = ctypes.c_void_p
+c_ptr = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/surf_hip.h one to one
+SIGNATURES = {
+    "surf_abi_version": (c_int, []),
+    "surf_pack_texel4": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "surf_ray_setup": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr,
+                               c_int, c_float, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_sdf_packed_floats": (c_i64, []),
+    "surf_sdf_pack_weights": (c_int, [c_ptr, c_ptr, c_ptr]),
+    "surf_sdf_scratch_bytes": (c_i64, [c_i64]),
+    "surf_sdf_mlp": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_blend_raw_floats": (c_int, []),
+    "surf_blend_packed_floats": (c_int, []),
+    "surf_blend_pack_weights": (c_int, [c_ptr, c_ptr]),
+    "surf_blend": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                           c_ptr, c_ptr]),
+    "surf_composite": (c_int, [c_ptr] * 9 + [c_int, c_int, c_float, c_float] + [c_ptr] * 12),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 (cross-compiles without a GPU)."""
+    script = os.path.join(_HERE, "csrc", "build.sh")
+    res = subprocess.run(["bash", script], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise RuntimeError("building libsurf_hip.so failed")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with surf_amd/csrc/build.sh (or __graft_entry__.build()). "
+                "There is no CPU fallback for the SuRF hot path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(_lib, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+    return _lib
+
+
+class SurfHipError(RuntimeError):
+    pass
+
+
+def check(code, what):
+    if code != 0:
+        kind = {-1: "invalid argument", -2: "exceeds a SURF_MAX_* limit"}.get(code, f"hipError {code}")
+        raise SurfHipError(f"{what}: {kind}")

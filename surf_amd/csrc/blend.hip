@@ -1,0 +1,462 @@
+// K10: multi-view feature fetch + IBRNet-style blending MLP, fp32 MFMA.
+//
+// Restates lookup_feature / compute_angle   projector.py:485-556
+//          BlendingNetwork.forward           blending_network.py:69-118
+//
+// Same register-resident scheme as sdf_mlp.hip: one wavefront owns 32 sample points, lane l =
+// (sample j = l & 31, half h = l >> 5); every Linear is W (A operand) x activations^T (B operand) with
+// v_mfma_f32_32x32x2_f32, so a layer's 32x32 accumulator tile is directly the next layer's B operand.
+// The 19 per-view input channels [rgb(3) F0(4) F1(4) | F2(4) F3(4)] are split between the lane halves:
+// half 0 fetches the image and pyramid levels 0,1 (11 channels), half 1 fetches levels 2,3 (8 channels),
+// so no texel is fetched twice.  Source views are unrolled (template NS); per view the chain is 144 MFMAs,
+// plus 48 per tile for the view-independent [mean | var] part of base_fc.0.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int DF = 19;  // d_feature(16) + 3
+constexpr int TILE = 32;
+
+// ---- raw (state_dict order) buffer, floats: surf_amd/_blend_pack.py concatenates in this order --------
+constexpr int R_S = 0;
+constexpr int R_RD0_W = R_S + 1, R_RD0_B = R_RD0_W + 16 * 4;
+constexpr int R_RD2_W = R_RD0_B + 16, R_RD2_B = R_RD2_W + DF * 16;
+constexpr int R_B0_W = R_RD2_B + DF, R_B0_B = R_B0_W + 64 * 57;
+constexpr int R_B2_W = R_B0_B + 64, R_B2_B = R_B2_W + 32 * 64;
+constexpr int R_V0_W = R_B2_B + 32, R_V0_B = R_V0_W + 32 * 32;
+constexpr int R_V2_W = R_V0_B + 32, R_V2_B = R_V2_W + 33 * 32;
+constexpr int R_W0_W = R_V2_B + 33, R_W0_B = R_W0_W + 32 * 32;
+constexpr int R_W2_W = R_W0_B + 32, R_W2_B = R_W2_W + 32;
+constexpr int R_R0_W = R_W2_B + 1, R_R0_B = R_R0_W + 16 * 37;
+constexpr int R_R2_W = R_R0_B + 16, R_R2_B = R_R2_W + 8 * 16;
+constexpr int R_R4_W = R_R2_B + 8, R_R4_B = R_R4_W + 8;
+constexpr int RAW_FLOATS = R_R4_B + 1;
+
+// ---- packed buffer (floats).  MFMA layers: [q][t][lane][4], NQ groups of 4 k-steps, NT tiles ---------
+enum { L_RD0, L_RD2, L_B0S, L_B0V, L_B2, L_V0, L_V2, L_W0, L_R0, L_R2, N_MMA };
+constexpr int LNQ[N_MMA] = {1, 2, 6, 3, 8, 4, 4, 4, 5, 2};
+constexpr int LNT[N_MMA] = {1, 1, 2, 2, 1, 1, 1, 1, 1, 1};
+constexpr int mma_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += LNQ[i] * LNT[i] * 256; return o; }
+constexpr int MMA_END = mma_off(N_MMA);
+// biases as accumulator init: [h][16] per tile
+enum { B_RD0, B_RD2, B_B0_T0, B_B0_T1, B_B2, B_V0, B_V2, B_W0, B_R0, B_R2, N_BIAS };
+constexpr int BIAS_OFF = MMA_END;
+// per-lane dot-product rows [h][16]: vis (row 32 of vis_fc.2), vis_fc2.2, rgb_fc.4
+enum { D_VIS, D_VIS2, D_RGB4, N_DOT };
+constexpr int DOT_OFF = BIAS_OFF + N_BIAS * 32;
+constexpr int SCAL_OFF = DOT_OFF + N_DOT * 32;  // [|s|, b_vis, b_vis2, b_rgb4]
+constexpr int PACKED_FLOATS = SCAL_OFF + 4;
+
+struct BlendArgs {
+  const float* pts;
+  const uint8_t* mask;
+  int64_t n;
+  const float* feats[4];
+  int hw[8];
+  const float* imgs;
+  float K[SURF_MAX_VIEWS][9];
+  float w2c[SURF_MAX_VIEWS][12];
+  float cpos[SURF_MAX_VIEWS][3];
+  const float* w;
+  float* color;
+  uint8_t* n_valid;
+};
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ f32x4 bload(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+__device__ __forceinline__ float elu(float x) { return x > 0.f ? x : expm1f(x); }
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <int NQ, int NT>
+__device__ __forceinline__ void mma_seg(f32x16 (&acc)[NT], const float* b, rsrc_t wr, int lane16, int off) {
+  f32x4 a_cur[NT], a_nxt[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) a_cur[t] = bload(wr, lane16, off + t * 1024);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (q + 1 < NQ) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a_nxt[t] = bload(wr, lane16, off + ((q + 1) * NT + t) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t][i], b[q * 4 + i], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ f32x16 load_row16(rsrc_t wr, int h64, int off_floats) {
+  f32x16 v;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 x = bload(wr, h64, off_floats * 4 + g * 16);
+    v[4 * g + 0] = x[0]; v[4 * g + 1] = x[1]; v[4 * g + 2] = x[2]; v[4 * g + 3] = x[3];
+  }
+  return v;
+}
+
+template <int NS>
+__global__ __launch_bounds__(256, 2) void blend_kernel(BlendArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  const int64_t n_tiles = (a.n + TILE - 1) / TILE;
+  const rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, PACKED_FLOATS * 4, 0x00020000);
+  const int lane16 = lane * 16, h64 = h * 64;
+  const float s_abs = a.w[SCAL_OFF + 0];
+
+  // the two pyramid levels this half fetches
+  const int lvA = h ? 2 : 0, lvB = h ? 3 : 1;
+  const float* __restrict__ mapA = h ? a.feats[2] : a.feats[0];
+  const float* __restrict__ mapB = h ? a.feats[3] : a.feats[1];
+  const int HA = h ? a.hw[4] : a.hw[0], WA = h ? a.hw[5] : a.hw[1];
+  const int HB = h ? a.hw[6] : a.hw[2], WB = h ? a.hw[7] : a.hw[3];
+  const float scA = h ? 0.25f : 1.0f, scB = h ? 0.125f : 0.5f;
+  (void)lvA; (void)lvB;
+
+  for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+    const int64_t i = tile * TILE + j;
+    const bool active = (i < a.n) && (!a.mask || a.mask[i] != 0);
+    if (__ballot(active) == 0ull) continue;
+    const int64_t ic = i < a.n ? i : a.n - 1;
+    const float px = a.pts[ic * 3 + 0], py = a.pts[ic * 3 + 1], pz = a.pts[ic * 3 + 2];
+
+    float floc[NS][12];  // this half's channels of rgb_feat + direction feature (11 or 8 used)
+    float rgb[NS][3];    // raw source colours (meaningful in half 0)
+    float rd[NS][4];
+    float mk[NS], ex[NS];
+
+    float ax = a.cpos[0][0] - px, ay = a.cpos[0][1] - py, az = a.cpos[0][2] - pz;
+    {
+      float nn = sqrtf(ax * ax + ay * ay + az * az) + 1e-6f;
+      ax /= nn; ay /= nn; az /= nn;
+    }
+    int nvalid = 0;
+    // ------------------------------ pass 1: fetch + direction feature per view -----------------------------
+#pragma unroll
+    for (int v = 0; v < NS; ++v) {
+      const int cam = v + 1;
+      // ray_diff (projector.py:485-498)
+      float bx = a.cpos[cam][0] - px, by = a.cpos[cam][1] - py, bz = a.cpos[cam][2] - pz;
+      float nn = sqrtf(bx * bx + by * by + bz * bz) + 1e-6f;
+      bx /= nn; by /= nn; bz /= nn;
+      float ddx = ax - bx, ddy = ay - by, ddz = az - bz;
+      float dn = fmaxf(sqrtf(ddx * ddx + ddy * ddy + ddz * ddz), 1e-6f);
+      rd[v][0] = ddx / dn; rd[v][1] = ddy / dn; rd[v][2] = ddz / dn;
+      rd[v][3] = ax * bx + ay * by + az * bz;
+      // projection (projector.py:527-539); level l uses intrinsics rows 0,1 x 0.5^l = exact scaling of u,v
+      const float* M = a.w2c[cam];
+      float X = M[0] * px + M[1] * py + M[2] * pz + M[3];
+      float Y = M[4] * px + M[5] * py + M[6] * pz + M[7];
+      float Z = M[8] * px + M[9] * py + M[10] * pz + M[11];
+      const float* K = a.K[cam];
+      float qx = K[0] * X + K[1] * Y + K[2] * Z;
+      float qy = K[3] * X + K[4] * Y + K[5] * Z;
+      float qz = K[6] * X + K[7] * Y + K[8] * Z;
+      float u0 = qx / qz, v0 = qy / qz;
+      bool ok = qz > 0.f;
+      f32x4 tA, tB, tC = {0.f, 0.f, 0.f, 0.f};
+      {
+        float u = u0 * scA, vv = v0 * scA;
+        ok = ok && (u >= 0.f) && (u < (float)WA) && (vv >= 0.f) && (vv < (float)HA);
+        float nx = u / ((float)(WA - 1) / 2.0f) - 1.0f, ny = vv / ((float)(HA - 1) / 2.0f) - 1.0f;
+        float gx = ((nx + 1.0f) * (float)WA - 1.0f) / 2.0f, gy = ((ny + 1.0f) * (float)HA - 1.0f) / 2.0f;
+        tA = bilinear_texel4(mapA + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
+        if (h == 0) tC = bilinear_texel4(a.imgs + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
+      }
+      {
+        float u = u0 * scB, vv = v0 * scB;
+        ok = ok && (u >= 0.f) && (u < (float)WB) && (vv >= 0.f) && (vv < (float)HB);
+        float nx = u / ((float)(WB - 1) / 2.0f) - 1.0f, ny = vv / ((float)(HB - 1) / 2.0f) - 1.0f;
+        float gx = ((nx + 1.0f) * (float)WB - 1.0f) / 2.0f, gy = ((ny + 1.0f) * (float)HB - 1.0f) / 2.0f;
+        tB = bilinear_texel4(mapB + (int64_t)cam * HB * WB * 4, HB, WB, gx, gy);
+      }
+      ok = ok && (__shfl_xor((int)ok, 32) != 0);  // AND over all four levels
+      mk[v] = ok ? 1.f : 0.f;
+      nvalid += ok ? 1 : 0;
+      rgb[v][0] = tC[0]; rgb[v][1] = tC[1]; rgb[v][2] = tC[2];
+      // local channel order: half 0 = [rgb, F0, F1], half 1 = [F2, F3, 0, 0, 0]
+      float g[12];
+      if (h == 0) {
+        g[0] = tC[0]; g[1] = tC[1]; g[2] = tC[2];
+        g[3] = tA[0]; g[4] = tA[1]; g[5] = tA[2]; g[6] = tA[3];
+        g[7] = tB[0]; g[8] = tB[1]; g[9] = tB[2]; g[10] = tB[3];
+      } else {
+        g[0] = tA[0]; g[1] = tA[1]; g[2] = tA[2]; g[3] = tA[3];
+        g[4] = tB[0]; g[5] = tB[1]; g[6] = tB[2]; g[7] = tB[3];
+        g[8] = g[9] = g[10] = 0.f;
+      }
+      g[11] = 0.f;
+      // direction feature ELU(L(ELU(L(ray_diff))))  4 -> 16 -> 19  (blending_network.py:72-74)
+      float bin[4] = {h ? rd[v][1] : rd[v][0], h ? rd[v][3] : rd[v][2], 0.f, 0.f};
+      f32x16 acc1[1] = {load_row16(wr, h64, BIAS_OFF + B_RD0 * 32)};
+      mma_seg<1, 1>(acc1, bin, wr, lane16, mma_off(L_RD0) * 4);
+      float h8[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) h8[r] = elu(acc1[0][r]);
+      f32x16 acc2[1] = {load_row16(wr, h64, BIAS_OFF + B_RD2 * 32)};
+      mma_seg<2, 1>(acc2, h8, wr, lane16, mma_off(L_RD2) * 4);
+#pragma unroll
+      for (int r = 0; r < 11; ++r) {
+        // rows of half 1 beyond its 8 channels carry zero weights and zero bias: elu(0) = 0
+        floc[v][r] = g[r] + elu(acc2[0][r]);
+      }
+      floc[v][11] = 0.f;
+      ex[v] = expf(s_abs * (rd[v][3] - 1.0f));
+    }
+    if (a.n_valid && active && h == 0) a.n_valid[i] = (uint8_t)nvalid;
+
+    // ------------------------------ pooling weights, weighted mean / variance (:76-86) ----------------------
+    float emin = ex[0];
+#pragma unroll
+    for (int v = 1; v < NS; ++v) emin = fminf(emin, ex[v]);
+    float wv[NS], wsum = 0.f;
+#pragma unroll
+    for (int v = 0; v < NS; ++v) { wv[v] = (ex[v] - emin) * mk[v]; wsum += wv[v]; }
+#pragma unroll
+    for (int v = 0; v < NS; ++v) wv[v] = wv[v] / (wsum + 1e-8f);
+    float mv[24];  // B operands of the view-independent part: [mean(12) | var(12)]
+#pragma unroll
+    for (int c = 0; c < 12; ++c) {
+      float mean = 0.f;
+#pragma unroll
+      for (int v = 0; v < NS; ++v) mean += floc[v][c] * wv[v];
+      float var = 0.f;
+#pragma unroll
+      for (int v = 0; v < NS; ++v) { float d = floc[v][c] - mean; var += wv[v] * (d * d); }
+      mv[c] = mean;
+      mv[12 + c] = var;
+    }
+    f32x16 G0[2] = {load_row16(wr, h64, BIAS_OFF + B_B0_T0 * 32), load_row16(wr, h64, BIAS_OFF + B_B0_T1 * 32)};
+    mma_seg<6, 2>(G0, mv, wr, lane16, mma_off(L_B0S) * 4);
+
+    // ------------------------------ pass 2: per-view chain, online softmax over views (:88-116) -------------
+    const f32x16 dvis = load_row16(wr, h64, DOT_OFF + D_VIS * 32);
+    const f32x16 dvis2 = load_row16(wr, h64, DOT_OFF + D_VIS2 * 32);
+    const f32x16 drgb4 = load_row16(wr, h64, DOT_OFF + D_RGB4 * 32);
+    const float b_vis = a.w[SCAL_OFF + 1], b_vis2 = a.w[SCAL_OFF + 2], b_rgb4 = a.w[SCAL_OFF + 3];
+    float Mx = -INFINITY, Zs = 0.f, o_r = 0.f, o_g = 0.f, o_b = 0.f;
+#pragma unroll
+    for (int v = 0; v < NS; ++v) {
+      // base_fc.0 (view part) + ELU : 57 -> 64
+      f32x16 acc64[2] = {G0[0], G0[1]};
+      mma_seg<3, 2>(acc64, floc[v], wr, lane16, mma_off(L_B0V) * 4);
+      float h32[32];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h32[16 * t + r] = elu(acc64[t][r]);
+      // base_fc.2 + ELU : 64 -> 32
+      f32x16 accx[1] = {load_row16(wr, h64, BIAS_OFF + B_B2 * 32)};
+      mma_seg<8, 1>(accx, h32, wr, lane16, mma_off(L_B2) * 4);
+      float x[16], xin[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { x[r] = elu(accx[0][r]); xin[r] = x[r] * wv[v]; }
+      // vis_fc: 32 -> 32 (ELU) -> 33 (ELU)
+      f32x16 acct[1] = {load_row16(wr, h64, BIAS_OFF + B_V0 * 32)};
+      mma_seg<4, 1>(acct, xin, wr, lane16, mma_off(L_V0) * 4);
+      float t16[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t16[r] = elu(acct[0][r]);
+      f32x16 accr[1] = {load_row16(wr, h64, BIAS_OFF + B_V2 * 32)};
+      mma_seg<4, 1>(accr, t16, wr, lane16, mma_off(L_V2) * 4);
+      float vraw = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) vraw = fmaf(dvis[r], t16[r], vraw);
+      vraw += __shfl_xor(vraw, 32);
+      const float vis = sigm(elu(vraw + b_vis)) * mk[v];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { x[r] = x[r] + elu(accr[0][r]); xin[r] = x[r] * vis; }
+      // vis_fc2: 32 -> 32 (ELU) -> 1 (sigmoid)
+      f32x16 accw[1] = {load_row16(wr, h64, BIAS_OFF + B_W0 * 32)};
+      mma_seg<4, 1>(accw, xin, wr, lane16, mma_off(L_W0) * 4);
+      float v2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v2 = fmaf(dvis2[r], elu(accw[0][r]), v2);
+      v2 += __shfl_xor(v2, 32);
+      const float vis2 = sigm(v2 + b_vis2) * mk[v];
+      // rgb_fc: [x(32), vis, ray_diff(4)] = 37 -> 16 (ELU) -> 8 (ELU) -> 1
+      float rin[20];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rin[r] = x[r];
+      rin[16] = h ? rd[v][0] : vis2;
+      rin[17] = h ? rd[v][2] : rd[v][1];
+      rin[18] = h ? 0.f : rd[v][3];
+      rin[19] = 0.f;
+      f32x16 acc16[1] = {load_row16(wr, h64, BIAS_OFF + B_R0 * 32)};
+      mma_seg<5, 1>(acc16, rin, wr, lane16, mma_off(L_R0) * 4);
+      float r8[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) r8[r] = elu(acc16[0][r]);
+      f32x16 acc8[1] = {load_row16(wr, h64, BIAS_OFF + B_R2 * 32)};
+      mma_seg<2, 1>(acc8, r8, wr, lane16, mma_off(L_R2) * 4);
+      float rr = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rr = fmaf(drgb4[r], elu(acc8[0][r]), rr);
+      rr += __shfl_xor(rr, 32);
+      rr += b_rgb4;
+      if (mk[v] == 0.f) rr = -1e9f;
+      const float Mn = fmaxf(Mx, rr);
+      const float sc = expf(Mx - Mn);  // exp(-inf) = 0 on the first view
+      const float e = expf(rr - Mn);
+      Zs = Zs * sc + e;
+      o_r = o_r * sc + e * rgb[v][0];
+      o_g = o_g * sc + e * rgb[v][1];
+      o_b = o_b * sc + e * rgb[v][2];
+      Mx = Mn;
+    }
+    if (active && h == 0) {
+      a.color[i * 3 + 0] = o_r / Zs;
+      a.color[i * 3 + 1] = o_g / Zs;
+      a.color[i * 3 + 2] = o_b / Zs;
+    }
+  }
+}
+
+int grid_blocks(int64_t n) {
+  int64_t tiles = (n + TILE - 1) / TILE;
+  int64_t blocks = (tiles + 3) / 4;
+  return (int)(blocks < 4096 ? blocks : 4096);
+}
+
+// ---- host packer --------------------------------------------------------------------------------------------
+inline int hk(int tt, int r, int h) { return 32 * tt + (r & 3) + 8 * (r >> 2) + 4 * h; }
+// local channel index (register r of half h) -> channel of the 19-vector, -1 = pad
+inline int loc_ch(int r, int h) { return h == 0 ? (r < 11 ? r : -1) : (r < 8 ? 11 + r : -1); }
+
+template <class RowF, class ColF>
+void pack_mma(float* dst, int NQ, int NT, const float* W, int ldw, RowF row_of, ColF col_of) {
+  for (int q = 0; q < NQ; ++q)
+    for (int t = 0; t < NT; ++t)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int i = 0; i < 4; ++i) {
+          const int step = 4 * q + i, h = lane >> 5, rho = lane & 31;
+          const int row = row_of(t, rho), col = col_of(step, h);
+          dst[((q * NT + t) * 64 + lane) * 4 + i] = (row >= 0 && col >= 0) ? W[row * ldw + col] : 0.f;
+        }
+}
+
+template <class RowF>
+void pack_rows(float* dst, const float* b, RowF feat_of) {  // [h][16] <- b[feat_of(r,h)]
+  for (int h = 0; h < 2; ++h)
+    for (int r = 0; r < 16; ++r) {
+      int f = feat_of(r, h);
+      dst[h * 16 + r] = f >= 0 ? b[f] : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int surf_blend_raw_floats(void) { return RAW_FLOATS; }
+extern "C" int surf_blend_packed_floats(void) { return PACKED_FLOATS; }
+
+extern "C" int surf_blend_pack_weights(const float* raw, float* out) {
+  if (!raw || !out) return SURF_E_ARG;
+  for (int i = 0; i < PACKED_FLOATS; ++i) out[i] = 0.f;
+  auto nat_row = [](int lim) { return [lim](int t, int rho) { int f = 32 * t + rho; return f < lim ? f : -1; }; };
+  auto nat_col = [](int lim) { return [lim](int step, int h) { int f = hk(step / 16, step % 16, h); return f < lim ? f : -1; }; };
+  // row map of the direction-feature output: D row rho -> (r, h_row) -> local channel
+  auto dir_row = [](int t, int rho) { int hr = (rho >> 2) & 1, r = (rho & 3) | ((rho >> 3) << 2); return loc_ch(r, hr); };
+  auto natf = [](int lim) { return [lim](int r, int h) { int f = hk(0, r, h); return f < lim ? f : -1; }; };
+
+  // ray_dir_fc.0: 4 -> 16; steps: (rd0|rd1), (rd2|rd3)
+  pack_mma(out + mma_off(L_RD0), 1, 1, raw + R_RD0_W, 4, nat_row(16),
+           [](int step, int h) { return step < 2 ? 2 * step + h : -1; });
+  pack_rows(out + BIAS_OFF + B_RD0 * 32, raw + R_RD0_B, natf(16));
+  // ray_dir_fc.2: 16 -> 19, output rows in local-channel order
+  pack_mma(out + mma_off(L_RD2), 2, 1, raw + R_RD2_W, 16, dir_row, nat_col(16));
+  pack_rows(out + BIAS_OFF + B_RD2 * 32, raw + R_RD2_B, [](int r, int h) { return loc_ch(r, h); });
+  // base_fc.0 shared part: [mean(12 steps) | var(12 steps)] -> 64
+  pack_mma(out + mma_off(L_B0S), 6, 2, raw + R_B0_W, 57, nat_row(64), [](int step, int h) {
+    int grp = step / 12, s = step % 12;
+    int ch = s < 11 ? loc_ch(s, h) : -1;
+    return ch >= 0 ? grp * DF + ch : -1;
+  });
+  pack_rows(out + BIAS_OFF + B_B0_T0 * 32, raw + R_B0_B, [](int r, int h) { return hk(0, r, h); });
+  pack_rows(out + BIAS_OFF + B_B0_T1 * 32, raw + R_B0_B, [](int r, int h) { return hk(1, r, h); });
+  // base_fc.0 view part: f (12 steps) -> 64
+  pack_mma(out + mma_off(L_B0V), 3, 2, raw + R_B0_W, 57, nat_row(64), [](int step, int h) {
+    int ch = step < 11 ? loc_ch(step, h) : -1;
+    return ch >= 0 ? 2 * DF + ch : -1;
+  });
+  // base_fc.2: 64 -> 32
+  pack_mma(out + mma_off(L_B2), 8, 1, raw + R_B2_W, 64, nat_row(32), nat_col(64));
+  pack_rows(out + BIAS_OFF + B_B2 * 32, raw + R_B2_B, natf(32));
+  // vis_fc.0: 32 -> 32 ; vis_fc.2 rows 0..31 (x_res) as MFMA, row 32 (vis) as a per-lane dot
+  pack_mma(out + mma_off(L_V0), 4, 1, raw + R_V0_W, 32, nat_row(32), nat_col(32));
+  pack_rows(out + BIAS_OFF + B_V0 * 32, raw + R_V0_B, natf(32));
+  pack_mma(out + mma_off(L_V2), 4, 1, raw + R_V2_W, 32, nat_row(32), nat_col(32));
+  pack_rows(out + BIAS_OFF + B_V2 * 32, raw + R_V2_B, natf(32));
+  pack_rows(out + DOT_OFF + D_VIS * 32, raw + R_V2_W + 32 * 32, natf(32));
+  // vis_fc2.0: 32 -> 32 ; vis_fc2.2: 32 -> 1 as a dot
+  pack_mma(out + mma_off(L_W0), 4, 1, raw + R_W0_W, 32, nat_row(32), nat_col(32));
+  pack_rows(out + BIAS_OFF + B_W0 * 32, raw + R_W0_B, natf(32));
+  pack_rows(out + DOT_OFF + D_VIS2 * 32, raw + R_W2_W, natf(32));
+  // rgb_fc.0: [x(32) | vis | rd(4)] -> 16 ; steps 16..18: (vis|rd0), (rd1|rd2), (rd3|-)
+  pack_mma(out + mma_off(L_R0), 5, 1, raw + R_R0_W, 37, nat_row(16), [](int step, int h) {
+    if (step < 16) return hk(0, step, h);
+    if (step == 16) return h ? 33 : 32;
+    if (step == 17) return h ? 35 : 34;
+    if (step == 18) return h ? -1 : 36;
+    return -1;
+  });
+  pack_rows(out + BIAS_OFF + B_R0 * 32, raw + R_R0_B, natf(16));
+  // rgb_fc.2: 16 -> 8 ; rgb_fc.4: 8 -> 1 as a dot over registers 0..3 (feature 4 h + r)
+  pack_mma(out + mma_off(L_R2), 2, 1, raw + R_R2_W, 16, nat_row(8), nat_col(16));
+  pack_rows(out + BIAS_OFF + B_R2 * 32, raw + R_R2_B, natf(8));
+  pack_rows(out + DOT_OFF + D_RGB4 * 32, raw + R_R4_W, [](int r, int h) { return r < 4 ? 4 * h + r : -1; });
+  out[SCAL_OFF + 0] = fabsf(raw[R_S]);
+  out[SCAL_OFF + 1] = raw[R_V2_B + 32];
+  out[SCAL_OFF + 2] = raw[R_W2_B];
+  out[SCAL_OFF + 3] = raw[R_R4_B];
+  return 0;
+}
+
+extern "C" int surf_blend(const float* pts, const uint8_t* mask, int64_t n, const float* const* h_feats,
+                          const int* h_hw, int n_level, const float* imgs, int nv, const float* h_intrs,
+                          const float* h_w2c, const float* h_c2w, const float* blend_w, float* color,
+                          uint8_t* n_valid, void* stream) {
+  if (!pts || !h_feats || !h_hw || !imgs || !h_intrs || !h_w2c || !h_c2w || !blend_w || !color) return SURF_E_ARG;
+  if (n <= 0 || nv < 2) return SURF_E_ARG;
+  if (n_level != 4 || nv > SURF_MAX_VIEWS) return SURF_E_LIMIT;  // d_feature = 16 = 4 levels x 4 channels
+  BlendArgs a;
+  a.pts = pts; a.mask = mask; a.n = n; a.imgs = imgs; a.w = blend_w; a.color = color; a.n_valid = n_valid;
+  for (int l = 0; l < 4; ++l) {
+    if (!h_feats[l]) return SURF_E_ARG;
+    a.feats[l] = h_feats[l];
+    a.hw[2 * l] = h_hw[2 * l];
+    a.hw[2 * l + 1] = h_hw[2 * l + 1];
+  }
+  for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
+    const int s = v < nv ? v : 0;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) a.K[v][r * 3 + c] = h_intrs[s * 16 + r * 4 + c];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) a.w2c[v][r * 4 + c] = h_w2c[s * 16 + r * 4 + c];
+    for (int r = 0; r < 3; ++r) a.cpos[v][r] = h_c2w[s * 16 + r * 4 + 3];
+  }
+  dim3 grid(grid_blocks(n)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (nv - 1) {
+    case 1: hipLaunchKernelGGL(blend_kernel<1>, grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL(blend_kernel<2>, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(blend_kernel<3>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(blend_kernel<4>, grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL(blend_kernel<5>, grid, block, 0, st, a); break;
+    case 6: hipLaunchKernelGGL(blend_kernel<6>, grid, block, 0, st, a); break;
+    case 7: hipLaunchKernelGGL(blend_kernel<7>, grid, block, 0, st, a); break;
+    default: return SURF_E_LIMIT;
+  }
+  return surf_check_launch();
+}

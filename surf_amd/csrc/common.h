@@ -1,0 +1,104 @@
+// Shared device helpers for the SuRF hot-path kernels (gfx950 / wave64 only).
+// The whole library is compiled with -ffp-contract=off: the reference computes coordinates with
+// separate fp32 multiplies and adds, and floor()/rint()/comparisons on them decide which voxel or
+// texel a sample lands in.  FMAs are written explicitly (fmaf) where they are wanted.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/surf_hip.h"
+
+#define SURF_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+
+// grid_sample's normalised->index rule for align_corners=False applied to a world coordinate in
+// [-1,1]: ((p + 1) * D - 1) / 2   (projector.py:406,415 use the default align_corners=False).
+__device__ __forceinline__ float unnorm_acf(float p, int D) { return ((p + 1.0f) * (float)D - 1.0f) / 2.0f; }
+
+// Trilinear fetch with zero padding from a dense [x][y][z] volume (F.grid_sample, zeros).
+__device__ __forceinline__ float trilinear_zeros(const float* __restrict__ vol, int D, float gx, float gy, float gz) {
+  float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+  float tx = gx - fx, ty = gy - fy, tz = gz - fz;
+  int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+  float acc = 0.0f;
+#pragma unroll
+  for (int dx = 0; dx < 2; ++dx) {
+    int xi = x0 + dx;
+    float wx = dx ? tx : 1.0f - tx;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      int yi = y0 + dy;
+      float wy = dy ? ty : 1.0f - ty;
+#pragma unroll
+      for (int dz = 0; dz < 2; ++dz) {
+        int zi = z0 + dz;
+        float wz = dz ? tz : 1.0f - tz;
+        bool ok = (xi >= 0) & (xi < D) & (yi >= 0) & (yi < D) & (zi >= 0) & (zi < D);
+        float v = 0.0f;
+        if (ok) v = vol[((int64_t)xi * D + yi) * D + zi];
+        acc += v * (wx * wy * wz);
+      }
+    }
+  }
+  return acc;
+}
+
+// Nearest lookup (nearbyint = half-to-even, zeros outside) of "is this voxel occupied" through the
+// int32 index table: the reference's mask volume is 1 exactly where the table is >= 0
+// (volume.py:112-116 vs :125-130).
+__device__ __forceinline__ bool occupied_nearest(const int32_t* __restrict__ table, int D, float px, float py, float pz) {
+  int xi = (int)rintf(unnorm_acf(px, D));
+  int yi = (int)rintf(unnorm_acf(py, D));
+  int zi = (int)rintf(unnorm_acf(pz, D));
+  bool ok = (xi >= 0) & (xi < D) & (yi >= 0) & (yi < D) & (zi >= 0) & (zi < D);
+  if (!ok) return false;
+  return table[((int64_t)xi * D + yi) * D + zi] >= 0;
+}
+
+// Bilinear fetch of a texel4 map (H,W,4) with zero padding per tap.
+__device__ __forceinline__ f32x4 bilinear_texel4(const float* __restrict__ map, int H, int W, float x, float y) {
+  float fx = floorf(x), fy = floorf(y);
+  float tx = x - fx, ty = y - fy;
+  int x0 = (int)fx, y0 = (int)fy;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    int yi = y0 + dy;
+    float wy = dy ? ty : 1.0f - ty;
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      int xi = x0 + dx;
+      float wx = dx ? tx : 1.0f - tx;
+      bool ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H);
+      if (ok) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(map + ((int64_t)yi * W + xi) * 4);
+        float w = wx * wy;
+        acc += v * w;
+      }
+    }
+  }
+  return acc;
+}
+
+static inline int surf_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

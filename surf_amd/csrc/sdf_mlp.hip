@@ -1,0 +1,568 @@
+// K9: sparse trilinear feature gather + SDF MLP forward + analytic gradient, fp32 MFMA.
+//
+// Restates lookup_sparse_volume / grid_sample_3d_sparse   projector.py:217-390
+//          SDFNetworkSparse.forward / sdf                   sdf_network.py:95-124
+//          first-order part of SDFNetworkSparse.gradient    sdf_network.py:129-141 (closed form, no autograd)
+//
+// Design (CDNA4, wave64, v_mfma_f32_32x32x2_f32 = exact fp32):
+//   * one wavefront owns a tile of 32 sample points for the whole network; lane l = (sample j = l & 31,
+//     half h = l >> 5).  Every layer is computed TRANSPOSED:  T^T (features x samples) = W (A operand)
+//     * X^T (B operand), so the 32x32 accumulator tile has the sample on the lane and 16 features in
+//     registers -- which is exactly the B-operand shape of the next layer.  Activations therefore never
+//     leave registers and never cross lanes: accumulator register r of input tile tt simply IS k-step
+//     16*tt + r of the next layer, with the k-permutation  k = 32 tt + (r&3) + 8 (r>>2) + 4 h  baked into
+//     the packed weights (surf_sdf_pack_weights).
+//   * the 28 sparse-volume channels and the 27 positional-encoding channels are split between the two
+//     lane halves (half h gathers stages 2h and 2h+1), so the gather work is not duplicated either.
+//   * weights (0.89 MB packed) stream from L2 as one 16-byte load per lane per 4 k-steps.
+//   * reverse sweep: G_in = W^T delta, same trick with the packed transpose; softplus'(t) of the five
+//     inner layers and the 14x3 feature Jacobian round-trip through a per-wave scratch slot.
+#include <math.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int HID = 128, NFEAT = 28, NE = 27, H2 = 101;
+constexpr int TILE = 32;  // samples per wavefront pass
+
+// ---- packed weight buffer (floats) --------------------------------------------------------------
+// forward layer l: [q][t][lane][4]; NQ groups of 4 k-steps, NT output tiles of 32 rows
+constexpr int FWD_NQ[6] = {4, 20, 20, 24, 20, 20};
+constexpr int BWD_NT[6] = {1, 5, 5, 6, 5, 5};  // backward of layer l: [H tiles..][E][P]
+constexpr int fwd_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += FWD_NQ[i] * 4 * 256; return o; }
+constexpr int FWD_TOTAL = fwd_off(6);
+constexpr int bwd_off(int l) { int o = FWD_TOTAL; for (int i = 0; i < l; ++i) o += 16 * BWD_NT[i] * 256; return o; }
+constexpr int BWD_TOTAL_END = bwd_off(6);
+constexpr int BIAS_OFF = BWD_TOTAL_END;            // [l][t][h][16]
+constexpr int W6H_OFF = BIAS_OFF + 6 * 4 * 2 * 16;  // [h][64]
+constexpr int W6P_OFF = W6H_OFF + 2 * 64;           // [h][16]
+constexpr int B6_OFF = W6P_OFF + 2 * 16;            // 1 (+3 pad)
+constexpr int PACKED_FLOATS = B6_OFF + 4;
+
+// ---- per-wave scratch slot (floats): softplus' of layers 0..4 + feature Jacobian ---------------------
+constexpr int SCR_S = 5 * 16 * 64 * 4;
+constexpr int SCR_J = 11 * 64 * 4;  // 42 floats per lane padded to 44
+constexpr int SCR_SLOT = SCR_S + SCR_J;
+
+constexpr int MAX_BLOCKS = 256 * 2;  // 2 blocks of 4 waves per CU
+
+struct SdfArgs {
+  const float* pts;
+  const uint8_t* mask;
+  int64_t n;
+  const float* vols[SURF_MAX_STAGES];
+  const int32_t* tables[SURF_MAX_STAGES];
+  int dims[SURF_MAX_STAGES];
+  const float* packed;
+  float* sdf;
+  float* grad;
+  float* scratch;
+};
+
+__device__ __forceinline__ int hid_k(int tt, int r, int h) { return 32 * tt + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+// 16-byte buffer load / store: wave-uniform descriptor + per-lane byte offset + compile-time byte offset.
+// (flat global loads made hipcc hoist one 64-bit address per unrolled load out of the tile loop and spill
+// hundreds of them; the buffer form needs a single offset VGPR.)
+__device__ __forceinline__ f32x4 bload(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, f32x4 v) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
+
+// acc[t] += W-tile(t) * b  over NQ groups of 4 k-steps; weights at byte offset `off`: [q][t][lane] x 16 B
+template <int NQ, int NT>
+__device__ __forceinline__ void mma_seg(f32x16 (&acc)[NT], const float* b, rsrc_t wr, int lane16, int off) {
+  f32x4 a_cur[NT], a_nxt[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) a_cur[t] = bload(wr, lane16, off + t * 1024);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (q + 1 < NQ) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a_nxt[t] = bload(wr, lane16, off + ((q + 1) * NT + t) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t][i], b[q * 4 + i], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
+    // keep the hand-made one-group-ahead prefetch in place
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ void load_bias(f32x16 (&acc)[4], rsrc_t wr, int l, int h64) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v = bload(wr, h64, (BIAS_OFF + (l * 4 + t) * 32) * 4 + g * 16);
+      acc[t][4 * g + 0] = v[0]; acc[t][4 * g + 1] = v[1]; acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3];
+    }
+  }
+}
+
+// nn.Softplus(beta=100, threshold=20) and its derivative from the pre-activation
+__device__ __forceinline__ void softplus100(float t, float& hv, float& sv) {
+  float bt = t * 100.0f;
+  float e = __expf(fminf(bt, 20.0f));
+  float hp = __logf(1.0f + e) * 0.01f;
+  float sp = e * __frcp_rn(1.0f + e);
+  bool lin = bt > 20.0f;
+  hv = lin ? t : hp;
+  sv = lin ? 1.0f : sp;
+}
+
+// acc (4 tiles) -> h[64] (activations) and, if STORE, softplus' to the wave's scratch slot (byte offset off)
+template <bool STORE>
+__device__ __forceinline__ void activate(const f32x16 (&acc)[4], float (&h)[64], rsrc_t sr, int svoff, int off) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 s;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float hv, sv;
+        softplus100(acc[t][4 * g + i], hv, sv);
+        h[16 * t + 4 * g + i] = hv;
+        s[i] = sv;
+      }
+      if (STORE) bstore(sr, svoff, off + (t * 4 + g) * 1024, s);
+    }
+  }
+}
+
+// delta[k] = softplus'(t_l)[k] * G[k], softplus' read back from scratch
+__device__ __forceinline__ void make_delta(const f32x16 (&G)[4], float (&delta)[64], rsrc_t sr, int svoff, int off) {
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 s = bload(sr, svoff, off + (t * 4 + g) * 1024);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) delta[16 * t + 4 * g + i] = s[i] * G[t][4 * g + i];
+    }
+  }
+}
+
+// sparse trilinear gather of the two stages owned by this lane half (projector.py:217-374):
+// g = (p+1)/voxel_size, weights from the unclamped floor, indices clamped, row -1 -> zeros.
+template <bool GRAD>
+__device__ __forceinline__ void gather_features(const SdfArgs& a, int h, float px, float py, float pz,
+                                                float (&phi)[16], float (&J)[14][3]) {
+#pragma unroll
+  for (int c = 0; c < 16; ++c) phi[c] = 0.f;
+  if (GRAD) {
+#pragma unroll
+    for (int c = 0; c < 14; ++c) J[c][0] = J[c][1] = J[c][2] = 0.f;
+  }
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int st = 2 * h + sl;
+    const int D = a.dims[st];
+    if (D <= 0) continue;  // fewer than 4 stages: missing ones contribute zeros
+    const int32_t* __restrict__ table = a.tables[st];
+    const float* __restrict__ vol = a.vols[st];
+    const float vs = 2.0f / ((float)D - 1.0f);
+    float gx = (px + 1.0f) / vs, gy = (py + 1.0f) / vs, gz = (pz + 1.0f) / vs;
+    float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+    float tx = gx - fx, ty = gy - fy, tz = gz - fz;
+    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int xi = min(max(x0 + dx, 0), D - 1);
+      const float wx = dx ? tx : 1.0f - tx;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const int yi = min(max(y0 + dy, 0), D - 1);
+        const float wy = dy ? ty : 1.0f - ty;
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz) {
+          const int zi = min(max(z0 + dz, 0), D - 1);
+          const float wz = dz ? tz : 1.0f - tz;
+          const int row = table[((int64_t)xi * D + yi) * D + zi];
+          if (row >= 0) {
+            const f32x4* fr = reinterpret_cast<const f32x4*>(vol + (int64_t)row * 8);
+            f32x4 f0 = fr[0], f1 = fr[1];
+            float f[7] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2]};
+            const float w = wx * wy * wz;
+            float cx = 0.f, cy = 0.f, cz = 0.f;
+            if (GRAD) {
+              cx = ((dx ? 1.0f : -1.0f) * wy * wz) / vs;
+              cy = ((dy ? 1.0f : -1.0f) * wx * wz) / vs;
+              cz = ((dz ? 1.0f : -1.0f) * wx * wy) / vs;
+            }
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+              phi[7 * sl + c] += f[c] * w;
+              if (GRAD) {
+                J[7 * sl + c][0] += f[c] * cx;
+                J[7 * sl + c][1] += f[c] * cy;
+                J[7 * sl + c][2] += f[c] * cz;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// positional encoding channels owned by this half (embedder.py:11-36): channel 14 h + s, s < 14;
+// optionally the diagonal Jacobian d e_c / d x_{c % 3}
+__device__ __forceinline__ void posenc_half(int h, float x, float y, float z, float (&e)[16], float (&je)[14], bool want_j) {
+  float all[28], jall[28];
+  all[0] = x; all[1] = y; all[2] = z;
+  jall[0] = jall[1] = jall[2] = 1.0f;
+  const float p[3] = {x, y, z};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float f = (float)(1 << k);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float s, co;
+      sincosf(p[c] * f, &s, &co);
+      all[3 + 6 * k + c] = s;
+      all[3 + 6 * k + 3 + c] = co;
+      jall[3 + 6 * k + c] = f * co;
+      jall[3 + 6 * k + 3 + c] = -f * s;
+    }
+  }
+  all[27] = 0.f; jall[27] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    e[s] = h ? all[14 + s] : all[s];
+    if (want_j) je[s] = h ? jall[14 + s] : jall[s];
+  }
+  e[14] = e[15] = 0.f;
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(256, 2) void sdf_mlp_kernel(SdfArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave_in_block;
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  const int64_t n_tiles = (a.n + TILE - 1) / TILE;
+  // wave-uniform descriptors; every per-lane part lives in the 32-bit offsets
+  const rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, PACKED_FLOATS * 4, 0x00020000);
+  const rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)a.scratch, 0, GRAD ? 0x7fffffff : 0, 0x00020000);
+  const int lane16 = lane * 16;                                  // weights: [..][lane] x 16 B
+  const int h64 = h * 64;                                        // bias rows: [h][16] floats
+  const int svoff = (int)(wave_id * (SCR_SLOT * 4)) + lane * 16;  // this wave's scratch slot
+
+  for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+    const int64_t i = tile * TILE + j;
+    const bool active = (i < a.n) && (!a.mask || a.mask[i] != 0);
+    if (__ballot(active) == 0ull) continue;
+    const int64_t ic = i < a.n ? i : a.n - 1;
+    const float px = a.pts[ic * 3 + 0], py = a.pts[ic * 3 + 1], pz = a.pts[ic * 3 + 2];
+
+    float phi[16];
+    float e[16];
+    {
+      float J[14][3];
+      gather_features<GRAD>(a, h, px, py, pz, phi, J);
+      if (GRAD) {
+        // spill the feature Jacobian: 42 floats -> 11 x 16 B
+#pragma unroll
+        for (int g = 0; g < 11; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int idx = 4 * g + q;
+            v[q] = idx < 42 ? J[idx / 3][idx % 3] : 0.f;
+          }
+          bstore(sr, svoff, SCR_S * 4 + g * 1024, v);
+        }
+      }
+      float je_unused[14];
+      posenc_half(h, px, py, pz, e, je_unused, false);
+    }
+
+    // ------------------------------------------------ forward ------------------------------------------
+    constexpr int SEG = 16 * 4 * 1024;  // bytes of the 16 hidden k-groups x 4 tiles
+    float hbuf[64];
+    f32x16 acc[4];
+    // layer 0: e(27) -> 128
+    load_bias(acc, wr, 0, h64);
+    mma_seg<4, 4>(acc, e, wr, lane16, fwd_off(0) * 4);
+    activate<GRAD>(acc, hbuf, sr, svoff, 0 * 16384);
+    // layer 1: [h0 | phi] -> 128
+    load_bias(acc, wr, 1, h64);
+    mma_seg<16, 4>(acc, hbuf, wr, lane16, fwd_off(1) * 4);
+    mma_seg<4, 4>(acc, phi, wr, lane16, fwd_off(1) * 4 + SEG);
+    activate<GRAD>(acc, hbuf, sr, svoff, 1 * 16384);
+    // layer 2: [h1 | phi] -> 101 (rows >= 101 are zero-padded)
+    load_bias(acc, wr, 2, h64);
+    mma_seg<16, 4>(acc, hbuf, wr, lane16, fwd_off(2) * 4);
+    mma_seg<4, 4>(acc, phi, wr, lane16, fwd_off(2) * 4 + SEG);
+    activate<GRAD>(acc, hbuf, sr, svoff, 2 * 16384);
+    // layer 3 (skip): [[h2 | e]/sqrt2 | phi] -> 128, 1/sqrt2 folded into the packed weights
+    load_bias(acc, wr, 3, h64);
+    mma_seg<16, 4>(acc, hbuf, wr, lane16, fwd_off(3) * 4);
+    mma_seg<4, 4>(acc, e, wr, lane16, fwd_off(3) * 4 + SEG);
+    mma_seg<4, 4>(acc, phi, wr, lane16, fwd_off(3) * 4 + SEG + 4 * 4 * 1024);
+    activate<GRAD>(acc, hbuf, sr, svoff, 3 * 16384);
+    // layer 4
+    load_bias(acc, wr, 4, h64);
+    mma_seg<16, 4>(acc, hbuf, wr, lane16, fwd_off(4) * 4);
+    mma_seg<4, 4>(acc, phi, wr, lane16, fwd_off(4) * 4 + SEG);
+    activate<GRAD>(acc, hbuf, sr, svoff, 4 * 16384);
+    // layer 5
+    load_bias(acc, wr, 5, h64);
+    mma_seg<16, 4>(acc, hbuf, wr, lane16, fwd_off(5) * 4);
+    mma_seg<4, 4>(acc, phi, wr, lane16, fwd_off(5) * 4 + SEG);
+
+    // layer 6, row 0 only (the 128 appearance outputs are unused downstream): y0 = w6 . [h5 | phi] + b6
+    float delta[64];
+    float y0 = 0.f;
+    const int h256 = h * 256;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 w = bload(wr, h256, W6H_OFF * 4 + (t * 4 + g) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float hv, sv;
+          softplus100(acc[t][4 * g + q], hv, sv);
+          y0 = fmaf(w[q], hv, y0);
+          delta[16 * t + 4 * g + q] = sv * w[q];  // delta5 = softplus'(t5) * W6[0, :128]
+        }
+      }
+    }
+    f32x16 accP;  // running sum over layers of d y0 / d phi, starts at W6[0, 128:156]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 w = bload(wr, h64, W6P_OFF * 4 + g * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        y0 = fmaf(w[q], phi[4 * g + q], y0);
+        accP[4 * g + q] = w[q];
+      }
+    }
+    y0 += __shfl_xor(y0, 32);
+    y0 += a.packed[B6_OFF];
+    if (active && h == 0) a.sdf[i] = y0;
+    if (!GRAD) continue;
+
+    // ------------------------------------------------ reverse sweep ---------------------------------------
+    f32x16 accE;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accE[r] = 0.f;
+    const f32x16 zero16 = accE;
+    // layers 5, 4: G = W^T delta -> [H0..H3 | P]
+#pragma unroll
+    for (int l = 5; l >= 4; --l) {
+      f32x16 G[5] = {zero16, zero16, zero16, zero16, accP};
+      mma_seg<16, 5>(G, delta, wr, lane16, bwd_off(l) * 4);
+      accP = G[4];
+      f32x16 Gh[4] = {G[0], G[1], G[2], G[3]};
+      make_delta(Gh, delta, sr, svoff, (l - 1) * 16384);
+    }
+    // layer 3: [H0..H3 (h2, /sqrt2) | E (/sqrt2) | P]
+    {
+      f32x16 G[6] = {zero16, zero16, zero16, zero16, accE, accP};
+      mma_seg<16, 6>(G, delta, wr, lane16, bwd_off(3) * 4);
+      accE = G[4];
+      accP = G[5];
+      f32x16 Gh[4] = {G[0], G[1], G[2], G[3]};
+      make_delta(Gh, delta, sr, svoff, 2 * 16384);
+    }
+    // layers 2, 1
+#pragma unroll
+    for (int l = 2; l >= 1; --l) {
+      f32x16 G[5] = {zero16, zero16, zero16, zero16, accP};
+      mma_seg<16, 5>(G, delta, wr, lane16, bwd_off(l) * 4);
+      accP = G[4];
+      f32x16 Gh[4] = {G[0], G[1], G[2], G[3]};
+      make_delta(Gh, delta, sr, svoff, (l - 1) * 16384);
+    }
+    // layer 0: E only
+    {
+      f32x16 G[1] = {accE};
+      mma_seg<16, 1>(G, delta, wr, lane16, bwd_off(0) * 4);
+      accE = G[0];
+    }
+    // grad = J_e^T G_e + J_phi^T G_phi; each half holds its own 14 (13) channels of both
+    float g3[3] = {0.f, 0.f, 0.f};
+    {
+      float e2[16], je[14];
+      posenc_half(h, px, py, pz, e2, je, true);
+#pragma unroll
+      for (int s = 0; s < 14; ++s) {
+        // channel 14 h + s differentiates w.r.t. coordinate (14 h + s) % 3
+        const int c0 = s % 3, c1 = (14 + s) % 3;
+        const float v = accE[s] * je[s];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) g3[ax] += ((h ? c1 : c0) == ax) ? v : 0.f;
+      }
+      float Jf[44];
+#pragma unroll
+      for (int g = 0; g < 11; ++g) {
+        f32x4 v = bload(sr, svoff, SCR_S * 4 + g * 1024);
+        Jf[4 * g + 0] = v[0]; Jf[4 * g + 1] = v[1]; Jf[4 * g + 2] = v[2]; Jf[4 * g + 3] = v[3];
+      }
+#pragma unroll
+      for (int c = 0; c < 14; ++c) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) g3[ax] = fmaf(accP[c], Jf[3 * c + ax], g3[ax]);
+      }
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) g3[ax] += __shfl_xor(g3[ax], 32);
+    if (active && h == 0) {
+      a.grad[i * 3 + 0] = g3[0];
+      a.grad[i * 3 + 1] = g3[1];
+      a.grad[i * 3 + 2] = g3[2];
+    }
+  }
+}
+
+int grid_blocks(int64_t n) {
+  int64_t tiles = (n + TILE - 1) / TILE;
+  int64_t blocks = (tiles + 3) / 4;
+  return (int)(blocks < MAX_BLOCKS ? blocks : MAX_BLOCKS);
+}
+
+}  // namespace
+
+extern "C" int64_t surf_sdf_packed_floats(void) { return PACKED_FLOATS; }
+
+extern "C" int64_t surf_sdf_scratch_bytes(int64_t n_points) {
+  if (n_points <= 0) return 0;
+  return (int64_t)grid_blocks(n_points) * 4 * SCR_SLOT * sizeof(float);
+}
+
+// Host-side packer: effective (weight-normed) matrices -> MFMA A-operand order.
+extern "C" int surf_sdf_pack_weights(const float* const* h_W, const float* const* h_b, float* out) {
+  if (!h_W || !h_b || !out) return SURF_E_ARG;
+  for (int l = 0; l < 7; ++l)
+    if (!h_W[l] || !h_b[l]) return SURF_E_ARG;
+  const int in_dim[7] = {NE, 156, 156, 156, 156, 156, 156};
+  const int out_dim[6] = {HID, HID, H2, HID, HID, HID};
+  const float rsqrt2 = (float)(1.0 / sqrt(2.0));
+  auto hk = [](int tt, int r, int h) { return 32 * tt + (r & 3) + 8 * (r >> 2) + 4 * h; };
+  for (int64_t i = 0; i < PACKED_FLOATS; ++i) out[i] = 0.f;
+
+  // -------- forward: value(l, step, h, row)
+  for (int l = 0; l < 6; ++l) {
+    const int NQ = FWD_NQ[l];
+    float* dst = out + fwd_off(l);
+    const int hid_in = (l == 3) ? H2 : HID;
+    for (int q = 0; q < NQ; ++q)
+      for (int t = 0; t < 4; ++t)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int i = 0; i < 4; ++i) {
+            const int step = 4 * q + i, h = lane >> 5, row = 32 * t + (lane & 31);
+            int col = -1;
+            float scale = 1.f;
+            if (l == 0) {  // 16 e-steps
+              int ch = 14 * h + step;
+              if (step < 14 && ch < NE) col = ch;
+            } else if (step < 64) {  // hidden steps
+              int k = hk(step / 16, step % 16, h);
+              if (k < hid_in) col = k;
+              if (l == 3) scale = rsqrt2;
+            } else if (l == 3 && step < 80) {  // e-steps of the skip layer
+              int s = step - 64, ch = 14 * h + s;
+              if (s < 14 && ch < NE) col = H2 + ch;
+              scale = rsqrt2;
+            } else {  // phi steps
+              int s = step - (l == 3 ? 80 : 64);
+              if (s < 14) col = 128 + 14 * h + s;
+            }
+            float v = 0.f;
+            if (col >= 0 && row < out_dim[l]) v = h_W[l][(int64_t)row * in_dim[l] + col] * scale;
+            dst[((q * 4 + t) * 64 + lane) * 4 + i] = v;
+          }
+  }
+  // -------- backward: G_in = W_l^T delta_l; tiles [H0..H3][E][P] as listed in BWD_NT
+  for (int l = 0; l < 6; ++l) {
+    const int NT = BWD_NT[l];
+    float* dst = out + bwd_off(l);
+    const int hid_in = (l == 3) ? H2 : HID;
+    for (int q = 0; q < 16; ++q)
+      for (int t = 0; t < NT; ++t)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int i = 0; i < 4; ++i) {
+            const int step = 4 * q + i, h = lane >> 5, rho = lane & 31;
+            const int krow = hk(step / 16, step % 16, h);  // feature of delta carried by this k-step
+            const int h_row = (rho >> 2) & 1, r_row = (rho & 3) | ((rho >> 3) << 2);
+            const int ch = 14 * h_row + r_row;
+            int col = -1;
+            float scale = 1.f;
+            // tile kind
+            int kind;  // 0 hidden, 1 E, 2 P
+            if (l == 0) kind = 1;
+            else if (t < 4) kind = 0;
+            else if (l == 3 && t == 4) kind = 1;
+            else kind = 2;
+            if (kind == 0) {
+              int c = 32 * t + rho;
+              if (c < hid_in) col = c;
+              if (l == 3) scale = rsqrt2;
+            } else if (kind == 1) {
+              if (r_row < 14 && ch < NE) col = (l == 3 ? H2 : 0) + ch;
+              if (l == 3) scale = rsqrt2;
+            } else {
+              if (r_row < 14) col = 128 + ch;
+            }
+            float v = 0.f;
+            if (col >= 0 && krow < out_dim[l]) v = h_W[l][(int64_t)krow * in_dim[l] + col] * scale;
+            dst[((q * NT + t) * 64 + lane) * 4 + i] = v;
+          }
+  }
+  // -------- biases [l][t][h][r]
+  for (int l = 0; l < 6; ++l)
+    for (int t = 0; t < 4; ++t)
+      for (int h = 0; h < 2; ++h)
+        for (int r = 0; r < 16; ++r) {
+          int k = hk(t, r, h);
+          out[BIAS_OFF + ((l * 4 + t) * 2 + h) * 16 + r] = k < out_dim[l] ? h_b[l][k] : 0.f;
+        }
+  // -------- last layer row 0
+  for (int h = 0; h < 2; ++h) {
+    for (int s = 0; s < 64; ++s) out[W6H_OFF + h * 64 + s] = h_W[6][hk(s / 16, s % 16, h)];
+    for (int s = 0; s < 14; ++s) out[W6P_OFF + h * 16 + s] = h_W[6][128 + 14 * h + s];
+  }
+  out[B6_OFF] = h_b[6][0];
+  return 0;
+}
+
+extern "C" int surf_sdf_mlp(const float* pts, const uint8_t* mask, int64_t n, const float* const* h_vols,
+                            const int32_t* const* h_tables, const int* h_dims, int n_vol, const float* packed,
+                            float* sdf, float* grad, void* scratch, void* stream) {
+  if (!pts || !h_vols || !h_tables || !h_dims || !packed || !sdf) return SURF_E_ARG;
+  if (n <= 0 || n_vol <= 0) return SURF_E_ARG;
+  if (n_vol > SURF_MAX_STAGES) return SURF_E_LIMIT;
+  if (grad && !scratch) return SURF_E_ARG;
+  SdfArgs a;
+  a.pts = pts; a.mask = mask; a.n = n; a.packed = packed; a.sdf = sdf; a.grad = grad; a.scratch = (float*)scratch;
+  for (int s = 0; s < SURF_MAX_STAGES; ++s) {
+    a.vols[s] = s < n_vol ? h_vols[s] : nullptr;
+    a.tables[s] = s < n_vol ? h_tables[s] : nullptr;
+    a.dims[s] = s < n_vol ? h_dims[s] : 0;
+    if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
+  }
+  dim3 grid(grid_blocks(n)), block(256);
+  if (grad)
+    hipLaunchKernelGGL(sdf_mlp_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(sdf_mlp_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+  return surf_check_launch();
+}

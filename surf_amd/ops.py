@@ -1,0 +1,264 @@
+"""Torch-facing wrappers of the C-ABI kernels (device memory and streams are PyTorch's; the math is HIP).
+
+Every function checks dtype / device / contiguity, allocates outputs with torch and launches on the
+current stream.  Nothing here computes on the CPU except the one-off weight re-layouts (host code of
+the library) and 4x4 camera inversions.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+BLEND_KEYS = ["s"] + [f"{m}.{i}.{p}" for m, idxs in (("ray_dir_fc", (0, 2)), ("base_fc", (0, 2)), ("vis_fc", (0, 2)),
+                                                      ("vis_fc2", (0, 2)), ("rgb_fc", (0, 2, 4)))
+                      for i in idxs for p in ("weight", "bias")]
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _chk(t, dtype, name, dev=True):
+    if not torch.is_tensor(t) or t.dtype != dtype or not t.is_contiguous():
+        raise TypeError(f"{name}: expected a contiguous {dtype} tensor")
+    if dev and not t.is_cuda:
+        raise TypeError(f"{name}: expected a GPU tensor (the SuRF hot path has no CPU fallback)")
+    return t
+
+
+def _host_f32(t):
+    return np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return arr
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ------------------------------------------------------------------------------------------------
+# layout helpers
+# ------------------------------------------------------------------------------------------------
+
+
+def pack_texel4(x):
+    """(n, C<=4, H, W) fp32 NCHW -> (n, H, W, 4) texel4 (surf_pack_texel4)."""
+    _chk(x, torch.float32, "x")
+    n, C, H, W = x.shape
+    out = torch.empty(n, H, W, 4, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().surf_pack_texel4(_p(x), n, C, H, W, _p(out), _stream()), "surf_pack_texel4")
+    return out
+
+
+class SparseVolumes:
+    """Per-stage sparse feature rows + dense int32 index tables, ordered fine -> coarse (surf.py:159)."""
+
+    def __init__(self, feats, tables):
+        self.vols, self.tables, self.dims = [], [], []
+        for f, t in zip(feats, tables):
+            if f.shape[1] != 8:
+                f8 = torch.zeros(f.shape[0], 8, dtype=torch.float32, device=f.device)
+                f8[:, :f.shape[1]] = f
+                f = f8
+            if t.dtype != torch.int32:
+                t = t.to(torch.int32)
+            self.vols.append(_chk(f.contiguous(), torch.float32, "sparse volume"))
+            self.tables.append(_chk(t.contiguous(), torch.int32, "index table"))
+            assert t.dim() == 3 and t.shape[0] == t.shape[1] == t.shape[2], "index tables must be cubic"
+            self.dims.append(int(t.shape[0]))
+        self.n = len(self.vols)
+        self._vp = _ptr_array(self.vols)
+        self._tp = _ptr_array(self.tables)
+        self._dp = (ctypes.c_int * self.n)(*self.dims)
+
+
+def sdf_effective_weights(sd, prefix="implicit_surface.sdf_network."):
+    """weight_norm(dim=0) re-parameterisation (sdf_network.py:88-89): W = g * v / ||v||_row."""
+    out = []
+    for l in range(7):
+        if f"{prefix}lin{l}.weight_v" in sd:
+            v = sd[f"{prefix}lin{l}.weight_v"].detach().to("cpu", torch.float32)
+            g = sd[f"{prefix}lin{l}.weight_g"].detach().to("cpu", torch.float32)
+            W = v * (g / torch.linalg.norm(v, dim=1, keepdim=True))
+        else:
+            W = sd[f"{prefix}lin{l}.weight"].detach().to("cpu", torch.float32)
+        out.append((W.contiguous(), sd[f"{prefix}lin{l}.bias"].detach().to("cpu", torch.float32).contiguous()))
+    return out
+
+
+def sdf_pack_weights_host(layers):
+    """[(W_l, b_l)] effective matrices -> packed numpy buffer (surf_sdf_pack_weights, host code)."""
+    shapes = [(128, 27), (128, 156), (101, 156), (128, 156), (128, 156), (128, 156)]
+    for l, (W, b) in enumerate(layers):
+        if l < 6 and tuple(W.shape) != shapes[l]:
+            raise NotImplementedError(
+                f"lin{l}.weight has shape {tuple(W.shape)}; the HIP SDF kernel implements the shipped architecture "
+                "(d_hidden 128, n_layers 6, skip_in [3], multires 4, feat_channels 28)")
+    if layers[6][0].shape[1] != 156:
+        raise NotImplementedError("lin6 must take 156 inputs")
+    Ws = [_host_f32(W) for W, _ in layers]
+    bs = [_host_f32(b) for _, b in layers]
+    L = _lib.lib()
+    out = np.zeros(L.surf_sdf_packed_floats(), dtype=np.float32)
+    wp = (ctypes.c_void_p * 7)(*[w.ctypes.data for w in Ws])
+    bp = (ctypes.c_void_p * 7)(*[b.ctypes.data for b in bs])
+    _lib.check(L.surf_sdf_pack_weights(wp, bp, _np_ptr(out)), "surf_sdf_pack_weights")
+    return out
+
+
+def sdf_pack_weights(sd, device, prefix="implicit_surface.sdf_network."):
+    return torch.from_numpy(sdf_pack_weights_host(sdf_effective_weights(sd, prefix))).to(device)
+
+
+def blend_raw_weights(sd, prefix="implicit_surface.color_network."):
+    return np.concatenate([_host_f32(sd[prefix + k]).reshape(-1) for k in BLEND_KEYS])
+
+
+def blend_pack_weights_host(raw):
+    L = _lib.lib()
+    if raw.size != L.surf_blend_raw_floats():
+        raise NotImplementedError("colour network shape differs from the shipped BlendingNetwork(d_feature=16)")
+    out = np.zeros(L.surf_blend_packed_floats(), dtype=np.float32)
+    _lib.check(L.surf_blend_pack_weights(_np_ptr(np.ascontiguousarray(raw, dtype=np.float32)), _np_ptr(out)),
+               "surf_blend_pack_weights")
+    return out
+
+
+def blend_pack_weights(sd, device, prefix="implicit_surface.color_network."):
+    return torch.from_numpy(blend_pack_weights_host(blend_raw_weights(sd, prefix))).to(device)
+
+
+# ------------------------------------------------------------------------------------------------
+# kernels
+# ------------------------------------------------------------------------------------------------
+
+
+def ray_setup(rays_o, rays_d, near, far, mvol, volumes, n_samples, sample_ranges, n_depth, want_z=False):
+    """implicit_surface.py:268-311 (perturb=0) + :72-86.  Returns dict(mid_z, dists, pts, vmask[, z_vals])."""
+    R = rays_o.shape[0]
+    S = int(sum(n_samples))
+    dev = rays_o.device
+    _chk(rays_o, torch.float32, "rays_o")
+    _chk(rays_d, torch.float32, "rays_d")
+    near = _chk(near.reshape(-1).contiguous(), torch.float32, "near")
+    far = _chk(far.reshape(-1).contiguous(), torch.float32, "far")
+    _chk(mvol, torch.float32, "matching volume")
+    assert near.numel() == R and far.numel() == R
+    lin_depth = torch.linspace(0.0, 1.0, n_depth, dtype=torch.float32).to(dev)
+    lin_s = torch.cat([torch.linspace(0.0, 1.0, int(n), dtype=torch.float32) for n in n_samples]).to(dev)
+    out = {
+        "mid_z": torch.empty(R, S, dtype=torch.float32, device=dev),
+        "dists": torch.empty(R, S, dtype=torch.float32, device=dev),
+        "pts": torch.empty(R * S, 3, dtype=torch.float32, device=dev),
+        "vmask": torch.empty(R * S, dtype=torch.uint8, device=dev),
+    }
+    if want_z:
+        out["z_vals"] = torch.empty(R, S, dtype=torch.float32, device=dev)
+    ns = (ctypes.c_int * len(n_samples))(*[int(n) for n in n_samples])
+    rg = (ctypes.c_float * len(sample_ranges))(*[float(r) for r in sample_ranges])
+    rc = _lib.lib().surf_ray_setup(_p(rays_o), _p(rays_d), _p(near), _p(far), R, _p(mvol), int(mvol.shape[-1]),
+                                   _p(lin_depth), int(n_depth), _p(lin_s), ns, rg, len(n_samples),
+                                   ctypes.c_float(2.0 / n_samples[0]), volumes._tp, volumes._dp, volumes.n,
+                                   _p(out.get("z_vals")), _p(out["mid_z"]), _p(out["dists"]), _p(out["pts"]),
+                                   _p(out["vmask"]), _stream())
+    _lib.check(rc, "surf_ray_setup")
+    return out
+
+
+_scratch_cache = {}
+
+
+def _sdf_scratch(n, device):
+    need = _lib.lib().surf_sdf_scratch_bytes(int(n))
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _scratch_cache.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, dtype=torch.uint8, device=device)
+        _scratch_cache[key] = buf
+    return buf
+
+
+def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True):
+    """sdf_network.py:95-141 at n points.  Returns (sdf (n,), grad (n,3) or None); masked-out rows are
+    left at sdf=100 / grad=0 (what render_core substitutes, implicit_surface.py:93,99)."""
+    _chk(pts, torch.float32, "pts")
+    _chk(packed, torch.float32, "packed weights")
+    n = pts.shape[0]
+    dev = pts.device
+    if mask is not None:
+        _chk(mask, torch.uint8, "mask")
+        sdf = torch.full((n,), 100.0, dtype=torch.float32, device=dev)
+        grad = torch.zeros(n, 3, dtype=torch.float32, device=dev) if want_grad else None
+    else:
+        sdf = torch.empty(n, dtype=torch.float32, device=dev)
+        grad = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_grad else None
+    scratch = _sdf_scratch(n, dev) if want_grad else None
+    rc = _lib.lib().surf_sdf_mlp(_p(pts), _p(mask), n, volumes._vp, volumes._tp, volumes._dp, volumes.n, _p(packed),
+                                 _p(sdf), _p(grad), _p(scratch), _stream())
+    _lib.check(rc, "surf_sdf_mlp")
+    return sdf, grad
+
+
+class Cameras:
+    """Host copies of the 4x4 camera matrices the kernels take by value."""
+
+    def __init__(self, intrs, c2ws):
+        self.nv = int(intrs.shape[0])
+        c2w_cpu = c2ws.detach().to("cpu", torch.float32)
+        self.intrs = np.ascontiguousarray(intrs.detach().to("cpu", torch.float32).numpy())
+        self.c2w = np.ascontiguousarray(c2w_cpu.numpy())
+        self.w2c = np.ascontiguousarray(torch.inverse(c2w_cpu).numpy())
+        self.rot_ref = np.ascontiguousarray(torch.inverse(c2w_cpu[0, :3, :3]).numpy())
+
+
+def blend(pts, feats_t4, imgs_t4, cams, packed, mask=None):
+    """projector.py:501-556 + blending_network.py:69-118.  feats_t4: list fine -> coarse of (nv,H,W,4).
+    Returns (color (n,3), n_valid (n) uint8); masked-out rows are zero."""
+    _chk(pts, torch.float32, "pts")
+    n = pts.shape[0]
+    dev = pts.device
+    for f in feats_t4:
+        _chk(f, torch.float32, "feature map")
+    _chk(imgs_t4, torch.float32, "imgs")
+    color = torch.zeros(n, 3, dtype=torch.float32, device=dev)
+    nvalid = torch.zeros(n, dtype=torch.uint8, device=dev)
+    hw = (ctypes.c_int * (2 * len(feats_t4)))(*[int(v) for f in feats_t4 for v in f.shape[1:3]])
+    fp = _ptr_array(feats_t4)
+    rc = _lib.lib().surf_blend(_p(pts), _p(mask), n, fp, hw, len(feats_t4), _p(imgs_t4), cams.nv, _np_ptr(cams.intrs),
+                               _np_ptr(cams.w2c), _np_ptr(cams.c2w), _p(packed), _p(color), _p(nvalid), _stream())
+    _lib.check(rc, "surf_blend")
+    return color, nvalid
+
+
+def composite(sdf, grad, color, n_valid, setup, rays_d, inv_s, cos_anneal_ratio, cams, per_sample=True):
+    """implicit_surface.py:126-166,181-216.  Returns the per-ray dict (+ weights / inside_sphere if per_sample)."""
+    R, S = setup["mid_z"].shape
+    dev = sdf.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    out = {
+        "color_fine": torch.empty(R, 3, **f32), "render_depth": torch.empty(R, **f32),
+        "sdf_depth": torch.empty(R, 1, **f32), "normal": torch.empty(R, 3, **f32),
+        "normal_val": torch.empty(R, 3, **f32), "valid_mask": torch.empty(R, 1, dtype=torch.uint8, device=dev),
+        "mid_inside_sphere": torch.empty(R, 1, dtype=torch.uint8, device=dev), "eik": torch.empty(R, 2, **f32),
+    }
+    if per_sample:
+        out["weights"] = torch.empty(R, S, **f32)
+        out["inside_sphere"] = torch.empty(R, S, **f32)
+    rc = _lib.lib().surf_composite(_p(sdf), _p(grad), _p(color), _p(n_valid), _p(setup["mid_z"]), _p(setup["dists"]),
+                                   _p(setup["pts"]), _p(setup["vmask"]), _p(rays_d), R, S, ctypes.c_float(inv_s),
+                                   ctypes.c_float(cos_anneal_ratio), _np_ptr(cams.rot_ref), _p(out["color_fine"]),
+                                   _p(out["render_depth"]), _p(out["sdf_depth"]), _p(out["normal"]),
+                                   _p(out["normal_val"]), _p(out["valid_mask"]), _p(out["mid_inside_sphere"]),
+                                   _p(out.get("weights")), _p(out.get("inside_sphere")), _p(out["eik"]), _stream())
+    _lib.check(rc, "surf_composite")
+    return out
