@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsurf_hip.so")
+LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p

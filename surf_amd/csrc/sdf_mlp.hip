@@ -72,9 +72,14 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ f32x4 bload(rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// gfx950 hazard (observed, not handled by hipcc when soffset is an SGPR): a VALU write to the data VGPRs
+// directly after a buffer_store_dwordx4 corrupts the stored data of some lanes.  Two wait states fix it.
 __device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, f32x4 v) {
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+  asm volatile("s_nop 1");
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // acc[t] += W-tile(t) * b  over NQ groups of 4 k-steps; weights at byte offset `off`: [q][t][lane] x 16 B
@@ -144,15 +149,17 @@ __device__ __forceinline__ void activate(const f32x16 (&acc)[4], float (&h)[64],
   }
 }
 
-// delta[k] = softplus'(t_l)[k] * G[k], softplus' read back from scratch
+// delta[k] = softplus'(t_l)[k] * G[k], softplus' read back from scratch (all 16 loads in flight at once)
 __device__ __forceinline__ void make_delta(const f32x16 (&G)[4], float (&delta)[64], rsrc_t sr, int svoff, int off) {
+  f32x4 s[16];
+#pragma unroll
+  for (int tg = 0; tg < 16; ++tg) s[tg] = bload(sr, svoff, off + tg * 1024);
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      f32x4 s = bload(sr, svoff, off + (t * 4 + g) * 1024);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) delta[16 * t + 4 * g + i] = s[i] * G[t][4 * g + i];
+      for (int i = 0; i < 4; ++i) delta[16 * t + 4 * g + i] = s[t * 4 + g][i] * G[t][4 * g + i];
     }
   }
 }
@@ -250,7 +257,10 @@ __device__ __forceinline__ void posenc_half(int h, float x, float y, float z, fl
 }
 
 template <bool GRAD>
-__global__ __launch_bounds__(256, 2) void sdf_mlp_kernel(SdfArgs a) {
+#ifndef SURF_SDF_OCC
+#define SURF_SDF_OCC 2  // wavefronts per SIMD the register budget is sized for
+#endif
+__global__ __launch_bounds__(256, SURF_SDF_OCC) void sdf_mlp_kernel(SdfArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
