@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the SuRF hot path on MI355X: full-image render throughput (rays/s).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the render hot path (ray set-up -> SDF MLP + gradient -> multi-view blending ->
+NeuS compositing) over every pixel ray of the 576x800 reference view of a synthetic 5-view scene with
+128 samples per ray (BASELINE.json configs[1]; synthetic sphere pyramid 88^3 -> 704^3).
+Inputs are resident in HBM before the timed region.  With N > 1 every rank renders its own scene
+(seed = rank): scenes are independent, there is no data-path collective (weak scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (sdf_mlp, fp32 MFMA bound) timed
+with HIP events on the launch stream inside the timed region; `cpu_baseline` is the CPU oracle
+(oracle/surf_oracle.py, a port of the reference algorithm) timed on this host on a bounded ray subset.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE_SDF = 2 * (99240 + 99240)          # forward + reverse-mode gradient MACs x 2
+FLOP_PER_SAMPLE_BLEND_PER_VIEW = 2 * 9928
+FP32_MFMA_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md, chip-level parameters
+
+
+def model_conf(n_samples):
+    from surf_amd import conf
+    return conf.from_dict({
+        "sdf_network": {"d_out": 129, "d_in": 3, "d_hidden": 128, "n_layers": 6, "skip_in": [3], "multires": 4,
+                        "bias": 0.5, "scale": 1.0, "geometric_init": True, "weight_norm": True, "feat_channels": 28,
+                        "feat_multires": 0},
+        "color_network": {"d_feature": 16},
+        "variance_network": {"init_val": 0.3},
+        "render": {"n_samples": n_samples, "sample_ranges": [1.0, 0.4, 0.1, 0.01], "n_depth": 256, "perturb": 0.0},
+    })
+
+
+def cpu_baseline(model, cpu_scene, rays_o, rays_d, near, far, n_samples, budget_s, gpu_out, ray_idx):
+    """Time the CPU oracle on 256-ray chunks (implicit_surface.py:367) of a strided ray subset."""
+    from oracle import surf_oracle as O
+    torch.set_num_threads(os.cpu_count())
+    sd = {"implicit_surface." + k: v.detach().cpu() for k, v in model.state_dict().items()}
+    done, t0, max_err = 0, time.perf_counter(), 0.0
+    for s in range(0, rays_o.shape[0], 256):
+        sl = slice(s, s + 256)
+        out = O.render(sd, rays_o[sl], rays_d[sl], near[sl], far[sl], cpu_scene["mvol"], cpu_scene["vols"],
+                       cpu_scene["tabs"], cpu_scene["masks"], cpu_scene["feats"], cpu_scene["imgs"], cpu_scene["intrs"],
+                       cpu_scene["c2ws"], n_samples, [1.0, 0.4, 0.1, 0.01], 256, 1.0)
+        done += out["color_fine"].shape[0]
+        ref = out["color_fine"]
+        got = gpu_out["color_fine"][ray_idx[sl]].cpu()
+        max_err = max(max_err, float((got - ref).abs().max()))
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return done / dt, done, dt, max_err
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--base-dim", type=int, default=88)
+    ap.add_argument("--height", type=int, default=576)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--views", type=int, default=5)
+    ap.add_argument("--n-samples", type=str, default="64,32,16,16")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from surf_amd import synthetic
+    from surf_amd.implicit_surface import ImplicitSurface
+
+    n_samples = [int(x) for x in args.n_samples.split(",")]
+    S = sum(n_samples)
+    H, W, nv = args.height, args.width, args.views
+    torch.manual_seed(0)
+    model = ImplicitSurface(model_conf(n_samples)).to(dev)
+
+    # ---- scene (seed = rank), resident in HBM before the timed region ------------------------------------
+    seed = rank
+    intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
+    imgs = synthetic.procedural_images(nv, H, W, seed, dev)
+    feats = synthetic.feature_pyramid(nv, H, W, seed, dev)                     # fine -> coarse
+    vols, tabs, mvol = synthetic.sphere_pyramid(args.base_dim, dev, seed=seed)  # coarse -> fine
+    scene = model.scene(mvol, vols[::-1], tabs[::-1], None, feats, imgs, intrs.to(dev), c2ws.to(dev))
+    rays_o, rays_d = synthetic.pixel_rays(intrs[0], c2ws[0], H, W, 1, dev)
+    R = rays_o.shape[0]
+    near = near_fars[0, 0].reshape(1, 1).repeat(R, 1).to(dev)
+    far = near_fars[0, 1].reshape(1, 1).repeat(R, 1).to(dev)
+
+    def step():
+        return model.render_scene(rays_o, rays_d, near, far, scene, 1.0, per_sample=False)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    model.kernel_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    events, model.kernel_events = model.kernel_events, None
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel durations from the HIP events recorded inside the timed region -----------------------
+    per_kernel = {}
+    for name, a, b in events:
+        per_kernel.setdefault(name, []).append(a.elapsed_time(b))
+    kernel_ms = {k: sum(v) / len(v) for k, v in per_kernel.items()}
+    active = int(model.last_active_samples.sum().item())
+
+    if rank == 0:
+        sdf_ms = kernel_ms["sdf_mlp"]
+        flops = active * FLOP_PER_SAMPLE_SDF
+        achieved = flops / (sdf_ms * 1e-3) / 1e12
+        result = {
+            "metric": "rays/sec (576x800, 5-view, 128 samp/ray render, whole job)",
+            "value": world * R * args.steps / elapsed,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"render {H}x{W} ref view, {nv} views, samples {n_samples} (={S}/ray), sphere pyramid "
+                                   f"{args.base_dim}^3->{args.base_dim * 8}^3, one scene per GPU",
+                       "rays_per_step": R, "samples_per_ray": S, "active_samples": active},
+            "per_gpu_rays_per_s": R * args.steps / elapsed,
+            "kernel_ms": kernel_ms,
+            "roofline": {"kernel": "sdf_mlp_kernel<true>", "bound": "mfma", "achieved": achieved,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": None, "flop_per_sample": FLOP_PER_SAMPLE_SDF, "samples_per_launch": active,
+                         "avg_launch_ms": sdf_ms},
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            n_sub = 2048
+            idx = torch.linspace(0, R - 1, n_sub).long()
+            cpu_scene = {
+                "mvol": mvol.cpu(), "vols": [v[:, :7].cpu() for v in vols[::-1]],
+                "tabs": [t.cpu().long() for t in tabs[::-1]], "feats": [f.cpu() for f in feats], "imgs": imgs.cpu(),
+                "intrs": intrs, "c2ws": c2ws,
+            }
+            cpu_scene["masks"] = [(t >= 0).float() for t in cpu_scene["tabs"]]
+            rps, n_done, dt, err = cpu_baseline(model, cpu_scene, rays_o.cpu()[idx], rays_d.cpu()[idx], near.cpu()[idx],
+                                                far.cpu()[idx], n_samples, args.cpu_seconds, out, idx)
+            result["cpu_baseline"] = {"value": rps, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+                                      "sample": f"{n_done} rays (every {R // n_sub}th pixel ray, 256-ray chunks) of the same "
+                                                f"scene in {dt:.1f} s, torch CPU fp32",
+                                      "max_abs_rgb_diff_vs_gpu": err}
+        print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

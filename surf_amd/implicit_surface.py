@@ -1,0 +1,277 @@
+"""Host-side mirror of the reference's implicit-surface stage (models/modules/implicit_surface.py).
+
+Same module / parameter names (so reference checkpoints load with ``load_state_dict``), same
+``render`` / ``validate`` / ``extract_geometry`` / ``forward`` entry points and output keys; the
+arithmetic runs in the HIP kernels behind ``surf_amd.ops`` (no PyTorch fallback).
+
+Scope of this mirror: inference (`val`) semantics with ``render.perturb = 0``;
+the loss-only outputs of ``render_core`` (``ref_gray_val`` / ``sampled_gray_val`` patch warps,
+``smooth_error``, ``sparse_sdf`` random points) belong to the training row.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class _WNLinear(nn.Module):
+    """Parameter container with ``nn.utils.weight_norm``'s names: weight_g (out,1), weight_v (out,in), bias."""
+
+    def __init__(self, weight, bias):
+        super().__init__()
+        self.weight_g = nn.Parameter(torch.linalg.norm(weight, dim=1, keepdim=True).clone())
+        self.weight_v = nn.Parameter(weight.clone())
+        self.bias = nn.Parameter(bias.clone())
+
+
+class SDFNetworkSparse(nn.Module):
+    """sdf_network.py:27-93: parameters + geometric initialisation.  Evaluation: ops.sdf_mlp."""
+
+    def __init__(self, d_in=3, d_out=129, d_hidden=128, n_layers=6, skip_in=(3,), multires=4, bias=0.5, scale=1.0,
+                 geometric_init=True, weight_norm=True, inside_outside=False, feat_channels=28, feat_multires=0):
+        super().__init__()
+        if not (d_in == 3 and d_hidden == 128 and n_layers == 6 and tuple(skip_in) == (3,) and multires == 4
+                and feat_channels == 28 and feat_multires == 0 and float(scale) == 1.0 and weight_norm):
+            raise NotImplementedError("the HIP SDF kernel implements the architecture shipped in confs/*.conf "
+                                      "(d_hidden 128, n_layers 6, skip_in [3], multires 4, feat_channels 28, scale 1)")
+        self.scale = scale
+        in0 = 3 + 3 * 2 * multires
+        dims = [in0] + [d_hidden + feat_channels] * n_layers + [d_out]
+        self.num_layers = len(dims)
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in skip_in else dims[l + 1]
+            if l < self.num_layers - 2:
+                out_dim -= feat_channels
+            lin = nn.Linear(dims[l], out_dim)
+            if geometric_init:  # sdf_network.py:62-86
+                with torch.no_grad():
+                    if l == self.num_layers - 2:
+                        sgn = -1.0 if inside_outside else 1.0
+                        nn.init.normal_(lin.weight, mean=sgn * math.sqrt(math.pi) / math.sqrt(dims[l]), std=0.0001)
+                        nn.init.constant_(lin.bias, -sgn * bias)
+                        lin.weight[:, -feat_channels:] = 0.0
+                        lin.bias[-feat_channels:] = 0.0
+                    elif l == 0:
+                        nn.init.constant_(lin.bias, 0.0)
+                        lin.weight[:, 3:] = 0.0
+                        nn.init.normal_(lin.weight[:, :3], 0.0, math.sqrt(2) / math.sqrt(out_dim))
+                    elif l in skip_in:
+                        nn.init.constant_(lin.bias, 0.0)
+                        nn.init.normal_(lin.weight, 0.0, math.sqrt(2) / math.sqrt(out_dim))
+                        lin.weight[:, -(dims[0] - 3 + feat_channels):] = 0.0
+                    else:
+                        nn.init.constant_(lin.bias, 0.0)
+                        nn.init.normal_(lin.weight, 0.0, math.sqrt(2) / math.sqrt(out_dim))
+                        lin.weight[:, -feat_channels:] = 0.0
+            setattr(self, f"lin{l}", _WNLinear(lin.weight.detach(), lin.bias.detach()))
+
+
+class BlendingNetwork(nn.Module):
+    """blending_network.py:22-67: parameters + initialisation.  Evaluation: ops.blend."""
+
+    def __init__(self, d_feature=16, anti_alias_pooling=True):
+        super().__init__()
+        if d_feature != 16 or not anti_alias_pooling:
+            raise NotImplementedError("the HIP blending kernel implements BlendingNetwork(d_feature=16, anti_alias_pooling=True)")
+        self.s = nn.Parameter(torch.tensor(0.2))
+        act = nn.ELU(inplace=True)
+        f = d_feature + 3
+        self.ray_dir_fc = nn.Sequential(nn.Linear(4, 16), act, nn.Linear(16, f), act)
+        self.base_fc = nn.Sequential(nn.Linear(f * 3, 64), act, nn.Linear(64, 32), act)
+        self.vis_fc = nn.Sequential(nn.Linear(32, 32), act, nn.Linear(32, 33), act)
+        self.vis_fc2 = nn.Sequential(nn.Linear(32, 32), act, nn.Linear(32, 1), nn.Sigmoid())
+        self.rgb_fc = nn.Sequential(nn.Linear(32 + 1 + 4, 16), act, nn.Linear(16, 8), act, nn.Linear(8, 1))
+        for seq in (self.base_fc, self.vis_fc2, self.vis_fc, self.rgb_fc):  # blending_network.py:8-12,63-66
+            for m in seq:
+                if isinstance(m, nn.Linear):
+                    nn.init.kaiming_normal_(m.weight.data)
+                    nn.init.zeros_(m.bias.data)
+
+
+class SingleVarianceNetwork(nn.Module):
+    """variance_network.py:5-11."""
+
+    def __init__(self, init_val):
+        super().__init__()
+        self.register_parameter("variance", nn.Parameter(torch.tensor(float(init_val))))
+
+    def inv_s(self):
+        return float(torch.exp(self.variance.detach() * 10.0).clamp(1e-6, 1e6))
+
+
+class SceneVolumes:
+    """Device-resident inputs of the renderer for one scene, in the kernels' layouts."""
+
+    def __init__(self, matching_volume, volumes, sparse_idxes, features, imgs, intrs, c2ws):
+        dev = imgs.device
+        mv = matching_volume
+        if mv.dim() == 5:
+            mv = mv[0, 0]
+        self.mvol = mv.contiguous().float()
+        self.sv = ops.SparseVolumes([v.detach().float() for v in volumes], list(sparse_idxes))
+        self.feats_t4 = [ops.pack_texel4(f.detach().float().contiguous()) for f in features]  # NCHW -> texel4
+        self.imgs_t4 = ops.pack_texel4(imgs.detach().float().contiguous())
+        self.cams = ops.Cameras(intrs, c2ws)
+        self.device = dev
+
+
+class ImplicitSurface(nn.Module):
+    """implicit_surface.py:50-436 (inference semantics)."""
+
+    def __init__(self, confs):
+        super().__init__()
+        self.n_samples = [int(n) for n in confs.get_list("render.n_samples")]
+        self.sample_ranges = [float(r) for r in confs.get_list("render.sample_ranges")]
+        self.n_depth = confs.get_int("render.n_depth")
+        self.perturb = confs.get_float("render.perturb")
+        self.sdf_network = SDFNetworkSparse(**dict(confs["sdf_network"]))
+        self.color_network = BlendingNetwork(**dict(confs["color_network"]))
+        self.deviation_network = SingleVarianceNetwork(**dict(confs["variance_network"]))
+        self._packed = None
+        self.kernel_events = None
+        self.last_active_samples = None
+
+    # ---- weight re-layouts are cached and refreshed whenever parameters change -------------------------
+    def packed_weights(self, device):
+        ver = tuple((p._version, p.data_ptr()) for p in self.parameters()) + (str(device),)
+        if self._packed is None or self._packed[0] != ver:
+            sd = {k: v for k, v in self.state_dict().items()}
+            self._packed = (ver, ops.sdf_pack_weights(sd, device, "sdf_network."),
+                            ops.blend_pack_weights(sd, device, "color_network."))
+        return self._packed[1], self._packed[2]
+
+    def scene(self, matching_volume, volumes, sparse_idxes, mask_volumes, features, imgs, intrs, c2ws):
+        """mask_volumes are redundant with the index tables (mask == table >= 0, volume.py:112-130) and unused."""
+        return SceneVolumes(matching_volume, volumes, sparse_idxes, features, imgs, intrs, c2ws)
+
+    def render_scene(self, rays_o, rays_d, near, far, scene, cos_anneal_ratio=1.0, per_sample=True):
+        """render (:268-335) + render_core (:64-266) on prepared SceneVolumes."""
+        if self.perturb > 0:
+            raise NotImplementedError("stochastic sampling (render.perturb > 0) is not implemented: set perturb = 0 "
+                                      "(the reference jitters even in val, implicit_surface.py:274-277)")
+        dev = rays_o.device
+        sdf_w, blend_w = self.packed_weights(dev)
+        rays_o = rays_o.float().contiguous()
+        rays_d = rays_d.float().contiguous()
+        ev = self.kernel_events                      # optional per-kernel HIP event pairs (bench.py)
+
+        def timed(name, fn):
+            if ev is None:
+                return fn()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            r = fn()
+            b.record()
+            ev.append((name, a, b))
+            return r
+
+        st = timed("ray_setup", lambda: ops.ray_setup(rays_o, rays_d, near.float(), far.float(), scene.mvol, scene.sv,
+                                                      self.n_samples, self.sample_ranges, self.n_depth))
+        sdf, grad = timed("sdf_mlp", lambda: ops.sdf_mlp(st["pts"], scene.sv, sdf_w, mask=st["vmask"]))
+        col, nvalid = timed("blend", lambda: ops.blend(st["pts"], scene.feats_t4, scene.imgs_t4, scene.cams, blend_w,
+                                                       mask=st["vmask"]))
+        out = timed("composite", lambda: ops.composite(sdf, grad, col, nvalid, st, rays_d, self.deviation_network.inv_s(),
+                                                       float(cos_anneal_ratio), scene.cams, per_sample=per_sample))
+        if ev is not None:
+            self.last_active_samples = st["vmask"]
+        R, S = st["mid_z"].shape
+        eik = out.pop("eik").sum(dim=0)
+        out["gradient_error"] = eik[0] / (eik[1] + 1e-5)
+        out["valid_mask"] = out["valid_mask"].bool()
+        out["mid_inside_sphere"] = out["mid_inside_sphere"].float()
+        out["mid_z_vals"] = st["mid_z"]
+        if per_sample:
+            out["gradients"] = grad.view(R, S, 3)
+            out["sdf"] = sdf.view(R, S)
+        out["s_val"] = torch.full((1, 1), 1.0 / self.deviation_network.inv_s(), device=dev)
+        return out
+
+    def render(self, rays_o, rays_d, near, far, matching_volume, volumes, sparse_idxes, mask_volumes, imgs, features,
+               match_features, intrs, c2ws, cos_anneal_ratio, step):
+        scene = self.scene(matching_volume, volumes, sparse_idxes, mask_volumes, features, imgs, intrs, c2ws)
+        return self.render_scene(rays_o, rays_d, near, far, scene, cos_anneal_ratio)
+
+    def sdf_grid(self, scene, bound_min, bound_max, resolution):
+        """The lattice of extract_geometry (:337-351): u[x,y,z] = -sdf, evaluated by the forward-only kernel."""
+        dev = scene.device
+        sdf_w, _ = self.packed_weights(dev)
+        bmin = bound_min.detach().to("cpu", torch.float32)
+        bmax = bound_max.detach().to("cpu", torch.float32)
+        axes = [torch.linspace(float(bmin[a]), float(bmax[a]), resolution).to(dev) for a in range(3)]
+        u = torch.empty(resolution, resolution, resolution, dtype=torch.float32, device=dev)
+        slab = max(1, (1 << 24) // (resolution * resolution))      # ~16M points per launch
+        for x0 in range(0, resolution, slab):
+            xs = axes[0][x0:x0 + slab]
+            xx, yy, zz = torch.meshgrid(xs, axes[1], axes[2], indexing="ij")
+            pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1).contiguous()
+            sdf, _ = ops.sdf_mlp(pts, scene.sv, sdf_w, want_grad=False)
+            u[x0:x0 + slab] = -sdf.view(len(xs), resolution, resolution)
+        return u
+
+    def extract_geometry(self, volumes, sparse_idxes, bound_min, bound_max, resolution, threshold, scene=None):
+        from .marching_cubes import marching_cubes
+        u = self.sdf_grid(scene, bound_min, bound_max, resolution)
+        vertices, triangles = marching_cubes(u, threshold)
+        b_max_np = bound_max.detach().cpu().numpy()
+        b_min_np = bound_min.detach().cpu().numpy()
+        vertices = vertices / (resolution - 1.0) * (b_max_np - b_min_np)[None, :] + b_min_np[None, :]
+        return vertices, triangles
+
+    def validate(self, rays_o, rays_d, near, far, scene, bound_min, bound_max, hw, cos_anneal_ratio=1.0, step=None,
+                 extract_geometry=True, mesh_resolution=512, threshold=0.0, chunk=65536):
+        """implicit_surface.py:359-402.  The reference's 256-ray chunks exist to bound autograd memory; here
+        rays are independent (perturb = 0), so the chunk is only a scratch-size knob."""
+        outputs = {}
+        if extract_geometry:
+            v, t = self.extract_geometry(None, None, bound_min, bound_max, mesh_resolution, threshold, scene=scene)
+            outputs["vertices"], outputs["triangles"] = v, t
+        height, width = int(hw[0]), int(hw[1])
+        cols, nrms, sdeps, rdeps = [], [], [], []
+        for s in range(0, rays_o.shape[0], chunk):
+            o = self.render_scene(rays_o[s:s + chunk], rays_d[s:s + chunk], near[s:s + chunk], far[s:s + chunk], scene,
+                                  cos_anneal_ratio, per_sample=False)
+            cols.append(o["color_fine"])
+            nrms.append(o["normal_val"])
+            sdeps.append(o["sdf_depth"])
+            rdeps.append(o["render_depth"])
+        color_fine = torch.cat(cols).cpu()
+        outputs["color_fine"] = color_fine
+        outputs["img_fine"] = (color_fine.numpy().reshape([height, width, 3]) * 256).clip(0, 255)
+        normal_img = torch.cat(nrms).cpu().numpy()
+        rot = scene.cams.rot_ref
+        outputs["normal_img"] = (np.matmul(rot[None, :, :], normal_img[:, :, None]).reshape([height, width, 3]) * 128
+                                 + 128).clip(0, 255)
+        outputs["sdf_depth"] = torch.cat(sdeps).cpu().numpy().reshape([height, width])
+        outputs["render_depth"] = torch.cat(rdeps).cpu().numpy().reshape([height, width])
+        return outputs
+
+    def forward(self, mode, ipts, matching_volume, volumes, sparse_idxes, mask_volumes, features, match_features,
+                cos_anneal_ratio=1.0, step=None):
+        rays_o, rays_d = ipts["rays_o"], ipts["rays_d"]
+        near, far = ipts["near"], ipts["far"]
+        if near.shape[0] == 1:
+            near = near.repeat(rays_o.shape[0], 1)
+            far = far.repeat(rays_o.shape[0], 1)
+        scene = self.scene(matching_volume, volumes, sparse_idxes, mask_volumes, features, ipts["imgs"], ipts["intrs"],
+                           ipts["c2ws"])
+        if mode == "val":
+            outputs = self.validate(rays_o, rays_d, near, far, scene, ipts["bound_min"], ipts["bound_max"], ipts["hw"],
+                                    cos_anneal_ratio, step)
+        else:
+            outputs = self.render_scene(rays_o, rays_d, near, far, scene, cos_anneal_ratio)
+        if "pseudo_pts" in ipts:  # implicit_surface.py:425-434
+            pp = ipts["pseudo_pts"].float().contiguous()
+            occ = torch.zeros(pp.shape[0], dtype=torch.bool, device=pp.device)
+            for t in scene.sv.tables:
+                D = t.shape[0]
+                g = torch.round(((pp + 1.0) * D - 1.0) / 2.0).long()
+                ok = ((g >= 0) & (g < D)).all(dim=1)
+                gc = g.clamp(0, D - 1)
+                occ |= ok & (t[gc[:, 0], gc[:, 1], gc[:, 2]] >= 0)
+            sdf_w, _ = self.packed_weights(pp.device)
+            sdf, _ = ops.sdf_mlp(pp, scene.sv, sdf_w, mask=occ.to(torch.uint8), want_grad=False)
+            outputs["pseudo_sdf"] = torch.where(occ, sdf, torch.zeros_like(sdf))[:, None]
+        return outputs

@@ -1,0 +1,75 @@
+"""CPU checks of the host-side mirror: checkpoint key contract, conf parser, argument validation."""
+import pytest
+import torch
+
+from surf_amd import conf as C
+
+
+def _model():
+    from bench import model_conf
+    from surf_amd.implicit_surface import ImplicitSurface
+    return ImplicitSurface(model_conf([64, 32, 16, 16]))
+
+
+def test_reference_state_dict_loads_strict(weights):
+    m = _model()
+    sd = {k[len("implicit_surface."):]: v for k, v in weights.items() if k.startswith("implicit_surface.")}
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    assert m.sdf_network.lin2.weight_v.shape == (101, 156)
+    assert m.color_network.base_fc[0].weight.shape == (64, 57)
+    assert abs(m.deviation_network.inv_s() - float(torch.exp(sd["deviation_network.variance"] * 10))) < 1e-3
+
+
+def test_geometric_init_properties():
+    """sdf_network.py:62-86: negative near the origin, positive far out, and zero feature influence at init."""
+    from oracle import surf_oracle as O
+    torch.manual_seed(0)
+    m = _model()
+    sd = {"implicit_surface." + k: v.detach() for k, v in m.state_dict().items()}
+    layers = O.sdf_weights(sd)
+    g = torch.Generator().manual_seed(1)
+    pts = torch.nn.functional.normalize(torch.randn(64, 3, generator=g), dim=1) * torch.linspace(0.05, 1.0, 64)[:, None]
+    sdf_a, _, _ = O.sdf_mlp(layers, pts, torch.randn(64, 28, generator=g))
+    sdf_b, _, _ = O.sdf_mlp(layers, pts, torch.zeros(64, 28))
+    assert torch.equal(sdf_a, sdf_b)
+    r = pts.norm(dim=1)
+    assert float(sdf_a[r < 0.2].max()) < 0 < float(sdf_a[r > 0.9].min())
+
+
+def test_conf_parser_subset():
+    c = C.parse_string("""
+    general { base_exp_dir = <your output save path> }
+    model {
+        range_ratios = [1.0, 0.4, 0.1, 0.01]   # comment
+        volume { base_volume_dim = [88, 88, 88] }
+        implicit_surface { render { n_samples = [64, 32, 24, 16], perturb = 1.0 }
+                           color_network { d_feature = 16
+                             # d_feature = 128
+                           } }
+        flag = true
+        a.b.c = 3
+    }""")
+    assert c["general.base_exp_dir"] == "<your output save path>"
+    assert c.get_list("model.range_ratios") == [1.0, 0.4, 0.1, 0.01]
+    assert c["model"]["volume"].get_list("base_volume_dim") == [88, 88, 88]
+    assert c.get_float("model.implicit_surface.render.perturb") == 1.0
+    assert c.get_bool("model.flag") is True and c.get_bool("model.has_vol", default=False) is False
+    assert c.get_int("model.a.b.c") == 3
+    assert dict(c["model.implicit_surface.color_network"]) == {"d_feature": 16}
+    with pytest.raises(KeyError):
+        c["model.nope"]
+
+
+def test_unsupported_architectures_fail_loudly():
+    from surf_amd.implicit_surface import BlendingNetwork, SDFNetworkSparse
+    with pytest.raises(NotImplementedError):
+        SDFNetworkSparse(d_hidden=256)
+    with pytest.raises(NotImplementedError):
+        BlendingNetwork(d_feature=128)
+
+
+def test_ops_reject_cpu_tensors():
+    from surf_amd import ops
+    with pytest.raises(TypeError):
+        ops.pack_texel4(torch.zeros(1, 3, 4, 4))
