@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 FLOP_PER_SAMPLE_SDF = 2 * (99240 + 99240)          # forward + reverse-mode gradient MACs x 2
 FLOP_PER_SAMPLE_BLEND_PER_VIEW = 2 * 9928
 FP32_MFMA_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md, chip-level parameters
+CPU_THREADS = min(32, os.cpu_count() or 1)
 
 
 def model_conf(n_samples):
@@ -41,10 +42,28 @@ def model_conf(n_samples):
     })
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC summary of this same command
+    (profiles/rNN_bench_pmc.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE is
+    doubled per the gfx950 correction of MI355X_MICROARCH.md section HBM).  None if no profile is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc.csv")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
+    for r in rows:
+        if r["kernel"] == kernel and r["FETCH_SIZE"] and r["WRITE_SIZE"]:
+            return {"bytes": (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0,
+                    "source": os.path.basename(files[-1])}
+    return None
+
+
 def cpu_baseline(model, cpu_scene, rays_o, rays_d, near, far, n_samples, budget_s, gpu_out, ray_idx):
     """Time the CPU oracle on 256-ray chunks (implicit_surface.py:367) of a strided ray subset."""
     from oracle import surf_oracle as O
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(CPU_THREADS)   # more threads than this only add OpenMP overhead on these small ops
     sd = {"implicit_surface." + k: v.detach().cpu() for k, v in model.state_dict().items()}
     done, t0, max_err = 0, time.perf_counter(), 0.0
     for s in range(0, rays_o.shape[0], 256):
@@ -164,11 +183,11 @@ def main():
             "kernel_ms": kernel_ms,
             "roofline": {"kernel": "sdf_mlp_kernel<true>", "bound": "mfma", "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": None, "flop_per_sample": FLOP_PER_SAMPLE_SDF, "samples_per_launch": active,
+                         "traffic": pmc_traffic("sdf_mlp_kernel<true>"), "flop_per_sample": FLOP_PER_SAMPLE_SDF, "samples_per_launch": active,
                          "avg_launch_ms": sdf_ms},
         }
         if world == 1 and args.cpu_seconds > 0:
-            n_sub = 2048
+            n_sub = 8192
             idx = torch.linspace(0, R - 1, n_sub).long()
             cpu_scene = {
                 "mvol": mvol.cpu(), "vols": [v[:, :7].cpu() for v in vols[::-1]],
@@ -178,7 +197,7 @@ def main():
             cpu_scene["masks"] = [(t >= 0).float() for t in cpu_scene["tabs"]]
             rps, n_done, dt, err = cpu_baseline(model, cpu_scene, rays_o.cpu()[idx], rays_d.cpu()[idx], near.cpu()[idx],
                                                 far.cpu()[idx], n_samples, args.cpu_seconds, out, idx)
-            result["cpu_baseline"] = {"value": rps, "unit": "rays/s", "cores": os.cpu_count(), "kind": "port",
+            result["cpu_baseline"] = {"value": rps, "unit": "rays/s", "cores": CPU_THREADS, "kind": "port",
                                       "sample": f"{n_done} rays (every {R // n_sub}th pixel ray, 256-ray chunks) of the same "
                                                 f"scene in {dt:.1f} s, torch CPU fp32",
                                       "max_abs_rgb_diff_vs_gpu": err}

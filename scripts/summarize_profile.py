@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Condense a scripts/profile_bench.sh output directory (gpurun_out/prof_<tag>) into profiles/<tag>_*.csv."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+OURS = ("sdf_mlp", "blend_kernel", "ray_setup", "composite_kernel", "pack_texel4", "costvol", "densify", "matching_depth",
+        "filter", "spconv", "fpn_", "surf_")
+
+f = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+rows = list(csv.DictReader(open(f)))
+with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w") as w:
+    w.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0   (MI355X, {tag})\n")
+    w.write("# surf_amd kernels verbatim; torch helper kernels (synthetic scene construction) summed in the last row\n")
+    w.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
+    other = 0
+    for r in rows:
+        if any(s in r["Name"] for s in OURS) and "at::native" not in r["Name"]:
+            w.write(",".join('"%s"' % r[k] if k == "Name" else r[k]
+                             for k in ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"]) + "\n")
+        else:
+            other += int(r["TotalDurationNs"])
+    w.write('"(all torch / runtime helper kernels)",,%d,,,,,\n' % other)
+
+agg = collections.defaultdict(dict)
+for name in ("pmc_fetch", "pmc_write", "pmc_mfma"):
+    fs = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))
+    if not fs:
+        continue
+    for row in csv.DictReader(open(fs[0])):
+        k = row["Kernel_Name"]
+        if any(s in k for s in OURS) and "at::native" not in k:
+            short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            agg[short].setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+with open(os.path.join(dst, f"{tag}_bench_pmc.csv"), "w") as w:
+    w.write("# rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 (one pass per group)\n")
+    w.write("# per-launch averages; FETCH_SIZE / WRITE_SIZE in KiB as reported (raw, uncorrected)\n")
+    cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
+    w.write("kernel,launches," + ",".join(cols) + "\n")
+    for k, v in agg.items():
+        n = max(len(x) for x in v.values())
+        w.write(k + f",{n}," + ",".join(str(sum(v[c]) / len(v[c])) if c in v else "" for c in cols) + "\n")
+print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read())
+print(open(os.path.join(dst, f"{tag}_bench_pmc.csv")).read())

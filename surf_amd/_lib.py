@@ -7,6 +7,8 @@ import ctypes
 import os
 import subprocess
 
+import torch  # noqa: F401  (load PyTorch's HIP runtime first: one runtime per process, whichever import order the caller uses)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
