@@ -125,6 +125,64 @@ int surf_composite(const float* sdf, const float* grad, const float* color, cons
                    float* out_normal, float* out_normal_val, uint8_t* out_valid, uint8_t* out_mid_inside,
                    float* out_weights, float* out_inside, float* out_eik, void* stream);
 
+/* =====================================================================================================
+ * Volume build (surf.py:80-131).  Voxel coordinates are int32 triples; voxel_size = 2/(D-1), origin -1.
+ * ===================================================================================================== */
+
+/*
+ * Children + depth-band test.  Replaces Volume.up_sample (volume.py:35-52) and the test of
+ * Volume.depth_filtering (volume.py:134-165).  Child o of parent p has coordinate 2*parent + pos_list[o]
+ * (order of volume.py:42).  flags[8 p + o] = 1 iff |warped depth - voxel depth| < depth_range in > 1 views.
+ *   parents (n_parents,3) on the D/2 lattice; D = child lattice side; depths (nv,H,W) previous-stage maps
+ */
+int surf_upsample_filter(const int32_t* parents, int64_t n_parents, int D, const float* depths, int nv, int H, int W,
+                         const float* h_intrs, const float* h_w2c, float depth_range, uint8_t* flags, void* stream);
+
+/*
+ * Homography warp + softmax mean/variance cost volume.  Replaces Volume.back_proj_multiscale
+ * (volume.py:54-97).  Voxel i = site i of the full D^3 lattice (parents == idx == NULL, n == D^3, x slowest,
+ * volume.py:21-33) or child (idx[i] & 7) of parent (idx[i] >> 3).
+ *   h_feats[4]: texel4 pyramids COARSE -> fine (the reference's `features` order), h_hw[8] their (H,W);
+ *   levels stage..3 are summed; h_agg: agg_mlp as [0.weight(8x4) | 0.bias(8) | 2.weight(8) | 2.bias(1)] (HOST)
+ * outputs: coords (n,3), feat (n,8) = [mean | var], keep (n) = (#views in frustum > 1)
+ */
+int surf_costvol(const int32_t* parents, const int32_t* idx, int64_t n, int D, const float* const* h_feats,
+                 const int* h_hw, int stage, int nv, const float* h_intrs, const float* h_w2c, const float* h_agg,
+                 int32_t* coords, float* feat, uint8_t* keep, void* stream);
+
+/* Stable stream compaction: idx_out = ascending indices i with flags[i] != 0, *total = their number
+ * (device int).  Replaces the boolean-mask indexing of volume.py:165-166 / surf.py:104-108.
+ * workspace: surf_compact_workspace_ints(n) int32; idx_out must hold up to n entries. */
+int64_t surf_compact_workspace_ints(int64_t n);
+int surf_compact(const uint8_t* flags, int64_t n, int32_t* workspace, int32_t* idx_out, int32_t* total, void* stream);
+
+/* dst[i, off:off+row_words] = src[idx[i] >> idx_shift, :]  (rows of 32-bit words; idx_shift 3 = row of the parent) */
+int surf_gather_rows(const void* src, const int32_t* idx, int64_t n, int row_words, int idx_shift, int dst_stride_words,
+                     int dst_offset_words, void* dst, void* stream);
+/* out[i] = a[b[i]] */
+int surf_compose_index(const int32_t* a, const int32_t* b, int64_t n, int32_t* out, void* stream);
+
+/*
+ * Dense matching volume + index table.  Replaces Volume.sparse2dense and Volume.get_index
+ * (volume.py:99-121, 123-132): dense = x2 trilinear upsample (align_corners=False) of prev (D/2)^3, or zeros
+ * if prev == NULL; dense[coords[i]] = rows[i*row_stride]; table = -1 then table[coords[i]] = i.
+ */
+int surf_densify(const int32_t* coords, const float* rows, int row_stride, int64_t n, int D, const float* prev,
+                 float* dense, int32_t* table, void* stream);
+
+/*
+ * Matching field: per-view softmax-expected depth.  Replaces MatchingField.forward / depth_render
+ * (matching_field.py:73-141, 18-71, perturb False).
+ *   h_kinv (nv,3,3) = inverse(intrs)[:, :3, :3]; h_c2w (nv,4,4); h_rinv (nv,3,3) = inverse(c2w[:, :3, :3]);
+ *   h_near_fars (nv,2) -- HOST.  lin_x/lin_y/lin_n: device copies of torch.linspace(0,W-1,w), (0,H-1,h), (0,1,n).
+ *   pre_depths (nv,H,W) or NULL (stage 0); ratio_cur/ratio_prev = range_ratios[stage], [stage-1]
+ * outputs: depth_lr (nv,h,w) and depth_full (nv,H,W) = bilinear upsample (align_corners=False)
+ */
+int surf_matching_depth(const float* mvol, int D, int nv, const float* h_kinv, const float* h_c2w, const float* h_rinv,
+                        const float* h_near_fars, int H, int W, int h, int w, const float* lin_x, const float* lin_y,
+                        const float* lin_n, int n, const float* pre_depths, float ratio_cur, float ratio_prev,
+                        float* depth_lr, float* depth_full, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,16 @@ SIGNATURES = {
     "surf_blend": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                            c_ptr, c_ptr]),
     "surf_composite": (c_int, [c_ptr] * 9 + [c_int, c_int, c_float, c_float] + [c_ptr] * 12),
+    "surf_upsample_filter": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_float, c_ptr, c_ptr]),
+    "surf_costvol": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                             c_ptr]),
+    "surf_compact_workspace_ints": (c_i64, [c_i64]),
+    "surf_compact": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_gather_rows": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "surf_compose_index": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    "surf_densify": (c_int, [c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_matching_depth": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr,
+                                    c_ptr, c_int, c_ptr, c_float, c_float, c_ptr, c_ptr, c_ptr]),
 }
 
 _lib = None

@@ -1,0 +1,140 @@
+// K7: matching field -- per-view expected depth from the dense matching volume.
+// Restates MatchingField.forward / depth_render  matching_field.py:73-141, 18-71  (perturb = False).
+//
+// One thread = one low-resolution pixel ray of one view (neighbouring threads walk neighbouring voxels,
+// which keeps the 8-tap trilinear gathers in L2); the softmax expectation over the n (or 2n) samples is
+// accumulated online, so nothing is stored per sample and the reference's sort of the two bands is not
+// needed (a softmax-weighted mean does not depend on sample order).
+#include "common.h"
+
+namespace {
+
+struct MatchArgs {
+  const float* mvol;
+  int D;
+  int nv;
+  float Kinv[SURF_MAX_VIEWS][9];  // inverse(intrinsics)[:3,:3]
+  float R[SURF_MAX_VIEWS][9];     // c2w[:3,:3]
+  float Rinv[SURF_MAX_VIEWS][9];  // inverse(c2w[:3,:3])
+  float t[SURF_MAX_VIEWS][3];
+  float nearv[SURF_MAX_VIEWS], farv[SURF_MAX_VIEWS];
+  int H, W, h, w;
+  const float* lin_x;  // torch.linspace(0, W-1, w)
+  const float* lin_y;  // torch.linspace(0, H-1, h)
+  const float* lin_n;  // torch.linspace(0, 1, n)
+  int n;
+  const float* pre;    // (nv,H,W) previous-stage depths or null
+  float ratio_cur, ratio_prev;
+  float* out;          // (nv,h,w)
+};
+
+__device__ __forceinline__ void band(float zc, float half, float n0, float f0, float& lo, float& hi) {
+  lo = zc - half;
+  hi = zc + half;
+  if (hi > f0) lo = lo - (hi - f0);
+  if (lo < n0) hi = hi + (n0 - lo);
+  lo = fminf(fmaxf(lo, n0), f0);
+  hi = fminf(fmaxf(hi, n0), f0);
+}
+
+__global__ __launch_bounds__(256) void matching_depth_kernel(MatchArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per_view = (int64_t)a.h * a.w;
+  if (i >= per_view * a.nv) return;
+  const int v = (int)(i / per_view);
+  const int p = (int)(i % per_view);
+  const float px = a.lin_x[p % a.w], py = a.lin_y[p / a.w];
+  const float* Ki = a.Kinv[v];
+  float cx = Ki[0] * px + Ki[1] * py + Ki[2];
+  float cy = Ki[3] * px + Ki[4] * py + Ki[5];
+  float cz_ = Ki[6] * px + Ki[7] * py + Ki[8];
+  const float nrm = sqrtf(cx * cx + cy * cy + cz_ * cz_);
+  cx /= nrm; cy /= nrm; cz_ /= nrm;
+  const float* R = a.R[v];
+  const float dx = R[0] * cx + R[1] * cy + R[2] * cz_;
+  const float dy = R[3] * cx + R[4] * cy + R[5] * cz_;
+  const float dz = R[6] * cx + R[7] * cy + R[8] * cz_;
+  const float* Ri = a.Rinv[v];
+  const float cosz = Ri[6] * dx + Ri[7] * dy + Ri[8] * dz;  // z of the ray direction in the camera frame
+  const float ox = a.t[v][0], oy = a.t[v][1], oz = a.t[v][2];
+  const float n0 = a.nearv[v], f0 = a.farv[v];
+
+  float lo[2], hi[2];
+  int nb = 1;
+  lo[0] = n0; hi[0] = f0; lo[1] = n0; hi[1] = f0;
+  if (a.pre) {
+    const float pre = a.pre[((int64_t)v * a.H + (int)py) * a.W + (int)px];
+    const float zc = pre / cosz;
+    band(zc, ((f0 - n0) * a.ratio_cur) / 2.0f, n0, f0, lo[0], hi[0]);
+    band(zc, ((f0 - n0) * a.ratio_prev) / 2.0f, n0, f0, lo[1], hi[1]);
+    nb = 2;
+  }
+  float m = -INFINITY, den = 0.f, num = 0.f;
+  for (int b = 0; b < nb; ++b) {
+    const float rng = hi[b] - lo[b];
+    for (int k = 0; k < a.n; ++k) {
+      const float z = lo[b] + rng * a.lin_n[k];
+      const float qx = ox + dx * z, qy = oy + dy * z, qz = oz + dz * z;
+      const float rho = trilinear_zeros(a.mvol, a.D, unnorm_acf(qx, a.D), unnorm_acf(qy, a.D), unnorm_acf(qz, a.D));
+      const float mn = fmaxf(m, rho);
+      const float sc = expf(m - mn), e = expf(rho - mn);
+      den = den * sc + e;
+      num = num * sc + e * z;
+      m = mn;
+    }
+  }
+  a.out[i] = (num / den) * cosz;
+}
+
+// F.interpolate(size=(H,W), mode='bilinear', align_corners=False) of (nv,h,w) maps  (matching_field.py:137)
+__global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ src, int nv, int h, int w, int H,
+                                                                int W, float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)H * W;
+  if (i >= per * nv) return;
+  const int v = (int)(i / per);
+  const int y = (int)((i % per) / W), x = (int)(i % W);
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  float fy = sy * ((float)y + 0.5f) - 0.5f, fx = sx * ((float)x + 0.5f) - 0.5f;
+  if (fy < 0.f) fy = 0.f;
+  if (fx < 0.f) fx = 0.f;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.0f - ly, hx = 1.0f - lx;
+  const float* s = src + (int64_t)v * h * w;
+  dst[i] = hy * (hx * s[y0 * w + x0] + lx * s[y0 * w + x1]) + ly * (hx * s[y1 * w + x0] + lx * s[y1 * w + x1]);
+}
+
+}  // namespace
+
+extern "C" int surf_matching_depth(const float* mvol, int D, int nv, const float* h_kinv, const float* h_c2w,
+                                   const float* h_rinv, const float* h_near_fars, int H, int W, int h, int w,
+                                   const float* lin_x, const float* lin_y, const float* lin_n, int n, const float* pre_depths,
+                                   float ratio_cur, float ratio_prev, float* depth_lr, float* depth_full, void* stream) {
+  if (!mvol || !h_kinv || !h_c2w || !h_rinv || !h_near_fars || !lin_x || !lin_y || !lin_n || !depth_lr || !depth_full)
+    return SURF_E_ARG;
+  if (D < 2 || H < 1 || W < 1 || h < 1 || w < 1 || n < 1) return SURF_E_ARG;
+  if (nv < 1 || nv > SURF_MAX_VIEWS) return SURF_E_LIMIT;
+  MatchArgs a;
+  a.mvol = mvol; a.D = D; a.nv = nv; a.H = H; a.W = W; a.h = h; a.w = w; a.lin_x = lin_x; a.lin_y = lin_y; a.lin_n = lin_n;
+  a.n = n; a.pre = pre_depths; a.ratio_cur = ratio_cur; a.ratio_prev = ratio_prev; a.out = depth_lr;
+  for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
+    const int s = v < nv ? v : 0;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        a.Kinv[v][r * 3 + c] = h_kinv[s * 9 + r * 3 + c];
+        a.R[v][r * 3 + c] = h_c2w[s * 16 + r * 4 + c];
+        a.Rinv[v][r * 3 + c] = h_rinv[s * 9 + r * 3 + c];
+      }
+    for (int r = 0; r < 3; ++r) a.t[v][r] = h_c2w[s * 16 + r * 4 + 3];
+    a.nearv[v] = h_near_fars[s * 2 + 0];
+    a.farv[v] = h_near_fars[s * 2 + 1];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n_lr = (int64_t)nv * h * w, n_full = (int64_t)nv * H * W;
+  hipLaunchKernelGGL(matching_depth_kernel, dim3((unsigned)((n_lr + 255) / 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(upsample_bilinear_kernel, dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, st, depth_lr, nv, h, w,
+                     H, W, depth_full);
+  return surf_check_launch();
+}

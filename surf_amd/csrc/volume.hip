@@ -1,0 +1,425 @@
+// Volume-build kernels: K2 cost volume, K3/K4 upsample + depth-band filter, stream compaction,
+// row gathers, K6 densify.
+//
+// Restates Volume.up_sample / depth_filtering / back_proj_multiscale / sparse2dense / get_index
+//          volume.py:35-52, 134-168, 54-97, 99-121, 123-132  and the row selections of surf.py:104-109.
+#include "common.h"
+
+namespace {
+
+struct ViewSet {
+  int nv;
+  float w2c[SURF_MAX_VIEWS][12];  // rows 0..2 of inverse(c2w)
+  float K[SURF_MAX_VIEWS][12];    // rows 0..2 of the 4x4 intrinsics
+};
+
+__constant__ int kChildOff[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {1, 1, 0}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+
+// voxel -> normalised image coordinates of view v (volume.py:64-77); returns in-frustum flag
+__device__ __forceinline__ bool project_voxel(const ViewSet& vs, int v, float wx, float wy, float wz, float half_w,
+                                              float half_h, float& nx, float& ny, float& qz) {
+  const float* M = vs.w2c[v];
+  float X = M[0] * wx + M[1] * wy + M[2] * wz + M[3];
+  float Y = M[4] * wx + M[5] * wy + M[6] * wz + M[7];
+  float Z = M[8] * wx + M[9] * wy + M[10] * wz + M[11];
+  const float* K = vs.K[v];
+  float qx = K[0] * X + K[1] * Y + K[2] * Z + K[3];
+  float qy = K[4] * X + K[5] * Y + K[6] * Z + K[7];
+  qz = K[8] * X + K[9] * Y + K[10] * Z + K[11];
+  float x = qx / qz, y = qy / qz;
+  nx = x / half_w - 1.0f;
+  ny = y / half_h - 1.0f;
+  return (fabsf(nx) <= 1.0f) && (fabsf(ny) <= 1.0f) && (qz > 0.0f);
+}
+
+// align_corners=True unnormalisation (volume.py:83,159)
+__device__ __forceinline__ float unnorm_act(float g, int size) { return ((g + 1.0f) / 2.0f) * (float)(size - 1); }
+
+__device__ __forceinline__ float bilinear_scalar(const float* __restrict__ map, int H, int W, float x, float y) {
+  float fx = floorf(x), fy = floorf(y);
+  float tx = x - fx, ty = y - fy;
+  int x0 = (int)fx, y0 = (int)fy;
+  float acc = 0.f;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy) {
+    int yi = y0 + dy;
+    float wy = dy ? ty : 1.0f - ty;
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      int xi = x0 + dx;
+      float wx = dx ? tx : 1.0f - tx;
+      if ((xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)) acc += map[(int64_t)yi * W + xi] * (wx * wy);
+    }
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3/K4: children of every parent voxel tested against the previous stage's depth maps.
+// flags[8 p + o] = 1 iff child o of parent p is depth-consistent in more than one view.
+// ---------------------------------------------------------------------------------------------------------
+struct FilterArgs {
+  const int32_t* parents;  // (n_par,3) coords on the D/2 lattice
+  int64_t n_par;
+  int D;                   // child lattice side
+  float voxel_size;
+  const float* depths;     // (nv,H,W)
+  int H, W;
+  float depth_range;
+  ViewSet vs;
+  uint8_t* flags;
+};
+
+__global__ __launch_bounds__(256) void upsample_filter_kernel(FilterArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_par * 8) return;
+  const int64_t p = i >> 3;
+  const int o = (int)(i & 7);
+  const float cx = (float)(2 * a.parents[p * 3 + 0] + kChildOff[o][0]);
+  const float cy = (float)(2 * a.parents[p * 3 + 1] + kChildOff[o][1]);
+  const float cz = (float)(2 * a.parents[p * 3 + 2] + kChildOff[o][2]);
+  const float wx = cx * a.voxel_size + (-1.0f), wy = cy * a.voxel_size + (-1.0f), wz = cz * a.voxel_size + (-1.0f);
+  const float half_w = (float)(a.W - 1) / 2.0f, half_h = (float)(a.H - 1) / 2.0f;
+  int cnt = 0;
+  for (int v = 0; v < a.vs.nv; ++v) {
+    float nx, ny, qz;
+    bool m = project_voxel(a.vs, v, wx, wy, wz, half_w, half_h, nx, ny, qz);
+    float d = bilinear_scalar(a.depths + (int64_t)v * a.H * a.W, a.H, a.W, unnorm_act(nx, a.W), unnorm_act(ny, a.H));
+    cnt += ((fabsf(d - qz) < a.depth_range) && m) ? 1 : 0;
+  }
+  a.flags[i] = cnt > 1 ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K2: homography warp + softmax-weighted mean / variance cost volume for a list of voxels.
+// Voxel i is either (mode 0) the i-th site of the full D^3 lattice, x slowest (volume.py:21-33), or
+// (mode 1) child (idx[i] & 7) of parent (idx[i] >> 3).  Writes coords (n,3), feat (n,8), keep (n).
+// ---------------------------------------------------------------------------------------------------------
+struct CostVolArgs {
+  const int32_t* parents;
+  const int32_t* idx;
+  int64_t n;
+  int D;
+  float voxel_size;
+  const float* feats[4];  // texel4 pyramids coarse -> fine
+  int hw[8];
+  int stage;              // levels stage..3 are summed (volume.py:82)
+  ViewSet vs;
+  float w1[32], b1[8], w2[8], b2;  // agg_mlp: Linear(4,8), ELU, Linear(8,1)
+  int32_t* coords;
+  float* feat;
+  uint8_t* keep;
+};
+
+__global__ __launch_bounds__(256) void costvol_kernel(CostVolArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  int cx, cy, cz;
+  if (a.idx) {
+    const int64_t j = a.idx[i];
+    const int64_t p = j >> 3;
+    const int o = (int)(j & 7);
+    cx = 2 * a.parents[p * 3 + 0] + kChildOff[o][0];
+    cy = 2 * a.parents[p * 3 + 1] + kChildOff[o][1];
+    cz = 2 * a.parents[p * 3 + 2] + kChildOff[o][2];
+  } else {
+    cz = (int)(i % a.D);
+    cy = (int)((i / a.D) % a.D);
+    cx = (int)(i / ((int64_t)a.D * a.D));
+  }
+  a.coords[i * 3 + 0] = cx; a.coords[i * 3 + 1] = cy; a.coords[i * 3 + 2] = cz;
+  const float wx = (float)cx * a.voxel_size + (-1.0f), wy = (float)cy * a.voxel_size + (-1.0f),
+              wz = (float)cz * a.voxel_size + (-1.0f);
+  const int Hf = a.hw[6], Wf = a.hw[7];  // finest level sets the normalisation (volume.py:62,72-73)
+  const float half_w = (float)(Wf - 1) / 2.0f, half_h = (float)(Hf - 1) / 2.0f;
+
+  float f[SURF_MAX_VIEWS][4];
+  float logit[SURF_MAX_VIEWS];
+  int cnt = 0;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
+    f[v][0] = f[v][1] = f[v][2] = f[v][3] = 0.f;
+    logit[v] = -INFINITY;
+    if (v < a.vs.nv) {
+      float nx, ny, qz;
+      bool m = project_voxel(a.vs, v, wx, wy, wz, half_w, half_h, nx, ny, qz);
+      cnt += m ? 1 : 0;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int l = a.stage; l < 4; ++l) {
+        const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
+        acc += bilinear_texel4(a.feats[l] + (int64_t)v * H * W * 4, H, W, unnorm_act(nx, W), unnorm_act(ny, H));
+      }
+      f[v][0] = acc[0]; f[v][1] = acc[1]; f[v][2] = acc[2]; f[v][3] = acc[3];
+      float s = a.b2;
+#pragma unroll
+      for (int o = 0; o < 8; ++o) {
+        float h = a.b1[o];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) h += a.w1[o * 4 + c] * f[v][c];
+        h = h > 0.f ? h : expm1f(h);
+        s += a.w2[o] * h;
+      }
+      logit[v] = m ? s : -1e9f;
+      mx = fmaxf(mx, logit[v]);
+    }
+  }
+  float den = 0.f;
+  float e[SURF_MAX_VIEWS];
+#pragma unroll
+  for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
+    e[v] = (v < a.vs.nv) ? expf(logit[v] - mx) : 0.f;
+    den += e[v];
+  }
+  float mean[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
+    if (v < a.vs.nv) {
+      const float w = e[v] / den;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float wf = f[v][c] * w;
+        mean[c] += wf;
+        sq[c] += wf * wf;
+      }
+    }
+  }
+  f32x4 o0 = {mean[0], mean[1], mean[2], mean[3]};
+  f32x4 o1 = {sq[0] - mean[0] * mean[0], sq[1] - mean[1] * mean[1], sq[2] - mean[2] * mean[2], sq[3] - mean[3] * mean[3]};
+  *reinterpret_cast<f32x4*>(a.feat + i * 8) = o0;
+  *reinterpret_cast<f32x4*>(a.feat + i * 8 + 4) = o1;
+  a.keep[i] = cnt > 1 ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Stable stream compaction of a byte flag array: idx_out = ascending list of i with flags[i] != 0.
+// Three launches: per-block counts, single-block scan of the counts, scatter.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int CP_ITEMS = 16, CP_THREADS = 256, CP_BLOCK = CP_ITEMS * CP_THREADS;
+
+__global__ __launch_bounds__(CP_THREADS) void compact_count_kernel(const uint8_t* __restrict__ flags, int64_t n,
+                                                                   int32_t* __restrict__ block_counts) {
+  __shared__ int s_part[CP_THREADS / 64];
+  const int64_t base = (int64_t)blockIdx.x * CP_BLOCK + (int64_t)threadIdx.x * CP_ITEMS;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < CP_ITEMS; ++k) c += (base + k < n && flags[base + k]) ? 1 : 0;
+  c = (int)wave_sum((float)c);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+}
+
+__global__ __launch_bounds__(1024) void compact_scan_kernel(int32_t* __restrict__ block_counts, int nb,
+                                                            int32_t* __restrict__ total) {
+  // exclusive scan in place by one block, chunks of 1024
+  __shared__ int s_buf[1024];
+  __shared__ int s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < nb; c0 += 1024) {
+    const int i = c0 + threadIdx.x;
+    const int v = i < nb ? block_counts[i] : 0;
+    s_buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int t = threadIdx.x >= o ? s_buf[threadIdx.x - o] : 0;
+      __syncthreads();
+      s_buf[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const int incl = s_buf[threadIdx.x];
+    const int carry = s_carry;
+    if (i < nb) block_counts[i] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = carry + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = s_carry;
+}
+
+__global__ __launch_bounds__(CP_THREADS) void compact_scatter_kernel(const uint8_t* __restrict__ flags, int64_t n,
+                                                                     const int32_t* __restrict__ block_offsets,
+                                                                     int32_t* __restrict__ idx_out) {
+  __shared__ int s_part[CP_THREADS / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * CP_BLOCK + (int64_t)threadIdx.x * CP_ITEMS;
+  int c = 0;
+  unsigned bits = 0;
+#pragma unroll
+  for (int k = 0; k < CP_ITEMS; ++k) {
+    const bool f = base + k < n && flags[base + k];
+    bits |= (f ? 1u : 0u) << k;
+    c += f ? 1 : 0;
+  }
+  // exclusive scan of c across the wave, then across the 4 waves
+  int incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_part[wave] = incl;
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < wave; ++w) wave_off += s_part[w];
+  int pos = block_offsets[blockIdx.x] + wave_off + incl - c;
+#pragma unroll
+  for (int k = 0; k < CP_ITEMS; ++k)
+    if (bits & (1u << k)) idx_out[pos++] = (int32_t)(base + k);
+}
+
+// dst[i, 0:w] = src[idx[i] >> shift, 0:w]   (rows of w 32-bit words; shift = 3 selects the parent row)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint32_t* __restrict__ src, const int32_t* __restrict__ idx,
+                                                          int64_t n, int w, int shift, int dst_stride, int dst_off,
+                                                          uint32_t* __restrict__ dst) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * w) return;
+  const int64_t i = t / w;
+  const int c = (int)(t % w);
+  dst[i * dst_stride + dst_off + c] = src[(int64_t)(idx[i] >> shift) * w + c];
+}
+
+// idx_out[i] = a[b[i]]  (composition of two index lists)
+__global__ __launch_bounds__(256) void compose_index_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b,
+                                                            int64_t n, int32_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[b[i]];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K6 densify: background = x2 trilinear upsample of the previous matching volume (align_corners=False) or 0,
+// index table = -1; then scatter the stage's logits and row numbers.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void up2_src(int i, int Dp, int& i0, int& i1, float& l1) {
+  float src = ((float)i + 0.5f) * 0.5f - 0.5f;  // area_pixel_compute_source_index, scale 0.5
+  if (src < 0.f) src = 0.f;
+  i0 = (int)floorf(src);
+  i1 = min(i0 + 1, Dp - 1);
+  l1 = src - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void dense_init_kernel(const float* __restrict__ prev, int D, float* __restrict__ dense,
+                                                         int32_t* __restrict__ table) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)D * D * D;
+  if (i >= total) return;
+  table[i] = -1;
+  float v = 0.f;
+  if (prev) {
+    const int Dp = D / 2;
+    const int z = (int)(i % D), y = (int)((i / D) % D), x = (int)(i / ((int64_t)D * D));
+    int x0, x1, y0, y1, z0, z1;
+    float lx, ly, lz;
+    up2_src(x, Dp, x0, x1, lx);
+    up2_src(y, Dp, y0, y1, ly);
+    up2_src(z, Dp, z0, z1, lz);
+    const float hx = 1.0f - lx, hy = 1.0f - ly, hz = 1.0f - lz;
+    auto P = [&](int xi, int yi, int zi) { return prev[((int64_t)xi * Dp + yi) * Dp + zi]; };
+    // ATen upsample_trilinear3d: w_d (w_h (w_w a + w_w b) + ...) with d = our x, h = y, w = z
+    v = hx * (hy * (hz * P(x0, y0, z0) + lz * P(x0, y0, z1)) + ly * (hz * P(x0, y1, z0) + lz * P(x0, y1, z1))) +
+        lx * (hy * (hz * P(x1, y0, z0) + lz * P(x1, y0, z1)) + ly * (hz * P(x1, y1, z0) + lz * P(x1, y1, z1)));
+  }
+  dense[i] = v;
+}
+
+__global__ __launch_bounds__(256) void dense_scatter_kernel(const int32_t* __restrict__ coords, const float* __restrict__ rows,
+                                                            int row_stride, int64_t n, int D, float* __restrict__ dense,
+                                                            int32_t* __restrict__ table) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t o = ((int64_t)coords[i * 3 + 0] * D + coords[i * 3 + 1]) * D + coords[i * 3 + 2];
+  dense[o] = rows[i * row_stride];
+  table[o] = (int32_t)i;
+}
+
+void fill_views(ViewSet& vs, int nv, const float* h_intrs, const float* h_w2c) {
+  vs.nv = nv;
+  for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
+    const int s = v < nv ? v : 0;
+    for (int k = 0; k < 12; ++k) {
+      vs.w2c[v][k] = h_w2c[s * 16 + k];
+      vs.K[v][k] = h_intrs[s * 16 + k];
+    }
+  }
+}
+
+inline dim3 grid1d(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+}  // namespace
+
+extern "C" int surf_upsample_filter(const int32_t* parents, int64_t n_parents, int D, const float* depths, int nv, int H,
+                                    int W, const float* h_intrs, const float* h_w2c, float depth_range, uint8_t* flags,
+                                    void* stream) {
+  if (!parents || !depths || !h_intrs || !h_w2c || !flags || n_parents <= 0 || D < 2 || H < 2 || W < 2) return SURF_E_ARG;
+  if (nv < 1 || nv > SURF_MAX_VIEWS) return SURF_E_LIMIT;
+  FilterArgs a;
+  a.parents = parents; a.n_par = n_parents; a.D = D; a.voxel_size = (float)(2.0 / (double)(D - 1));
+  a.depths = depths; a.H = H; a.W = W; a.depth_range = depth_range; a.flags = flags;
+  fill_views(a.vs, nv, h_intrs, h_w2c);
+  hipLaunchKernelGGL(upsample_filter_kernel, grid1d(n_parents * 8, 256), dim3(256), 0, (hipStream_t)stream, a);
+  return surf_check_launch();
+}
+
+extern "C" int surf_costvol(const int32_t* parents, const int32_t* idx, int64_t n, int D, const float* const* h_feats,
+                            const int* h_hw, int stage, int nv, const float* h_intrs, const float* h_w2c,
+                            const float* h_agg /* w1(8x4) b1(8) w2(8) b2(1) */, int32_t* coords, float* feat,
+                            uint8_t* keep, void* stream) {
+  if (!h_feats || !h_hw || !h_intrs || !h_w2c || !h_agg || !coords || !feat || !keep || n <= 0 || D < 2) return SURF_E_ARG;
+  if ((idx != nullptr) != (parents != nullptr)) return SURF_E_ARG;
+  if (!idx && n != (int64_t)D * D * D) return SURF_E_ARG;
+  if (nv < 1 || nv > SURF_MAX_VIEWS || stage < 0 || stage > 3) return SURF_E_LIMIT;
+  CostVolArgs a;
+  a.parents = parents; a.idx = idx; a.n = n; a.D = D; a.voxel_size = (float)(2.0 / (double)(D - 1)); a.stage = stage;
+  for (int l = 0; l < 4; ++l) {
+    if (!h_feats[l]) return SURF_E_ARG;
+    a.feats[l] = h_feats[l];
+    a.hw[2 * l] = h_hw[2 * l];
+    a.hw[2 * l + 1] = h_hw[2 * l + 1];
+  }
+  fill_views(a.vs, nv, h_intrs, h_w2c);
+  for (int k = 0; k < 32; ++k) a.w1[k] = h_agg[k];
+  for (int k = 0; k < 8; ++k) { a.b1[k] = h_agg[32 + k]; a.w2[k] = h_agg[40 + k]; }
+  a.b2 = h_agg[48];
+  a.coords = coords; a.feat = feat; a.keep = keep;
+  hipLaunchKernelGGL(costvol_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, a);
+  return surf_check_launch();
+}
+
+extern "C" int64_t surf_compact_workspace_ints(int64_t n) { return (n + CP_BLOCK - 1) / CP_BLOCK + 1; }
+
+extern "C" int surf_compact(const uint8_t* flags, int64_t n, int32_t* workspace, int32_t* idx_out, int32_t* total,
+                            void* stream) {
+  if (!flags || !workspace || !idx_out || !total || n <= 0) return SURF_E_ARG;
+  if (n > 0x7fffffffLL) return SURF_E_LIMIT;
+  const int nb = (int)((n + CP_BLOCK - 1) / CP_BLOCK);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(compact_count_kernel, dim3(nb), dim3(CP_THREADS), 0, st, flags, n, workspace);
+  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, st, workspace, nb, total);
+  hipLaunchKernelGGL(compact_scatter_kernel, dim3(nb), dim3(CP_THREADS), 0, st, flags, n, workspace, idx_out);
+  return surf_check_launch();
+}
+
+extern "C" int surf_gather_rows(const void* src, const int32_t* idx, int64_t n, int row_words, int idx_shift,
+                                int dst_stride_words, int dst_offset_words, void* dst, void* stream) {
+  if (!src || !idx || !dst || n <= 0 || row_words <= 0 || idx_shift < 0 || dst_stride_words < row_words) return SURF_E_ARG;
+  hipLaunchKernelGGL(gather_rows_kernel, grid1d(n * row_words, 256), dim3(256), 0, (hipStream_t)stream,
+                     (const uint32_t*)src, idx, n, row_words, idx_shift, dst_stride_words, dst_offset_words, (uint32_t*)dst);
+  return surf_check_launch();
+}
+
+extern "C" int surf_compose_index(const int32_t* a, const int32_t* b, int64_t n, int32_t* out, void* stream) {
+  if (!a || !b || !out || n <= 0) return SURF_E_ARG;
+  hipLaunchKernelGGL(compose_index_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, a, b, n, out);
+  return surf_check_launch();
+}
+
+extern "C" int surf_densify(const int32_t* coords, const float* rows, int row_stride, int64_t n, int D, const float* prev,
+                            float* dense, int32_t* table, void* stream) {
+  if (!coords || !rows || !dense || !table || n <= 0 || D < 2 || row_stride < 1) return SURF_E_ARG;
+  if (prev && (D & 1)) return SURF_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dense_init_kernel, grid1d((int64_t)D * D * D, 256), dim3(256), 0, st, prev, D, dense, table);
+  hipLaunchKernelGGL(dense_scatter_kernel, grid1d(n, 256), dim3(256), 0, st, coords, rows, row_stride, n, D, dense, table);
+  return surf_check_launch();
+}

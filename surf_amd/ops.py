@@ -262,3 +262,116 @@ def composite(sdf, grad, color, n_valid, setup, rays_d, inv_s, cos_anneal_ratio,
                                    _p(out.get("weights")), _p(out.get("inside_sphere")), _p(out["eik"]), _stream())
     _lib.check(rc, "surf_composite")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# volume build (surf.py:80-131)
+# ------------------------------------------------------------------------------------------------
+
+
+def _cams_ext(cams, intrs, c2ws):
+    """Extra host matrices of the matching field: inverse(intrs)[:, :3, :3], inverse(c2w[:, :3, :3])."""
+    if not hasattr(cams, "kinv"):
+        i_cpu = intrs.detach().to("cpu", torch.float32)
+        c_cpu = c2ws.detach().to("cpu", torch.float32)
+        cams.kinv = np.ascontiguousarray(torch.inverse(i_cpu)[:, :3, :3].contiguous().numpy())
+        cams.rinv = np.ascontiguousarray(torch.inverse(c_cpu[:, :3, :3]).contiguous().numpy())
+    return cams
+
+
+def upsample_filter(parents, D, depths, cams, depth_range):
+    """volume.py:35-52 + 134-165: flags (8 N,) uint8 over the children of `parents` (N,3) int32."""
+    _chk(parents, torch.int32, "parents")
+    _chk(depths, torch.float32, "depths")
+    nv, H, W = depths.shape
+    flags = torch.empty(parents.shape[0] * 8, dtype=torch.uint8, device=parents.device)
+    rc = _lib.lib().surf_upsample_filter(_p(parents), parents.shape[0], int(D), _p(depths), nv, H, W, _np_ptr(cams.intrs),
+                                         _np_ptr(cams.w2c), ctypes.c_float(float(depth_range)), _p(flags), _stream())
+    _lib.check(rc, "surf_upsample_filter")
+    return flags
+
+
+def agg_mlp_host(sd, prefix="volume."):
+    return np.concatenate([_host_f32(sd[prefix + k]).reshape(-1) for k in
+                           ("agg_mlp.0.weight", "agg_mlp.0.bias", "agg_mlp.2.weight", "agg_mlp.2.bias")])
+
+
+def costvol(feats_t4_c2f, stage, D, cams, agg, parents=None, idx=None):
+    """volume.py:54-97 on the full lattice (parents/idx None) or on children idx of parents.
+    feats_t4_c2f: texel4 pyramids coarse -> fine.  Returns coords (n,3) int32, feat (n,8), keep (n,) uint8."""
+    dev = feats_t4_c2f[0].device
+    n = int(D) ** 3 if idx is None else int(idx.shape[0])
+    coords = torch.empty(n, 3, dtype=torch.int32, device=dev)
+    feat = torch.empty(n, 8, dtype=torch.float32, device=dev)
+    keep = torch.empty(n, dtype=torch.uint8, device=dev)
+    hw = (ctypes.c_int * 8)(*[int(v) for f in feats_t4_c2f for v in f.shape[1:3]])
+    fp = _ptr_array(feats_t4_c2f)
+    agg = np.ascontiguousarray(agg, dtype=np.float32)
+    rc = _lib.lib().surf_costvol(_p(parents), _p(idx), n, int(D), fp, hw, int(stage), cams.nv, _np_ptr(cams.intrs),
+                                 _np_ptr(cams.w2c), _np_ptr(agg), _p(coords), _p(feat), _p(keep), _stream())
+    _lib.check(rc, "surf_costvol")
+    return coords, feat, keep
+
+
+def compact(flags):
+    """Ascending indices of the set flags (int32).  One host sync to size the result -- the reference syncs at the
+    same places (boolean-mask indexing, volume.py:165-166, surf.py:104-108)."""
+    _chk(flags, torch.uint8, "flags")
+    n = flags.numel()
+    dev = flags.device
+    ws = torch.empty(_lib.lib().surf_compact_workspace_ints(n), dtype=torch.int32, device=dev)
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().surf_compact(_p(flags), n, _p(ws), _p(idx), _p(total), _stream()), "surf_compact")
+    return idx[:int(total.item())]
+
+
+def gather_rows(src, idx, shift=0, dst=None, dst_off=0):
+    """dst[i, off:off+w] = src[idx[i] >> shift]; src rows of 32-bit elements."""
+    assert src.is_contiguous() and src.element_size() == 4 and src.is_cuda
+    _chk(idx, torch.int32, "idx")
+    w = src.shape[1]
+    n = idx.shape[0]
+    if dst is None:
+        dst = torch.empty(n, w, dtype=src.dtype, device=src.device)
+    rc = _lib.lib().surf_gather_rows(_p(src), _p(idx), n, w, int(shift), dst.shape[1], int(dst_off), _p(dst), _stream())
+    _lib.check(rc, "surf_gather_rows")
+    return dst
+
+
+def compose_index(a, b):
+    out = torch.empty_like(b)
+    _lib.check(_lib.lib().surf_compose_index(_p(a), _p(b), b.shape[0], _p(out), _stream()), "surf_compose_index")
+    return out
+
+
+def densify(coords, rows, D, prev=None):
+    """volume.py:99-132: dense matching volume (D,D,D) f32 and index table (D,D,D) int32; logit = rows[:, 0]."""
+    _chk(coords, torch.int32, "coords")
+    _chk(rows, torch.float32, "rows")
+    dev = coords.device
+    dense = torch.empty(D, D, D, dtype=torch.float32, device=dev)
+    table = torch.empty(D, D, D, dtype=torch.int32, device=dev)
+    rc = _lib.lib().surf_densify(_p(coords), _p(rows), rows.shape[1], coords.shape[0], int(D), _p(prev), _p(dense), _p(table),
+                                 _stream())
+    _lib.check(rc, "surf_densify")
+    return dense, table
+
+
+def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, ratio_cur=1.0, ratio_prev=1.0):
+    """matching_field.py:73-141 (perturb False).  Returns depth maps (nv,H,W)."""
+    _chk(mvol, torch.float32, "matching volume")
+    dev = mvol.device
+    h, w = H // res_level, W // res_level
+    lin_x = torch.linspace(0, W - 1, w).to(dev)
+    lin_y = torch.linspace(0, H - 1, h).to(dev)
+    lin_n = torch.linspace(0.0, 1.0, n).to(dev)
+    nf = np.ascontiguousarray(near_fars.detach().to("cpu", torch.float32).numpy())
+    lr = torch.empty(cams.nv, h, w, dtype=torch.float32, device=dev)
+    full = torch.empty(cams.nv, H, W, dtype=torch.float32, device=dev)
+    rc = _lib.lib().surf_matching_depth(_p(mvol), int(mvol.shape[0]), cams.nv, _np_ptr(cams.kinv), _np_ptr(cams.c2w),
+                                        _np_ptr(cams.rinv), _np_ptr(nf), H, W, h, w, _p(lin_x), _p(lin_y), _p(lin_n), int(n),
+                                        _p(pre_depths), ctypes.c_float(float(ratio_cur)), ctypes.c_float(float(ratio_prev)),
+                                        _p(lr), _p(full), _stream())
+    _lib.check(rc, "surf_matching_depth")
+    return full

@@ -160,3 +160,60 @@ def test_render_matches_golden(scene, weights, gpu_scene, golden_render):
         assert torch.equal(out["mid_inside_sphere"].cpu().float(), g["mid_inside_sphere"])
         eik = out["eik"].cpu().sum(0)
         rel_close(eik[0] / (eik[1] + 1e-5), g["gradient_error"], 1e-3, 1e-5)
+
+
+def test_volume_build_matches_golden(scene, weights, golden_fpn, golden_pipe):
+    """Rows a2-a4, a6, a7: every stage of the volume build against the reference's own outputs.  The stub
+    regulariser's outputs are taken from the fixture so that each stage is compared on equal inputs."""
+    from surf_amd import ops
+    d = dev()
+    gp = golden_pipe
+    feats_c2f = [ops.pack_texel4(golden_fpn[f"out{i}"].to(d).contiguous()) for i in range(4)]
+    cams = ops._cams_ext(ops.Cameras(scene["intrs"], scene["c2ws"]), scene["intrs"], scene["c2ws"])
+    agg = ops.agg_mlp_host(weights)
+    H, W = scene["imgs"].shape[-2:]
+    base_range = float((scene["far"] - scene["near"]).squeeze())
+    D = CFG["base_volume_dim"]
+    depths, mvol, coords = None, None, None
+    for s in range(4):
+        if s == 0:
+            c_all, cv, keep = ops.costvol(feats_c2f, 0, D, cams, agg)
+            idx1 = None
+        else:
+            D *= 2
+            flags = ops.upsample_filter(coords, D, depths, cams, base_range * CFG["range_ratios"][s])
+            idx1 = ops.compact(flags)
+            c_all, cv, keep = ops.costvol(feats_c2f, s, D, cams, agg, parents=coords, idx=idx1)
+            assert torch.equal(c_all.cpu().to(torch.int16), gp[f"s{s}_filt_coords"])
+        assert torch.equal(keep.cpu().bool(), gp[f"s{s}_keep"])
+        rel_close(cv, gp[f"s{s}_costvol"], 1e-3, 2e-5)
+        idx2 = ops.compact(keep)
+        coords = ops.gather_rows(c_all, idx2)
+        assert torch.equal(coords.cpu().to(torch.int16), gp[f"s{s}_coords"])
+        reg_in = torch.empty(idx2.shape[0], 8 if s == 0 else 16, dtype=torch.float32, device=d)
+        ops.gather_rows(cv, idx2, dst=reg_in, dst_off=0)
+        if s > 0:
+            prev_mid = gp[f"s{s-1}_reg_mid"].to(d).contiguous()
+            ops.gather_rows(prev_mid, ops.compose_index(idx1, idx2), shift=3, dst=reg_in, dst_off=8)
+        rel_close(reg_in, gp[f"s{s}_reg_in"], 1e-3, 2e-5)
+        out = gp[f"s{s}_reg_out"].to(d).contiguous()
+        mvol, table = ops.densify(coords, out, D, mvol)
+        rel_close(mvol, gp[f"s{s}_mvol"], 1e-4, 2e-5)
+        assert torch.equal(table.cpu(), gp[f"s{s}_table"])
+        depths = ops.matching_depth(mvol, cams, scene["near_fars"], H, W, CFG["depth_res_levels"][s],
+                                    CFG["n_samples_depths"][s], depths, CFG["range_ratios"][s],
+                                    CFG["range_ratios"][s - 1] if s > 0 else 1.0)
+        rel_close(depths, gp[f"s{s}_depths"], 1e-3, 5e-5)
+        # continue from the reference's tensors so that rounding differences cannot move a voxel across a threshold
+        depths = gp[f"s{s}_depths"].to(d).contiguous()
+        mvol = gp[f"s{s}_mvol"].to(d).contiguous()
+
+
+def test_compact_large_and_edge_cases():
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(5)
+    for n, p in ((1, 1.0), (4095, 0.5), (4096, 0.0), (1_000_003, 0.3), (9_000_000, 0.9)):
+        flags = (torch.rand(n, generator=g) < p).to(torch.uint8)
+        idx = ops.compact(flags.to(d))
+        assert torch.equal(idx.cpu().long(), flags.nonzero().view(-1))
