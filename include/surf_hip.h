@@ -183,6 +183,48 @@ int surf_matching_depth(const float* mvol, int D, int nv, const float* h_kinv, c
                         const float* lin_n, int n, const float* pre_depths, float ratio_cur, float ratio_prev,
                         float* depth_lr, float* depth_full, void* stream);
 
+/* =====================================================================================================
+ * Sparse 3D U-Net pieces (reg_network.py:38-88 over torchsparse 2.1.0 -- third party, PARITY UNPINNED).
+ * Kernel (27, C_in, C_out), offsets enumerated x fastest / z slowest; rows of C floats, C in {8,16,32,64}.
+ * ===================================================================================================== */
+
+/*
+ * One sparse convolution with fused BatchNorm(eval) + ReLU (+ skip add after the ReLU, reg_network.py:79-83).
+ *   mode 0 submanifold (stride 1): out site c gathers input sites c + o            (in_table on the same lattice)
+ *   mode 1 down (k3, stride 2):    out site q gathers input sites 2q + o          (in_table on the fine lattice)
+ *   mode 2 up (transposed, s2):    out site c gathers input sites q with 2q + o = c (in_table on the coarse lattice)
+ *   bn_scale = gamma / sqrt(running_var + eps), bn_shift = beta - running_mean * bn_scale (device, C_out), or both NULL
+ */
+int surf_spconv(const float* in, int cin, const int32_t* in_table, int D_in, const int32_t* out_coords, int64_t n_out,
+                int mode, const float* weight, int cout, const float* bn_scale, const float* bn_shift, const float* skip,
+                float* out, void* stream);
+
+/* Output sites of a k3/s2 conv: marks[(D/2+1)^3] |= 1 at q when 2q lies in the 3^3 window of an input voxel and
+ * inside the inputs' bounding box h_lo..h_hi (HOST int[3] each).  marks must be zeroed by the caller. */
+int surf_mark_down_sites(const int32_t* coords, int64_t n, int D, const int* h_lo, const int* h_hi, uint8_t* marks,
+                         void* stream);
+/* keys (ascending lattice site numbers, e.g. from surf_compact) -> coords (n,3) and table[key] = rank */
+int surf_sites_from_keys(const int32_t* keys, int64_t n, int D, int32_t* coords, int32_t* table, void* stream);
+/* table[coords[i]] = i (table pre-filled with -1 by the caller) */
+int surf_table_from_coords(const int32_t* coords, int64_t n, int D, int32_t* table, void* stream);
+/* out = in @ W^T for rows of 8 floats (out_lin, reg_network.py:67,86) */
+int surf_row_linear8(const float* in, const float* weight, int64_t n, float* out, void* stream);
+
+/* =====================================================================================================
+ * FPN (feature_network.py:126-178).  Activations NHWC fp32, channels a multiple of 4 (the RGB input is the
+ * texel4 image); weights repacked by the host to [ky][kx][c_in][c_out].
+ * ===================================================================================================== */
+
+/* 3x3 convolution, padding 1, stride 1 or 2, no bias (feature_network.py:15,151).  out (N, H/stride, W/stride, cout). */
+int surf_conv3x3(const float* in, const float* weight, int N, int H, int W, int cin, int cout, int stride, float* out,
+                 void* stream);
+/* ConvTranspose2d(3x3, stride 2, padding 1, output_padding 1), no bias (feature_network.py:66,155).  out (N,2H,2W,cout). */
+int surf_deconv3x3_s2(const float* in, const float* weight, int N, int H, int W, int cin, int cout, float* out, void* stream);
+/* In place: x = relu(InstanceNorm2d(x)) (+ skip)  (feature_network.py:16-17,21-24; skip add :170).
+ * workspace: surf_inorm_workspace_doubles(N,H,W,C) doubles; stats (N,C,2) receives mean and 1/sqrt(var+1e-5). */
+int64_t surf_inorm_workspace_doubles(int N, int H, int W, int C);
+int surf_inorm_relu(float* x, int N, int H, int W, int C, const float* skip, double* workspace, float* stats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

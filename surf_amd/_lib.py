@@ -42,6 +42,15 @@ SIGNATURES = {
     "surf_gather_rows": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "surf_compose_index": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "surf_densify": (c_int, [c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_spconv": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_mark_down_sites": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_sites_from_keys": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
+    "surf_table_from_coords": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr]),
+    "surf_row_linear8": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
+    "surf_conv3x3": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "surf_deconv3x3_s2": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "surf_inorm_workspace_doubles": (c_i64, [c_int, c_int, c_int, c_int]),
+    "surf_inorm_relu": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_matching_depth": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr,
                                     c_ptr, c_int, c_ptr, c_float, c_float, c_ptr, c_ptr, c_ptr]),
 }

@@ -1,0 +1,190 @@
+// K5: sparse 3D convolutions of the cost-regularisation U-Net (3^3 kernels; submanifold, stride-2 down,
+// transposed stride-2 up) with BatchNorm(eval) + ReLU (+ skip add) fused in the epilogue.
+//
+// Restates SparseCostRegNet  reg_network.py:38-88  over torchsparse 2.1.0 `spnn.Conv3d / BatchNorm / ReLU`
+// (third-party, source absent: PARITY UNPINNED -- semantics documented in oracle/surf_oracle.py sparse_unet).
+//
+// Output-stationary gather form, no atomics: one thread owns one output voxel and all C_out channels; for each
+// of the 27 offsets it looks the contributing input row up in a dense int32 index table, reads it with 16-byte
+// loads and applies the (C_in x C_out) slice of the kernel, whose entries are wave-uniform (scalar loads).
+// Kernel-offset enumeration: x fastest, z slowest (k = (oz+1)*9 + (oy+1)*3 + (ox+1)), torchsparse's order for
+// odd kernel volumes.
+#include "common.h"
+
+namespace {
+
+enum { MODE_SUBM = 0, MODE_DOWN = 1, MODE_UP = 2 };
+
+struct SpconvArgs {
+  const float* in;          // (n_in, CIN)
+  const int32_t* in_table;  // (Din^3) row of the input site or -1
+  int Din;
+  const int32_t* out_coords;  // (n_out, 3)
+  int64_t n_out;
+  int mode;
+  const float* weight;  // (27, CIN, COUT)
+  const float* scale;   // (COUT) gamma / sqrt(var + eps)      -- or null: no BN/ReLU
+  const float* shift;   // (COUT) beta - mean * scale
+  const float* skip;    // (n_out, COUT) added after the ReLU, or null
+  float* out;           // (n_out, COUT)
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void spconv_kernel(SpconvArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_out) return;
+  const int cx = a.out_coords[i * 3 + 0], cy = a.out_coords[i * 3 + 1], cz = a.out_coords[i * 3 + 2];
+  const int D = a.Din;
+  float acc[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+  const float* __restrict__ W = a.weight;
+
+  for (int k = 0; k < 27; ++k) {
+    const int ox = k % 3 - 1, oy = (k / 3) % 3 - 1, oz = k / 9 - 1;
+    int x, y, z;
+    bool ok = true;
+    if (a.mode == MODE_SUBM) {
+      x = cx + ox; y = cy + oy; z = cz + oz;
+    } else if (a.mode == MODE_DOWN) {
+      x = 2 * cx + ox; y = 2 * cy + oy; z = 2 * cz + oz;
+    } else {  // MODE_UP: coarse site q with 2 q + o == c
+      const int tx = cx - ox, ty = cy - oy, tz = cz - oz;
+      ok = ((tx | ty | tz) & 1) == 0;
+      x = tx >> 1; y = ty >> 1; z = tz >> 1;
+    }
+    ok = ok && x >= 0 && x < D && y >= 0 && y < D && z >= 0 && z < D;
+    int row = -1;
+    if (ok) row = a.in_table[((int64_t)x * D + y) * D + z];
+    if (row < 0) continue;
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.in + (int64_t)row * CIN);
+    const float* __restrict__ Wk = W + (int64_t)k * CIN * COUT;
+    for (int c4 = 0; c4 < CIN / 4; ++c4) {
+      const f32x4 xv = src[c4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float xq = xv[q];
+        const float* __restrict__ Wr = Wk + (c4 * 4 + q) * COUT;
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = fmaf(xq, Wr[co], acc[co]);
+      }
+    }
+  }
+  float* __restrict__ dst = a.out + i * COUT;
+  const float* __restrict__ sk = a.skip ? a.skip + i * COUT : nullptr;
+#pragma unroll
+  for (int c4 = 0; c4 < COUT / 4; ++c4) {
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = c4 * 4 + q;
+      float y = acc[co];
+      if (a.scale) y = fmaxf(y * a.scale[co] + a.shift[co], 0.f);
+      if (sk) y += sk[co];
+      v[q] = y;
+    }
+    reinterpret_cast<f32x4*>(dst)[c4] = v;
+  }
+}
+
+// marks[q] = 1 for every coarse site q such that 2q is within the 3^3 window of an input voxel and inside the
+// bounding box of the input coordinates (the output-site rule of a k3/s2 sparse conv, "dilate" in the oracle)
+__global__ __launch_bounds__(256) void mark_down_sites_kernel(const int32_t* __restrict__ coords, int64_t n, int D2,
+                                                              int lox, int loy, int loz, int hix, int hiy, int hiz,
+                                                              uint8_t* __restrict__ marks) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * 27) return;
+  const int64_t i = t / 27;
+  const int k = (int)(t % 27);
+  const int x = coords[i * 3 + 0] + (k % 3 - 1), y = coords[i * 3 + 1] + ((k / 3) % 3 - 1), z = coords[i * 3 + 2] + (k / 9 - 1);
+  if (((x | y | z) & 1) != 0) return;
+  if (x < lox || x > hix || y < loy || y > hiy || z < loz || z > hiz) return;
+  marks[((int64_t)(x >> 1) * D2 + (y >> 1)) * D2 + (z >> 1)] = 1;
+}
+
+// keys (ascending site numbers of a D^3 lattice) -> coords (n,3) and table[key] = rank
+__global__ __launch_bounds__(256) void sites_from_keys_kernel(const int32_t* __restrict__ keys, int64_t n, int D,
+                                                              int32_t* __restrict__ coords, int32_t* __restrict__ table) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int key = keys[i];
+  coords[i * 3 + 0] = key / (D * D);
+  coords[i * 3 + 1] = (key / D) % D;
+  coords[i * 3 + 2] = key % D;
+  table[key] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(256) void table_from_coords_kernel(const int32_t* __restrict__ coords, int64_t n, int D,
+                                                                int32_t* __restrict__ table) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  table[((int64_t)coords[i * 3 + 0] * D + coords[i * 3 + 1]) * D + coords[i * 3 + 2]] = (int32_t)i;
+}
+
+// out[i, :] = in[i, :C] @ W^T   (nn.Linear without bias, reg_network.py:67,86)
+template <int C>
+__global__ __launch_bounds__(256) void row_linear_kernel(const float* __restrict__ in, const float* __restrict__ W, int64_t n,
+                                                         float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) x[c] = in[i * C + c];
+#pragma unroll
+  for (int o = 0; o < C; ++o) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc = fmaf(x[c], W[o * C + c], acc);
+    out[i * C + o] = acc;
+  }
+}
+
+inline dim3 grid1d(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+}  // namespace
+
+#define SPCONV_CASE(CI, CO)                                                                                  \
+  if (cin == CI && cout == CO) {                                                                             \
+    hipLaunchKernelGGL((spconv_kernel<CI, CO>), grid1d(n_out, 256), dim3(256), 0, (hipStream_t)stream, a);   \
+    return surf_check_launch();                                                                              \
+  }
+
+extern "C" int surf_spconv(const float* in, int cin, const int32_t* in_table, int D_in, const int32_t* out_coords,
+                           int64_t n_out, int mode, const float* weight, int cout, const float* bn_scale,
+                           const float* bn_shift, const float* skip, float* out, void* stream) {
+  if (!in || !in_table || !out_coords || !weight || !out || n_out <= 0 || D_in < 1) return SURF_E_ARG;
+  if (mode < 0 || mode > 2 || ((bn_scale == nullptr) != (bn_shift == nullptr))) return SURF_E_ARG;
+  SpconvArgs a;
+  a.in = in; a.in_table = in_table; a.Din = D_in; a.out_coords = out_coords; a.n_out = n_out; a.mode = mode;
+  a.weight = weight; a.scale = bn_scale; a.shift = bn_shift; a.skip = skip; a.out = out;
+  SPCONV_CASE(8, 8) SPCONV_CASE(16, 8) SPCONV_CASE(8, 16) SPCONV_CASE(16, 16) SPCONV_CASE(16, 32) SPCONV_CASE(32, 32)
+  SPCONV_CASE(32, 64) SPCONV_CASE(64, 64) SPCONV_CASE(64, 32) SPCONV_CASE(32, 16)
+  return SURF_E_LIMIT;  // channel pair not instantiated (reg_network.py uses d_base = 8 only)
+}
+
+extern "C" int surf_mark_down_sites(const int32_t* coords, int64_t n, int D, const int* h_lo, const int* h_hi,
+                                    uint8_t* marks, void* stream) {
+  if (!coords || !h_lo || !h_hi || !marks || n <= 0 || D < 2) return SURF_E_ARG;
+  const int D2 = D / 2 + 1;
+  hipLaunchKernelGGL(mark_down_sites_kernel, grid1d(n * 27, 256), dim3(256), 0, (hipStream_t)stream, coords, n, D2, h_lo[0],
+                     h_lo[1], h_lo[2], h_hi[0], h_hi[1], h_hi[2], marks);
+  return surf_check_launch();
+}
+
+extern "C" int surf_sites_from_keys(const int32_t* keys, int64_t n, int D, int32_t* coords, int32_t* table, void* stream) {
+  if (!keys || !coords || !table || n <= 0 || D < 1) return SURF_E_ARG;
+  hipLaunchKernelGGL(sites_from_keys_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, keys, n, D, coords, table);
+  return surf_check_launch();
+}
+
+extern "C" int surf_table_from_coords(const int32_t* coords, int64_t n, int D, int32_t* table, void* stream) {
+  if (!coords || !table || n <= 0 || D < 1) return SURF_E_ARG;
+  hipLaunchKernelGGL(table_from_coords_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, coords, n, D, table);
+  return surf_check_launch();
+}
+
+extern "C" int surf_row_linear8(const float* in, const float* weight, int64_t n, float* out, void* stream) {
+  if (!in || !weight || !out || n <= 0) return SURF_E_ARG;
+  hipLaunchKernelGGL(row_linear_kernel<8>, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, in, weight, n, out);
+  return surf_check_launch();
+}

@@ -375,3 +375,95 @@ def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, r
                                         _p(lr), _p(full), _stream())
     _lib.check(rc, "surf_matching_depth")
     return full
+
+
+# ------------------------------------------------------------------------------------------------
+# sparse 3D U-Net pieces (reg_network.py)
+# ------------------------------------------------------------------------------------------------
+
+SUBM, DOWN, UP = 0, 1, 2
+
+
+def table_from_coords(coords, D):
+    table = torch.full((D, D, D), -1, dtype=torch.int32, device=coords.device)
+    _lib.check(_lib.lib().surf_table_from_coords(_p(coords), coords.shape[0], int(D), _p(table), _stream()),
+               "surf_table_from_coords")
+    return table
+
+
+def down_sites(coords, D):
+    """Output sites of a k3/s2 sparse conv on the (D//2+1)^3 lattice: (coords2 (M,3) int32, table2, D2)."""
+    _chk(coords, torch.int32, "coords")
+    dev = coords.device
+    D2 = D // 2 + 1
+    lo = coords.amin(dim=0).cpu().numpy().astype(np.int32)
+    hi = coords.amax(dim=0).cpu().numpy().astype(np.int32)
+    marks = torch.zeros(D2 * D2 * D2, dtype=torch.uint8, device=dev)
+    lo_c, hi_c = (ctypes.c_int * 3)(*lo.tolist()), (ctypes.c_int * 3)(*hi.tolist())
+    _lib.check(_lib.lib().surf_mark_down_sites(_p(coords), coords.shape[0], int(D), lo_c, hi_c, _p(marks), _stream()),
+               "surf_mark_down_sites")
+    keys = compact(marks)
+    c2 = torch.empty(keys.shape[0], 3, dtype=torch.int32, device=dev)
+    t2 = torch.full((D2, D2, D2), -1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().surf_sites_from_keys(_p(keys), keys.shape[0], D2, _p(c2), _p(t2), _stream()), "surf_sites_from_keys")
+    return c2, t2, D2
+
+
+def spconv(x, in_table, out_coords, mode, weight, bn_scale=None, bn_shift=None, skip=None):
+    """One sparse conv + BN(eval) + ReLU (+ skip).  x (n_in, Cin); weight (27, Cin, Cout); returns (n_out, Cout)."""
+    _chk(x, torch.float32, "x")
+    _chk(in_table, torch.int32, "in_table")
+    _chk(out_coords, torch.int32, "out_coords")
+    _chk(weight, torch.float32, "weight")
+    cin, cout = int(weight.shape[1]), int(weight.shape[2])
+    assert x.shape[1] == cin and weight.shape[0] == 27
+    out = torch.empty(out_coords.shape[0], cout, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().surf_spconv(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords), out_coords.shape[0], int(mode),
+                                _p(weight), cout, _p(bn_scale), _p(bn_shift), _p(skip), _p(out), _stream())
+    _lib.check(rc, "surf_spconv")
+    return out
+
+
+def row_linear8(x, weight):
+    _chk(x, torch.float32, "x")
+    _chk(weight, torch.float32, "weight")
+    assert x.shape[1] == 8 and tuple(weight.shape) == (8, 8)
+    out = torch.empty_like(x)
+    _lib.check(_lib.lib().surf_row_linear8(_p(x), _p(weight), x.shape[0], _p(out), _stream()), "surf_row_linear8")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# FPN pieces (feature_network.py)
+# ------------------------------------------------------------------------------------------------
+
+
+def conv3x3(x, w_packed, cout, stride=1):
+    """x (N,H,W,Cin) NHWC, w_packed [3][3][Cin][Cout] -> (N,H/stride,W/stride,Cout)."""
+    _chk(x, torch.float32, "x")
+    _chk(w_packed, torch.float32, "weight")
+    N, H, W, cin = x.shape
+    out = torch.empty(N, H // stride, W // stride, cout, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().surf_conv3x3(_p(x), _p(w_packed), N, H, W, cin, cout, stride, _p(out), _stream())
+    _lib.check(rc, f"surf_conv3x3({cin}->{cout}, stride {stride})")
+    return out
+
+
+def deconv3x3_s2(x, w_packed, cout):
+    _chk(x, torch.float32, "x")
+    _chk(w_packed, torch.float32, "weight")
+    N, H, W, cin = x.shape
+    out = torch.empty(N, 2 * H, 2 * W, cout, dtype=torch.float32, device=x.device)
+    rc = _lib.lib().surf_deconv3x3_s2(_p(x), _p(w_packed), N, H, W, cin, cout, _p(out), _stream())
+    _lib.check(rc, f"surf_deconv3x3_s2({cin}->{cout})")
+    return out
+
+
+def inorm_relu_(x, skip=None):
+    """In place x = relu(instance_norm(x)) (+ skip); x (N,H,W,C) NHWC."""
+    _chk(x, torch.float32, "x")
+    N, H, W, C = x.shape
+    ws = torch.empty(_lib.lib().surf_inorm_workspace_doubles(N, H, W, C), dtype=torch.float64, device=x.device)
+    stats = torch.empty(N, C, 2, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().surf_inorm_relu(_p(x), N, H, W, C, _p(skip), _p(ws), _p(stats), _stream()), "surf_inorm_relu")
+    return x

@@ -1,0 +1,94 @@
+"""Host-side mirror of models/modules/reg_network.py (SparseCostRegNet / SparseCostRegNetList).
+
+Parameter names follow torchsparse 2.1's modules inside the reference's blocks so that the reference's
+checkpoints load: ``nets.{s}.conv{i}.net.0.kernel`` (27, C_in, C_out), ``nets.{s}.conv{i}.net.1.{weight,bias,
+running_mean,running_var,num_batches_tracked}``, ``nets.{s}.out_lin.weight``.  The arithmetic runs in
+``surf_spconv`` (csrc/spconv.hip).  torchsparse itself is absent here (third party): the convolution
+semantics are those documented in ``oracle.surf_oracle.sparse_unet`` -- PARITY UNPINNED.
+Only eval-mode BatchNorm (running statistics) is implemented; batch statistics belong to the training row.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class _SpConv3d(nn.Module):
+    def __init__(self, inc, outc, transposed=False):
+        super().__init__()
+        self.kernel = nn.Parameter(torch.zeros(27, inc, outc))
+        std = 1.0 / math.sqrt((outc if transposed else inc) * 27)   # torchsparse Conv3d.reset_parameters
+        with torch.no_grad():
+            self.kernel.uniform_(-std, std)
+
+
+class _Block(nn.Module):
+    """BasicSparseConvolutionBlock / BasicSparseDeconvolutionBlock: net = [Conv3d, BatchNorm, ReLU]."""
+
+    def __init__(self, inc, outc, stride=1, transposed=False):
+        super().__init__()
+        self.stride, self.transposed = stride, transposed
+        self.net = nn.Sequential(_SpConv3d(inc, outc, transposed), nn.BatchNorm1d(outc), nn.ReLU(True))
+
+    def bn_affine(self):
+        bn = self.net[1]
+        scale = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+        shift = bn.bias.detach() - bn.running_mean * scale
+        return scale.float().contiguous(), shift.float().contiguous()
+
+
+class SparseCostRegNet(nn.Module):
+    def __init__(self, d_in, d_out=8, d_base=8):
+        super().__init__()
+        if d_base != 8 or d_out != 8 or d_in not in (8, 16):
+            raise NotImplementedError("surf_spconv is instantiated for d_base = d_out = 8, d_in in {8, 16} (confs/*.conf)")
+        b = d_base
+        self.conv0 = _Block(d_in, b)
+        self.conv1 = _Block(b, 2 * b, stride=2)
+        self.conv2 = _Block(2 * b, 2 * b)
+        self.conv3 = _Block(2 * b, 4 * b, stride=2)
+        self.conv4 = _Block(4 * b, 4 * b)
+        self.conv5 = _Block(4 * b, 8 * b, stride=2)
+        self.conv6 = _Block(8 * b, 8 * b)
+        self.conv7 = _Block(8 * b, 4 * b, stride=2, transposed=True)
+        self.conv9 = _Block(4 * b, 2 * b, stride=2, transposed=True)
+        self.conv11 = _Block(2 * b, b, stride=2, transposed=True)
+        self.out_lin = nn.Linear(b, d_out, bias=False)
+
+    def _conv(self, blk, x, table, out_coords, mode, skip=None):
+        if self.training:
+            raise NotImplementedError("BatchNorm batch statistics (train mode) are not implemented: call .eval()")
+        scale, shift = blk.bn_affine()
+        return ops.spconv(x, table, out_coords, mode, blk.net[0].kernel.detach().float().contiguous(), scale, shift, skip)
+
+    def forward(self, feats, coords, D, table=None):
+        """feats (N, d_in) fp32, coords (N,3) int32 on the D lattice -> (out (N,8), mid (N,8))  (reg_network.py:69-88)"""
+        t0 = table if table is not None else ops.table_from_coords(coords, D)
+        c0 = self._conv(self.conv0, feats, t0, coords, ops.SUBM)
+        cd1, t1, D1 = ops.down_sites(coords, D)
+        x = self._conv(self.conv1, c0, t0, cd1, ops.DOWN)
+        c2 = self._conv(self.conv2, x, t1, cd1, ops.SUBM)
+        cd2, t2, D2 = ops.down_sites(cd1, D1)
+        x = self._conv(self.conv3, c2, t1, cd2, ops.DOWN)
+        c4 = self._conv(self.conv4, x, t2, cd2, ops.SUBM)
+        cd3, t3, D3 = ops.down_sites(cd2, D2)
+        x = self._conv(self.conv5, c4, t2, cd3, ops.DOWN)
+        x = self._conv(self.conv6, x, t3, cd3, ops.SUBM)
+        x = self._conv(self.conv7, x, t3, cd2, ops.UP, skip=c4)
+        x = self._conv(self.conv9, x, t2, cd1, ops.UP, skip=c2)
+        x = self._conv(self.conv11, x, t1, coords, ops.UP, skip=c0)
+        out = ops.row_linear8(x, self.out_lin.weight.detach().float().contiguous())
+        return out, x
+
+
+class SparseCostRegNetList(nn.Module):
+    def __init__(self, confs):
+        super().__init__()
+        d_in, d_out, d_base = confs.get_list("d_in"), confs.get_list("d_out"), confs.get_list("d_base")
+        self.num_stages = len(d_in)
+        self.nets = nn.ModuleList([SparseCostRegNet(d_in[i], d_out[i], d_base[i]) for i in range(self.num_stages)])
+
+    def forward(self, feats, coords, D, stage_idx, table=None):
+        return self.nets[stage_idx](feats, coords, D, table)

@@ -217,3 +217,44 @@ def test_compact_large_and_edge_cases():
         flags = (torch.rand(n, generator=g) < p).to(torch.uint8)
         idx = ops.compact(flags.to(d))
         assert torch.equal(idx.cpu().long(), flags.nonzero().view(-1))
+
+
+def test_sparse_unet_matches_oracle(golden_pipe):
+    """Row a5 (parity unpinned vs torchsparse): the HIP sparse U-Net against the oracle's restatement, on the
+    stage-1 and stage-2 voxel sets of the pipeline fixture with seeded weights and non-trivial BN statistics."""
+    from surf_amd import conf
+    from surf_amd.reg_network import SparseCostRegNetList
+    d = dev()
+    torch.manual_seed(3)
+    net = SparseCostRegNetList(conf.from_dict({"d_in": [8, 16, 16, 16], "d_out": [8] * 4, "d_base": [8] * 4})).eval()
+    g = torch.Generator().manual_seed(4)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            with torch.no_grad():
+                m.weight.copy_(1 + 0.2 * torch.randn(m.num_features, generator=g))
+                m.bias.copy_(0.1 * torch.randn(m.num_features, generator=g))
+    sd = {"reg_network." + k: v.detach().clone() for k, v in net.state_dict().items()}
+    assert "reg_network.nets.1.conv7.net.0.kernel" in sd and "reg_network.nets.0.conv0.net.1.running_mean" in sd
+    net = net.to(d)
+    for s, D in ((1, 16), (2, 32)):
+        coords = golden_pipe[f"s{s}_coords"].to(torch.int32)
+        feats = golden_pipe[f"s{s}_reg_in"].contiguous()
+        out_ref, mid_ref = O.sparse_unet(sd, feats, coords.long(), D, s)
+        out, mid = net(feats.to(d), coords.to(d).contiguous(), D, s)
+        rel_close(mid, mid_ref, 1e-3, 1e-4)
+        rel_close(out, out_ref, 1e-3, 1e-4)
+        assert float(mid_ref.abs().max()) > 0.05
+
+
+def test_fpn_matches_golden(scene, weights, golden_fpn):
+    from surf_amd import conf
+    from surf_amd.feature_network import FeatureNetwork
+    d = dev()
+    net = FeatureNetwork(conf.from_dict({"d_in": 3, "d_base": 8, "d_out": [4, 4, 4, 4]}))
+    sd = {k[len("feature_network."):]: v for k, v in weights.items() if k.startswith("feature_network.")}
+    net.load_state_dict(sd, strict=True)
+    outs = net.to(d)(scene["imgs"].to(d))
+    for i, o in enumerate(outs):
+        rel_close(o.permute(0, 3, 1, 2), golden_fpn[f"out{i}"], 1e-3, 1e-4)
