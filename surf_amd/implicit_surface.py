@@ -117,6 +117,18 @@ class SceneVolumes:
         self.cams = ops.Cameras(intrs, c2ws)
         self.device = dev
 
+    @classmethod
+    def from_device_layouts(cls, mvol, volumes, tables, feats_t4, imgs_t4, cams):
+        """Already in kernel layouts (the SuRF pipeline): no re-packing.  volumes: (N,7) or (N,8) rows, fine -> coarse."""
+        self = cls.__new__(cls)
+        self.mvol = mvol
+        self.sv = ops.SparseVolumes(list(volumes), list(tables))
+        self.feats_t4 = list(feats_t4)
+        self.imgs_t4 = imgs_t4
+        self.cams = cams
+        self.device = mvol.device
+        return self
+
 
 class ImplicitSurface(nn.Module):
     """implicit_surface.py:50-436 (inference semantics)."""

@@ -396,6 +396,8 @@ def down_sites(coords, D):
     _chk(coords, torch.int32, "coords")
     dev = coords.device
     D2 = D // 2 + 1
+    if coords.shape[0] == 0:
+        return (torch.empty(0, 3, dtype=torch.int32, device=dev), torch.full((D2, D2, D2), -1, dtype=torch.int32, device=dev), D2)
     lo = coords.amin(dim=0).cpu().numpy().astype(np.int32)
     hi = coords.amax(dim=0).cpu().numpy().astype(np.int32)
     marks = torch.zeros(D2 * D2 * D2, dtype=torch.uint8, device=dev)
@@ -405,6 +407,8 @@ def down_sites(coords, D):
     keys = compact(marks)
     c2 = torch.empty(keys.shape[0], 3, dtype=torch.int32, device=dev)
     t2 = torch.full((D2, D2, D2), -1, dtype=torch.int32, device=dev)
+    if keys.shape[0] == 0:          # degenerate tiny lattices: no even site inside the inputs' bounding box
+        return c2, t2, D2
     _lib.check(_lib.lib().surf_sites_from_keys(_p(keys), keys.shape[0], D2, _p(c2), _p(t2), _stream()), "surf_sites_from_keys")
     return c2, t2, D2
 
@@ -418,6 +422,10 @@ def spconv(x, in_table, out_coords, mode, weight, bn_scale=None, bn_shift=None, 
     cin, cout = int(weight.shape[1]), int(weight.shape[2])
     assert x.shape[1] == cin and weight.shape[0] == 27
     out = torch.empty(out_coords.shape[0], cout, dtype=torch.float32, device=x.device)
+    if out_coords.shape[0] == 0:
+        return out
+    if x.shape[0] == 0:             # no input rows: every lookup misses, the output is relu(bn_shift) (+ skip)
+        x = torch.zeros(1, cin, dtype=torch.float32, device=x.device)
     rc = _lib.lib().surf_spconv(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords), out_coords.shape[0], int(mode),
                                 _p(weight), cout, _p(bn_scale), _p(bn_shift), _p(skip), _p(out), _stream())
     _lib.check(rc, "surf_spconv")

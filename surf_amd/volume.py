@@ -1,0 +1,47 @@
+"""Host-side mirror of models/modules/volume.py Volume: holds ``agg_mlp`` (reference key names) and drives the
+volume-build kernels (csrc/volume.hip).  Voxel coordinates are int32 triples on a cubic lattice."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Volume(nn.Module):
+    def __init__(self, confs):
+        super().__init__()
+        dims = confs.get_list("base_volume_dim")
+        if len(set(dims)) != 1:
+            raise NotImplementedError("only cubic base_volume_dim is supported (the reference's sparse lookup "
+                                      "projector.py:336-351 is itself only correct for cubic grids)")
+        if confs.get("bounding", None) not in (None, [[-1, 1], [-1, 1], [-1, 1]]):
+            raise NotImplementedError("only the default bounding box [-1,1]^3 is supported (projector.py:229 hard-codes it)")
+        self.base_volume_dim = int(dims[0])
+        self.agg_mlp = nn.Sequential(nn.Linear(4, 8), nn.ELU(inplace=True), nn.Linear(8, 1))
+
+    def agg_host(self):
+        return np.concatenate([p.detach().to("cpu", torch.float32).numpy().reshape(-1) for p in
+                               (self.agg_mlp[0].weight, self.agg_mlp[0].bias, self.agg_mlp[2].weight, self.agg_mlp[2].bias)])
+
+    def stage_inputs(self, stage, D, feats_c2f, cams, parents=None, parent_feats=None, depths=None, depth_range=None):
+        """up_sample + depth_filtering + back_proj_multiscale + the row selections of surf.py:97-109.
+        Returns coords (N,3) int32 and the U-Net input rows (N, 8 or 16)."""
+        agg = self.agg_host()
+        if stage == 0:
+            c_all, cv, keep = ops.costvol(feats_c2f, 0, D, cams, agg)
+            idx1 = None
+        else:
+            flags = ops.upsample_filter(parents, D, depths, cams, depth_range)
+            idx1 = ops.compact(flags)
+            if idx1.shape[0] == 0:
+                raise RuntimeError(f"stage {stage}: depth filtering removed every voxel")
+            c_all, cv, keep = ops.costvol(feats_c2f, stage, D, cams, agg, parents=parents, idx=idx1)
+        idx2 = ops.compact(keep)
+        if idx2.shape[0] == 0:
+            raise RuntimeError(f"stage {stage}: no voxel is visible in more than one view")
+        coords = ops.gather_rows(c_all, idx2)
+        reg_in = torch.empty(idx2.shape[0], 8 if stage == 0 else 16, dtype=torch.float32, device=coords.device)
+        ops.gather_rows(cv, idx2, dst=reg_in, dst_off=0)
+        if stage > 0:
+            ops.gather_rows(parent_feats, ops.compose_index(idx1, idx2), shift=3, dst=reg_in, dst_off=8)
+        return coords, reg_in

@@ -258,3 +258,51 @@ def test_fpn_matches_golden(scene, weights, golden_fpn):
     outs = net.to(d)(scene["imgs"].to(d))
     for i, o in enumerate(outs):
         rel_close(o.permute(0, 3, 1, 2), golden_fpn[f"out{i}"], 1e-3, 1e-4)
+
+
+def test_surf_forward_end_to_end_vs_oracle(scene):
+    """Row a17: SuRF.forward('val') (FPN -> 4-stage volume build with the sparse U-Net -> render) against the oracle
+    pipeline with the same seeded weights.  Voxel keep/drop decisions are thresholded, so a handful of voxels may
+    flip between fp32 implementations: sets and images are compared with a small outlier allowance."""
+    from surf_amd import conf
+    from surf_amd.surf import SuRF
+    from tests.golden.make_golden import MODEL_CONF
+    d = dev()
+    cfg = {k: v for k, v in MODEL_CONF.items()}
+    cfg["reg_network"] = {"d_in": [8, 16, 16, 16], "d_base": [8] * 4, "d_out": [8] * 4}
+    torch.manual_seed(1)
+    model = SuRF(conf.from_dict(cfg)).eval()
+    with torch.no_grad():
+        model.implicit_surface.deviation_network.variance.fill_(0.45)
+        for net in model.reg_network.nets:       # make the matching logits peak near the r = 0.5 sphere-ish region
+            net.out_lin.weight.mul_(4.0)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(d)
+    H, W = scene["imgs"].shape[-2:]
+    ipts = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    ipts["bound_min"], ipts["bound_max"] = torch.tensor([-0.8] * 3), torch.tensor([0.8] * 3)
+    ipts["hw"] = (7, 8)                           # the fixture's strided ray lattice: 7 rows x 8 columns
+    ipts["mesh_resolution"] = 32
+    out = model("val", ipts, 1.0)
+    torch.cuda.synchronize()
+
+    feats = O.fpn_forward(sd, scene["imgs"])
+    ocfg = {"range_ratios": cfg["range_ratios"], "base_volume_dim": 8, "n_samples_depths": [128, 64, 32, 16],
+            "depth_res_levels": [4, 2, 2, 1]}
+    ref = O.build_volumes(sd, scene, feats, ocfg)
+    for s in range(4):
+        dref = ref["depths"][s][0]
+        got = out[f"depth_stage{s}"].cpu()
+        frac = float(((got - dref).abs() < 2e-3).float().mean())
+        assert frac > 0.97, (s, frac)
+    R = scene["rays_o"].shape[0]
+    near, far = scene["near"].repeat(R, 1), scene["far"].repeat(R, 1)
+    rr = O.render(sd, scene["rays_o"], scene["rays_d"], near, far, ref["matching_volume"], ref["volumes"][::-1],
+                  ref["tables"][::-1], ref["masks"][::-1], feats[::-1], scene["imgs"], scene["intrs"], scene["c2ws"],
+                  cfg["implicit_surface"]["render"]["n_samples"], [1.0, 0.4, 0.1, 0.01], 256, 1.0)
+    ok = ((out["color_fine"] - rr["color_fine"]).abs().max(dim=1).values < 2e-3).float().mean()
+    assert float(ok) > 0.95, float(ok)
+    okd = ((torch.from_numpy(out["render_depth"]).reshape(-1) - rr["render_depth"]).abs() < 2e-3).float().mean()
+    assert float(okd) > 0.95, float(okd)
+    assert out["img_fine"].shape == (7, 8, 3) and out["normal_img"].shape == (7, 8, 3)
+    assert out["vertices"].shape[1] == 3 and out["triangles"].shape[1] == 3
