@@ -55,8 +55,7 @@ def pmc_traffic(kernel):
         rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
     for r in rows:
         if r["kernel"] == kernel and r["FETCH_SIZE"] and r["WRITE_SIZE"]:
-            return {"bytes": (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0,
-                    "source": os.path.basename(files[-1])}
+            return (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
     return None
 
 

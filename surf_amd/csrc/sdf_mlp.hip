@@ -18,10 +18,26 @@
 //   * reverse sweep: G_in = W^T delta, same trick with the packed transpose; softplus'(t) of the five
 //     inner layers and the 14x3 feature Jacobian round-trip through a per-wave scratch slot.
 #include <math.h>
-
-#include <vector>
+#include <stdlib.h>
 
 #include "common.h"
+
+// build-time knobs
+#ifndef SURF_SDF_STAGGER
+#define SURF_SDF_STAGGER 0   // start delay of waves 4..7, x 8,128 cycles (measured: no effect, kept as a knob)
+#endif
+#ifndef SURF_SDF_PRIO
+#define SURF_SDF_PRIO 0
+#endif
+#ifndef SURF_SDF_NOWEIGHTS
+#define SURF_SDF_NOWEIGHTS 0
+#endif
+#ifndef SURF_SDF_NOSOFTPLUS
+#define SURF_SDF_NOSOFTPLUS 0
+#endif
+#ifndef SURF_SDF_NOSCRATCH
+#define SURF_SDF_NOSCRATCH 0  // 1 = timing-only diagnostic build (wrong gradients): no softplus' round trip
+#endif
 
 namespace {
 
@@ -47,7 +63,11 @@ constexpr int SCR_S = 5 * 16 * 64 * 4;
 constexpr int SCR_J = 11 * 64 * 4;  // 42 floats per lane padded to 44
 constexpr int SCR_SLOT = SCR_S + SCR_J;
 
-constexpr int MAX_BLOCKS = 256 * 2;  // 2 blocks of 4 waves per CU
+#ifndef SURF_SDF_WPB
+#define SURF_SDF_WPB 8
+#endif
+constexpr int WPB = SURF_SDF_WPB;          // wavefronts per workgroup; 8 = two per SIMD, partners are w and w + 4
+constexpr int MAX_BLOCKS = 256 * 8 / WPB;  // two wavefronts per SIMD on every CU
 
 struct SdfArgs {
   const float* pts;
@@ -82,27 +102,44 @@ __device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, f32x4 v) {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// acc[t] += W-tile(t) * b  over NQ groups of 4 k-steps; weights at byte offset `off`: [q][t][lane] x 16 B
-template <int NQ, int NT>
+__device__ __forceinline__ f32x4 wload(rsrc_t r, int voff, int soff) {
+#if SURF_SDF_NOWEIGHTS  // timing-only diagnostic: no weight traffic at all
+  const float v = __builtin_bit_cast(float, voff + soff);
+  return f32x4{v, v, v, v};
+#else
+  return bload(r, voff, soff);
+#endif
+}
+
+// acc[t] += W-tile(t) * b  over NQ groups of 4 k-steps; weights at byte offset `off`: [q][t][lane] x 16 B.
+// The A operands are prefetched PF groups ahead through a ring of PF+1 register buffers (statically indexed after
+// full unrolling); the L2 round trip of a group is longer than the 16 MFMAs (1,024 cycles) of one group.
+#ifndef SURF_SDF_PF
+#define SURF_SDF_PF 2
+#endif
+template <int NQ, int NT, int PF = SURF_SDF_PF>
 __device__ __forceinline__ void mma_seg(f32x16 (&acc)[NT], const float* b, rsrc_t wr, int lane16, int off) {
-  f32x4 a_cur[NT], a_nxt[NT];
+  f32x4 a[PF + 1][NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) a_cur[t] = bload(wr, lane16, off + t * 1024);
+  for (int p = 0; p < PF; ++p) {
+    if (p < NQ) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a[p][t] = wload(wr, lane16, off + (p * NT + t) * 1024);
+    }
+  }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    if (q + 1 < NQ) {
+    if (q + PF < NQ) {
 #pragma unroll
-      for (int t = 0; t < NT; ++t) a_nxt[t] = bload(wr, lane16, off + ((q + 1) * NT + t) * 1024);
+      for (int t = 0; t < NT; ++t) a[(q + PF) % (PF + 1)][t] = wload(wr, lane16, off + ((q + PF) * NT + t) * 1024);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int t = 0; t < NT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t][i], b[q * 4 + i], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q % (PF + 1)][t][i], b[q * 4 + i], acc[t], 0, 0, 0);
     }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
-    // keep the hand-made one-group-ahead prefetch in place
+    // keep the hand-made prefetch distance in place
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -118,13 +155,19 @@ __device__ __forceinline__ void load_bias(f32x16 (&acc)[4], rsrc_t wr, int l, in
   }
 }
 
-// nn.Softplus(beta=100, threshold=20) and its derivative from the pre-activation
+// nn.Softplus(beta=100, threshold=20) and its derivative from the pre-activation.
+// Raw v_exp_f32 / v_log_f32 / v_rcp_f32 (1 ulp): 1 + e >= 1 is never denormal, and an e that underflows to 0
+// gives h = 0, s = 0, the fp32 limits.  Absolute error of h <= 2e-8, of s <= 3e-7.
 __device__ __forceinline__ void softplus100(float t, float& hv, float& sv) {
-  float bt = t * 100.0f;
-  float e = __expf(fminf(bt, 20.0f));
-  float hp = __logf(1.0f + e) * 0.01f;
-  float sp = e * __frcp_rn(1.0f + e);
-  bool lin = bt > 20.0f;
+#if SURF_SDF_NOSOFTPLUS  // timing-only diagnostic
+  hv = fmaxf(t, 0.f); sv = t > 0.f ? 1.f : 0.f; return;
+#endif
+  const float bt = t * 100.0f;
+  const float e = __builtin_amdgcn_exp2f(fminf(bt, 20.0f) * 1.44269504088896341f);
+  const float d = 1.0f + e;
+  const float hp = __builtin_amdgcn_logf(d) * (0.69314718055994531f * 0.01f);
+  const float sp = e * __builtin_amdgcn_rcpf(d);
+  const bool lin = bt > 20.0f;
   hv = lin ? t : hp;
   sv = lin ? 1.0f : sp;
 }
@@ -144,7 +187,7 @@ __device__ __forceinline__ void activate(const f32x16 (&acc)[4], float (&h)[64],
         h[16 * t + 4 * g + i] = hv;
         s[i] = sv;
       }
-      if (STORE) bstore(sr, svoff, off + (t * 4 + g) * 1024, s);
+      if (STORE && !SURF_SDF_NOSCRATCH) bstore(sr, svoff, off + (t * 4 + g) * 1024, s);
     }
   }
 }
@@ -153,7 +196,10 @@ __device__ __forceinline__ void activate(const f32x16 (&acc)[4], float (&h)[64],
 __device__ __forceinline__ void make_delta(const f32x16 (&G)[4], float (&delta)[64], rsrc_t sr, int svoff, int off) {
   f32x4 s[16];
 #pragma unroll
-  for (int tg = 0; tg < 16; ++tg) s[tg] = bload(sr, svoff, off + tg * 1024);
+  for (int tg = 0; tg < 16; ++tg) {
+    if (SURF_SDF_NOSCRATCH) s[tg] = f32x4{0.5f, 0.5f, 0.5f, 0.5f};  // timing-only diagnostic build
+    else s[tg] = bload(sr, svoff, off + tg * 1024);
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -166,6 +212,8 @@ __device__ __forceinline__ void make_delta(const f32x16 (&G)[4], float (&delta)[
 
 // sparse trilinear gather of the two stages owned by this lane half (projector.py:217-374):
 // g = (p+1)/voxel_size, weights from the unclamped floor, indices clamped, row -1 -> zeros.
+// Branch-free and batched: all 16 table lookups are issued before the first is consumed, then the 16 row
+// fetches of a stage (empty corners read row 0 with weight 0), so a tile pays ~3 memory round trips, not 32.
 template <bool GRAD>
 __device__ __forceinline__ void gather_features(const SdfArgs& a, int h, float px, float py, float pz,
                                                 float (&phi)[16], float (&J)[14][3]) {
@@ -175,52 +223,59 @@ __device__ __forceinline__ void gather_features(const SdfArgs& a, int h, float p
 #pragma unroll
     for (int c = 0; c < 14; ++c) J[c][0] = J[c][1] = J[c][2] = 0.f;
   }
+  int rows[2][8];
+  float tx[2], ty[2], tz[2], inv_vs[2];
 #pragma unroll
   for (int sl = 0; sl < 2; ++sl) {
     const int st = 2 * h + sl;
     const int D = a.dims[st];
-    if (D <= 0) continue;  // fewer than 4 stages: missing ones contribute zeros
     const int32_t* __restrict__ table = a.tables[st];
-    const float* __restrict__ vol = a.vols[st];
     const float vs = 2.0f / ((float)D - 1.0f);
-    float gx = (px + 1.0f) / vs, gy = (py + 1.0f) / vs, gz = (pz + 1.0f) / vs;
-    float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
-    float tx = gx - fx, ty = gy - fy, tz = gz - fz;
-    int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    inv_vs[sl] = 1.0f / vs;
+    const float gx = (px + 1.0f) / vs, gy = (py + 1.0f) / vs, gz = (pz + 1.0f) / vs;
+    const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+    tx[sl] = gx - fx; ty[sl] = gy - fy; tz[sl] = gz - fz;
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
 #pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int xi = min(max(x0 + dx, 0), D - 1);
-      const float wx = dx ? tx : 1.0f - tx;
+    for (int c = 0; c < 8; ++c) {
+      const int xi = min(max(x0 + (c >> 2), 0), D - 1);
+      const int yi = min(max(y0 + ((c >> 1) & 1), 0), D - 1);
+      const int zi = min(max(z0 + (c & 1), 0), D - 1);
+      rows[sl][c] = D > 0 ? table[((int64_t)xi * D + yi) * D + zi] : -1;  // D == 0: stage absent
+    }
+  }
 #pragma unroll
-      for (int dy = 0; dy < 2; ++dy) {
-        const int yi = min(max(y0 + dy, 0), D - 1);
-        const float wy = dy ? ty : 1.0f - ty;
+  for (int sl = 0; sl < 2; ++sl) {
+    const float* __restrict__ vol = a.vols[2 * h + sl];
+    f32x4 f0[8], f1[8];
 #pragma unroll
-        for (int dz = 0; dz < 2; ++dz) {
-          const int zi = min(max(z0 + dz, 0), D - 1);
-          const float wz = dz ? tz : 1.0f - tz;
-          const int row = table[((int64_t)xi * D + yi) * D + zi];
-          if (row >= 0) {
-            const f32x4* fr = reinterpret_cast<const f32x4*>(vol + (int64_t)row * 8);
-            f32x4 f0 = fr[0], f1 = fr[1];
-            float f[7] = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2]};
-            const float w = wx * wy * wz;
-            float cx = 0.f, cy = 0.f, cz = 0.f;
-            if (GRAD) {
-              cx = ((dx ? 1.0f : -1.0f) * wy * wz) / vs;
-              cy = ((dy ? 1.0f : -1.0f) * wx * wz) / vs;
-              cz = ((dz ? 1.0f : -1.0f) * wx * wy) / vs;
-            }
+    for (int c = 0; c < 8; ++c) {
+      const f32x4* fr = reinterpret_cast<const f32x4*>(vol + (int64_t)max(rows[sl][c], 0) * 8);
+      f0[c] = fr[0];
+      f1[c] = fr[1];
+    }
 #pragma unroll
-            for (int c = 0; c < 7; ++c) {
-              phi[7 * sl + c] += f[c] * w;
-              if (GRAD) {
-                J[7 * sl + c][0] += f[c] * cx;
-                J[7 * sl + c][1] += f[c] * cy;
-                J[7 * sl + c][2] += f[c] * cz;
-              }
-            }
-          }
+    for (int c = 0; c < 8; ++c) {  // corner order x, y, z-fastest = the reference's summation order
+      const int dx = c >> 2, dy = (c >> 1) & 1, dz = c & 1;
+      const float ok = rows[sl][c] >= 0 ? 1.0f : 0.0f;
+      const float wx = dx ? tx[sl] : 1.0f - tx[sl];
+      const float wy = dy ? ty[sl] : 1.0f - ty[sl];
+      const float wz = dz ? tz[sl] : 1.0f - tz[sl];
+      const float w = wx * wy * wz * ok;
+      const float f[7] = {f0[c][0], f0[c][1], f0[c][2], f0[c][3], f1[c][0], f1[c][1], f1[c][2]};
+      float cx = 0.f, cy = 0.f, cz = 0.f;
+      if (GRAD) {  // d w / d p: the product of the other two weights over the voxel size
+        cx = ((dx ? 1.0f : -1.0f) * wy * wz) * (inv_vs[sl] * ok);
+        cy = ((dy ? 1.0f : -1.0f) * wx * wz) * (inv_vs[sl] * ok);
+        cz = ((dz ? 1.0f : -1.0f) * wx * wy) * (inv_vs[sl] * ok);
+      }
+#pragma unroll
+      for (int ch = 0; ch < 7; ++ch) {
+        phi[7 * sl + ch] += f[ch] * w;
+        if (GRAD) {
+          J[7 * sl + ch][0] += f[ch] * cx;
+          J[7 * sl + ch][1] += f[ch] * cy;
+          J[7 * sl + ch][2] += f[ch] * cz;
         }
       }
     }
@@ -235,16 +290,22 @@ __device__ __forceinline__ void posenc_half(int h, float x, float y, float z, fl
   jall[0] = jall[1] = jall[2] = 1.0f;
   const float p[3] = {x, y, z};
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float f = (float)(1 << k);
+  for (int c = 0; c < 3; ++c) {
+    // accurate sin/cos of the coordinate, then exact double-angle steps for 2x, 4x, 8x (error doubles per step:
+    // <= 1e-6 at 8x, against the 1e-4 SDF tolerance)
+    float s, co;
+    sincosf(p[c], &s, &co);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float s, co;
-      sincosf(p[c] * f, &s, &co);
+    for (int k = 0; k < 4; ++k) {
+      const float f = (float)(1 << k);
       all[3 + 6 * k + c] = s;
       all[3 + 6 * k + 3 + c] = co;
       jall[3 + 6 * k + c] = f * co;
       jall[3 + 6 * k + 3 + c] = -f * s;
+      const float s2 = 2.0f * s * co;
+      const float c2 = fmaf(-2.0f * s, s, 1.0f);
+      s = s2;
+      co = c2;
     }
   }
   all[27] = 0.f; jall[27] = 0.f;
@@ -260,12 +321,12 @@ template <bool GRAD>
 #ifndef SURF_SDF_OCC
 #define SURF_SDF_OCC 2  // wavefronts per SIMD the register budget is sized for
 #endif
-__global__ __launch_bounds__(256, SURF_SDF_OCC) void sdf_mlp_kernel(SdfArgs a) {
+__global__ __launch_bounds__(WPB * 64, SURF_SDF_OCC) void sdf_mlp_kernel(SdfArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int64_t wave_id = (int64_t)blockIdx.x * 4 + wave_in_block;
-  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  const int64_t wave_id = (int64_t)blockIdx.x * WPB + wave_in_block;
+  const int64_t n_waves = (int64_t)gridDim.x * WPB;
   const int64_t n_tiles = (a.n + TILE - 1) / TILE;
   // wave-uniform descriptors; every per-lane part lives in the 32-bit offsets
   const rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, PACKED_FLOATS * 4, 0x00020000);
@@ -274,6 +335,14 @@ __global__ __launch_bounds__(256, SURF_SDF_OCC) void sdf_mlp_kernel(SdfArgs a) {
   const int h64 = h * 64;                                        // bias rows: [h][16] floats
   const int svoff = (int)(wave_id * (SCR_SLOT * 4)) + lane * 16;  // this wave's scratch slot
 
+#if SURF_SDF_STAGGER
+  // The two wavefronts that share a SIMD (w and w + 4 of an 8-wave workgroup) run the same program and fall into
+  // lockstep: their MFMA phases collide and their VALU / memory phases leave the matrix pipe idle.  Delay the
+  // second half once.
+  if (WPB == 8 && wave_in_block >= 4) {
+    for (int k = 0; k < SURF_SDF_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
   for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
     const int64_t i = tile * TILE + j;
     const bool active = (i < a.n) && (!a.mask || a.mask[i] != 0);
@@ -443,10 +512,19 @@ __global__ __launch_bounds__(256, SURF_SDF_OCC) void sdf_mlp_kernel(SdfArgs a) {
   }
 }
 
+int max_blocks() {
+  static const int v = [] {
+    const char* e = getenv("SURF_SDF_MAX_BLOCKS");  // tuning / diagnostics only
+    int x = e ? atoi(e) : 0;
+    return x > 0 ? x : MAX_BLOCKS;
+  }();
+  return v;
+}
+
 int grid_blocks(int64_t n) {
   int64_t tiles = (n + TILE - 1) / TILE;
-  int64_t blocks = (tiles + 3) / 4;
-  return (int)(blocks < MAX_BLOCKS ? blocks : MAX_BLOCKS);
+  int64_t blocks = (tiles + WPB - 1) / WPB;
+  return (int)(blocks < max_blocks() ? blocks : max_blocks());
 }
 
 }  // namespace
@@ -455,7 +533,7 @@ extern "C" int64_t surf_sdf_packed_floats(void) { return PACKED_FLOATS; }
 
 extern "C" int64_t surf_sdf_scratch_bytes(int64_t n_points) {
   if (n_points <= 0) return 0;
-  return (int64_t)grid_blocks(n_points) * 4 * SCR_SLOT * sizeof(float);
+  return (int64_t)grid_blocks(n_points) * WPB * SCR_SLOT * sizeof(float);
 }
 
 // Host-side packer: effective (weight-normed) matrices -> MFMA A-operand order.
@@ -564,12 +642,12 @@ extern "C" int surf_sdf_mlp(const float* pts, const uint8_t* mask, int64_t n, co
   SdfArgs a;
   a.pts = pts; a.mask = mask; a.n = n; a.packed = packed; a.sdf = sdf; a.grad = grad; a.scratch = (float*)scratch;
   for (int s = 0; s < SURF_MAX_STAGES; ++s) {
-    a.vols[s] = s < n_vol ? h_vols[s] : nullptr;
+    a.vols[s] = s < n_vol ? h_vols[s] : h_vols[0];  // absent stage: dims = 0, every corner misses, row 0 is read with weight 0
     a.tables[s] = s < n_vol ? h_tables[s] : nullptr;
     a.dims[s] = s < n_vol ? h_dims[s] : 0;
     if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
   }
-  dim3 grid(grid_blocks(n)), block(256);
+  dim3 grid(grid_blocks(n)), block(WPB * 64);
   if (grad)
     hipLaunchKernelGGL(sdf_mlp_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
   else

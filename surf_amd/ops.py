@@ -66,8 +66,8 @@ class SparseVolumes:
     def __init__(self, feats, tables):
         self.vols, self.tables, self.dims = [], [], []
         for f, t in zip(feats, tables):
-            if f.shape[1] != 8:
-                f8 = torch.zeros(f.shape[0], 8, dtype=torch.float32, device=f.device)
+            if f.shape[1] != 8 or f.shape[0] == 0:   # the kernels read row 0 (with weight 0) for empty corners
+                f8 = torch.zeros(max(f.shape[0], 1), 8, dtype=torch.float32, device=f.device)
                 f8[:, :f.shape[1]] = f
                 f = f8
             if t.dtype != torch.int32:
