@@ -80,6 +80,53 @@ def cpu_baseline(model, cpu_scene, rays_o, rays_d, near, far, n_samples, budget_
     return done / dt, done, dt, max_err
 
 
+def volume_build_timing(args, dev):
+    """One full-size volume build through surf_amd.surf.SuRF (FPN -> cost volume -> sparsify -> sparse U-Net ->
+    densify -> matching field, rows a1-a7) on the synthetic 5-view scene, reported beside the render metric.
+    Weights are random-init, so the U-Net's matching logit is replaced by the analytic sphere logit
+    (-20 | |x| - 0.5 |) to obtain the surface-concentrated pyramid a trained network would produce."""
+    from surf_amd import conf, synthetic
+    from surf_amd.surf import SuRF
+    H, W, nv = args.height, args.width, args.views
+    cfg = {
+        "range_ratios": [1.0, 0.4, 0.1, 0.01],
+        "feature_network": {"d_in": 3, "d_base": 8, "d_out": [4, 4, 4, 4]},
+        "volume": {"base_volume_dim": [args.base_dim] * 3},
+        "reg_network": {"d_in": [8, 16, 16, 16], "d_base": [8] * 4, "d_out": [8] * 4},
+        "matching_field": {"n_samples_depths": [128, 64, 32, 16], "n_importance_depths": [128, 64, 32, 16],
+                           "up_sample_steps": [4, 4, 4, 4], "depth_res_levels": [4, 2, 2, 1]},
+        "implicit_surface": dict(model_conf([64, 32, 16, 16])),
+    }
+    torch.manual_seed(0)
+    model = SuRF(conf.from_dict(cfg)).eval().to(dev)
+    intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
+    ipts = {"imgs": synthetic.procedural_images(nv, H, W, 0, dev), "intrs": intrs.to(dev), "c2ws": c2ws.to(dev),
+            "near_fars": near_fars.to(dev), "near": near_fars[0, 0].reshape(1, 1).to(dev),
+            "far": near_fars[0, 1].reshape(1, 1).to(dev)}
+
+    def sphere_logit(coords, D):
+        world = coords.float() * (2.0 / (D - 1)) - 1.0
+        return -20.0 * (world.norm(dim=1) - 0.5).abs()
+
+    res = {}
+    for it in range(2):                      # first pass warms allocator and code objects
+        timings = {}
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        feats = model.feature_network(ipts["imgs"])
+        e1.record()
+        model.build_volumes(ipts, feats, logit_override=sphere_logit, timings=timings)
+        e2.record()
+        torch.cuda.synchronize()
+        res = {"fpn_ms": e0.elapsed_time(e1), "stages_ms": e1.elapsed_time(e2), "total_ms": e0.elapsed_time(e2), "stages": []}
+        for s in sorted(timings):
+            ev = timings[s]["events"]
+            res["stages"].append({"n_voxels": timings[s]["n_voxels"],
+                                  "filter_costvol_ms": ev[0].elapsed_time(ev[1]), "sparse_unet_ms": ev[1].elapsed_time(ev[2]),
+                                  "densify_ms": ev[2].elapsed_time(ev[3]), "matching_field_ms": ev[3].elapsed_time(ev[4])})
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,20 +138,18 @@ def main():
     ap.add_argument("--views", type=int, default=5)
     ap.add_argument("--n-samples", type=str, default="64,32,16,16")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--build", type=int, default=1, help="also time one full volume build (FPN + 4 stages), N=1 only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    from surf_amd import dist as D
+    D.init_from_env("nccl", dev)          # RCCL; only used for the barrier and the MAX of the elapsed time
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     from surf_amd import synthetic
     from surf_amd.implicit_surface import ImplicitSurface
@@ -133,30 +178,25 @@ def main():
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    D.barrier()
     torch.cuda.synchronize()
     model.kernel_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
+    D.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     events, model.kernel_events = model.kernel_events, None
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = D.max_over_ranks(elapsed, dev)
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region -----------------------
     per_kernel = {}
     for name, a, b in events:
         per_kernel.setdefault(name, []).append(a.elapsed_time(b))
     kernel_ms = {k: sum(v) / len(v) for k, v in per_kernel.items()}
-    active = int(model.last_active_samples.sum().item())
+    active = int(model.last_active_samples)
 
     if rank == 0:
         sdf_ms = kernel_ms["sdf_mlp"]
@@ -200,9 +240,11 @@ def main():
                                       "sample": f"{n_done} rays (every {R // n_sub}th pixel ray, 256-ray chunks) of the same "
                                                 f"scene in {dt:.1f} s, torch CPU fp32",
                                       "max_abs_rgb_diff_vs_gpu": err}
+        if world == 1 and args.build:
+            result["volume_build"] = volume_build_timing(args, dev)
         print(json.dumps(result))
-    if dist is not None:
-        dist.destroy_process_group()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

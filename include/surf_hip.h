@@ -37,7 +37,7 @@ extern "C" {
 #define SURF_E_LIMIT (-2)    /* exceeds SURF_MAX_* */
 
 /* ABI version, bumped whenever a signature below changes. */
-int surf_abi_version(void);
+int surf_abi_version(void);   /* currently 2 */
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
 int surf_pack_texel4(const float* src, int n, int C, int H, int W, float* dst, void* stream);
@@ -78,13 +78,15 @@ int64_t surf_sdf_scratch_bytes(int64_t n_points);
  * Replaces lookup_sparse_volume/grid_sample_3d_sparse (projector.py:217-390),
  * SDFNetworkSparse.forward/sdf (sdf_network.py:95-124) and the first-order part of
  * SDFNetworkSparse.gradient (sdf_network.py:129-141).
- *   pts (n,3); mask (n) uint8 or NULL (NULL = all points active)
+ *   pts (.,3); mask (.) uint8 or NULL (NULL = all points active)
+ *   idx: NULL -> points 0..n-1 are evaluated; else the n point indices to evaluate (e.g. surf_compact of the mask):
+ *        inputs are gathered and outputs scattered through idx, so wavefront tiles hold active points only
  *   h_vols[n_vol]: (N_s,8) rows; h_tables[n_vol]: (D_s^3) int32; fine -> coarse
  *   packed: device copy of surf_sdf_pack_weights output
  *   sdf (n); grad (n,3) or NULL (forward only); scratch: >= surf_sdf_scratch_bytes(n) or NULL if grad NULL
  * Points with mask 0 are not written.
  */
-int surf_sdf_mlp(const float* pts, const uint8_t* mask, int64_t n, const float* const* h_vols,
+int surf_sdf_mlp(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_vols,
                  const int32_t* const* h_tables, const int* h_dims, int n_vol, const float* packed,
                  float* sdf, float* grad, void* scratch, void* stream);
 
@@ -105,7 +107,7 @@ int surf_blend_packed_floats(void);  /* floats of the MFMA-ordered buffer the ke
  * base_fc.0.*, base_fc.2.*, vis_fc.0.*, vis_fc.2.*, vis_fc2.0.*, vis_fc2.2.*, rgb_fc.0.*, rgb_fc.2.*,
  * rgb_fc.4.*} (weight then bias, row-major), i.e. blending_network.py:34-64 in declaration order. */
 int surf_blend_pack_weights(const float* h_raw, float* h_packed);
-int surf_blend(const float* pts, const uint8_t* mask, int64_t n, const float* const* h_feats, const int* h_hw,
+int surf_blend(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_feats, const int* h_hw,
                int n_level, const float* imgs, int nv, const float* h_intrs, const float* h_w2c,
                const float* h_c2w, const float* blend_w, float* color, uint8_t* n_valid, void* stream);
 

@@ -27,11 +27,11 @@ SIGNATURES = {
     "surf_sdf_packed_floats": (c_i64, []),
     "surf_sdf_pack_weights": (c_int, [c_ptr, c_ptr, c_ptr]),
     "surf_sdf_scratch_bytes": (c_i64, [c_i64]),
-    "surf_sdf_mlp": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_sdf_mlp": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_blend_raw_floats": (c_int, []),
     "surf_blend_packed_floats": (c_int, []),
     "surf_blend_pack_weights": (c_int, [c_ptr, c_ptr]),
-    "surf_blend": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+    "surf_blend": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                            c_ptr, c_ptr]),
     "surf_composite": (c_int, [c_ptr] * 9 + [c_int, c_int, c_float, c_float] + [c_ptr] * 12),
     "surf_upsample_filter": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_float, c_ptr, c_ptr]),

@@ -52,6 +52,7 @@ constexpr int PACKED_FLOATS = SCAL_OFF + 4;
 struct BlendArgs {
   const float* pts;
   const uint8_t* mask;
+  const int32_t* idx;  // optional list of point indices (n entries)
   int64_t n;
   const float* feats[4];
   int hw[8];
@@ -69,8 +70,37 @@ __device__ __forceinline__ f32x4 bload(rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-__device__ __forceinline__ float elu(float x) { return x > 0.f ? x : expm1f(x); }
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+// ELU / sigmoid through the raw v_exp_f32 (absolute error <= 1e-7, far inside the 1e-3 colour tolerance)
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float elu(float x) { return x > 0.f ? x : fexp(x) - 1.0f; }
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + fexp(-x)); }
+
+// Bilinear fetch of a texel4 map with zero padding, branch-free: out-of-range taps read a clamped texel with
+// weight 0, so all four 16-byte loads of a fetch (and of every fetch of a view) can be in flight together.
+struct Tap4 {
+  f32x4 v[4];
+  float w[4];
+};
+__device__ __forceinline__ void tap_issue(Tap4& t, const float* __restrict__ map, int H, int W, float x, float y) {
+  const float fx = floorf(x), fy = floorf(y);
+  const float tx = x - fx, ty = y - fy;
+  const int x0 = (int)fx, y0 = (int)fy;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {  // order (y0,x0), (y0,x1), (y1,x0), (y1,x1) = grid_sample's nw, ne, sw, se
+    const int dx = k & 1, dy = k >> 1;
+    const int xi = x0 + dx, yi = y0 + dy;
+    const bool ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H);
+    const int xc = min(max(xi, 0), W - 1), yc = min(max(yi, 0), H - 1);
+    t.v[k] = *reinterpret_cast<const f32x4*>(map + ((int64_t)yc * W + xc) * 4);
+    t.w[k] = ok ? (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) : 0.0f;
+  }
+}
+__device__ __forceinline__ f32x4 tap_finish(const Tap4& t) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc += t.v[k] * t.w[k];
+  return acc;
+}
 
 template <int NQ, int NT>
 __device__ __forceinline__ void mma_seg(f32x16 (&acc)[NT], const float* b, rsrc_t wr, int lane16, int off) {
@@ -126,11 +156,12 @@ __global__ __launch_bounds__(256, 2) void blend_kernel(BlendArgs a) {
   (void)lvA; (void)lvB;
 
   for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
-    const int64_t i = tile * TILE + j;
-    const bool active = (i < a.n) && (!a.mask || a.mask[i] != 0);
+    const int64_t slot = tile * TILE + j;
+    const int64_t sc = slot < a.n ? slot : a.n - 1;
+    const int64_t i = a.idx ? (int64_t)a.idx[sc] : sc;
+    const bool active = (slot < a.n) && (!a.mask || a.mask[i] != 0);
     if (__ballot(active) == 0ull) continue;
-    const int64_t ic = i < a.n ? i : a.n - 1;
-    const float px = a.pts[ic * 3 + 0], py = a.pts[ic * 3 + 1], pz = a.pts[ic * 3 + 2];
+    const float px = a.pts[i * 3 + 0], py = a.pts[i * 3 + 1], pz = a.pts[i * 3 + 2];
 
     float floc[NS][12];  // this half's channels of rgb_feat + direction feature (11 or 8 used)
     float rgb[NS][3];    // raw source colours (meaningful in half 0)
@@ -166,22 +197,27 @@ __global__ __launch_bounds__(256, 2) void blend_kernel(BlendArgs a) {
       float qz = K[6] * X + K[7] * Y + K[8] * Z;
       float u0 = qx / qz, v0 = qy / qz;
       bool ok = qz > 0.f;
-      f32x4 tA, tB, tC = {0.f, 0.f, 0.f, 0.f};
+      // the three fetches of this half (level A, level B, and the image for half 0) are issued together
+      Tap4 qA, qB, qC;
       {
         float u = u0 * scA, vv = v0 * scA;
         ok = ok && (u >= 0.f) && (u < (float)WA) && (vv >= 0.f) && (vv < (float)HA);
         float nx = u / ((float)(WA - 1) / 2.0f) - 1.0f, ny = vv / ((float)(HA - 1) / 2.0f) - 1.0f;
         float gx = ((nx + 1.0f) * (float)WA - 1.0f) / 2.0f, gy = ((ny + 1.0f) * (float)HA - 1.0f) / 2.0f;
-        tA = bilinear_texel4(mapA + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
-        if (h == 0) tC = bilinear_texel4(a.imgs + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
+        tap_issue(qA, mapA + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
+        // half 1 re-reads its level-A taps instead of the image (same addresses: L1 hits), result unused
+        tap_issue(qC, (h == 0 ? a.imgs : mapA) + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
       }
       {
         float u = u0 * scB, vv = v0 * scB;
         ok = ok && (u >= 0.f) && (u < (float)WB) && (vv >= 0.f) && (vv < (float)HB);
         float nx = u / ((float)(WB - 1) / 2.0f) - 1.0f, ny = vv / ((float)(HB - 1) / 2.0f) - 1.0f;
         float gx = ((nx + 1.0f) * (float)WB - 1.0f) / 2.0f, gy = ((ny + 1.0f) * (float)HB - 1.0f) / 2.0f;
-        tB = bilinear_texel4(mapB + (int64_t)cam * HB * WB * 4, HB, WB, gx, gy);
+        tap_issue(qB, mapB + (int64_t)cam * HB * WB * 4, HB, WB, gx, gy);
       }
+      const f32x4 tA = tap_finish(qA), tB = tap_finish(qB);
+      f32x4 tC = tap_finish(qC);
+      if (h != 0) tC = f32x4{0.f, 0.f, 0.f, 0.f};
       ok = ok && (__shfl_xor((int)ok, 32) != 0);  // AND over all four levels
       mk[v] = ok ? 1.f : 0.f;
       nvalid += ok ? 1 : 0;
@@ -214,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void blend_kernel(BlendArgs a) {
       }
       floc[v][11] = 0.f;
       ex[v] = expf(s_abs * (rd[v][3] - 1.0f));
+      __builtin_amdgcn_sched_barrier(0);  // one view's 12 texel loads in flight at a time (register budget)
     }
     if (a.n_valid && active && h == 0) a.n_valid[i] = (uint8_t)nvalid;
 
@@ -423,7 +460,7 @@ extern "C" int surf_blend_pack_weights(const float* raw, float* out) {
   return 0;
 }
 
-extern "C" int surf_blend(const float* pts, const uint8_t* mask, int64_t n, const float* const* h_feats,
+extern "C" int surf_blend(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_feats,
                           const int* h_hw, int n_level, const float* imgs, int nv, const float* h_intrs,
                           const float* h_w2c, const float* h_c2w, const float* blend_w, float* color,
                           uint8_t* n_valid, void* stream) {
@@ -431,7 +468,7 @@ extern "C" int surf_blend(const float* pts, const uint8_t* mask, int64_t n, cons
   if (n <= 0 || nv < 2) return SURF_E_ARG;
   if (n_level != 4 || nv > SURF_MAX_VIEWS) return SURF_E_LIMIT;  // d_feature = 16 = 4 levels x 4 channels
   BlendArgs a;
-  a.pts = pts; a.mask = mask; a.n = n; a.imgs = imgs; a.w = blend_w; a.color = color; a.n_valid = n_valid;
+  a.pts = pts; a.mask = mask; a.idx = idx; a.n = n; a.imgs = imgs; a.w = blend_w; a.color = color; a.n_valid = n_valid;
   for (int l = 0; l < 4; ++l) {
     if (!h_feats[l]) return SURF_E_ARG;
     a.feats[l] = h_feats[l];

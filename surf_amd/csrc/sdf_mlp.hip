@@ -72,6 +72,7 @@ constexpr int MAX_BLOCKS = 256 * 8 / WPB;  // two wavefronts per SIMD on every C
 struct SdfArgs {
   const float* pts;
   const uint8_t* mask;
+  const int32_t* idx;  // optional list of point indices to evaluate (n entries); outputs are scattered back
   int64_t n;
   const float* vols[SURF_MAX_STAGES];
   const int32_t* tables[SURF_MAX_STAGES];
@@ -344,11 +345,12 @@ __global__ __launch_bounds__(WPB * 64, SURF_SDF_OCC) void sdf_mlp_kernel(SdfArgs
   }
 #endif
   for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
-    const int64_t i = tile * TILE + j;
-    const bool active = (i < a.n) && (!a.mask || a.mask[i] != 0);
+    const int64_t slot = tile * TILE + j;
+    const int64_t sc = slot < a.n ? slot : a.n - 1;
+    const int64_t i = a.idx ? (int64_t)a.idx[sc] : sc;  // point index (inputs gathered / outputs scattered)
+    const bool active = (slot < a.n) && (!a.mask || a.mask[i] != 0);
     if (__ballot(active) == 0ull) continue;
-    const int64_t ic = i < a.n ? i : a.n - 1;
-    const float px = a.pts[ic * 3 + 0], py = a.pts[ic * 3 + 1], pz = a.pts[ic * 3 + 2];
+    const float px = a.pts[i * 3 + 0], py = a.pts[i * 3 + 1], pz = a.pts[i * 3 + 2];
 
     float phi[16];
     float e[16];
@@ -632,7 +634,7 @@ extern "C" int surf_sdf_pack_weights(const float* const* h_W, const float* const
   return 0;
 }
 
-extern "C" int surf_sdf_mlp(const float* pts, const uint8_t* mask, int64_t n, const float* const* h_vols,
+extern "C" int surf_sdf_mlp(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_vols,
                             const int32_t* const* h_tables, const int* h_dims, int n_vol, const float* packed,
                             float* sdf, float* grad, void* scratch, void* stream) {
   if (!pts || !h_vols || !h_tables || !h_dims || !packed || !sdf) return SURF_E_ARG;
@@ -640,7 +642,7 @@ extern "C" int surf_sdf_mlp(const float* pts, const uint8_t* mask, int64_t n, co
   if (n_vol > SURF_MAX_STAGES) return SURF_E_LIMIT;
   if (grad && !scratch) return SURF_E_ARG;
   SdfArgs a;
-  a.pts = pts; a.mask = mask; a.n = n; a.packed = packed; a.sdf = sdf; a.grad = grad; a.scratch = (float*)scratch;
+  a.pts = pts; a.mask = mask; a.idx = idx; a.n = n; a.packed = packed; a.sdf = sdf; a.grad = grad; a.scratch = (float*)scratch;
   for (int s = 0; s < SURF_MAX_STAGES; ++s) {
     a.vols[s] = s < n_vol ? h_vols[s] : h_vols[0];  // absent stage: dims = 0, every corner misses, row 0 is read with weight 0
     a.tables[s] = s < n_vol ? h_tables[s] : nullptr;

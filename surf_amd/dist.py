@@ -1,0 +1,51 @@
+"""Multi-GPU plumbing of the hot path.  Inference shards by scene: scenes are independent, every rank
+renders its own share, there is NO data-path collective.  torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in
+the CPU tests) is only used for the barrier / max-over-ranks timing of bench.py and to gather small per-scene
+result records."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend="nccl", device=None):
+    """env:// rendezvous as launched by torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, **kw)
+    return rank, local_rank, world
+
+
+def shard_scenes(n_scenes, rank, world):
+    """Round-robin scene -> rank map (the reference's DistributedSampler without shuffling, datasets/__init__.py:37-38;
+    no padding: a rank may get one scene fewer)."""
+    return list(range(rank, n_scenes, world))
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value, device="cpu"):
+    """MAX all-reduce of a python float (the timing contract of bench.py)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_records(record, dst=0):
+    """Collect one small picklable record per rank on `dst` (per-scene metrics); None elsewhere."""
+    if not dist.is_initialized():
+        return [record]
+    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(record, out, dst=dst)
+    return out

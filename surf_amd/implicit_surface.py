@@ -182,13 +182,14 @@ class ImplicitSurface(nn.Module):
 
         st = timed("ray_setup", lambda: ops.ray_setup(rays_o, rays_d, near.float(), far.float(), scene.mvol, scene.sv,
                                                       self.n_samples, self.sample_ranges, self.n_depth))
-        sdf, grad = timed("sdf_mlp", lambda: ops.sdf_mlp(st["pts"], scene.sv, sdf_w, mask=st["vmask"]))
+        act = timed("compact", lambda: ops.compact(st["vmask"]))      # masked-in samples, ray-major order
+        sdf, grad = timed("sdf_mlp", lambda: ops.sdf_mlp(st["pts"], scene.sv, sdf_w, mask=st["vmask"], active_idx=act))
         col, nvalid = timed("blend", lambda: ops.blend(st["pts"], scene.feats_t4, scene.imgs_t4, scene.cams, blend_w,
-                                                       mask=st["vmask"]))
+                                                       mask=st["vmask"], active_idx=act))
         out = timed("composite", lambda: ops.composite(sdf, grad, col, nvalid, st, rays_d, self.deviation_network.inv_s(),
                                                        float(cos_anneal_ratio), scene.cams, per_sample=per_sample))
         if ev is not None:
-            self.last_active_samples = st["vmask"]
+            self.last_active_samples = int(act.shape[0])
         R, S = st["mid_z"].shape
         eik = out.pop("eik").sum(dim=0)
         out["gradient_error"] = eik[0] / (eik[1] + 1e-5)

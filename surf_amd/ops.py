@@ -188,7 +188,7 @@ def _sdf_scratch(n, device):
     return buf
 
 
-def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True):
+def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True, compact_active=True, active_idx=None):
     """sdf_network.py:95-141 at n points.  Returns (sdf (n,), grad (n,3) or None); masked-out rows are
     left at sdf=100 / grad=0 (what render_core substitutes, implicit_surface.py:93,99)."""
     _chk(pts, torch.float32, "pts")
@@ -202,8 +202,18 @@ def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True):
     else:
         sdf = torch.empty(n, dtype=torch.float32, device=dev)
         grad = torch.empty(n, 3, dtype=torch.float32, device=dev) if want_grad else None
-    scratch = _sdf_scratch(n, dev) if want_grad else None
-    rc = _lib.lib().surf_sdf_mlp(_p(pts), _p(mask), n, volumes._vp, volumes._tp, volumes._dp, volumes.n, _p(packed),
+    idx, n_eval = None, n
+    if active_idx is not None:
+        idx, n_eval = active_idx, int(active_idx.shape[0])
+        if n_eval == 0:
+            return sdf, grad
+    elif mask is not None and compact_active:
+        idx = compact(mask)                 # wavefront tiles of active points only (one host sync for the count)
+        n_eval = int(idx.shape[0])
+        if n_eval == 0:
+            return sdf, grad
+    scratch = _sdf_scratch(n_eval, dev) if want_grad else None
+    rc = _lib.lib().surf_sdf_mlp(_p(pts), _p(None if idx is not None else mask), _p(idx), n_eval, volumes._vp, volumes._tp, volumes._dp, volumes.n, _p(packed),
                                  _p(sdf), _p(grad), _p(scratch), _stream())
     _lib.check(rc, "surf_sdf_mlp")
     return sdf, grad
@@ -221,7 +231,7 @@ class Cameras:
         self.rot_ref = np.ascontiguousarray(torch.inverse(c2w_cpu[0, :3, :3]).numpy())
 
 
-def blend(pts, feats_t4, imgs_t4, cams, packed, mask=None):
+def blend(pts, feats_t4, imgs_t4, cams, packed, mask=None, compact_active=True, active_idx=None):
     """projector.py:501-556 + blending_network.py:69-118.  feats_t4: list fine -> coarse of (nv,H,W,4).
     Returns (color (n,3), n_valid (n) uint8); masked-out rows are zero."""
     _chk(pts, torch.float32, "pts")
@@ -234,7 +244,15 @@ def blend(pts, feats_t4, imgs_t4, cams, packed, mask=None):
     nvalid = torch.zeros(n, dtype=torch.uint8, device=dev)
     hw = (ctypes.c_int * (2 * len(feats_t4)))(*[int(v) for f in feats_t4 for v in f.shape[1:3]])
     fp = _ptr_array(feats_t4)
-    rc = _lib.lib().surf_blend(_p(pts), _p(mask), n, fp, hw, len(feats_t4), _p(imgs_t4), cams.nv, _np_ptr(cams.intrs),
+    idx, n_eval = None, n
+    if active_idx is not None:
+        idx, n_eval = active_idx, int(active_idx.shape[0])
+    elif mask is not None and compact_active:
+        idx = compact(mask)
+        n_eval = int(idx.shape[0])
+    if n_eval == 0:
+        return color, nvalid
+    rc = _lib.lib().surf_blend(_p(pts), _p(None if idx is not None else mask), _p(idx), n_eval, fp, hw, len(feats_t4), _p(imgs_t4), cams.nv, _np_ptr(cams.intrs),
                                _np_ptr(cams.w2c), _np_ptr(cams.c2w), _p(packed), _p(color), _p(nvalid), _stream())
     _lib.check(rc, "surf_blend")
     return color, nvalid

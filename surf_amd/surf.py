@@ -43,9 +43,12 @@ class SuRF(nn.Module):
         return groups
 
     @torch.no_grad()
-    def build_volumes(self, ipts, features_c2f, cams=None):
+    def build_volumes(self, ipts, features_c2f, cams=None, logit_override=None, timings=None):
         """surf.py:80-131 (perturb False).  features_c2f: texel4 maps coarse -> fine.
-        Returns (outputs, volumes, tables, matching_volume) with per-stage lists coarse -> fine."""
+        Returns (outputs, volumes, tables, matching_volume) with per-stage lists coarse -> fine.
+        `logit_override(coords, D) -> (N,)` (bench / tests only) replaces the U-Net's matching logit so that an
+        untrained network still produces a realistic, surface-concentrated pyramid; `timings` (dict) receives
+        per-stage HIP-event pairs."""
         intrs, c2ws = ipts["intrs"], ipts["c2ws"]
         if cams is None:
             cams = ops._cams_ext(ops.Cameras(intrs, c2ws), intrs, c2ws)
@@ -58,12 +61,22 @@ class SuRF(nn.Module):
         for s in range(self.num_stage):
             if s > 0:
                 D *= 2
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timings is not None else None
+            if ev: ev[0].record()
             coords, reg_in = self.volume.stage_inputs(s, D, features_c2f, cams, coords, mid, depths,
                                                       base_range * self.range_ratios[s])
+            if ev: ev[1].record()
             table = ops.table_from_coords(coords, D)
             out, mid = self.reg_network(reg_in, coords, D, s, table=table)
+            if logit_override is not None:
+                out[:, 0] = logit_override(coords, D)
+            if ev: ev[2].record()
             mvol, table = ops.densify(coords, out, D, mvol)
+            if ev: ev[3].record()
             depths = self.matching_field(cams, ipts["near_fars"], (H, W), mvol, s, self.range_ratios, depths)
+            if ev:
+                ev[4].record()
+                timings[s] = {"n_voxels": int(coords.shape[0]), "events": ev}
             volumes.append(out)          # rows [logit | 7 feature channels]; the SDF kernel reads channels 1..7
             tables.append(table)
             outputs[f"depth_stage{s}"] = depths[0]
