@@ -28,6 +28,7 @@ FLOP_PER_SAMPLE_SDF = 2 * (99240 + 99240)          # forward + revers
 FLOP_PER_SAMPLE_BLEND_PER_VIEW = 2 * 9928
 FP32_MFMA_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md, chip-level parameters
 CPU_THREADS = min(32, os.cpu_count() or 1)
+SDF_KERNEL = "sdf_mlp_kernel2<true>"               # dominant kernel (csrc/sdf_mlp.hip)
 
 
 def model_conf(n_samples):
@@ -220,9 +221,9 @@ def main():
                        "rays_per_step": R, "samples_per_ray": S, "active_samples": active},
             "per_gpu_rays_per_s": R * args.steps / elapsed,
             "kernel_ms": kernel_ms,
-            "roofline": {"kernel": "sdf_mlp_kernel<true>", "bound": "mfma", "achieved": achieved,
+            "roofline": {"kernel": SDF_KERNEL, "bound": "mfma", "achieved": achieved,
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic("sdf_mlp_kernel<true>"), "flop_per_sample": FLOP_PER_SAMPLE_SDF, "samples_per_launch": active,
+                         "traffic": pmc_traffic(SDF_KERNEL), "flop_per_sample": FLOP_PER_SAMPLE_SDF, "samples_per_launch": active,
                          "avg_launch_ms": sdf_ms},
         }
         if world == 1 and args.cpu_seconds > 0:

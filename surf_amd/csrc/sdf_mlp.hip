@@ -29,6 +29,9 @@
 #ifndef SURF_SDF_PRIO
 #define SURF_SDF_PRIO 0
 #endif
+#ifndef SURF_SDF_V2
+#define SURF_SDF_V2 1   // 1 = tile-major schedule (sdf_mlp_kernel2), 0 = first schedule (sdf_mlp_kernel)
+#endif
 #ifndef SURF_SDF_NOWEIGHTS
 #define SURF_SDF_NOWEIGHTS 0
 #endif
@@ -514,6 +517,330 @@ __global__ __launch_bounds__(WPB * 64, SURF_SDF_OCC) void sdf_mlp_kernel(SdfArgs
   }
 }
 
+// =================================================================================================================
+// v2 schedule: output-tile-major layers.  Each 32-row output tile runs its whole k-loop alone (a dependent MFMA
+// chain issues back to back at the 64-cycle rate), so the softplus VALU work of tile t is issued between the MFMAs
+// of tile t+1 and hides under them instead of idling the matrix pipe; all-zero k-groups (features 104..127 of the
+// 101-wide layer) are skipped; the weight stream is one compile-time sequence of 16-byte groups with a register ring
+// that prefetches across tile, layer and forward/backward boundaries.
+// =================================================================================================================
+constexpr int fwd_ngt(int l) { return l == 0 ? 4 : (l == 3 ? 21 : 20); }  // k-groups per output tile
+constexpr int fwd_gbase(int l, int t) {
+  int g = 0;
+  for (int i = 0; i < l; ++i) g += 4 * fwd_ngt(i);
+  return g + t * fwd_ngt(l);
+}
+constexpr int FWD_GROUPS = fwd_gbase(6, 0);
+constexpr int bwd_ngt(int l) { return l == 2 ? 13 : 16; }
+constexpr int bwd_gbase(int l, int t) {  // layers run 5,4,3,2,1,0
+  int g = 0;
+  for (int i = 5; i > l; --i) g += BWD_NT[i] * bwd_ngt(i);
+  return g + t * bwd_ngt(l);
+}
+constexpr int BWD_GROUPS = bwd_gbase(0, 0) + bwd_ngt(0);
+constexpr int ALL_GROUPS = FWD_GROUPS + BWD_GROUPS;
+
+struct GroupTable { int off[ALL_GROUPS + 8]; };
+constexpr GroupTable make_groups() {
+  GroupTable g{};
+  int n = 0;
+  for (int l = 0; l < 6; ++l)
+    for (int t = 0; t < 4; ++t) {
+      const int base = fwd_off(l) * 4 + t * 1024;
+      if (l == 0) {
+        for (int q = 0; q < 4; ++q) g.off[n++] = base + q * 4096;
+      } else {
+        const int nh = l == 3 ? 13 : 16;
+        for (int q = 0; q < nh; ++q) g.off[n++] = base + q * 4096;
+        for (int q = 16; q < FWD_NQ[l]; ++q) g.off[n++] = base + q * 4096;
+      }
+    }
+  for (int l = 5; l >= 0; --l)
+    for (int t = 0; t < BWD_NT[l]; ++t)
+      for (int q = 0; q < bwd_ngt(l); ++q) g.off[n++] = bwd_off(l) * 4 + (q * BWD_NT[l] + t) * 1024;
+  for (int k = 0; k < 8; ++k) g.off[n + k] = g.off[n - 1];
+  return g;
+}
+constexpr GroupTable GROUPS = make_groups();
+
+#ifndef SURF_SDF_RPF
+#define SURF_SDF_RPF 2
+#endif
+constexpr int RPF = SURF_SDF_RPF;  // weight groups in flight ahead of the one being multiplied
+struct WRing { f32x4 a[RPF + 1]; };
+
+// NQ consecutive groups of the weight stream starting at global group GBASE: acc += W-groups x b[0 .. 4 NQ);
+// fn(q) runs after the four MFMAs of group q (VALU work that hides under them).
+template <int GBASE, int NQ, int NTOTAL, class F>
+__device__ __forceinline__ void stream_mma(WRing& ring, f32x16& acc, const float* b, rsrc_t wr, int lane16, F fn) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    if (GBASE + q + RPF < NTOTAL) ring.a[(GBASE + q + RPF) % (RPF + 1)] = wload(wr, lane16, GROUPS.off[GBASE + q + RPF]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ring.a[(GBASE + q) % (RPF + 1)][i], b[q * 4 + i], acc, 0, 0, 0);
+    fn(q);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ f32x16 bias_tile(rsrc_t wr, int l, int t, int h64) {
+  f32x16 acc;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    f32x4 v = bload(wr, h64, (BIAS_OFF + (l * 4 + t) * 32) * 4 + g * 16);
+    acc[4 * g + 0] = v[0]; acc[4 * g + 1] = v[1]; acc[4 * g + 2] = v[2]; acc[4 * g + 3] = v[3];
+  }
+  return acc;
+}
+
+struct SdfCtx {
+  rsrc_t wr, sr;
+  int lane16, h64, h256, svoff;
+};
+
+// One forward output tile (layer L, tile T).  `raw` holds the pre-activations of the previously finished tile and is
+// converted (softplus, softplus' -> scratch) under this tile's MFMAs; on return it holds this tile's pre-activations.
+template <bool GRAD, int L, int T, int NTOTAL>
+__device__ __forceinline__ void fwd_tile(const SdfCtx& c, WRing& ring, f32x16& raw, float* hin, float* hout, const float* e,
+                                         const float* phi, float* delta, float& y0) {
+  constexpr int NH = L == 0 ? 4 : (L == 3 ? 13 : 16);  // k-groups over the main input (e for layer 0)
+  constexpr int NE = L == 3 ? 4 : 0;
+  constexpr int GB = fwd_gbase(L, T);
+  f32x16 acc = bias_tile(c.wr, L, T, c.h64);
+  const f32x16 prev = raw;
+  f32x4 w6[4];
+  if (L == 5 && T > 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) w6[g] = bload(c.wr, c.h256, W6H_OFF * 4 + ((T - 1) * 4 + g) * 16);
+  }
+  f32x4 sbuf = {0.f, 0.f, 0.f, 0.f};
+  auto cv = [&](int gi) __attribute__((always_inline)) {
+    if (L == 0) {
+      if (T > 0 && gi < 4) {  // 4 elements of layer-0 tile T-1 per group
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float hv, sv;
+          softplus100(prev[4 * gi + u], hv, sv);
+          hout[16 * (T - 1) + 4 * gi + u] = hv;
+          sbuf[u] = sv;
+        }
+        if (GRAD && !SURF_SDF_NOSCRATCH) bstore(c.sr, c.svoff, ((T - 1) * 4 + gi) * 1024, sbuf);
+      }
+    } else if (T == 0) {
+      if (gi >= 1 && gi <= 8) {  // tile 3 of the previous layer, needed from k-group 12 on
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int el = 2 * (gi - 1) + u;
+          float hv, sv;
+          softplus100(prev[el], hv, sv);
+          hin[48 + el] = hv;
+          sbuf[el & 3] = sv;
+          if (GRAD && (el & 3) == 3 && !SURF_SDF_NOSCRATCH)
+            bstore(c.sr, c.svoff, (L - 1) * 16384 + (12 + (el >> 2)) * 1024, sbuf);
+        }
+      }
+    } else if (gi >= 1 && gi <= 16) {  // tile T-1 of this layer, one element per k-group
+      const int el = gi - 1;
+      float hv, sv;
+      softplus100(prev[el], hv, sv);
+      if (L < 5) {
+        hout[16 * (T - 1) + el] = hv;
+        sbuf[el & 3] = sv;
+        if (GRAD && (el & 3) == 3 && !SURF_SDF_NOSCRATCH)
+          bstore(c.sr, c.svoff, L * 16384 + ((T - 1) * 4 + (el >> 2)) * 1024, sbuf);
+      } else {  // last hidden layer: fold straight into y0 = W6[0] . h5 and delta5 = softplus' * W6[0]
+        const float w = w6[el >> 2][el & 3];
+        y0 = fmaf(w, hv, y0);
+        if (GRAD) delta[16 * (T - 1) + el] = sv * w;
+      }
+    }
+  };
+  stream_mma<GB, NH, NTOTAL>(ring, acc, L == 0 ? e : hin, c.wr, c.lane16, [&](int q) __attribute__((always_inline)) { cv(q); });
+  if (NE) stream_mma<GB + NH, NE ? NE : 1, NTOTAL>(ring, acc, e, c.wr, c.lane16, [&](int q) __attribute__((always_inline)) { cv(NH + q); });
+  if (L > 0)
+    stream_mma<GB + NH + NE, 4, NTOTAL>(ring, acc, phi, c.wr, c.lane16, [&](int q) __attribute__((always_inline)) { cv(NH + NE + q); });
+  raw = acc;
+}
+
+template <bool GRAD, int L, int NTOTAL>
+__device__ __forceinline__ void fwd_layer(const SdfCtx& c, WRing& ring, f32x16& raw, float* hin, float* hout, const float* e,
+                                          const float* phi, float* delta, float& y0) {
+  fwd_tile<GRAD, L, 0, NTOTAL>(c, ring, raw, hin, hout, e, phi, delta, y0);
+  fwd_tile<GRAD, L, 1, NTOTAL>(c, ring, raw, hin, hout, e, phi, delta, y0);
+  fwd_tile<GRAD, L, 2, NTOTAL>(c, ring, raw, hin, hout, e, phi, delta, y0);
+  fwd_tile<GRAD, L, 3, NTOTAL>(c, ring, raw, hin, hout, e, phi, delta, y0);
+}
+
+// One hidden output tile of the reverse sweep of layer L: dout[16T..] = softplus'(t_{L-1})[tile T] * (W_L^T din)[tile T]
+template <int L, int T>
+__device__ __forceinline__ void bwd_hidden_tile(const SdfCtx& c, WRing& ring, const float* din, float* dout) {
+  f32x4 sS[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (SURF_SDF_NOSCRATCH) sS[g] = f32x4{0.5f, 0.5f, 0.5f, 0.5f};
+    else sS[g] = bload(c.sr, c.svoff, (L - 1) * 16384 + (T * 4 + g) * 1024);
+  }
+  f32x16 G;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) G[r] = 0.f;
+  stream_mma<FWD_GROUPS + bwd_gbase(L, T), bwd_ngt(L), ALL_GROUPS>(ring, G, din, c.wr, c.lane16, [](int) {});
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dout[16 * T + r] = sS[r >> 2][r & 3] * G[r];
+}
+
+template <int L, int T>
+__device__ __forceinline__ void bwd_acc_tile(const SdfCtx& c, WRing& ring, const float* din, f32x16& acc) {
+  stream_mma<FWD_GROUPS + bwd_gbase(L, T), bwd_ngt(L), ALL_GROUPS>(ring, acc, din, c.wr, c.lane16, [](int) {});
+}
+
+template <int L>
+__device__ __forceinline__ void bwd_layer(const SdfCtx& c, WRing& ring, const float* din, float* dout, f32x16& accE, f32x16& accP) {
+  bwd_hidden_tile<L, 0>(c, ring, din, dout);
+  bwd_hidden_tile<L, 1>(c, ring, din, dout);
+  bwd_hidden_tile<L, 2>(c, ring, din, dout);
+  bwd_hidden_tile<L, 3>(c, ring, din, dout);
+  if (L == 3) {
+    bwd_acc_tile<L, 4>(c, ring, din, accE);
+    bwd_acc_tile<L, BWD_NT[L] - 1>(c, ring, din, accP);
+  } else {
+    bwd_acc_tile<L, 4>(c, ring, din, accP);
+  }
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(WPB * 64, SURF_SDF_OCC) void sdf_mlp_kernel2(SdfArgs a) {
+  constexpr int NTOTAL = GRAD ? ALL_GROUPS : FWD_GROUPS;
+  const int lane = threadIdx.x & 63;
+  const int h = lane >> 5;
+  const int64_t wave_id = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * WPB;
+  const int64_t n_tiles = (a.n + TILE - 1) / TILE;
+  SdfCtx c;
+  c.wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, PACKED_FLOATS * 4, 0x00020000);
+  c.sr = __builtin_amdgcn_make_buffer_rsrc((void*)a.scratch, 0, GRAD ? 0x7fffffff : 0, 0x00020000);
+  c.lane16 = lane * 16;
+  c.h64 = h * 64;
+  c.h256 = h * 256;
+  c.svoff = (int)(wave_id * (SCR_SLOT * 4)) + lane * 16;
+
+  for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+    const int64_t slot = tile * TILE + (lane & 31);
+    const int64_t sc = slot < a.n ? slot : a.n - 1;
+    const int64_t i = a.idx ? (int64_t)a.idx[sc] : sc;
+    const bool active = (slot < a.n) && (!a.mask || a.mask[i] != 0);
+    if (__ballot(active) == 0ull) continue;
+    const float px = a.pts[i * 3 + 0], py = a.pts[i * 3 + 1], pz = a.pts[i * 3 + 2];
+
+    WRing ring;
+#pragma unroll
+    for (int p = 0; p < RPF; ++p) ring.a[p] = wload(c.wr, c.lane16, GROUPS.off[p]);  // weights fly during the gather
+
+    float phi[16], e[16];
+    {
+      float J[14][3];
+      gather_features<GRAD>(a, h, px, py, pz, phi, J);
+      if (GRAD) {
+#pragma unroll
+        for (int g = 0; g < 11; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int idx = 4 * g + q;
+            v[q] = idx < 42 ? J[idx / 3][idx % 3] : 0.f;
+          }
+          bstore(c.sr, c.svoff, SCR_S * 4 + g * 1024, v);
+        }
+      }
+      float je_unused[14];
+      posenc_half(h, px, py, pz, e, je_unused, false);
+    }
+
+    // ------------------------------------------------ forward ------------------------------------------------
+    float hA[64], hB[64], delta[64];
+    f32x16 raw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) raw[r] = 0.f;
+    float y0 = 0.f;
+    fwd_layer<GRAD, 0, NTOTAL>(c, ring, raw, hA, hA, e, phi, delta, y0);   // h0 -> hA (tile 3 finished in layer 1)
+    fwd_layer<GRAD, 1, NTOTAL>(c, ring, raw, hA, hB, e, phi, delta, y0);
+    fwd_layer<GRAD, 2, NTOTAL>(c, ring, raw, hB, hA, e, phi, delta, y0);
+    fwd_layer<GRAD, 3, NTOTAL>(c, ring, raw, hA, hB, e, phi, delta, y0);
+    fwd_layer<GRAD, 4, NTOTAL>(c, ring, raw, hB, hA, e, phi, delta, y0);
+    fwd_layer<GRAD, 5, NTOTAL>(c, ring, raw, hA, hB, e, phi, delta, y0);
+    // tile 3 of layer 5 and the feature part of the last layer: y0 = W6[0] . [h5 | phi] + b6
+    {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 w = bload(c.wr, c.h256, W6H_OFF * 4 + (12 + g) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float hv, sv;
+          softplus100(raw[4 * g + q], hv, sv);
+          y0 = fmaf(w[q], hv, y0);
+          if (GRAD) delta[48 + 4 * g + q] = sv * w[q];
+        }
+      }
+    }
+    f32x16 accP;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 w = bload(c.wr, c.h64, W6P_OFF * 4 + g * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        y0 = fmaf(w[q], phi[4 * g + q], y0);
+        accP[4 * g + q] = w[q];
+      }
+    }
+    y0 += __shfl_xor(y0, 32);
+    y0 += a.packed[B6_OFF];
+    if (active && h == 0) a.sdf[i] = y0;
+    if (!GRAD) continue;
+
+    // ------------------------------------------------ reverse sweep ------------------------------------------
+    f32x16 accE;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accE[r] = 0.f;
+    bwd_layer<5>(c, ring, delta, hA, accE, accP);
+    bwd_layer<4>(c, ring, hA, delta, accE, accP);
+    bwd_layer<3>(c, ring, delta, hA, accE, accP);
+    bwd_layer<2>(c, ring, hA, delta, accE, accP);
+    bwd_layer<1>(c, ring, delta, hA, accE, accP);
+    bwd_acc_tile<0, 0>(c, ring, hA, accE);
+
+    float g3[3] = {0.f, 0.f, 0.f};
+    {
+      float e2[16], je[14];
+      posenc_half(h, px, py, pz, e2, je, true);
+#pragma unroll
+      for (int s2 = 0; s2 < 14; ++s2) {
+        const int c0 = s2 % 3, c1 = (14 + s2) % 3;
+        const float v = accE[s2] * je[s2];
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) g3[ax] += ((h ? c1 : c0) == ax) ? v : 0.f;
+      }
+      float Jf[44];
+#pragma unroll
+      for (int g = 0; g < 11; ++g) {
+        f32x4 v = bload(c.sr, c.svoff, SCR_S * 4 + g * 1024);
+        Jf[4 * g + 0] = v[0]; Jf[4 * g + 1] = v[1]; Jf[4 * g + 2] = v[2]; Jf[4 * g + 3] = v[3];
+      }
+#pragma unroll
+      for (int ch = 0; ch < 14; ++ch) {
+#pragma unroll
+        for (int ax = 0; ax < 3; ++ax) g3[ax] = fmaf(accP[ch], Jf[3 * ch + ax], g3[ax]);
+      }
+    }
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) g3[ax] += __shfl_xor(g3[ax], 32);
+    if (active && h == 0) {
+      a.grad[i * 3 + 0] = g3[0];
+      a.grad[i * 3 + 1] = g3[1];
+      a.grad[i * 3 + 2] = g3[2];
+    }
+  }
+}
+
 int max_blocks() {
   static const int v = [] {
     const char* e = getenv("SURF_SDF_MAX_BLOCKS");  // tuning / diagnostics only
@@ -650,9 +977,16 @@ extern "C" int surf_sdf_mlp(const float* pts, const uint8_t* mask, const int32_t
     if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
   }
   dim3 grid(grid_blocks(n)), block(WPB * 64);
+#if SURF_SDF_V2
+  if (grad)
+    hipLaunchKernelGGL(sdf_mlp_kernel2<true>, grid, block, 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(sdf_mlp_kernel2<false>, grid, block, 0, (hipStream_t)stream, a);
+#else
   if (grad)
     hipLaunchKernelGGL(sdf_mlp_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(sdf_mlp_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
+#endif
   return surf_check_launch();
 }
