@@ -607,7 +607,9 @@ __device__ __forceinline__ void fwd_tile(const SdfCtx& c, WRing& ring, f32x16& r
   constexpr int NH = L == 0 ? 4 : (L == 3 ? 13 : 16);  // k-groups over the main input (e for layer 0)
   constexpr int NE = L == 3 ? 4 : 0;
   constexpr int GB = fwd_gbase(L, T);
-  f32x16 acc = bias_tile(c.wr, L, T, c.h64);
+  f32x16 acc;  // the bias arrives through k-step 14 of the last segment (B operand 1.0), no separate loads
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const f32x16 prev = raw;
   f32x4 w6[4];
   if (L == 5 && T > 0) {
@@ -754,6 +756,8 @@ __global__ __launch_bounds__(WPB * 64, SURF_SDF_OCC) void sdf_mlp_kernel2(SdfArg
       }
       float je_unused[14];
       posenc_half(h, px, py, pz, e, je_unused, false);
+      e[14] = 1.0f;    // bias steps (see surf_sdf_pack_weights)
+      phi[14] = 1.0f;
     }
 
     // ------------------------------------------------ forward ------------------------------------------------
@@ -888,9 +892,11 @@ extern "C" int surf_sdf_pack_weights(const float* const* h_W, const float* const
             const int step = 4 * q + i, h = lane >> 5, row = 32 * t + (lane & 31);
             int col = -1;
             float scale = 1.f;
+            bool is_bias = false;  // k-step 14 of the last segment carries the bias (its B operand is the constant 1)
             if (l == 0) {  // 16 e-steps
               int ch = 14 * h + step;
               if (step < 14 && ch < NE) col = ch;
+              is_bias = (step == 14 && h == 0);
             } else if (step < 64) {  // hidden steps
               int k = hk(step / 16, step % 16, h);
               if (k < hid_in) col = k;
@@ -902,9 +908,11 @@ extern "C" int surf_sdf_pack_weights(const float* const* h_W, const float* const
             } else {  // phi steps
               int s = step - (l == 3 ? 80 : 64);
               if (s < 14) col = 128 + 14 * h + s;
+              is_bias = (s == 14 && h == 0);
             }
             float v = 0.f;
             if (col >= 0 && row < out_dim[l]) v = h_W[l][(int64_t)row * in_dim[l] + col] * scale;
+            if (is_bias && row < out_dim[l]) v = h_b[l][row];
             dst[((q * 4 + t) * 64 + lane) * 4 + i] = v;
           }
   }

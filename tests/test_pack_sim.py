@@ -57,8 +57,9 @@ W6P_OFF = W6H_OFF + 128
 B6_OFF = W6P_OFF + 32
 
 
-def sim_sdf(packed, pts, phi_full, jphi_full):
-    """32 points -> sdf (32,), grad (32,3) through the packed buffers."""
+def sim_sdf(packed, pts, phi_full, jphi_full, bias_step=False):
+    """32 points -> sdf (32,), grad (32,3) through the packed buffers.  bias_step: accumulators start at zero and
+    the bias comes in through k-step 14 of the last input segment with a constant-one operand (schedule v2)."""
     n = pts.shape[0]
     assert n == 32
     x = pts[J].astype(np.float64)
@@ -72,7 +73,13 @@ def sim_sdf(packed, pts, phi_full, jphi_full):
     phi = np.zeros((64, 16)); phi[:, :14] = np.take_along_axis(phi_full[J], sel, 1)
     Jl = np.stack([np.take_along_axis(jphi_full[J][:, :, a], sel, 1) for a in range(3)], -1)  # (64,14,3)
 
+    if bias_step:
+        e[:, 14] = 1.0
+        phi[:, 14] = 1.0
+
     def bias(l):
+        if bias_step:
+            return [np.zeros((64, 16)) for t in range(4)]
         return [rows16(packed, BIAS_OFF + ((l * 4 + t) * 2) * 16) for t in range(4)]
 
     S = []
@@ -124,6 +131,10 @@ def test_sdf_pack_matches_oracle(weights, golden_pipe, golden_render):
     assert np.abs(sdf_s - sdf_o.numpy()).max() < 2e-5
     assert np.abs(grad_s - grad_o.numpy()).max() < 2e-4
     assert np.abs(grad_o.numpy()).max() > 0.1
+    sdf_b, grad_b = sim_sdf(packed.astype(np.float64), pts.numpy(), phi.numpy().astype(np.float64),
+                            jphi.numpy().astype(np.float64), bias_step=True)
+    assert np.abs(sdf_b - sdf_o.numpy()).max() < 2e-5
+    assert np.abs(grad_b - grad_o.numpy()).max() < 2e-4
 
 
 # ---- blend ----------------------------------------------------------------------------------------
