@@ -102,27 +102,82 @@ __device__ __forceinline__ f32x4 tap_finish(const Tap4& t) {
   return acc;
 }
 
-template <int NQ, int NT>
-__device__ __forceinline__ void mma_seg(f32x16 (&acc)[NT], const float* b, rsrc_t wr, int lane16, int off) {
-  f32x4 a_cur[NT], a_nxt[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) a_cur[t] = bload(wr, lane16, off + t * 1024);
+// ---- one weight stream per tile: [RD0, RD2] x NS, B0S, [B0V, B2, V0, V2, W0, R0, R2] x NS ----------------------
+// A group = 16 bytes per lane = 4 k-steps of one 32-row tile.  A ring of RPF+1 register buffers keeps RPF groups in
+// flight across layer, view and section boundaries, so no layer starts by waiting for its first weights.  Every
+// section is a multiple of RPF+1 = 3 groups long, so a group's ring slot depends only on its position in its section
+// (which keeps all register indices compile-time constants although the views are a loop).
+constexpr int RPF = 2;
+struct WRing { f32x4 a[RPF + 1]; };
+
+struct SeqNone { static constexpr int LEN = 0; static constexpr int off(int) { return 0; } };
+struct SeqPV {  // per-view chain of pass 2
+  static constexpr int LEN = 33;
+  static constexpr int off(int p) {
+    if (p < 6) return mma_off(L_B0V) * 4 + p * 1024;
+    if (p < 14) return mma_off(L_B2) * 4 + (p - 6) * 1024;
+    if (p < 18) return mma_off(L_V0) * 4 + (p - 14) * 1024;
+    if (p < 22) return mma_off(L_V2) * 4 + (p - 18) * 1024;
+    if (p < 26) return mma_off(L_W0) * 4 + (p - 22) * 1024;
+    if (p < 31) return mma_off(L_R0) * 4 + (p - 26) * 1024;
+    return mma_off(L_R2) * 4 + (p - 31) * 1024;
+  }
+};
+struct SeqBS {  // view-independent [mean | var] part of base_fc.0, two tiles, [q][t] order
+  static constexpr int LEN = 12;
+  static constexpr int off(int p) { return mma_off(L_B0S) * 4 + p * 1024; }
+};
+struct SeqP1 {  // direction MLP of pass 1
+  static constexpr int LEN = 3;
+  static constexpr int off(int p) { return p == 0 ? mma_off(L_RD0) * 4 : mma_off(L_RD2) * 4 + (p - 1) * 1024; }
+};
+static_assert(SeqPV::LEN % (RPF + 1) == 0 && SeqBS::LEN % (RPF + 1) == 0 && SeqP1::LEN % (RPF + 1) == 0, "ring phase");
+
+// issue the prefetch that belongs to position p of section SEQ (it targets position p + RPF, possibly in the next
+// repetition of SEQ or, for the last repetition, in section NEXT)
+template <class SEQ, class NEXT>
+__device__ __forceinline__ void ring_prefetch(WRing& ring, int p, bool last, rsrc_t wr, int lane16) {
+  const int t = p + RPF;
+  if (t < SEQ::LEN) ring.a[t % (RPF + 1)] = bload(wr, lane16, SEQ::off(t));
+  else if (!last) ring.a[t % (RPF + 1)] = bload(wr, lane16, SEQ::off(t - SEQ::LEN));
+  else if (NEXT::LEN > 0) ring.a[t % (RPF + 1)] = bload(wr, lane16, NEXT::off(t - SEQ::LEN));
+}
+
+// NQ groups of one 32-row tile starting at position POS of section SEQ
+template <class SEQ, class NEXT, int POS, int NQ>
+__device__ __forceinline__ void stream_mma(WRing& ring, f32x16& acc, const float* b, bool last, rsrc_t wr, int lane16) {
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
-    if (q + 1 < NQ) {
+    ring_prefetch<SEQ, NEXT>(ring, POS + q, last, wr, lane16);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) a_nxt[t] = bload(wr, lane16, off + ((q + 1) * NT + t) * 1024);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t][i], b[q * 4 + i], acc[t], 0, 0, 0);
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) a_cur[t] = a_nxt[t];
+    for (int i = 0; i < 4; ++i)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ring.a[(POS + q) % (RPF + 1)][i], b[q * 4 + i], acc, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
   }
+}
+// NQ k-groups of two 32-row tiles (stream order [q][t])
+template <class SEQ, class NEXT, int POS, int NQ>
+__device__ __forceinline__ void stream_mma2(WRing& ring, f32x16& acc0, f32x16& acc1, const float* b, bool last, rsrc_t wr,
+                                            int lane16) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    ring_prefetch<SEQ, NEXT>(ring, POS + 2 * q, last, wr, lane16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ring.a[(POS + 2 * q) % (RPF + 1)][i], b[q * 4 + i], acc0, 0, 0, 0);
+    ring_prefetch<SEQ, NEXT>(ring, POS + 2 * q + 1, last, wr, lane16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ring.a[(POS + 2 * q + 1) % (RPF + 1)][i], b[q * 4 + i], acc1, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 v;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = 0.f;
+  return v;
 }
 
 __device__ __forceinline__ f32x16 load_row16(rsrc_t wr, int h64, int off_floats) {
@@ -136,7 +191,9 @@ __device__ __forceinline__ f32x16 load_row16(rsrc_t wr, int h64, int off_floats)
 }
 
 template <int NS>
-__global__ __launch_bounds__(256, 2) void blend_kernel(BlendArgs a) {
+// Two wavefronts per SIMD only while the per-view state fits 256 registers (NS <= 2); with more source views one
+// wavefront per SIMD and the whole register file beats two spilling ones (57.9 vs 67.1 ms at NS = 4).
+__global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void blend_kernel(BlendArgs a) {
   const int lane = threadIdx.x & 63;
   const int j = lane & 31, h = lane >> 5;
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -162,6 +219,10 @@ __global__ __launch_bounds__(256, 2) void blend_kernel(BlendArgs a) {
     const bool active = (slot < a.n) && (!a.mask || a.mask[i] != 0);
     if (__ballot(active) == 0ull) continue;
     const float px = a.pts[i * 3 + 0], py = a.pts[i * 3 + 1], pz = a.pts[i * 3 + 2];
+
+    WRing ring;
+#pragma unroll
+    for (int p = 0; p < RPF; ++p) ring.a[p] = bload(wr, lane16, SeqP1::off(p));
 
     float floc[NS][12];  // this half's channels of rgb_feat + direction feature (11 or 8 used)
     float rgb[NS][3];    // raw source colours (meaningful in half 0)
@@ -236,17 +297,24 @@ __global__ __launch_bounds__(256, 2) void blend_kernel(BlendArgs a) {
       g[11] = 0.f;
       // direction feature ELU(L(ELU(L(ray_diff))))  4 -> 16 -> 19  (blending_network.py:72-74)
       float bin[4] = {h ? rd[v][1] : rd[v][0], h ? rd[v][3] : rd[v][2], 0.f, 0.f};
-      f32x16 acc1[1] = {load_row16(wr, h64, BIAS_OFF + B_RD0 * 32)};
-      mma_seg<1, 1>(acc1, bin, wr, lane16, mma_off(L_RD0) * 4);
+      // bias rows are loaded before the MFMAs they follow and added in the activation: their latency hides under
+      // the matrix work and no accumulator waits for an initial value
+      int h64p = h64;
+      asm volatile("" : "+v"(h64p));  // see pass 2: keeps the per-view bias loads from being merged and kept live
+      const f32x16 bias1 = load_row16(wr, h64p, BIAS_OFF + B_RD0 * 32);
+      const f32x16 bias2 = load_row16(wr, h64p, BIAS_OFF + B_RD2 * 32);
+      const bool lastv = (v == NS - 1);
+      f32x16 acc1 = zero16();
+      stream_mma<SeqP1, SeqBS, 0, 1>(ring, acc1, bin, lastv, wr, lane16);
       float h8[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) h8[r] = elu(acc1[0][r]);
-      f32x16 acc2[1] = {load_row16(wr, h64, BIAS_OFF + B_RD2 * 32)};
-      mma_seg<2, 1>(acc2, h8, wr, lane16, mma_off(L_RD2) * 4);
+      for (int r = 0; r < 8; ++r) h8[r] = elu(acc1[r] + bias1[r]);
+      f32x16 acc2 = zero16();
+      stream_mma<SeqP1, SeqBS, 1, 2>(ring, acc2, h8, lastv, wr, lane16);
 #pragma unroll
       for (int r = 0; r < 11; ++r) {
         // rows of half 1 beyond its 8 channels carry zero weights and zero bias: elu(0) = 0
-        floc[v][r] = g[r] + elu(acc2[0][r]);
+        floc[v][r] = g[r] + elu(acc2[r] + bias2[r]);
       }
       floc[v][11] = 0.f;
       ex[v] = expf(s_abs * (rd[v][3] - 1.0f));
@@ -275,52 +343,60 @@ __global__ __launch_bounds__(256, 2) void blend_kernel(BlendArgs a) {
       mv[c] = mean;
       mv[12 + c] = var;
     }
-    f32x16 G0[2] = {load_row16(wr, h64, BIAS_OFF + B_B0_T0 * 32), load_row16(wr, h64, BIAS_OFF + B_B0_T1 * 32)};
-    mma_seg<6, 2>(G0, mv, wr, lane16, mma_off(L_B0S) * 4);
+    // view-independent part of base_fc.0 (bias added at the activation below)
+    f32x16 G0a = zero16(), G0b = zero16();
+    stream_mma2<SeqBS, SeqPV, 0, 6>(ring, G0a, G0b, mv, true, wr, lane16);
 
     // ------------------------------ pass 2: per-view chain, online softmax over views (:88-116) -------------
-    const f32x16 dvis = load_row16(wr, h64, DOT_OFF + D_VIS * 32);
-    const f32x16 dvis2 = load_row16(wr, h64, DOT_OFF + D_VIS2 * 32);
-    const f32x16 drgb4 = load_row16(wr, h64, DOT_OFF + D_RGB4 * 32);
     const float b_vis = a.w[SCAL_OFF + 1], b_vis2 = a.w[SCAL_OFF + 2], b_rgb4 = a.w[SCAL_OFF + 3];
     float Mx = -INFINITY, Zs = 0.f, o_r = 0.f, o_g = 0.f, o_b = 0.f;
 #pragma unroll
     for (int v = 0; v < NS; ++v) {
+      const bool lastv = (v == NS - 1);
+      // Per-view copy of the row offset that the compiler cannot see through: otherwise the (identical) bias-row loads
+      // of all views are merged into one set of 160 registers kept live across the whole pass.
+      int h64v = h64;
+      asm volatile("" : "+v"(h64v));
       // base_fc.0 (view part) + ELU : 57 -> 64
-      f32x16 acc64[2] = {G0[0], G0[1]};
-      mma_seg<3, 2>(acc64, floc[v], wr, lane16, mma_off(L_B0V) * 4);
+      const f32x16 bb0 = load_row16(wr, h64v, BIAS_OFF + B_B0_T0 * 32), bb1 = load_row16(wr, h64v, BIAS_OFF + B_B0_T1 * 32);
+      f32x16 a64a = G0a, a64b = G0b;
+      stream_mma2<SeqPV, SeqNone, 0, 3>(ring, a64a, a64b, floc[v], lastv, wr, lane16);
       float h32[32];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) h32[16 * t + r] = elu(acc64[t][r]);
+      for (int r = 0; r < 16; ++r) { h32[r] = elu(a64a[r] + bb0[r]); h32[16 + r] = elu(a64b[r] + bb1[r]); }
       // base_fc.2 + ELU : 64 -> 32
-      f32x16 accx[1] = {load_row16(wr, h64, BIAS_OFF + B_B2 * 32)};
-      mma_seg<8, 1>(accx, h32, wr, lane16, mma_off(L_B2) * 4);
+      const f32x16 bx = load_row16(wr, h64v, BIAS_OFF + B_B2 * 32);
+      f32x16 accx = zero16();
+      stream_mma<SeqPV, SeqNone, 6, 8>(ring, accx, h32, lastv, wr, lane16);
       float x[16], xin[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { x[r] = elu(accx[0][r]); xin[r] = x[r] * wv[v]; }
+      for (int r = 0; r < 16; ++r) { x[r] = elu(accx[r] + bx[r]); xin[r] = x[r] * wv[v]; }
       // vis_fc: 32 -> 32 (ELU) -> 33 (ELU)
-      f32x16 acct[1] = {load_row16(wr, h64, BIAS_OFF + B_V0 * 32)};
-      mma_seg<4, 1>(acct, xin, wr, lane16, mma_off(L_V0) * 4);
+      const f32x16 bt = load_row16(wr, h64v, BIAS_OFF + B_V0 * 32);
+      f32x16 acct = zero16();
+      stream_mma<SeqPV, SeqNone, 14, 4>(ring, acct, xin, lastv, wr, lane16);
       float t16[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) t16[r] = elu(acct[0][r]);
-      f32x16 accr[1] = {load_row16(wr, h64, BIAS_OFF + B_V2 * 32)};
-      mma_seg<4, 1>(accr, t16, wr, lane16, mma_off(L_V2) * 4);
+      for (int r = 0; r < 16; ++r) t16[r] = elu(acct[r] + bt[r]);
+      const f32x16 br = load_row16(wr, h64v, BIAS_OFF + B_V2 * 32);
+      const f32x16 dvis = load_row16(wr, h64v, DOT_OFF + D_VIS * 32);
+      f32x16 accr = zero16();
+      stream_mma<SeqPV, SeqNone, 18, 4>(ring, accr, t16, lastv, wr, lane16);
       float vraw = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) vraw = fmaf(dvis[r], t16[r], vraw);
       vraw += __shfl_xor(vraw, 32);
       const float vis = sigm(elu(vraw + b_vis)) * mk[v];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { x[r] = x[r] + elu(accr[0][r]); xin[r] = x[r] * vis; }
+      for (int r = 0; r < 16; ++r) { x[r] = x[r] + elu(accr[r] + br[r]); xin[r] = x[r] * vis; }
       // vis_fc2: 32 -> 32 (ELU) -> 1 (sigmoid)
-      f32x16 accw[1] = {load_row16(wr, h64, BIAS_OFF + B_W0 * 32)};
-      mma_seg<4, 1>(accw, xin, wr, lane16, mma_off(L_W0) * 4);
+      const f32x16 bw = load_row16(wr, h64v, BIAS_OFF + B_W0 * 32);
+      const f32x16 dvis2 = load_row16(wr, h64v, DOT_OFF + D_VIS2 * 32);
+      f32x16 accw = zero16();
+      stream_mma<SeqPV, SeqNone, 22, 4>(ring, accw, xin, lastv, wr, lane16);
       float v2 = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v2 = fmaf(dvis2[r], elu(accw[0][r]), v2);
+      for (int r = 0; r < 16; ++r) v2 = fmaf(dvis2[r], elu(accw[r] + bw[r]), v2);
       v2 += __shfl_xor(v2, 32);
       const float vis2 = sigm(v2 + b_vis2) * mk[v];
       // rgb_fc: [x(32), vis, ray_diff(4)] = 37 -> 16 (ELU) -> 8 (ELU) -> 1
@@ -331,16 +407,19 @@ __global__ __launch_bounds__(256, 2) void blend_kernel(BlendArgs a) {
       rin[17] = h ? rd[v][2] : rd[v][1];
       rin[18] = h ? 0.f : rd[v][3];
       rin[19] = 0.f;
-      f32x16 acc16[1] = {load_row16(wr, h64, BIAS_OFF + B_R0 * 32)};
-      mma_seg<5, 1>(acc16, rin, wr, lane16, mma_off(L_R0) * 4);
+      const f32x16 b16 = load_row16(wr, h64v, BIAS_OFF + B_R0 * 32);
+      f32x16 acc16 = zero16();
+      stream_mma<SeqPV, SeqNone, 26, 5>(ring, acc16, rin, lastv, wr, lane16);
       float r8[8];
 #pragma unroll
-      for (int r = 0; r < 8; ++r) r8[r] = elu(acc16[0][r]);
-      f32x16 acc8[1] = {load_row16(wr, h64, BIAS_OFF + B_R2 * 32)};
-      mma_seg<2, 1>(acc8, r8, wr, lane16, mma_off(L_R2) * 4);
+      for (int r = 0; r < 8; ++r) r8[r] = elu(acc16[r] + b16[r]);
+      const f32x16 b8 = load_row16(wr, h64v, BIAS_OFF + B_R2 * 32);
+      const f32x16 drgb4 = load_row16(wr, h64v, DOT_OFF + D_RGB4 * 32);
+      f32x16 acc8 = zero16();
+      stream_mma<SeqPV, SeqNone, 31, 2>(ring, acc8, r8, lastv, wr, lane16);
       float rr = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) rr = fmaf(drgb4[r], elu(acc8[0][r]), rr);
+      for (int r = 0; r < 4; ++r) rr = fmaf(drgb4[r], elu(acc8[r] + b8[r]), rr);
       rr += __shfl_xor(rr, 32);
       rr += b_rgb4;
       if (mk[v] == 0.f) rr = -1e9f;
