@@ -564,7 +564,7 @@ constexpr GroupTable make_groups() {
 constexpr GroupTable GROUPS = make_groups();
 
 #ifndef SURF_SDF_RPF
-#define SURF_SDF_RPF 2
+#define SURF_SDF_RPF 4
 #endif
 constexpr int RPF = SURF_SDF_RPF;  // weight groups in flight ahead of the one being multiplied
 struct WRing { f32x4 a[RPF + 1]; };
