@@ -91,6 +91,19 @@ int surf_sdf_mlp(const float* pts, const uint8_t* mask, const int32_t* idx, int6
                  float* sdf, float* grad, void* scratch, void* stream);
 
 /*
+ * The same evaluation on the bf16 matrix pipe with fp32-equivalent accuracy: every fp32 operand is split exactly into
+ * three bf16 pieces and six partial products are accumulated in fp32 (error ~2^-24 per product).  Arguments as
+ * surf_sdf_mlp; `packed` is the output of surf_sdf_pack_weights_bf16 (surf_sdf_bf16_packed_bytes() bytes, device copy),
+ * `scratch` >= surf_sdf_bf16_scratch_bytes(n).
+ */
+int64_t surf_sdf_bf16_packed_bytes(void);
+int64_t surf_sdf_bf16_scratch_bytes(int64_t n_points);
+int surf_sdf_pack_weights_bf16(const float* const* h_W, const float* const* h_b, unsigned char* h_packed);
+int surf_sdf_mlp_bf16x3(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_vols,
+                        const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* sdf,
+                        float* grad, void* scratch, void* stream);
+
+/*
  * Multi-view feature fetch + blending MLP.
  * Replaces lookup_feature/compute_angle (projector.py:485-556) and BlendingNetwork.forward
  * (blending_network.py:69-118).

@@ -18,6 +18,9 @@ R = rays_o.shape[0]
 near = near_fars[0, 0].reshape(1, 1).repeat(R, 1).to(dev); far = near_fars[0, 1].reshape(1, 1).repeat(R, 1).to(dev)
 st = ops.ray_setup(rays_o, rays_d, near, far, mvol, sv, n_samples, [1.0, 0.4, 0.1, 0.01], 256)
 sdf_w, blend_w = model.packed_weights(dev)
+if os.environ.get('SURF_BF16'):
+    sd = {k: v for k, v in model.state_dict().items()}
+    sdf_w = ops.sdf_pack_weights_bf16(sd, dev, 'sdf_network.')
 n_act = int(st["vmask"].sum())
 for grad in (False, True):
     for it in range(3):

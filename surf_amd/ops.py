@@ -116,6 +116,23 @@ def sdf_pack_weights_host(layers):
     return out
 
 
+def sdf_pack_weights_bf16_host(layers):
+    """[(W_l, b_l)] effective matrices -> byte stream of 3-way bf16 split weights (surf_sdf_pack_weights_bf16)."""
+    sdf_pack_weights_host(layers)  # shape validation only
+    Ws = [_host_f32(W) for W, _ in layers]
+    bs = [_host_f32(b) for _, b in layers]
+    L = _lib.lib()
+    out = np.zeros(L.surf_sdf_bf16_packed_bytes(), dtype=np.uint8)
+    wp = (ctypes.c_void_p * 7)(*[w.ctypes.data for w in Ws])
+    bp = (ctypes.c_void_p * 7)(*[b.ctypes.data for b in bs])
+    _lib.check(L.surf_sdf_pack_weights_bf16(wp, bp, _np_ptr(out)), "surf_sdf_pack_weights_bf16")
+    return out
+
+
+def sdf_pack_weights_bf16(sd, device, prefix="implicit_surface.sdf_network."):
+    return torch.from_numpy(sdf_pack_weights_bf16_host(sdf_effective_weights(sd, prefix))).to(device)
+
+
 def sdf_pack_weights(sd, device, prefix="implicit_surface.sdf_network."):
     return torch.from_numpy(sdf_pack_weights_host(sdf_effective_weights(sd, prefix))).to(device)
 
@@ -178,8 +195,8 @@ def ray_setup(rays_o, rays_d, near, far, mvol, volumes, n_samples, sample_ranges
 _scratch_cache = {}
 
 
-def _sdf_scratch(n, device):
-    need = _lib.lib().surf_sdf_scratch_bytes(int(n))
+def _sdf_scratch(n, device, bf16=False):
+    need = (_lib.lib().surf_sdf_bf16_scratch_bytes if bf16 else _lib.lib().surf_sdf_scratch_bytes)(int(n))
     key = (device.index if device.index is not None else torch.cuda.current_device())
     buf = _scratch_cache.get(key)
     if buf is None or buf.numel() < need:
@@ -192,7 +209,8 @@ def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True, compact_active=True
     """sdf_network.py:95-141 at n points.  Returns (sdf (n,), grad (n,3) or None); masked-out rows are
     left at sdf=100 / grad=0 (what render_core substitutes, implicit_surface.py:93,99)."""
     _chk(pts, torch.float32, "pts")
-    _chk(packed, torch.float32, "packed weights")
+    bf16 = packed.dtype == torch.uint8          # stream of surf_sdf_pack_weights_bf16 -> bf16x3 kernel
+    _chk(packed, torch.uint8 if bf16 else torch.float32, "packed weights")
     n = pts.shape[0]
     dev = pts.device
     if mask is not None:
@@ -212,10 +230,11 @@ def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True, compact_active=True
         n_eval = int(idx.shape[0])
         if n_eval == 0:
             return sdf, grad
-    scratch = _sdf_scratch(n_eval, dev) if want_grad else None
-    rc = _lib.lib().surf_sdf_mlp(_p(pts), _p(None if idx is not None else mask), _p(idx), n_eval, volumes._vp, volumes._tp, volumes._dp, volumes.n, _p(packed),
-                                 _p(sdf), _p(grad), _p(scratch), _stream())
-    _lib.check(rc, "surf_sdf_mlp")
+    scratch = _sdf_scratch(n_eval, dev, bf16) if want_grad else None
+    fn = _lib.lib().surf_sdf_mlp_bf16x3 if bf16 else _lib.lib().surf_sdf_mlp
+    rc = fn(_p(pts), _p(None if idx is not None else mask), _p(idx), n_eval, volumes._vp, volumes._tp, volumes._dp, volumes.n,
+            _p(packed), _p(sdf), _p(grad), _p(scratch), _stream())
+    _lib.check(rc, "surf_sdf_mlp_bf16x3" if bf16 else "surf_sdf_mlp")
     return sdf, grad
 
 

@@ -306,3 +306,32 @@ def test_surf_forward_end_to_end_vs_oracle(scene):
     assert float(okd) > 0.95, float(okd)
     assert out["img_fine"].shape == (7, 8, 3) and out["normal_img"].shape == (7, 8, 3)
     assert out["vertices"].shape[1] == 3 and out["triangles"].shape[1] == 3
+
+
+def test_sdf_mlp_bf16x3_matches_golden(weights, gpu_scene, golden_render):
+    """The bf16 three-way-split kernel (fp32-equivalent products on the bf16 MFMA pipe) against the reference's outputs,
+    at the same tolerances as the fp32 kernel, and against the fp32 kernel itself."""
+    from surf_amd import ops
+    d = dev()
+    pts = golden_render["pts"]
+    w16 = ops.sdf_pack_weights_bf16(weights, d)
+    sdf, grad = ops.sdf_mlp(pts.to(d).contiguous(), gpu_scene["sv"], w16)
+    torch.cuda.synchronize()
+    rel_close(sdf, golden_render["sdf_out"][:, 0], 0, 1e-4)
+    rel_close(grad, golden_render["sdf_grad"], 1e-3, 2e-4)
+    s32, g32 = ops.sdf_mlp(pts.to(d).contiguous(), gpu_scene["sv"], gpu_scene["sdf_w"])
+    rel_close(sdf, s32, 0, 2e-6)
+    rel_close(grad, g32, 1e-4, 2e-5)
+    # many rounds per workgroup, ragged tail, mask + compaction, forward-only variant
+    g = torch.Generator().manual_seed(12)
+    base = (torch.rand(3000, 3, generator=g) * 2 - 1) * 0.9
+    big = base.repeat(30, 1).contiguous().to(d)                      # 90,000 points
+    mask = (torch.arange(big.shape[0]) % 7 != 0).to(torch.uint8).to(d)
+    sa, ga = ops.sdf_mlp(big, gpu_scene["sv"], w16, mask=mask)
+    sb, gb = ops.sdf_mlp(big, gpu_scene["sv"], gpu_scene["sdf_w"], mask=mask)
+    rel_close(sa, sb, 0, 2e-6)
+    rel_close(ga, gb, 1e-4, 2e-5)
+    sf, gf = ops.sdf_mlp(big, gpu_scene["sv"], w16, want_grad=False)
+    assert gf is None
+    m = mask.bool().cpu()
+    rel_close(sf.cpu()[m], sa.cpu()[m], 0, 1e-6)

@@ -259,3 +259,133 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name)
     assert L.surf_abi_version() == 2
     assert L.surf_sdf_scratch_bytes(1 << 20) > 0
+
+
+# ---- bf16x3 stream (sdf_mlp_bf16.hip) --------------------------------------------------------------------
+def _bf16_to_f64(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+class Bf16Stream:
+    """Decoder of surf_sdf_pack_weights_bf16's chunk stream: A operand of k-step ks = sum of the three pieces."""
+    BWD_NT = [1, 5, 5, 6, 5, 5]
+
+    def __init__(self, packed):
+        self.u16 = packed[: (len(packed) // 2) * 2].view(np.uint16)
+        self.packed = packed
+        fwd_ks = [2, 10, 10, 11, 10, 10]
+        self.ks, self.off = [], []
+        o = 0
+        for l in range(6):
+            for t in range(4):
+                self.off.append(o); self.ks.append(fwd_ks[l]); o += fwd_ks[l] * 3072
+        for l in range(5, -1, -1):
+            for t in range(self.BWD_NT[l]):
+                k = 7 if l == 2 else 8
+                self.off.append(o); self.ks.append(k); o += k * 3072
+        self.stream_bytes = o
+        self.tail = packed[o:o + 164 * 4].view(np.float32).astype(np.float64)
+
+    def fwd_chunk(self, l, t):
+        return l * 4 + t
+
+    def bwd_chunk(self, l, t):
+        return 24 + sum(self.BWD_NT[i] for i in range(5, l, -1)) + t
+
+    def A(self, ci, ks):
+        """(64 lanes, 8) float64 = exact sum of the three bf16 pieces; also checks piece sizes decay."""
+        base = (self.off[ci] + ks * 3072) // 2
+        pieces = [_bf16_to_f64(self.u16[base + p * 512: base + (p + 1) * 512]).reshape(64, 8) for p in range(3)]
+        assert (np.abs(pieces[1]) <= np.abs(pieces[0]) * 2.0 ** -7 + 1e-45).all()
+        return pieces[0] + pieces[1] + pieces[2]
+
+
+def mma16(acc, A, Bfrag):
+    """one K=16 step: A (64,8): lane l -> A[row l&31][k = 8 (l>>5) + j]; Bfrag (64,8): B[k = 8 h + j][col l&31]."""
+    Am = np.zeros((32, 16)); Bm = np.zeros((16, 32))
+    for j in range(8):
+        Am[J, 8 * H + j] = A[:, j]
+        Bm[8 * H + j, J] = Bfrag[:, j]
+    D = Am @ Bm
+    acc += D[ROW[None, :] + 4 * H[:, None], J[:, None]]
+
+
+def sim_sdf_bf16(packed, pts, phi_full, jphi_full):
+    S_ = Bf16Stream(packed)
+    e_all = np.zeros((64, 28)); je_all = np.zeros((64, 28))
+    e_all[:, :27] = O.posenc(torch.from_numpy(pts)).numpy()[J]
+    je_all[:, :27] = O.posenc_jac_diag(torch.from_numpy(pts)).numpy()[J]
+    sel = 14 * H[:, None] + np.arange(14)[None, :]
+    e = np.zeros((64, 16)); e[:, :14] = np.take_along_axis(e_all, sel, 1); e[:, 14] = 1.0
+    je = np.take_along_axis(je_all, sel, 1)
+    phi = np.zeros((64, 16)); phi[:, :14] = np.take_along_axis(phi_full[J], sel, 1); phi[:, 14] = 1.0
+    Jl = np.stack([np.take_along_axis(jphi_full[J][:, :, a], sel, 1) for a in range(3)], -1)
+    frags = lambda v: [v[:, 8 * s:8 * s + 8] for s in range(v.shape[1] // 8)]   # register order == fragment order
+
+    def fwd_layer(l, hin):
+        out = []
+        for t in range(4):
+            acc = np.zeros((64, 16))
+            ci = S_.fwd_chunk(l, t)
+            bs = (frags(e) if l == 0 else frags(hin)[:7 if l == 3 else 8] + (frags(e) if l == 3 else []) + frags(phi))
+            assert len(bs) == S_.ks[ci]
+            for ks, b in enumerate(bs):
+                mma16(acc, S_.A(ci, ks), b)
+            out.append(acc)
+        return np.concatenate(out, 1)
+
+    Sg, h = [], None
+    for l in range(6):
+        t = fwd_layer(l, h)
+        h, sv = softplus(t)
+        if l < 5:
+            Sg.append(sv)
+    w6h = S_.tail[:128].reshape(2, 64)[H]
+    w6p = S_.tail[128:160].reshape(2, 16)[H]
+    y0 = (w6h * h).sum(1) + (w6p[:, :14] * phi[:, :14]).sum(1)
+    y0 = y0 + y0[LANES ^ 32] + S_.tail[160]
+    delta = sv * w6h
+    accP = w6p.copy(); accE = np.zeros((64, 16))
+    for l in (5, 4, 3, 2, 1):
+        din = frags(delta)[:7 if l == 2 else 8]
+        G = []
+        for t in range(S_.BWD_NT[l]):
+            acc = np.zeros((64, 16)) if t < 4 else (accE if (l == 3 and t == 4) else accP)
+            ci = S_.bwd_chunk(l, t)
+            for ks, b in enumerate(din):
+                mma16(acc, S_.A(ci, ks), b)
+            G.append(acc)
+        delta = Sg[l - 1] * np.concatenate(G[:4], 1)
+    for ks, b in enumerate(frags(delta)):
+        mma16(accE, S_.A(S_.bwd_chunk(0, 0), ks), b)
+    g3 = np.zeros((64, 3))
+    ch = 14 * H[:, None] + np.arange(14)[None, :]
+    for a in range(3):
+        g3[:, a] = (accE[:, :14] * je * ((ch % 3) == a)).sum(1) + (accP[:, :14] * Jl[:, :, a]).sum(1)
+    g3 = g3 + g3[LANES ^ 32]
+    return y0[:32], g3[:32]
+
+
+def test_sdf_bf16x3_pack_matches_oracle(weights, golden_pipe, golden_render):
+    vols, tabs, _, _ = pipeline_views(golden_pipe)
+    pts = golden_render["pts"][100:132].contiguous()
+    layers = O.sdf_weights(weights)
+    packed = ops.sdf_pack_weights_bf16_host(ops.sdf_effective_weights(weights))
+    phi, jphi = O.lookup_sparse_volume(pts, vols, tabs, with_jac=True)
+    sdf_o, grad_o, _ = O.sdf_mlp(layers, pts, phi, jphi)
+    sdf_s, grad_s = sim_sdf_bf16(packed, pts.numpy(), phi.numpy().astype(np.float64), jphi.numpy().astype(np.float64))
+    assert np.abs(sdf_s - sdf_o.numpy()).max() < 2e-5
+    assert np.abs(grad_s - grad_o.numpy()).max() < 2e-4
+
+
+def test_bf16_three_way_split_is_exact():
+    g = np.random.default_rng(0)
+    x = (g.standard_normal(4096) * np.exp(g.uniform(-20, 10, 4096))).astype(np.float32)
+
+    def rne(v):
+        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+        u = u + 0x7FFF + ((u >> 16) & 1)
+        return ((u >> 16).astype(np.uint32) << 16).view(np.float32)
+    p1 = rne(x); r = x - p1; p2 = rne(r); p3 = rne(r - p2)
+    assert np.array_equal((p1.astype(np.float64) + p2 + p3).astype(np.float32), x)
+    assert np.abs(x - (p1 + p2 + p3)).max() == 0.0
