@@ -26,12 +26,18 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE_SDF = 2 * (99240 + 99240)          # forward + reverse-mode gradient MACs x 2
 FLOP_PER_SAMPLE_BLEND_PER_VIEW = 2 * 9928
-FP32_MFMA_PEAK_TFLOPS = 157.3                      # MI355X_MICROARCH.md, chip-level parameters
 CPU_THREADS = min(32, os.cpu_count() or 1)
-SDF_KERNEL = "sdf_mlp_kernel2<true>"               # dominant kernel (csrc/sdf_mlp.hip)
+# Dominant kernel per SDF precision: (kernel name as the profile summaries spell it, matrix pipe, dense peak of that
+# pipe in TFLOP/s from MI355X_MICROARCH.md, MFMA products issued per fp32-equivalent product).  `roofline.peak` is the
+# pipe's dense peak divided by the products per fp32 product: the fp32-equivalent rate the pipe could deliver at best.
+SDF_KERNELS = {
+    "f32": ("sdf_mlp_kernel2<true>", "v_mfma_f32_32x32x2_f32", 157.3, 1),
+    "bf16x3": ("sdf_mlp_split_kernel<PolBf3, true>", "v_mfma_f32_32x32x16_bf16", 2500.0, 6),
+    "f16x2": ("sdf_mlp_split_kernel<PolH2, true>", "v_mfma_f32_32x32x16_f16", 2500.0, 3),
+}
 
 
-def model_conf(n_samples):
+def model_conf(n_samples, sdf_precision="bf16x3"):
     from surf_amd import conf
     return conf.from_dict({
         "sdf_network": {"d_out": 129, "d_in": 3, "d_hidden": 128, "n_layers": 6, "skip_in": [3], "multires": 4,
@@ -39,7 +45,8 @@ def model_conf(n_samples):
                         "feat_multires": 0},
         "color_network": {"d_feature": 16},
         "variance_network": {"init_val": 0.3},
-        "render": {"n_samples": n_samples, "sample_ranges": [1.0, 0.4, 0.1, 0.01], "n_depth": 256, "perturb": 0.0},
+        "render": {"n_samples": n_samples, "sample_ranges": [1.0, 0.4, 0.1, 0.01], "n_depth": 256, "perturb": 0.0,
+                   "sdf_precision": sdf_precision},
     })
 
 
@@ -140,6 +147,11 @@ def main():
     ap.add_argument("--n-samples", type=str, default="64,32,16,16")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline (0 = skip)")
     ap.add_argument("--build", type=int, default=1, help="also time one full volume build (FPN + 4 stages), N=1 only")
+    ap.add_argument("--sdf-precision", default="bf16x3", choices=sorted(SDF_KERNELS),
+                    help="SDF kernel: f32 MFMA, bf16x3 (exact 3-way bf16 split, fp32-equivalent; default), "
+                         "f16x2 (22-bit operands, fastest)")
+    ap.add_argument("--also", default="f16x2", help="comma list of further precisions timed after the headline run "
+                                                    "(reported under other_precisions; '' = none)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,7 +171,7 @@ def main():
     S = sum(n_samples)
     H, W, nv = args.height, args.width, args.views
     torch.manual_seed(0)
-    model = ImplicitSurface(model_conf(n_samples)).to(dev)
+    model = ImplicitSurface(model_conf(n_samples, args.sdf_precision)).to(dev)
 
     # ---- scene (seed = rank), resident in HBM before the timed region ------------------------------------
     seed = rank
@@ -199,10 +211,32 @@ def main():
     kernel_ms = {k: sum(v) / len(v) for k, v in per_kernel.items()}
     active = int(model.last_active_samples)
 
+    # ---- the other SDF precisions on the same scene (N = 1 only; after the timed region, reported separately) ----
+    others = {}
+    if world == 1:
+        for prec in [p for p in args.also.split(",") if p and p != args.sdf_precision]:
+            model.sdf_precision = prec
+            out_o = step()
+            torch.cuda.synchronize()
+            model.kernel_events = []
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                out_o = step()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            ev_o, model.kernel_events = model.kernel_events, None
+            sdf_o = [a.elapsed_time(b) for name, a, b in ev_o if name == "sdf_mlp"]
+            others[prec] = {"rays_per_s": R * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
+                            "sdf_mlp_ms": sum(sdf_o) / len(sdf_o),
+                            "max_abs_rgb_diff_vs_headline": float((out_o["color_fine"] - out["color_fine"]).abs().max())}
+        model.sdf_precision = args.sdf_precision
+
     if rank == 0:
+        sdf_kernel, sdf_pipe, pipe_peak, n_prod = SDF_KERNELS[args.sdf_precision]
         sdf_ms = kernel_ms["sdf_mlp"]
         flops = active * FLOP_PER_SAMPLE_SDF
         achieved = flops / (sdf_ms * 1e-3) / 1e12
+        peak = pipe_peak / n_prod
         result = {
             "metric": "rays/sec (576x800, 5-view, 128 samp/ray render, whole job)",
             "value": world * R * args.steps / elapsed,
@@ -214,18 +248,22 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": {"f32": "f32", "bf16x3": "f32 (operands split exactly into 3 bf16 pieces, fp32 accumulate)",
+                      "f16x2": "f32 accumulate, 22-bit operands (2 fp16 pieces)"}[args.sdf_precision],
             "data": "synthetic",
             "config": {"workload": f"render {H}x{W} ref view, {nv} views, samples {n_samples} (={S}/ray), sphere pyramid "
                                    f"{args.base_dim}^3->{args.base_dim * 8}^3, one scene per GPU",
                        "rays_per_step": R, "samples_per_ray": S, "active_samples": active},
             "per_gpu_rays_per_s": R * args.steps / elapsed,
             "kernel_ms": kernel_ms,
-            "roofline": {"kernel": SDF_KERNEL, "bound": "mfma", "achieved": achieved,
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": pmc_traffic(SDF_KERNEL), "flop_per_sample": FLOP_PER_SAMPLE_SDF, "samples_per_launch": active,
-                         "avg_launch_ms": sdf_ms},
+            "roofline": {"kernel": sdf_kernel, "bound": "mfma", "achieved": achieved,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": pmc_traffic(sdf_kernel), "flop_per_sample": FLOP_PER_SAMPLE_SDF, "samples_per_launch": active,
+                         "avg_launch_ms": sdf_ms, "pipe": sdf_pipe, "pipe_dense_peak": pipe_peak,
+                         "mfma_products_per_fp32_product": n_prod, "frac_of_fp32_mfma_peak": achieved / 157.3},
         }
+        if others:
+            result["other_precisions"] = others
         if world == 1 and args.cpu_seconds > 0:
             n_sub = 8192
             idx = torch.linspace(0, R - 1, n_sub).long()

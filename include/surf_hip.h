@@ -91,10 +91,13 @@ int surf_sdf_mlp(const float* pts, const uint8_t* mask, const int32_t* idx, int6
                  float* sdf, float* grad, void* scratch, void* stream);
 
 /*
- * The same evaluation on the bf16 matrix pipe with fp32-equivalent accuracy: every fp32 operand is split exactly into
- * three bf16 pieces and six partial products are accumulated in fp32 (error ~2^-24 per product).  Arguments as
- * surf_sdf_mlp; `packed` is the output of surf_sdf_pack_weights_bf16 (surf_sdf_bf16_packed_bytes() bytes, device copy),
- * `scratch` >= surf_sdf_bf16_scratch_bytes(n).
+ * The same evaluation on the 16-bit matrix pipes with fp32 accumulation (surf_amd/csrc/sdf_mlp_split.hip).  Arguments
+ * as surf_sdf_mlp; `packed` is the output of the matching surf_sdf_pack_weights_* (…_packed_bytes() bytes, device copy),
+ * `scratch` >= …_scratch_bytes(n).
+ *   bf16x3: every fp32 operand is split exactly into three bf16 pieces and six partial products are accumulated
+ *           (dropped terms <= 2^-23 per product): fp32-equivalent results.
+ *   f16x2:  two fp16 pieces per operand (22 significant bits, second piece scaled by 2^11), three partial products:
+ *           operand error <= 2^-22; activations must stay below 65504 in magnitude.  The fast path.
  */
 int64_t surf_sdf_bf16_packed_bytes(void);
 int64_t surf_sdf_bf16_scratch_bytes(int64_t n_points);
@@ -102,6 +105,12 @@ int surf_sdf_pack_weights_bf16(const float* const* h_W, const float* const* h_b,
 int surf_sdf_mlp_bf16x3(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_vols,
                         const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* sdf,
                         float* grad, void* scratch, void* stream);
+int64_t surf_sdf_f16_packed_bytes(void);
+int64_t surf_sdf_f16_scratch_bytes(int64_t n_points);
+int surf_sdf_pack_weights_f16(const float* const* h_W, const float* const* h_b, unsigned char* h_packed);
+int surf_sdf_mlp_f16x2(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_vols,
+                       const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* sdf,
+                       float* grad, void* scratch, void* stream);
 
 /*
  * Multi-view feature fetch + blending MLP.

@@ -43,9 +43,10 @@ with open(os.path.join(dst, f"{tag}_bench_pmc.csv"), "w") as w:
     w.write("# rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 (one pass per group)\n")
     w.write("# per-launch averages; FETCH_SIZE / WRITE_SIZE in KiB as reported (raw, uncorrected)\n")
     cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
-    w.write("kernel,launches," + ",".join(cols) + "\n")
+    cw = csv.writer(w)
+    cw.writerow(["kernel", "launches"] + cols)
     for k, v in agg.items():
         n = max(len(x) for x in v.values())
-        w.write(k + f",{n}," + ",".join(str(sum(v[c]) / len(v[c])) if c in v else "" for c in cols) + "\n")
+        cw.writerow([k, n] + [str(sum(v[c]) / len(v[c])) if c in v else "" for c in cols])
 print(open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv")).read())
 print(open(os.path.join(dst, f"{tag}_bench_pmc.csv")).read())

@@ -19,8 +19,10 @@ near = near_fars[0, 0].reshape(1, 1).repeat(R, 1).to(dev); far = near_fars[0, 1]
 st = ops.ray_setup(rays_o, rays_d, near, far, mvol, sv, n_samples, [1.0, 0.4, 0.1, 0.01], 256)
 sdf_w, blend_w = model.packed_weights(dev)
 if os.environ.get('SURF_BF16'):
+    os.environ.setdefault('SURF_PREC', 'bf16x3')
+if os.environ.get('SURF_PREC', 'f32') != 'f32':
     sd = {k: v for k, v in model.state_dict().items()}
-    sdf_w = ops.sdf_pack_weights_bf16(sd, dev, 'sdf_network.')
+    sdf_w = ops.sdf_pack_weights_split(sd, dev, 'sdf_network.', os.environ['SURF_PREC'])
 n_act = int(st["vmask"].sum())
 for grad in (False, True):
     for it in range(3):
@@ -29,3 +31,12 @@ for grad in (False, True):
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     flop = n_act * (396960 if grad else 198480)
     print(f"grad={grad}: {dt*1e3:.1f} ms, {flop/dt/1e12:.1f} TFLOP/s algorithmic ({flop/dt/1e12/157.3:.3f} of peak), tiles/s {st['pts'].shape[0]/32/dt:.3e}")
+    from surf_amd import _lib
+    import ctypes
+    L = _lib.lib()
+    if hasattr(L, 'surf_debug_phases'):
+        buf = (ctypes.c_ulonglong * 8)()
+        L.surf_debug_phases(buf, 1)
+        v = list(buf); tot = sum(v) or 1
+        names = ['gather', 'forward', 'tail', 'backward', 'epilogue', 'stage_wait', 'lds_commit', 'barrier']
+        print('  phases (3 runs, wave 0 clocks): ' + ', '.join(f'{n} {x/tot:.3f}' for n, x in zip(names, v)) + f'  total/run/block {tot/3/256:.0f} clk')

@@ -32,6 +32,10 @@ SIGNATURES = {
     "surf_sdf_bf16_scratch_bytes": (c_i64, [c_i64]),
     "surf_sdf_pack_weights_bf16": (c_int, [c_ptr, c_ptr, c_ptr]),
     "surf_sdf_mlp_bf16x3": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_sdf_f16_packed_bytes": (c_i64, []),
+    "surf_sdf_f16_scratch_bytes": (c_i64, [c_i64]),
+    "surf_sdf_pack_weights_f16": (c_int, [c_ptr, c_ptr, c_ptr]),
+    "surf_sdf_mlp_f16x2": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_blend_raw_floats": (c_int, []),
     "surf_blend_packed_floats": (c_int, []),
     "surf_blend_pack_weights": (c_int, [c_ptr, c_ptr]),

@@ -1,0 +1,942 @@
+// K9b: SDF MLP forward + analytic gradient on the 16-bit MFMA pipes with fp32 accumulation ("split" kernels).
+//
+// Same network, same transposed / register-resident chaining as sdf_mlp.hip (see there for the reference citations),
+// but every fp32 operand (weights on the host, activations on the fly) is split into 16-bit pieces and the partial
+// products are accumulated in fp32 by v_mfma_f32_32x32x16_{bf16,f16} (K = 16, 32 cycles) instead of
+// v_mfma_f32_32x32x2_f32 (K = 2, 64 cycles).  Two precisions:
+//
+//   bf16x3  exact three-way split a = a1 + a2 + a3 (8 + 8 + 8 significant bits); six products
+//           a1b1 + a1b2 + a2b1 + a2b2 + a1b3 + a3b1, dropped terms <= 2^-23 |a b|: fp32-equivalent.      2.67x fewer
+//           matrix-pipe cycles than fp32.  One wavefront per SIMD (the three-piece activations need the register file).
+//   f16x2   two-way split a ~= a1 + a2 (11 + 11 significant bits; weights and deltas pre-scaled by 2^8 so that the second
+//           piece stays normal); three products a1b1 + a1b2 + a2b1; operand error <= 2^-22 (or 2^-25 absolute).
+//           5.3x fewer matrix-pipe cycles than fp32; two workgroups per CU.  |activations| must stay below 65504 and
+//           |weights| below 255.
+//
+// The weight stream is consumed several times faster than one wavefront could pull it from L2, so the four wavefronts of
+// a workgroup (one per SIMD) run in lockstep over a double-buffered LDS image of it: one chunk = all k-steps x pieces of
+// one 32-row output tile, filled by LDS-DMA (buffer_load ... lds) one chunk ahead, cyclically across rounds.
+// Softplus, operand splitting and scratch stores of output tile t are issued between the MFMAs of tile t+1.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int HID = 128, NE = 27, H2 = 101, TILE = 32;
+constexpr int BWD_NT[6] = {1, 5, 5, 6, 5, 5};
+constexpr int WPB = 4;
+constexpr int MAX_KS = 12;
+
+// ---- chunk stream ------------------------------------------------------------------------------------------------
+// forward chunk (l, t): k-steps = [e s=0,1 (l = 0, 3)][phi s=0,1 (l >= 1)][hidden (tt, s) ...]: the hidden fragments of
+// the previous layer's last tile are still being converted during the first k-steps of tile 0
+constexpr int fwd_nh(int l) { return l == 0 ? 0 : (l == 3 ? 7 : 8); }
+constexpr int fwd_ne(int l) { return (l == 0 || l == 3) ? 2 : 0; }
+constexpr int fwd_np(int l) { return l == 0 ? 0 : 2; }
+constexpr int fwd_nl(int l) { return fwd_ne(l) + fwd_np(l); }
+constexpr int fwd_ks(int l) { return fwd_nh(l) + fwd_nl(l); }
+constexpr int bwd_ks(int l) { return l == 2 ? 7 : 8; }
+constexpr int N_FWD_CHUNKS = 24;
+constexpr int n_bwd_chunks() { int n = 0; for (int l = 0; l < 6; ++l) n += BWD_NT[l]; return n; }
+constexpr int N_BWD_CHUNKS = n_bwd_chunks();
+constexpr int N_CHUNKS = N_FWD_CHUNKS + N_BWD_CHUNKS;
+
+struct ChunkTable {
+  int off[N_CHUNKS + 1];  // byte offset into the packed stream
+  int ks[N_CHUNKS + 1];
+};
+constexpr ChunkTable make_chunks(int np) {  // one k-step = np pieces x 64 lanes x 16 B
+  ChunkTable c{};
+  int n = 0, o = 0;
+  for (int l = 0; l < 6; ++l)
+    for (int t = 0; t < 4; ++t) { c.off[n] = o; c.ks[n] = fwd_ks(l); o += fwd_ks(l) * np * 1024; ++n; }
+  for (int l = 5; l >= 0; --l)
+    for (int t = 0; t < BWD_NT[l]; ++t) { c.off[n] = o; c.ks[n] = bwd_ks(l); o += bwd_ks(l) * np * 1024; ++n; }
+  c.off[n] = o;
+  c.ks[n] = 0;
+  return c;
+}
+constexpr int fwd_chunk(int l, int t) { return l * 4 + t; }
+constexpr int bwd_chunk(int l, int t) {
+  int n = N_FWD_CHUNKS;
+  for (int i = 5; i > l; --i) n += BWD_NT[i];
+  return n + t;
+}
+// fp32 tail of the packed buffer (floats): W6[0] in lane order, b6
+constexpr int TAIL_W6H = 0;               // [h][64]
+constexpr int TAIL_W6P = TAIL_W6H + 128;  // [h][16]
+constexpr int TAIL_B6 = TAIL_W6P + 32;
+constexpr int TAIL_FLOATS = TAIL_B6 + 4;
+
+// per-wave scratch slot (floats): softplus' of layers 0..4 + feature Jacobian (same layout as sdf_mlp.hip)
+constexpr int SCR_S = 5 * 16 * 64 * 4;
+constexpr int SCR_J = 12 * 64 * 4;
+constexpr int SCR_SLOT = SCR_S + SCR_J;
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NP>
+struct FragT { u32x4 p[NP]; };  // B-operand fragments of a 16-wide k-step: NP pieces x 4 dwords (8 x 16 bit)
+
+// ---- precision policies ----------------------------------------------------------------------------------------------
+#ifndef SURF_X_NOGATHER  // timing experiments only (wrong results)
+#define SURF_X_NOGATHER 0
+#endif
+#ifndef SURF_X_NOSCRATCH
+#define SURF_X_NOSCRATCH 0
+#endif
+#ifndef SURF_BF3_NA  // independent accumulator chains of the bf16x3 policy (a dependent MFMA issues ~10 cycles late)
+#define SURF_BF3_NA 1
+#endif
+
+struct PolBf3 {
+  static constexpr int NP = 3, NA = SURF_BF3_NA, OCC = 1, PF = 1;
+  static constexpr ChunkTable CH = make_chunks(NP);
+  struct Acc { f32x16 v[NA]; };
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    uint32_t u = __builtin_bit_cast(uint32_t, v);
+    asm volatile("" : "+v"(u));  // keep the packed value: the residuals below come from its two halves
+    return u;
+  }
+  static __device__ __forceinline__ void split(float a, float b, uint32_t (&p)[NP]) {
+    p[0] = pack2(a, b);
+    const float ra = a - __builtin_bit_cast(float, p[0] << 16), rb = b - __builtin_bit_cast(float, p[0] & 0xffff0000u);
+    p[1] = pack2(ra, rb);
+    p[2] = pack2(ra - __builtin_bit_cast(float, p[1] << 16), rb - __builtin_bit_cast(float, p[1] & 0xffff0000u));
+  }
+  static __device__ __forceinline__ void mma(Acc& acc, const u32x4 (&a)[NP], const FragT<NP>& b) {
+#define SURF_MF(q, x, y) \
+  acc.v[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[x]), __builtin_bit_cast(bf16x8, b.p[y]), acc.v[q], 0, 0, 0)
+    SURF_MF(0, 2, 0);  // smallest terms first
+    SURF_MF(NA - 1, 0, 2);
+    SURF_MF(0, 1, 1);
+    SURF_MF(NA - 1, 1, 0);
+    SURF_MF(0, 0, 1);
+    SURF_MF(NA - 1, 0, 0);
+#undef SURF_MF
+  }
+  static __device__ __forceinline__ f32x16 finish(const Acc& acc) {
+    if (NA == 1) return acc.v[0];
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = acc.v[0][i] + acc.v[NA - 1][i];
+    return r;
+  }
+};
+
+struct PolH2 {
+#ifndef SURF_H2_PF
+#define SURF_H2_PF 2
+#endif
+  static constexpr int NP = 2, NA = 1, OCC = 2, PF = SURF_H2_PF;
+  static constexpr ChunkTable CH = make_chunks(NP);
+  struct Acc { f32x16 v[NA]; };
+  static __device__ __forceinline__ void split(float a, float b, uint32_t (&p)[NP]) {
+    const f32x2 v = {a, b};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);
+    p[0] = __builtin_bit_cast(uint32_t, h);
+    p[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+  }
+  static __device__ __forceinline__ void mma(Acc& acc, const u32x4 (&a)[NP], const FragT<NP>& b) {
+#define SURF_MF(x, y) \
+  acc.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[x]), __builtin_bit_cast(f16x8, b.p[y]), acc.v[0], 0, 0, 0)
+    SURF_MF(1, 0);
+    SURF_MF(0, 1);
+    SURF_MF(0, 0);
+#undef SURF_MF
+  }
+  static __device__ __forceinline__ f32x16 finish(const Acc& acc) { return acc.v[0]; }
+};
+
+// Power-of-two operand scales (exact): weights and back-propagated deltas are stored x 2^8 so that their second fp16
+// piece stays a normal number down to |v| ~ 5e-4 (activations are O(1) and stay unscaled; their second piece carries an
+// absolute error <= 2^-25).  Accumulators therefore come out x W_SCALE (forward) and x W_SCALE x D_SCALE (backward).
+template <class P> struct Scales { static constexpr float W = 1.0f, D = 1.0f; };
+template <> struct Scales<PolH2> { static constexpr float W = 256.0f, D = 256.0f; };
+
+template <class P> constexpr int stream_bytes() { return P::CH.off[N_CHUNKS]; }
+template <class P> constexpr int slot_bytes() { return MAX_KS * P::NP * 1024; }
+template <class P> constexpr int max_blocks() { return 256 * P::OCC; }
+
+struct SdfArgs {
+  const float* pts;
+  const uint8_t* mask;
+  const int32_t* idx;
+  int64_t n;
+  const float* vols[SURF_MAX_STAGES];
+  const int32_t* tables[SURF_MAX_STAGES];
+  int dims[SURF_MAX_STAGES];
+  const unsigned char* packed;
+  float* sdf;
+  float* grad;
+  float* scratch;
+};
+
+__device__ __forceinline__ f32x4 bload(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, f32x4 v) {  // see sdf_mlp.hip: store-data hazard
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+  asm volatile("s_nop 1");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <class P>
+__device__ __forceinline__ void frag_set_pair(FragT<P::NP>& f, int pair /*0..3*/, float a, float b) {
+  uint32_t p[P::NP];
+  P::split(a, b, p);
+#pragma unroll
+  for (int k = 0; k < P::NP; ++k) f.p[k][pair] = p[k];
+}
+
+// softplus(beta = 100, threshold = 20) and its derivative for a pair of pre-activations given x ACC_SCALE, in the
+// overflow-free form  h = max(t, 0) + log(1 + exp(-|100 t|)) / 100,  h' = (t >= 0 ? 1 : exp(-|100 t|)) / (1 + exp(-|100 t|)),
+// which equals torch's thresholded softplus to fp32 rounding (the linear branch differs from it by < 2^-33 relative).
+template <bool WANT_S>
+__device__ __forceinline__ void softplus_pair(f32x2 acc, float acc_scale_inv, f32x2& hv, f32x2& sv) {
+  const f32x2 arg = acc * (144.269504088896341f * acc_scale_inv);  // 100 log2(e) t
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(-__builtin_fabsf(arg[0]));
+  e[1] = __builtin_amdgcn_exp2f(-__builtin_fabsf(arg[1]));
+  const f32x2 d = e + 1.0f;
+  f32x2 l;
+  l[0] = __builtin_amdgcn_logf(d[0]);
+  l[1] = __builtin_amdgcn_logf(d[1]);
+  f32x2 m;
+  m[0] = fmaxf(acc[0], 0.0f);
+  m[1] = fmaxf(acc[1], 0.0f);
+  if (acc_scale_inv != 1.0f) m = m * acc_scale_inv;
+  hv[0] = fmaf(l[0], 0.69314718055994531f * 0.01f, m[0]);
+  hv[1] = fmaf(l[1], 0.69314718055994531f * 0.01f, m[1]);
+  if (WANT_S) {
+    f32x2 r, sel;
+    r[0] = __builtin_amdgcn_rcpf(d[0]);
+    r[1] = __builtin_amdgcn_rcpf(d[1]);
+    sel[0] = acc[0] >= 0.0f ? 1.0f : e[0];
+    sel[1] = acc[1] >= 0.0f ? 1.0f : e[1];
+    sv = sel * r;
+  }
+}
+
+#ifdef SURF_SDF_TIMING  // debug builds only: per-phase shader-clock totals of wavefront 0 of every workgroup
+__device__ unsigned long long g_phase[8];
+#define SURF_T(k)                                                 \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    c.tacc[k] += now_ - c.tprev;                                  \
+    c.tprev = now_;                                               \
+  } while (0)
+#else
+#define SURF_T(k)
+#endif
+
+struct Ctx {
+#ifdef SURF_SDF_TIMING
+  mutable unsigned long long tprev;
+  mutable unsigned long long tacc[8];
+#endif
+  rsrc_t wr, sr, sl, tr;  // packed stream, scratch (stores / loads), fp32 tail
+  int lane, lane16, h, svoff, wave;
+  char* lds;  // three slots
+};
+
+// ---- staging ------------------------------------------------------------------------------------------------------------
+// The chunk stream is cyclic over rounds and lives in a ring of three LDS slots (chunk CI in slot CI % 3; both stream
+// lengths are multiples of 3).  While chunk CI is consumed, chunk CI+2 is in flight by LDS-DMA (buffer_load ... lds,
+// 1 KB per instruction, lane-linear image) and chunk CI+1 is retired at the end of chunk CI by a counted vmcnt.
+// vmcnt retires in issue order, so everything older than that DMA has to be complete too: two chunks of slack keep the
+// softplus' stores of the previous chunk (acknowledged late by L2) out of that wait.
+template <class P, int CI>
+__device__ __forceinline__ void stage_dma(const Ctx& c) {
+  constexpr int NB = P::CH.ks[CI] * P::NP;
+  constexpr int OFF = P::CH.off[CI];
+  // blocks past the end of a chunk read into the next one / out of range (= 0) and land in the unused tail of the slot
+#pragma unroll
+  for (int k = 0; 4 * k < NB; ++k) {
+    const int blk = c.wave + 4 * k;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+        c.wr, (__attribute__((address_space(3))) void*)(c.lds + (CI % 3) * slot_bytes<P>() + blk * 1024), 16, c.lane16,
+        OFF + blk * 1024, 0, 0);
+  }
+}
+template <class P> constexpr int n_dma(int ci) { return (P::CH.ks[ci] * P::NP + 3) / 4; }
+// vector-memory operations a chunk issues by itself, in order: [pre: loads before its DMA] [DMA] [post: stores in fn]
+template <bool GRAD> constexpr int vm_pre(int ci) {
+  if (ci < N_FWD_CHUNKS) return (ci / 4 == 5 && ci % 4 > 0) ? 4 : 0;  // W6 slices
+  int l = 5, t = ci - N_FWD_CHUNKS;
+  while (t >= BWD_NT[l]) { t -= BWD_NT[l]; --l; }
+  return (l >= 1 && t < 4) ? 4 : 0;  // softplus' slices
+}
+template <bool GRAD> constexpr int vm_post(int ci) {
+  if (!GRAD || ci >= N_FWD_CHUNKS) return 0;
+  const int l = ci / 4, t = ci % 4;
+  return ((l == 0 && t == 0) || (l == 5 && t > 0)) ? 0 : 4;
+}
+// Retire the DMA of chunk CI+1, issued at the top of chunk CI-1: everything this wave issued after it may stay in flight
+// (operations between rounds are not counted, which only makes the wait stricter).  Then the LDS-only workgroup barrier.
+template <class P, bool GRAD, int CI, int NCH>
+__device__ __forceinline__ void stage_barrier() {
+  constexpr int PREV = (CI + NCH - 1) % NCH;
+  constexpr int N = (CI == 0 ? 0 : vm_post<GRAD>(PREV)) + vm_pre<GRAD>(CI) + n_dma<P>((CI + 2) % NCH) + vm_post<GRAD>(CI);
+  static_assert(N >= 0 && N < 64, "vmcnt");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// One chunk: NKS k-steps read from its LDS slot; B fragments come from bsel(ks); fn(ks) = VALU work to interleave.
+template <class P, bool GRAD, int CI, int NCH, class BSel, class F>
+__device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F fn) {
+  constexpr int NKS = P::CH.ks[CI];
+  constexpr int NP = P::NP;
+  const char* rd = c.lds + (CI % 3) * slot_bytes<P>() + c.lane16;
+  typename P::Acc acc;
+#pragma unroll
+  for (int q = 0; q < P::NA; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc.v[q][r] = 0.f;
+  constexpr int PF = P::PF;  // A fragments are read PF k-steps ahead of their MFMAs
+  u32x4 a_q[PF + 1][NP];
+#pragma unroll
+  for (int d = 0; d < PF; ++d)
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+      if (d < NKS) a_q[d][p] = *reinterpret_cast<const u32x4*>(rd + (d * NP + p) * 1024);
+  stage_dma<P, (CI + 2) % NCH>(c);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if (ks + PF < NKS) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p)
+        a_q[(ks + PF) % (PF + 1)][p] = *reinterpret_cast<const u32x4*>(rd + ((ks + PF) * NP + p) * 1024);
+    }
+    P::mma(acc, a_q[ks % (PF + 1)], bsel(ks));
+    fn(ks);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  SURF_T(CI < N_FWD_CHUNKS ? 1 : 3);
+  stage_barrier<P, GRAD, CI, NCH>();
+  SURF_T(7);
+  return P::finish(acc);
+}
+
+// ---- gather / posenc (identical arithmetic to sdf_mlp.hip) -------------------------------------------------------------
+// Sparse trilinear gather of this lane half's two pyramid levels: phi[7 sl + ch], and (GRAD) the feature Jacobian of each
+// level straight to the wave's scratch slot (6 x 16 B per level: [ch][axis], 21 values + pad) to keep registers free.
+template <bool GRAD>
+__device__ __forceinline__ void gather_features(const SdfArgs& a, const Ctx& c, float px, float py, float pz, float (&phi)[16]) {
+#pragma unroll
+  for (int ch = 0; ch < 16; ++ch) phi[ch] = 0.f;
+  int rows[2][8];
+  float tx[2], ty[2], tz[2], inv_vs[2];
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int st = 2 * c.h + sl;
+    const int D = a.dims[st];
+    const int32_t* __restrict__ table = a.tables[st];
+    const float vs = 2.0f / ((float)D - 1.0f);
+    inv_vs[sl] = 1.0f / vs;
+    const float gx = (px + 1.0f) / vs, gy = (py + 1.0f) / vs, gz = (pz + 1.0f) / vs;
+    const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+    tx[sl] = gx - fx; ty[sl] = gy - fy; tz[sl] = gz - fz;
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int xi = min(max(x0 + (k >> 2), 0), D - 1);
+      const int yi = min(max(y0 + ((k >> 1) & 1), 0), D - 1);
+      const int zi = min(max(z0 + (k & 1), 0), D - 1);
+      rows[sl][k] = D > 0 ? table[((int64_t)xi * D + yi) * D + zi] : -1;
+    }
+  }
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const float* __restrict__ vol = a.vols[2 * c.h + sl];
+    f32x4 f0[8], f1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const f32x4* fr = reinterpret_cast<const f32x4*>(vol + (int64_t)max(rows[sl][k], 0) * 8);
+      f0[k] = fr[0];
+      f1[k] = fr[1];
+    }
+    float Jl[24];
+#pragma unroll
+    for (int q = 0; q < 24; ++q) Jl[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int dx = k >> 2, dy = (k >> 1) & 1, dz = k & 1;
+      const float ok = rows[sl][k] >= 0 ? 1.0f : 0.0f;
+      const float wx = dx ? tx[sl] : 1.0f - tx[sl];
+      const float wy = dy ? ty[sl] : 1.0f - ty[sl];
+      const float wz = dz ? tz[sl] : 1.0f - tz[sl];
+      const float w = wx * wy * wz * ok;
+      const float f[7] = {f0[k][0], f0[k][1], f0[k][2], f0[k][3], f1[k][0], f1[k][1], f1[k][2]};
+      float cx = 0.f, cy = 0.f, cz = 0.f;
+      if (GRAD) {
+        cx = ((dx ? 1.0f : -1.0f) * wy * wz) * (inv_vs[sl] * ok);
+        cy = ((dy ? 1.0f : -1.0f) * wx * wz) * (inv_vs[sl] * ok);
+        cz = ((dz ? 1.0f : -1.0f) * wx * wy) * (inv_vs[sl] * ok);
+      }
+#pragma unroll
+      for (int ch = 0; ch < 7; ++ch) {
+        phi[7 * sl + ch] += f[ch] * w;
+        if (GRAD) {
+          Jl[3 * ch + 0] += f[ch] * cx;
+          Jl[3 * ch + 1] += f[ch] * cy;
+          Jl[3 * ch + 2] += f[ch] * cz;
+        }
+      }
+    }
+    if (GRAD) {
+#pragma unroll
+      for (int g = 0; g < 6; ++g) {
+        const f32x4 v = {Jl[4 * g], Jl[4 * g + 1], Jl[4 * g + 2], Jl[4 * g + 3]};
+        bstore(c.sr, c.svoff, SCR_S * 4 + (6 * sl + g) * 1024, v);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void posenc_half(int h, float x, float y, float z, float (&e)[16], float (&je)[14], bool want_j) {
+  float all[28], jall[28];
+  all[0] = x; all[1] = y; all[2] = z;
+  jall[0] = jall[1] = jall[2] = 1.0f;
+  const float p[3] = {x, y, z};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float s, co;
+    sincosf(p[c], &s, &co);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float f = (float)(1 << k);
+      all[3 + 6 * k + c] = s;
+      all[3 + 6 * k + 3 + c] = co;
+      jall[3 + 6 * k + c] = f * co;
+      jall[3 + 6 * k + 3 + c] = -f * s;
+      const float s2 = 2.0f * s * co;
+      const float c2 = fmaf(-2.0f * s, s, 1.0f);
+      s = s2;
+      co = c2;
+    }
+  }
+  all[27] = 0.f; jall[27] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    e[s] = h ? all[14 + s] : all[s];
+    if (want_j) je[s] = h ? jall[14 + s] : jall[s];
+  }
+  e[14] = e[15] = 0.f;
+}
+
+// 16 local channels (14 data + the bias one + pad) -> two k-step fragments
+template <class P>
+__device__ __forceinline__ void local_frags(const float (&v)[16], FragT<P::NP> (&f)[2]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) frag_set_pair<P>(f[s], pr, v[8 * s + 2 * pr], v[8 * s + 2 * pr + 1]);
+}
+
+// ---- forward tile (layer L, tile T) -----------------------------------------------------------------------------------
+// hin/hout: fragments of the 128 hidden activations: index 2*tile + s.  `raw` = pre-activations of the tile finished
+// before this one; they are converted under this tile's MFMAs (two elements per k-step).
+template <class P, bool GRAD, int L, int T>
+__device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>* hin, FragT<P::NP>* hout,
+                                         const FragT<P::NP> (&ef)[2], const FragT<P::NP> (&pf)[2], FragT<P::NP>* dfr,
+                                         float& y0) {
+  typedef FragT<P::NP> Frag;
+  constexpr int CI = fwd_chunk(L, T);
+  constexpr int NEk = fwd_ne(L), NL = fwd_nl(L);
+  constexpr bool LAST = (L == 5 && T > 0);          // previous tile belongs to layer 5: feeds lin6 row 0 directly
+  constexpr bool CONV = !(L == 0 && T == 0);         // there is a previous tile to convert
+  constexpr int STORES = (GRAD && CONV && !LAST) ? 4 : 0;
+  const f32x16 prev = raw;
+  f32x4 w6[4];
+  if (LAST) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) w6[g] = bload(c.tr, c.h * 256, (TAIL_W6H * 4) + ((T - 1) * 4 + g) * 16);
+  }
+  f32x4 sbuf = {0.f, 0.f, 0.f, 0.f};
+  // element pair (2q, 2q+1) of the previous tile
+  auto cvt_pair = [&](int q, Frag* dst, int dst_tile, int s_layer) __attribute__((always_inline)) {
+    f32x2 hv, sv;
+    const f32x2 t2 = {prev[2 * q], prev[2 * q + 1]};
+    softplus_pair<GRAD>(t2, 1.0f / Scales<P>::W, hv, sv);
+    const int el = 2 * q;
+    if (LAST) {
+      const float w0 = w6[el >> 2][el & 3], w1 = w6[(el + 1) >> 2][(el + 1) & 3];
+      y0 = fmaf(w0, hv[0], y0);
+      y0 = fmaf(w1, hv[1], y0);
+      if (GRAD)
+        frag_set_pair<P>(dfr[2 * dst_tile + (el >> 3)], (el & 7) >> 1, sv[0] * (w0 * Scales<P>::D), sv[1] * (w1 * Scales<P>::D));
+    } else {
+      frag_set_pair<P>(dst[2 * dst_tile + (el >> 3)], (el & 7) >> 1, hv[0], hv[1]);
+      sbuf[el & 3] = sv[0];
+      sbuf[(el & 3) + 1] = sv[1];
+      if (GRAD && (el & 3) == 2) bstore(c.sr, c.svoff, s_layer * 16384 + (dst_tile * 4 + (el >> 2)) * 1024, sbuf);
+    }
+  };
+  auto fn = [&](int ks) __attribute__((always_inline)) {
+    if (L == 0) {
+      if (T > 0 && ks < 2) {  // only two k-steps per tile in layer 0: four pairs each
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cvt_pair(4 * ks + u, hout, T - 1, 0);
+      }
+    } else if (ks < 8) {  // T == 0: tile 3 of the previous layer, first needed by hidden k-step 6 (position >= 8)
+      if (T == 0) cvt_pair(ks, hin, 3, L - 1);
+      else cvt_pair(ks, hout, T - 1, L);
+    }
+  };
+  auto bsel = [&](int ks) __attribute__((always_inline)) -> const Frag& {
+    if (ks < NEk) return ef[ks];
+    if (ks < NL) return pf[ks - NEk];
+    return hin[ks - NL];
+  };
+  static_assert(STORES == vm_post<GRAD>(CI) && (LAST ? 4 : 0) == vm_pre<GRAD>(CI), "vmcnt bookkeeping");
+  raw = run_chunk<P, GRAD, CI, GRAD ? N_CHUNKS : N_FWD_CHUNKS>(c, bsel, fn);
+}
+
+template <class P, bool GRAD, int L>
+__device__ __forceinline__ void fwd_layer(const Ctx& c, f32x16& raw, FragT<P::NP>* hin, FragT<P::NP>* hout,
+                                          const FragT<P::NP> (&ef)[2], const FragT<P::NP> (&pf)[2], FragT<P::NP>* dfr,
+                                          float& y0) {
+  fwd_tile<P, GRAD, L, 0>(c, raw, hin, hout, ef, pf, dfr, y0);
+  fwd_tile<P, GRAD, L, 1>(c, raw, hin, hout, ef, pf, dfr, y0);
+  fwd_tile<P, GRAD, L, 2>(c, raw, hin, hout, ef, pf, dfr, y0);
+  fwd_tile<P, GRAD, L, 3>(c, raw, hin, hout, ef, pf, dfr, y0);
+}
+
+// ---- backward tiles ----------------------------------------------------------------------------------------------------
+// G (= W^T delta) of hidden tile T is multiplied by softplus' and split under the MFMAs of the tile that follows it.
+struct BwdPend {
+  f32x16 G;
+  f32x4 s[4];
+};
+template <class P, int L, int T, bool CONVERT>
+__device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, const BwdPend& prev) {
+  typedef FragT<P::NP> Frag;
+  constexpr int CI = bwd_chunk(L, T);
+  constexpr int NKS = bwd_ks(L);
+  auto cvt = [&](int q) __attribute__((always_inline)) {
+    const int el = 2 * q;
+    constexpr float inv_w = 1.0f / Scales<P>::W;  // G arrives x W_SCALE x D_SCALE, deltas are kept x D_SCALE
+    float d0 = prev.s[el >> 2][el & 3] * prev.G[el], d1 = prev.s[(el + 1) >> 2][(el + 1) & 3] * prev.G[el + 1];
+    if (inv_w != 1.0f) { d0 *= inv_w; d1 *= inv_w; }
+    frag_set_pair<P>(dout[2 * (T - 1) + (el >> 3)], (el & 7) >> 1, d0, d1);
+  };
+  auto fn = [&](int ks) __attribute__((always_inline)) {
+    if (CONVERT) {
+      cvt(ks);
+      if (NKS == 7 && ks == 6) cvt(7);
+    }
+  };
+  return run_chunk<P, true, CI, N_CHUNKS>(c, [&](int ks) __attribute__((always_inline)) -> const Frag& { return din[ks]; }, fn);
+}
+template <class P, int L, int T>
+__device__ __forceinline__ void bwd_hidden_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, BwdPend& pend) {
+  BwdPend cur;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) cur.s[g] = bload(c.sl, c.svoff, (L - 1) * 16384 + (T * 4 + g) * 1024);
+  const BwdPend prev = pend;
+  cur.G = bwd_tile<P, L, T, (T > 0)>(c, din, dout, prev);
+  pend = cur;
+}
+template <class P, int L>
+__device__ __forceinline__ void bwd_layer(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, f32x16& accE,
+                                          f32x16& accP) {
+  BwdPend pend = {};
+  bwd_hidden_tile<P, L, 0>(c, din, dout, pend);
+  bwd_hidden_tile<P, L, 1>(c, din, dout, pend);
+  bwd_hidden_tile<P, L, 2>(c, din, dout, pend);
+  bwd_hidden_tile<P, L, 3>(c, din, dout, pend);
+  if (L == 3) {
+    accE += bwd_tile<P, L, 4, true>(c, din, dout, pend);
+    accP += bwd_tile<P, L, 5, false>(c, din, dout, pend);
+  } else {
+    accP += bwd_tile<P, L, 4, true>(c, din, dout, pend);
+  }
+}
+
+template <class P, bool GRAD>
+__global__ __launch_bounds__(WPB * 64, P::OCC) void sdf_mlp_split_kernel(SdfArgs a) {
+  typedef FragT<P::NP> Frag;
+  __shared__ __attribute__((aligned(16))) char lds[3 * slot_bytes<P>()];
+  static_assert(N_CHUNKS % 3 == 0 && N_FWD_CHUNKS % 3 == 0, "slot of a chunk = index % 3");
+  constexpr int NCH = GRAD ? N_CHUNKS : N_FWD_CHUNKS;
+  Ctx c;
+  c.lane = threadIdx.x & 63;
+  c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  c.h = c.lane >> 5;
+  c.lane16 = c.lane * 16;
+  c.lds = lds;
+  c.wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, stream_bytes<P>(), 0x00020000);
+  c.tr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.packed + stream_bytes<P>()), 0, TAIL_FLOATS * 4, 0x00020000);
+  c.sr = __builtin_amdgcn_make_buffer_rsrc((void*)a.scratch, 0, (GRAD && !(SURF_X_NOSCRATCH & 1)) ? 0x7fffffff : 0, 0x00020000);
+  c.sl = __builtin_amdgcn_make_buffer_rsrc((void*)a.scratch, 0, (GRAD && !(SURF_X_NOSCRATCH & 2)) ? 0x7fffffff : 0, 0x00020000);
+  const int64_t wave_id = (int64_t)blockIdx.x * WPB + c.wave;
+  c.svoff = (int)(wave_id * (SCR_SLOT * 4)) + c.lane * 16;
+  const int64_t n_tiles = (a.n + TILE - 1) / TILE;
+  const int64_t n_rounds = (n_tiles + WPB - 1) / WPB;
+
+  // stream prologue: chunks 0 and 1 (later rounds inherit them from the last two chunks of the round before)
+  stage_dma<P, 0>(c);
+  stage_dma<P, 1>(c);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef SURF_SDF_TIMING
+  c.tprev = __builtin_readcyclecounter();
+  for (int k = 0; k < 8; ++k) c.tacc[k] = 0;
+#endif
+  for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
+    const int64_t tile = round * WPB + c.wave;
+    const int64_t slot0 = tile * TILE + (c.lane & 31);
+    const int64_t sc = slot0 < a.n ? slot0 : a.n - 1;
+    const int64_t i = a.idx ? (int64_t)a.idx[sc] : sc;
+    const bool active = (slot0 < a.n) && (!a.mask || a.mask[i] != 0);
+    const float px = a.pts[i * 3 + 0], py = a.pts[i * 3 + 1], pz = a.pts[i * 3 + 2];
+
+    Frag ef[2], pf[2];
+    float y0 = 0.f;
+    {
+      float phi[16], e[16];
+      if (SURF_X_NOGATHER) {
+#pragma unroll
+        for (int ch = 0; ch < 16; ++ch) phi[ch] = px * (float)ch;
+      } else {
+        gather_features<GRAD>(a, c, px, py, pz, phi);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // feature part of the last layer
+        const f32x4 w = bload(c.tr, c.h * 64, TAIL_W6P * 4 + g * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (4 * g + q < 14) y0 = fmaf(w[q], phi[4 * g + q], y0);
+      }
+      float je_unused[14];
+      posenc_half(c.h, px, py, pz, e, je_unused, false);
+      e[14] = 1.0f;  // bias k-element (weights carry the bias there, lane half 0 only)
+      phi[14] = 1.0f;
+      local_frags<P>(e, ef);
+      local_frags<P>(phi, pf);
+    }
+    SURF_T(0);
+
+    // ------------------------------------------------ forward ----------------------------------------------------
+    Frag hA[8], hB[8], dA[8];
+    f32x16 raw;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) raw[r] = 0.f;
+    fwd_layer<P, GRAD, 0>(c, raw, hA, hA, ef, pf, dA, y0);
+    fwd_layer<P, GRAD, 1>(c, raw, hA, hB, ef, pf, dA, y0);
+    fwd_layer<P, GRAD, 2>(c, raw, hB, hA, ef, pf, dA, y0);
+    fwd_layer<P, GRAD, 3>(c, raw, hA, hB, ef, pf, dA, y0);
+    fwd_layer<P, GRAD, 4>(c, raw, hB, hA, ef, pf, dA, y0);
+    fwd_layer<P, GRAD, 5>(c, raw, hA, hB, ef, pf, dA, y0);
+    SURF_T(1);
+    {  // tile 3 of layer 5
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 w = bload(c.tr, c.h * 256, TAIL_W6H * 4 + (12 + g) * 16);
+        f32x2 hv[2], sv[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x2 t2 = {raw[4 * g + 2 * q], raw[4 * g + 2 * q + 1]};
+          softplus_pair<GRAD>(t2, 1.0f / Scales<P>::W, hv[q], sv[q]);
+          y0 = fmaf(w[2 * q], hv[q][0], y0);
+          y0 = fmaf(w[2 * q + 1], hv[q][1], y0);
+          if (GRAD)
+            frag_set_pair<P>(dA[6 + (g >> 1)], 2 * (g & 1) + q, sv[q][0] * (w[2 * q] * Scales<P>::D),
+                             sv[q][1] * (w[2 * q + 1] * Scales<P>::D));
+        }
+      }
+    }
+    y0 += __shfl_xor(y0, 32);
+    {
+      const f32x4 b6 = bload(c.tr, 0, TAIL_B6 * 4);
+      y0 += b6[0];
+    }
+    if (active && c.h == 0) a.sdf[i] = y0;
+    SURF_T(2);
+    if (GRAD) {
+      // ---------------------------------------------- reverse sweep ----------------------------------------------
+      f32x16 accE, accP;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accE[r] = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 w = bload(c.tr, c.h * 64, TAIL_W6P * 4 + g * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) accP[4 * g + q] = w[q] * (Scales<P>::W * Scales<P>::D);
+      }
+      bwd_layer<P, 5>(c, dA, hA, accE, accP);
+      bwd_layer<P, 4>(c, hA, dA, accE, accP);
+      bwd_layer<P, 3>(c, dA, hA, accE, accP);
+      bwd_layer<P, 2>(c, hA, dA, accE, accP);
+      bwd_layer<P, 1>(c, dA, hA, accE, accP);
+      {
+        const BwdPend none = {};
+        accE += bwd_tile<P, 0, 0, false>(c, hA, dA, none);
+      }
+      SURF_T(3);
+      float g3[3] = {0.f, 0.f, 0.f};
+      {
+        float e2[16], je[14];
+        posenc_half(c.h, px, py, pz, e2, je, true);
+#pragma unroll
+        for (int s2 = 0; s2 < 14; ++s2) {
+          const int c0 = s2 % 3, c1 = (14 + s2) % 3;
+          const float v = accE[s2] * je[s2];
+#pragma unroll
+          for (int ax = 0; ax < 3; ++ax) g3[ax] += ((c.h ? c1 : c0) == ax) ? v : 0.f;
+        }
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          float Jf[24];
+#pragma unroll
+          for (int g = 0; g < 6; ++g) {
+            const f32x4 v = bload(c.sl, c.svoff, SCR_S * 4 + (6 * sl + g) * 1024);
+            Jf[4 * g + 0] = v[0]; Jf[4 * g + 1] = v[1]; Jf[4 * g + 2] = v[2]; Jf[4 * g + 3] = v[3];
+          }
+#pragma unroll
+          for (int ch = 0; ch < 7; ++ch) {
+#pragma unroll
+            for (int ax = 0; ax < 3; ++ax) g3[ax] = fmaf(accP[7 * sl + ch], Jf[3 * ch + ax], g3[ax]);
+          }
+        }
+      }
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) g3[ax] = (g3[ax] + __shfl_xor(g3[ax], 32)) * (1.0f / (Scales<P>::W * Scales<P>::D));
+      if (active && c.h == 0) {
+        a.grad[i * 3 + 0] = g3[0];
+        a.grad[i * 3 + 1] = g3[1];
+        a.grad[i * 3 + 2] = g3[2];
+      }
+      SURF_T(4);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (unused) prefetches must land before the LDS is freed
+#ifdef SURF_SDF_TIMING
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_phase[k], c.tacc[k]);
+#endif
+}
+
+template <class P>
+int grid_blocks(int64_t n) {
+  int64_t tiles = (n + TILE - 1) / TILE;
+  int64_t rounds = (tiles + WPB - 1) / WPB;
+  return (int)(rounds < max_blocks<P>() ? rounds : max_blocks<P>());
+}
+
+// ---- host packer ------------------------------------------------------------------------------------------------------
+inline uint16_t bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline uint16_t f16_bits(float v) {
+  _Float16 h = (_Float16)v;  // round to nearest even
+  uint16_t b;
+  memcpy(&b, &h, 2);
+  return b;
+}
+inline float f16_to_f(uint16_t b) {
+  _Float16 h;
+  memcpy(&h, &b, 2);
+  return (float)h;
+}
+template <class P> void split_host(float v, uint16_t* p);
+template <> void split_host<PolBf3>(float v, uint16_t* p) {
+  p[0] = bf16_rne(v);
+  float r = v - bf16_to_f(p[0]);
+  p[1] = bf16_rne(r);
+  r = r - bf16_to_f(p[1]);
+  p[2] = bf16_rne(r);
+}
+template <> void split_host<PolH2>(float v, uint16_t* p) {
+  p[0] = f16_bits(v);
+  p[1] = f16_bits(v - f16_to_f(p[0]));
+}
+inline int frag_feat(int tt, int s, int j, int h) { return 32 * tt + 16 * s + (j & 3) + 8 * (j >> 2) + 4 * h; }
+
+// h_W / h_b: effective (weight-normed) fp32 matrices lin0..lin6, as for surf_sdf_pack_weights.
+template <class P>
+int pack_weights(const float* const* h_W, const float* const* h_b, unsigned char* out) {
+  if (!h_W || !h_b || !out) return SURF_E_ARG;
+  for (int l = 0; l < 7; ++l)
+    if (!h_W[l] || !h_b[l]) return SURF_E_ARG;
+  constexpr int NP = P::NP;
+  const int in_dim[7] = {NE, 156, 156, 156, 156, 156, 156};
+  const int out_dim[6] = {HID, HID, H2, HID, HID, HID};
+  const float rsqrt2 = (float)(1.0 / sqrt(2.0));
+  memset(out, 0, stream_bytes<P>() + TAIL_FLOATS * 4);
+  auto put = [&](int chunk, int ks, int lane, int j, float v) {
+    uint16_t p[NP];
+    split_host<P>(v * Scales<P>::W, p);
+    for (int pc = 0; pc < NP; ++pc) {
+      uint16_t* dst = reinterpret_cast<uint16_t*>(out + P::CH.off[chunk] + (ks * NP + pc) * 1024 + lane * 16);
+      dst[j] = p[pc];
+    }
+  };
+  // ---- forward
+  for (int l = 0; l < 6; ++l)
+    for (int t = 0; t < 4; ++t) {
+      const int ci = fwd_chunk(l, t);
+      const int hid_in = (l == 3) ? H2 : HID;
+      for (int ks = 0; ks < fwd_ks(l); ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int h = lane >> 5, row = 32 * t + (lane & 31);
+            int col = -1;
+            float scale = 1.f;
+            bool is_bias = false;
+            if (ks < fwd_ne(l)) {
+              const int cidx = 8 * ks + j;
+              if (cidx < 14 && 14 * h + cidx < NE) col = (l == 3 ? H2 : 0) + 14 * h + cidx;
+              if (l == 3) scale = rsqrt2;
+              if (l == 0) is_bias = (cidx == 14 && h == 0);
+            } else if (ks < fwd_nl(l)) {
+              const int cidx = 8 * (ks - fwd_ne(l)) + j;
+              if (cidx < 14) col = 128 + 14 * h + cidx;
+              is_bias = (cidx == 14 && h == 0);
+            } else {
+              const int hk = ks - fwd_nl(l);
+              const int f = frag_feat(hk >> 1, hk & 1, j, h);
+              if (f < hid_in) col = f;
+              if (l == 3) scale = rsqrt2;
+            }
+            float v = 0.f;
+            if (col >= 0 && row < out_dim[l]) v = h_W[l][(int64_t)row * in_dim[l] + col] * scale;
+            if (is_bias && row < out_dim[l]) v = h_b[l][row];
+            put(ci, ks, lane, j, v);
+          }
+    }
+  // ---- backward: G_in = W_l^T delta_l
+  for (int l = 0; l < 6; ++l)
+    for (int t = 0; t < BWD_NT[l]; ++t) {
+      const int ci = bwd_chunk(l, t);
+      const int hid_in = (l == 3) ? H2 : HID;
+      for (int ks = 0; ks < bwd_ks(l); ++ks)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int h = lane >> 5, rho = lane & 31;
+            const int krow = frag_feat(ks >> 1, ks & 1, j, h);
+            const int h_row = (rho >> 2) & 1, r_row = (rho & 3) | ((rho >> 3) << 2);
+            const int ch = 14 * h_row + r_row;
+            int kind;  // 0 hidden, 1 E, 2 P
+            if (l == 0) kind = 1;
+            else if (t < 4) kind = 0;
+            else if (l == 3 && t == 4) kind = 1;
+            else kind = 2;
+            int col = -1;
+            float scale = 1.f;
+            if (kind == 0) {
+              const int cc = 32 * t + rho;
+              if (cc < hid_in) col = cc;
+              if (l == 3) scale = rsqrt2;
+            } else if (kind == 1) {
+              if (r_row < 14 && ch < NE) col = (l == 3 ? H2 : 0) + ch;
+              if (l == 3) scale = rsqrt2;
+            } else {
+              if (r_row < 14) col = 128 + ch;
+            }
+            float v = 0.f;
+            if (col >= 0 && krow < out_dim[l]) v = h_W[l][(int64_t)krow * in_dim[l] + col] * scale;
+            put(ci, ks, lane, j, v);
+          }
+    }
+  // ---- fp32 tail: last layer row 0
+  float* tail = reinterpret_cast<float*>(out + stream_bytes<P>());
+  auto hk = [](int tt, int r, int h) { return 32 * tt + (r & 3) + 8 * (r >> 2) + 4 * h; };
+  for (int h = 0; h < 2; ++h) {
+    for (int s = 0; s < 64; ++s) tail[TAIL_W6H + h * 64 + s] = h_W[6][hk(s / 16, s % 16, h)];
+    for (int s = 0; s < 14; ++s) tail[TAIL_W6P + h * 16 + s] = h_W[6][128 + 14 * h + s];
+  }
+  tail[TAIL_B6] = h_b[6][0];
+  return 0;
+}
+
+template <class P>
+int launch(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_vols,
+           const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* sdf, float* grad,
+           void* scratch, void* stream) {
+  if (!pts || !h_vols || !h_tables || !h_dims || !packed || !sdf) return SURF_E_ARG;
+  if (n <= 0 || n_vol <= 0) return SURF_E_ARG;
+  if (n_vol > SURF_MAX_STAGES) return SURF_E_LIMIT;
+  if (grad && !scratch) return SURF_E_ARG;
+  SdfArgs a;
+  a.pts = pts; a.mask = mask; a.idx = idx; a.n = n; a.packed = (const unsigned char*)packed; a.sdf = sdf; a.grad = grad;
+  a.scratch = (float*)scratch;
+  for (int s = 0; s < SURF_MAX_STAGES; ++s) {
+    a.vols[s] = s < n_vol ? h_vols[s] : h_vols[0];
+    a.tables[s] = s < n_vol ? h_tables[s] : nullptr;
+    a.dims[s] = s < n_vol ? h_dims[s] : 0;
+    if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
+  }
+  dim3 grid(grid_blocks<P>(n)), block(WPB * 64);
+  if (grad)
+    hipLaunchKernelGGL((sdf_mlp_split_kernel<P, true>), grid, block, 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((sdf_mlp_split_kernel<P, false>), grid, block, 0, (hipStream_t)stream, a);
+  return surf_check_launch();
+}
+
+template <class P>
+int64_t scratch_bytes(int64_t n_points) {
+  if (n_points <= 0) return 0;
+  return (int64_t)grid_blocks<P>(n_points) * WPB * SCR_SLOT * sizeof(float);
+}
+
+}  // namespace
+
+#ifdef SURF_SDF_TIMING
+extern "C" int surf_debug_phases(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 8) != hipSuccess) return 100;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(z)) != hipSuccess) return 100;
+  }
+  return 0;
+}
+#endif
+
+extern "C" int64_t surf_sdf_bf16_packed_bytes(void) { return stream_bytes<PolBf3>() + TAIL_FLOATS * 4; }
+extern "C" int64_t surf_sdf_bf16_scratch_bytes(int64_t n_points) { return scratch_bytes<PolBf3>(n_points); }
+extern "C" int surf_sdf_pack_weights_bf16(const float* const* h_W, const float* const* h_b, unsigned char* out) {
+  return pack_weights<PolBf3>(h_W, h_b, out);
+}
+extern "C" int surf_sdf_mlp_bf16x3(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n,
+                                   const float* const* h_vols, const int32_t* const* h_tables, const int* h_dims, int n_vol,
+                                   const void* packed, float* sdf, float* grad, void* scratch, void* stream) {
+  return launch<PolBf3>(pts, mask, idx, n, h_vols, h_tables, h_dims, n_vol, packed, sdf, grad, scratch, stream);
+}
+
+extern "C" int64_t surf_sdf_f16_packed_bytes(void) { return stream_bytes<PolH2>() + TAIL_FLOATS * 4; }
+extern "C" int64_t surf_sdf_f16_scratch_bytes(int64_t n_points) { return scratch_bytes<PolH2>(n_points); }
+extern "C" int surf_sdf_pack_weights_f16(const float* const* h_W, const float* const* h_b, unsigned char* out) {
+  return pack_weights<PolH2>(h_W, h_b, out);
+}
+extern "C" int surf_sdf_mlp_f16x2(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n,
+                                  const float* const* h_vols, const int32_t* const* h_tables, const int* h_dims, int n_vol,
+                                  const void* packed, float* sdf, float* grad, void* scratch, void* stream) {
+  return launch<PolH2>(pts, mask, idx, n, h_vols, h_tables, h_dims, n_vol, packed, sdf, grad, scratch, stream);
+}

@@ -142,17 +142,23 @@ class ImplicitSurface(nn.Module):
         self.sdf_network = SDFNetworkSparse(**dict(confs["sdf_network"]))
         self.color_network = BlendingNetwork(**dict(confs["color_network"]))
         self.deviation_network = SingleVarianceNetwork(**dict(confs["variance_network"]))
+        # which SDF kernel evaluates sdf_network (ops.SDF_PRECISIONS): "f32" = fp32 MFMA; "bf16x3" = exact three-way bf16
+        # operand split on the bf16 pipe (fp32-equivalent, default); "f16x2" = two fp16 pieces (22-bit operands, fastest)
+        self.sdf_precision = confs.get_string("render.sdf_precision", "bf16x3")
+        if self.sdf_precision not in ops.SDF_PRECISIONS:
+            raise ValueError(f"render.sdf_precision must be one of {ops.SDF_PRECISIONS}, got {self.sdf_precision!r}")
         self._packed = None
         self.kernel_events = None
         self.last_active_samples = None
 
     # ---- weight re-layouts are cached and refreshed whenever parameters change -------------------------
     def packed_weights(self, device):
-        ver = tuple((p._version, p.data_ptr()) for p in self.parameters()) + (str(device),)
+        ver = tuple((p._version, p.data_ptr()) for p in self.parameters()) + (str(device), self.sdf_precision)
         if self._packed is None or self._packed[0] != ver:
             sd = {k: v for k, v in self.state_dict().items()}
-            self._packed = (ver, ops.sdf_pack_weights(sd, device, "sdf_network."),
-                            ops.blend_pack_weights(sd, device, "color_network."))
+            sdf_w = (ops.sdf_pack_weights(sd, device, "sdf_network.") if self.sdf_precision == "f32" else
+                     ops.sdf_pack_weights_split(sd, device, "sdf_network.", self.sdf_precision))
+            self._packed = (ver, sdf_w, ops.blend_pack_weights(sd, device, "color_network."))
         return self._packed[1], self._packed[2]
 
     def scene(self, matching_volume, volumes, sparse_idxes, mask_volumes, features, imgs, intrs, c2ws):

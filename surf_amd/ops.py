@@ -116,21 +116,45 @@ def sdf_pack_weights_host(layers):
     return out
 
 
-def sdf_pack_weights_bf16_host(layers):
-    """[(W_l, b_l)] effective matrices -> byte stream of 3-way bf16 split weights (surf_sdf_pack_weights_bf16)."""
+SDF_PRECISIONS = ("f32", "bf16x3", "f16x2")
+_SPLIT_ABI = {"bf16x3": "bf16", "f16x2": "f16"}   # precision -> infix of the C-ABI entry points
+
+
+def sdf_pack_weights_split_host(layers, precision):
+    """[(W_l, b_l)] effective matrices -> byte stream of split 16-bit weights (surf_sdf_pack_weights_{bf16,f16})."""
     sdf_pack_weights_host(layers)  # shape validation only
+    infix = _SPLIT_ABI[precision]
     Ws = [_host_f32(W) for W, _ in layers]
     bs = [_host_f32(b) for _, b in layers]
     L = _lib.lib()
-    out = np.zeros(L.surf_sdf_bf16_packed_bytes(), dtype=np.uint8)
+    out = np.zeros(getattr(L, f"surf_sdf_{infix}_packed_bytes")(), dtype=np.uint8)
     wp = (ctypes.c_void_p * 7)(*[w.ctypes.data for w in Ws])
     bp = (ctypes.c_void_p * 7)(*[b.ctypes.data for b in bs])
-    _lib.check(L.surf_sdf_pack_weights_bf16(wp, bp, _np_ptr(out)), "surf_sdf_pack_weights_bf16")
+    _lib.check(getattr(L, f"surf_sdf_pack_weights_{infix}")(wp, bp, _np_ptr(out)), f"surf_sdf_pack_weights_{infix}")
     return out
 
 
+def sdf_pack_weights_bf16_host(layers):
+    return sdf_pack_weights_split_host(layers, "bf16x3")
+
+
+def sdf_pack_weights_split(sd, device, prefix="implicit_surface.sdf_network.", precision="bf16x3"):
+    return torch.from_numpy(sdf_pack_weights_split_host(sdf_effective_weights(sd, prefix), precision)).to(device)
+
+
 def sdf_pack_weights_bf16(sd, device, prefix="implicit_surface.sdf_network."):
-    return torch.from_numpy(sdf_pack_weights_bf16_host(sdf_effective_weights(sd, prefix))).to(device)
+    return sdf_pack_weights_split(sd, device, prefix, "bf16x3")
+
+
+def sdf_packed_precision(packed):
+    """Which SDF kernel a packed weight tensor belongs to (fp32 tensors: the fp32 kernel; byte streams: by size)."""
+    if packed.dtype == torch.float32:
+        return "f32"
+    if packed.dtype == torch.uint8:
+        for precision, infix in _SPLIT_ABI.items():
+            if packed.numel() == getattr(_lib.lib(), f"surf_sdf_{infix}_packed_bytes")():
+                return precision
+    raise ValueError("packed SDF weights: not an output of surf_sdf_pack_weights / _bf16 / _f16")
 
 
 def sdf_pack_weights(sd, device, prefix="implicit_surface.sdf_network."):
@@ -195,8 +219,9 @@ def ray_setup(rays_o, rays_d, near, far, mvol, volumes, n_samples, sample_ranges
 _scratch_cache = {}
 
 
-def _sdf_scratch(n, device, bf16=False):
-    need = (_lib.lib().surf_sdf_bf16_scratch_bytes if bf16 else _lib.lib().surf_sdf_scratch_bytes)(int(n))
+def _sdf_scratch(n, device, precision="f32"):
+    fn = "surf_sdf_scratch_bytes" if precision == "f32" else f"surf_sdf_{_SPLIT_ABI[precision]}_scratch_bytes"
+    need = getattr(_lib.lib(), fn)(int(n))
     key = (device.index if device.index is not None else torch.cuda.current_device())
     buf = _scratch_cache.get(key)
     if buf is None or buf.numel() < need:
@@ -209,8 +234,8 @@ def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True, compact_active=True
     """sdf_network.py:95-141 at n points.  Returns (sdf (n,), grad (n,3) or None); masked-out rows are
     left at sdf=100 / grad=0 (what render_core substitutes, implicit_surface.py:93,99)."""
     _chk(pts, torch.float32, "pts")
-    bf16 = packed.dtype == torch.uint8          # stream of surf_sdf_pack_weights_bf16 -> bf16x3 kernel
-    _chk(packed, torch.uint8 if bf16 else torch.float32, "packed weights")
+    precision = sdf_packed_precision(packed)    # which kernel the packed weights were laid out for
+    _chk(packed, torch.float32 if precision == "f32" else torch.uint8, "packed weights")
     n = pts.shape[0]
     dev = pts.device
     if mask is not None:
@@ -230,11 +255,12 @@ def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True, compact_active=True
         n_eval = int(idx.shape[0])
         if n_eval == 0:
             return sdf, grad
-    scratch = _sdf_scratch(n_eval, dev, bf16) if want_grad else None
-    fn = _lib.lib().surf_sdf_mlp_bf16x3 if bf16 else _lib.lib().surf_sdf_mlp
+    scratch = _sdf_scratch(n_eval, dev, precision) if want_grad else None
+    name = {"f32": "surf_sdf_mlp", "bf16x3": "surf_sdf_mlp_bf16x3", "f16x2": "surf_sdf_mlp_f16x2"}[precision]
+    fn = getattr(_lib.lib(), name)
     rc = fn(_p(pts), _p(None if idx is not None else mask), _p(idx), n_eval, volumes._vp, volumes._tp, volumes._dp, volumes.n,
             _p(packed), _p(sdf), _p(grad), _p(scratch), _stream())
-    _lib.check(rc, "surf_sdf_mlp_bf16x3" if bf16 else "surf_sdf_mlp")
+    _lib.check(rc, name)
     return sdf, grad
 
 

@@ -261,28 +261,31 @@ def test_library_exports_every_declared_symbol():
     assert L.surf_sdf_scratch_bytes(1 << 20) > 0
 
 
-# ---- bf16x3 stream (sdf_mlp_bf16.hip) --------------------------------------------------------------------
+# ---- split 16-bit streams (sdf_mlp_split.hip) --------------------------------------------------------------
 def _bf16_to_f64(u16):
     return (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
 
 
-class Bf16Stream:
-    """Decoder of surf_sdf_pack_weights_bf16's chunk stream: A operand of k-step ks = sum of the three pieces."""
+class SplitStream:
+    """Decoder of surf_sdf_pack_weights_{bf16,f16}'s chunk stream: A operand of k-step ks = sum of its pieces."""
     BWD_NT = [1, 5, 5, 6, 5, 5]
 
-    def __init__(self, packed):
+    def __init__(self, packed, precision="bf16x3"):
         self.u16 = packed[: (len(packed) // 2) * 2].view(np.uint16)
         self.packed = packed
+        self.precision = precision
+        self.np = {"bf16x3": 3, "f16x2": 2}[precision]
+        KS = self.np * 1024
         fwd_ks = [2, 10, 10, 11, 10, 10]
         self.ks, self.off = [], []
         o = 0
         for l in range(6):
             for t in range(4):
-                self.off.append(o); self.ks.append(fwd_ks[l]); o += fwd_ks[l] * 3072
+                self.off.append(o); self.ks.append(fwd_ks[l]); o += fwd_ks[l] * KS
         for l in range(5, -1, -1):
             for t in range(self.BWD_NT[l]):
                 k = 7 if l == 2 else 8
-                self.off.append(o); self.ks.append(k); o += k * 3072
+                self.off.append(o); self.ks.append(k); o += k * KS
         self.stream_bytes = o
         self.tail = packed[o:o + 164 * 4].view(np.float32).astype(np.float64)
 
@@ -293,11 +296,16 @@ class Bf16Stream:
         return 24 + sum(self.BWD_NT[i] for i in range(5, l, -1)) + t
 
     def A(self, ci, ks):
-        """(64 lanes, 8) float64 = exact sum of the three bf16 pieces; also checks piece sizes decay."""
-        base = (self.off[ci] + ks * 3072) // 2
-        pieces = [_bf16_to_f64(self.u16[base + p * 512: base + (p + 1) * 512]).reshape(64, 8) for p in range(3)]
-        assert (np.abs(pieces[1]) <= np.abs(pieces[0]) * 2.0 ** -7 + 1e-45).all()
-        return pieces[0] + pieces[1] + pieces[2]
+        """(64 lanes, 8) float64 = exact sum of the pieces; also checks that piece sizes decay."""
+        base = (self.off[ci] + ks * self.np * 1024) // 2
+        raw = [self.u16[base + p * 512: base + (p + 1) * 512] for p in range(self.np)]
+        if self.precision == "bf16x3":
+            pieces = [_bf16_to_f64(r).reshape(64, 8) for r in raw]
+            assert (np.abs(pieces[1]) <= np.abs(pieces[0]) * 2.0 ** -7 + 1e-45).all()
+            return pieces[0] + pieces[1] + pieces[2]
+        hi, lo = [r.view(np.float16).astype(np.float64).reshape(64, 8) for r in raw]
+        assert (np.abs(lo) <= np.abs(hi) * 2.0 ** -11 + 2.0 ** -25).all()
+        return (hi + lo) / 256.0                                        # weights are stored x 2^8
 
 
 def mma16(acc, A, Bfrag):
@@ -310,8 +318,8 @@ def mma16(acc, A, Bfrag):
     acc += D[ROW[None, :] + 4 * H[:, None], J[:, None]]
 
 
-def sim_sdf_bf16(packed, pts, phi_full, jphi_full):
-    S_ = Bf16Stream(packed)
+def sim_sdf_split(packed, pts, phi_full, jphi_full, precision):
+    S_ = SplitStream(packed, precision)
     e_all = np.zeros((64, 28)); je_all = np.zeros((64, 28))
     e_all[:, :27] = O.posenc(torch.from_numpy(pts)).numpy()[J]
     je_all[:, :27] = O.posenc_jac_diag(torch.from_numpy(pts)).numpy()[J]
@@ -327,7 +335,7 @@ def sim_sdf_bf16(packed, pts, phi_full, jphi_full):
         for t in range(4):
             acc = np.zeros((64, 16))
             ci = S_.fwd_chunk(l, t)
-            bs = (frags(e) if l == 0 else frags(hin)[:7 if l == 3 else 8] + (frags(e) if l == 3 else []) + frags(phi))
+            bs = (frags(e) if l in (0, 3) else []) + (frags(phi) if l >= 1 else []) + (frags(hin)[:7 if l == 3 else 8] if l else [])
             assert len(bs) == S_.ks[ci]
             for ks, b in enumerate(bs):
                 mma16(acc, S_.A(ci, ks), b)
@@ -366,14 +374,16 @@ def sim_sdf_bf16(packed, pts, phi_full, jphi_full):
     return y0[:32], g3[:32]
 
 
-def test_sdf_bf16x3_pack_matches_oracle(weights, golden_pipe, golden_render):
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_sdf_split_pack_matches_oracle(weights, golden_pipe, golden_render, precision):
     vols, tabs, _, _ = pipeline_views(golden_pipe)
     pts = golden_render["pts"][100:132].contiguous()
     layers = O.sdf_weights(weights)
-    packed = ops.sdf_pack_weights_bf16_host(ops.sdf_effective_weights(weights))
+    packed = ops.sdf_pack_weights_split_host(ops.sdf_effective_weights(weights), precision)
     phi, jphi = O.lookup_sparse_volume(pts, vols, tabs, with_jac=True)
     sdf_o, grad_o, _ = O.sdf_mlp(layers, pts, phi, jphi)
-    sdf_s, grad_s = sim_sdf_bf16(packed, pts.numpy(), phi.numpy().astype(np.float64), jphi.numpy().astype(np.float64))
+    sdf_s, grad_s = sim_sdf_split(packed, pts.numpy(), phi.numpy().astype(np.float64), jphi.numpy().astype(np.float64),
+                                  precision)
     assert np.abs(sdf_s - sdf_o.numpy()).max() < 2e-5
     assert np.abs(grad_s - grad_o.numpy()).max() < 2e-4
 
@@ -389,3 +399,14 @@ def test_bf16_three_way_split_is_exact():
     p1 = rne(x); r = x - p1; p2 = rne(r); p3 = rne(r - p2)
     assert np.array_equal((p1.astype(np.float64) + p2 + p3).astype(np.float32), x)
     assert np.abs(x - (p1 + p2 + p3)).max() == 0.0
+
+
+def test_f16_two_way_split_error_bound():
+    """f16x2 operands: hi = fp16(x), lo = fp16(x - hi); |x - (hi + lo)| <= max(2^-22 |x|, 2^-25) inside fp16's range
+    (the absolute floor is the second piece going subnormal, for |x| < 0.125; weights and deltas are stored x 2^8)."""
+    g = np.random.default_rng(1)
+    x = (g.standard_normal(8192) * np.exp(g.uniform(-6, 6, 8192))).astype(np.float32)
+    hi = x.astype(np.float16)
+    lo = (x - hi.astype(np.float32)).astype(np.float16)
+    rec = hi.astype(np.float64) + lo.astype(np.float64)
+    assert (np.abs(rec - x) <= np.maximum(np.abs(x) * 2.0 ** -22, 2.0 ** -25)).all()
