@@ -94,12 +94,20 @@ struct FragT { u32x4 p[NP]; };  // B-operand fragments of a 16-wide k-step: NP p
 #ifndef SURF_X_NOSCRATCH
 #define SURF_X_NOSCRATCH 0
 #endif
-#ifndef SURF_BF3_NA  // independent accumulator chains of the bf16x3 policy (a dependent MFMA issues ~10 cycles late)
-#define SURF_BF3_NA 1
+#ifndef SURF_X_NOMMA
+#define SURF_X_NOMMA 0
+#endif
+#ifndef SURF_X_NOLDS
+#define SURF_X_NOLDS 0
+#endif
+#ifndef SURF_X_NOSOFTPLUS
+#define SURF_X_NOSOFTPLUS 0
 #endif
 
 struct PolBf3 {
-  static constexpr int NP = 3, NA = SURF_BF3_NA, OCC = 1, PF = 1;
+  // NA: accumulator chains (two independent ones measured no faster); PF: k-steps of LDS read-ahead (2, 3: no faster)
+  static constexpr int NP = 3, NA = 1, OCC = 1, PF = 1;
+  static constexpr bool DEEP = true;  // backward scratch reads two chunks ahead (registers to spare)
   static constexpr ChunkTable CH = make_chunks(NP);
   struct Acc { f32x16 v[NA]; };
   static __device__ __forceinline__ uint32_t pack2(float a, float b) {
@@ -137,10 +145,8 @@ struct PolBf3 {
 };
 
 struct PolH2 {
-#ifndef SURF_H2_PF
-#define SURF_H2_PF 2
-#endif
-  static constexpr int NP = 2, NA = 1, OCC = 2, PF = SURF_H2_PF;
+  static constexpr int NP = 2, NA = 1, OCC = 2, PF = 1;
+  static constexpr bool DEEP = false;  // at the 256-register cap: one chunk ahead (the second workgroup hides the rest)
   static constexpr ChunkTable CH = make_chunks(NP);
   struct Acc { f32x16 v[NA]; };
   static __device__ __forceinline__ void split(float a, float b, uint32_t (&p)[NP]) {
@@ -208,6 +214,11 @@ __device__ __forceinline__ void frag_set_pair(FragT<P::NP>& f, int pair /*0..3*/
 // which equals torch's thresholded softplus to fp32 rounding (the linear branch differs from it by < 2^-33 relative).
 template <bool WANT_S>
 __device__ __forceinline__ void softplus_pair(f32x2 acc, float acc_scale_inv, f32x2& hv, f32x2& sv) {
+  if (SURF_X_NOSOFTPLUS) {
+    hv = acc * acc_scale_inv;
+    sv = acc * 0.5f;
+    return;
+  }
   const f32x2 arg = acc * (144.269504088896341f * acc_scale_inv);  // 100 log2(e) t
   f32x2 e;
   e[0] = __builtin_amdgcn_exp2f(-__builtin_fabsf(arg[0]));
@@ -217,8 +228,8 @@ __device__ __forceinline__ void softplus_pair(f32x2 acc, float acc_scale_inv, f3
   l[0] = __builtin_amdgcn_logf(d[0]);
   l[1] = __builtin_amdgcn_logf(d[1]);
   f32x2 m;
-  m[0] = fmaxf(acc[0], 0.0f);
-  m[1] = fmaxf(acc[1], 0.0f);
+  m[0] = __builtin_amdgcn_fmed3f(acc[0], 0.0f, 3.0e38f);  // max(acc, 0) without the canonicalising extra v_max
+  m[1] = __builtin_amdgcn_fmed3f(acc[1], 0.0f, 3.0e38f);
   if (acc_scale_inv != 1.0f) m = m * acc_scale_inv;
   hv[0] = fmaf(l[0], 0.69314718055994531f * 0.01f, m[0]);
   hv[1] = fmaf(l[1], 0.69314718055994531f * 0.01f, m[1]);
@@ -260,26 +271,37 @@ struct Ctx {
 // 1 KB per instruction, lane-linear image) and chunk CI+1 is retired at the end of chunk CI by a counted vmcnt.
 // vmcnt retires in issue order, so everything older than that DMA has to be complete too: two chunks of slack keep the
 // softplus' stores of the previous chunk (acknowledged late by L2) out of that wait.
+template <class P> constexpr int n_dma(int ci) { return (P::CH.ks[ci] * P::NP + 3) / 4; }
 template <class P, int CI>
-__device__ __forceinline__ void stage_dma(const Ctx& c) {
-  constexpr int NB = P::CH.ks[CI] * P::NP;
+__device__ __forceinline__ void stage_dma_piece(const Ctx& c, int k) {  // blocks wave + 4 k of chunk CI
   constexpr int OFF = P::CH.off[CI];
   // blocks past the end of a chunk read into the next one / out of range (= 0) and land in the unused tail of the slot
-#pragma unroll
-  for (int k = 0; 4 * k < NB; ++k) {
-    const int blk = c.wave + 4 * k;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-        c.wr, (__attribute__((address_space(3))) void*)(c.lds + (CI % 3) * slot_bytes<P>() + blk * 1024), 16, c.lane16,
-        OFF + blk * 1024, 0, 0);
-  }
+  const int blk = c.wave + 4 * k;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(
+      c.wr, (__attribute__((address_space(3))) void*)(c.lds + (CI % 3) * slot_bytes<P>() + blk * 1024), 16, c.lane16,
+      OFF + blk * 1024, 0, 0);
 }
-template <class P> constexpr int n_dma(int ci) { return (P::CH.ks[ci] * P::NP + 3) / 4; }
+template <class P, int CI>
+__device__ __forceinline__ void stage_dma(const Ctx& c) {
+#pragma unroll
+  for (int k = 0; k < n_dma<P>(CI); ++k) stage_dma_piece<P, CI>(c, k);
+}
 // vector-memory operations a chunk issues by itself, in order: [pre: loads before its DMA] [DMA] [post: stores in fn]
-template <bool GRAD> constexpr int vm_pre(int ci) {
+// which softplus' slice the backward chunk (L, T) loads (layer < 0: none): DEEP: that of the hidden tile computed by the
+// NEXT chunk; otherwise that of its own tile
+constexpr int sprime_layer(bool deep, int L, int T) {
+  if (!deep) return (L >= 1 && T < 4) ? L - 1 : -1;
+  if (L >= 1 && T < 3) return L - 1;                // (L, T + 1)
+  if (L >= 2 && T == BWD_NT[L] - 1) return L - 2;   // last tile of the layer -> (L - 1, 0)
+  return -1;
+}
+constexpr int sprime_tile(bool deep, int L, int T) { return !deep ? T : ((L >= 1 && T < 3) ? T + 1 : 0); }
+template <class P> constexpr int vm_pre(int ci) {
   if (ci < N_FWD_CHUNKS) return (ci / 4 == 5 && ci % 4 > 0) ? 4 : 0;  // W6 slices
   int l = 5, t = ci - N_FWD_CHUNKS;
   while (t >= BWD_NT[l]) { t -= BWD_NT[l]; --l; }
-  return (l >= 1 && t < 4) ? 4 : 0;  // softplus' slices
+  if (l == 0) return P::DEEP ? 12 : 0;  // feature Jacobian for the epilogue
+  return sprime_layer(P::DEEP, l, t) >= 0 ? 4 : 0;
 }
 template <bool GRAD> constexpr int vm_post(int ci) {
   if (!GRAD || ci >= N_FWD_CHUNKS) return 0;
@@ -291,7 +313,9 @@ template <bool GRAD> constexpr int vm_post(int ci) {
 template <class P, bool GRAD, int CI, int NCH>
 __device__ __forceinline__ void stage_barrier() {
   constexpr int PREV = (CI + NCH - 1) % NCH;
-  constexpr int N = (CI == 0 ? 0 : vm_post<GRAD>(PREV)) + vm_pre<GRAD>(CI) + n_dma<P>((CI + 2) % NCH) + vm_post<GRAD>(CI);
+  // (that DMA's pieces are spread over the k-steps of chunk CI-1, so that chunk's own stores are not counted)
+  constexpr int N = vm_pre<P>(CI) + n_dma<P>((CI + 2) % NCH) + vm_post<GRAD>(CI);
+  (void)PREV;
   static_assert(N >= 0 && N < 64, "vmcnt");
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
@@ -314,17 +338,21 @@ __device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F fn) {
 #pragma unroll
     for (int p = 0; p < NP; ++p)
       if (d < NKS) a_q[d][p] = *reinterpret_cast<const u32x4*>(rd + (d * NP + p) * 1024);
-  stage_dma<P, (CI + 2) % NCH>(c);
+  constexpr int NXT = (CI + 2) % NCH, ND = n_dma<P>(NXT);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
     if (ks + PF < NKS) {
 #pragma unroll
       for (int p = 0; p < NP; ++p)
-        a_q[(ks + PF) % (PF + 1)][p] = *reinterpret_cast<const u32x4*>(rd + ((ks + PF) * NP + p) * 1024);
+        if (!SURF_X_NOLDS) a_q[(ks + PF) % (PF + 1)][p] = *reinterpret_cast<const u32x4*>(rd + ((ks + PF) * NP + p) * 1024);
     }
-    P::mma(acc, a_q[ks % (PF + 1)], bsel(ks));
+    if (!SURF_X_NOMMA) P::mma(acc, a_q[SURF_X_NOLDS ? 0 : ks % (PF + 1)], bsel(ks));
+    else acc.v[0][ks % 16] += __builtin_bit_cast(float, bsel(ks).p[0][0]) + __builtin_bit_cast(float, a_q[ks % (PF + 1)][0][0]);
     fn(ks);
+#pragma unroll
+    for (int k = 0; k < ND; ++k)  // this wave's DMA pieces of chunk CI+2, spread over the k-steps behind their MFMAs
+      if (k * NKS / ND == ks) stage_dma_piece<P, NXT>(c, k);
     __builtin_amdgcn_sched_barrier(0);
   }
   SURF_T(CI < N_FWD_CHUNKS ? 1 : 3);
@@ -353,12 +381,18 @@ __device__ __forceinline__ void gather_features(const SdfArgs& a, const Ctx& c, 
     const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
     tx[sl] = gx - fx; ty[sl] = gy - fy; tz[sl] = gz - fz;
     const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    // clamped corner coordinates; D <= 1024 (checked at launch), so 24-bit multiplies and 32-bit indices are exact
+    int xs[2], ys[2], zs[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      xs[d] = min(max(x0 + d, 0), D - 1);
+      ys[d] = min(max(y0 + d, 0), D - 1);
+      zs[d] = min(max(z0 + d, 0), D - 1);
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int xi = min(max(x0 + (k >> 2), 0), D - 1);
-      const int yi = min(max(y0 + ((k >> 1) & 1), 0), D - 1);
-      const int zi = min(max(z0 + (k & 1), 0), D - 1);
-      rows[sl][k] = D > 0 ? table[((int64_t)xi * D + yi) * D + zi] : -1;
+      const unsigned xy = __umul24(__umul24(xs[k >> 2], D) + ys[(k >> 1) & 1], D);
+      rows[sl][k] = D > 0 ? table[xy + zs[k & 1]] : -1;
     }
   }
 #pragma unroll
@@ -504,7 +538,7 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
     if (ks < NL) return pf[ks - NEk];
     return hin[ks - NL];
   };
-  static_assert(STORES == vm_post<GRAD>(CI) && (LAST ? 4 : 0) == vm_pre<GRAD>(CI), "vmcnt bookkeeping");
+  static_assert(STORES == vm_post<GRAD>(CI) && (LAST ? 4 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
   raw = run_chunk<P, GRAD, CI, GRAD ? N_CHUNKS : N_FWD_CHUNKS>(c, bsel, fn);
 }
 
@@ -520,15 +554,26 @@ __device__ __forceinline__ void fwd_layer(const Ctx& c, f32x16& raw, FragT<P::NP
 
 // ---- backward tiles ----------------------------------------------------------------------------------------------------
 // G (= W^T delta) of hidden tile T is multiplied by softplus' and split under the MFMAs of the tile that follows it.
+// The softplus' slice of a hidden tile is loaded from scratch during the chunk BEFORE the one that computes its G, two
+// chunks before it is used (an HBM round trip is longer than one chunk).
 struct BwdPend {
-  f32x16 G;
-  f32x4 s[4];
+  f32x16 G;     // finished tile waiting for its conversion
+  f32x4 s[4];   // its softplus' slice
+  f32x4 sn[4];  // slice of the tile whose G is being computed now
 };
+__device__ __forceinline__ void load_sprime(const Ctx& c, int layer, int tile, f32x4 (&dst)[4]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) dst[g] = bload(c.sl, c.svoff, layer * 16384 + (tile * 4 + g) * 1024);
+}
 template <class P, int L, int T, bool CONVERT>
-__device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, const BwdPend& prev) {
+__device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, const BwdPend& prev,
+                                           f32x4 (&s_load)[4]) {
   typedef FragT<P::NP> Frag;
   constexpr int CI = bwd_chunk(L, T);
   constexpr int NKS = bwd_ks(L);
+  constexpr int SL = sprime_layer(P::DEEP, L, T);
+  static_assert((SL >= 0 ? 4 : 0) + ((L == 0 && P::DEEP) ? 12 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
+  if (SL >= 0) load_sprime(c, SL, sprime_tile(P::DEEP, L, T), s_load);
   auto cvt = [&](int q) __attribute__((always_inline)) {
     const int el = 2 * q;
     constexpr float inv_w = 1.0f / Scales<P>::W;  // G arrives x W_SCALE x D_SCALE, deltas are kept x D_SCALE
@@ -546,26 +591,34 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
 }
 template <class P, int L, int T>
 __device__ __forceinline__ void bwd_hidden_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, BwdPend& pend) {
-  BwdPend cur;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) cur.s[g] = bload(c.sl, c.svoff, (L - 1) * 16384 + (T * 4 + g) * 1024);
   const BwdPend prev = pend;
-  cur.G = bwd_tile<P, L, T, (T > 0)>(c, din, dout, prev);
-  pend = cur;
+  f32x4 s_load[4];
+  const f32x16 G = bwd_tile<P, L, T, (T > 0)>(c, din, dout, prev, s_load);
+  pend.G = G;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (P::DEEP) {
+      pend.s[g] = prev.sn[g];
+      pend.sn[g] = s_load[g];  // (T == 3: nothing was loaded; the layer's last tile fills sn for the next layer)
+    } else {
+      pend.s[g] = s_load[g];
+    }
+  }
 }
 template <class P, int L>
 __device__ __forceinline__ void bwd_layer(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, f32x16& accE,
-                                          f32x16& accP) {
-  BwdPend pend = {};
+                                          f32x16& accP, BwdPend& pend) {
   bwd_hidden_tile<P, L, 0>(c, din, dout, pend);
   bwd_hidden_tile<P, L, 1>(c, din, dout, pend);
   bwd_hidden_tile<P, L, 2>(c, din, dout, pend);
   bwd_hidden_tile<P, L, 3>(c, din, dout, pend);
-  if (L == 3) {
-    accE += bwd_tile<P, L, 4, true>(c, din, dout, pend);
-    accP += bwd_tile<P, L, 5, false>(c, din, dout, pend);
+  const BwdPend prev = pend;
+  if constexpr (L == 3) {
+    f32x4 unused[4];
+    accE += bwd_tile<P, L, 4, true>(c, din, dout, prev, unused);
+    accP += bwd_tile<P, L, 5, false>(c, din, dout, prev, pend.sn);
   } else {
-    accP += bwd_tile<P, L, 4, true>(c, din, dout, pend);
+    accP += bwd_tile<P, L, 4, true>(c, din, dout, prev, pend.sn);
   }
 }
 
@@ -679,14 +732,21 @@ __global__ __launch_bounds__(WPB * 64, P::OCC) void sdf_mlp_split_kernel(SdfArgs
 #pragma unroll
         for (int q = 0; q < 4; ++q) accP[4 * g + q] = w[q] * (Scales<P>::W * Scales<P>::D);
       }
-      bwd_layer<P, 5>(c, dA, hA, accE, accP);
-      bwd_layer<P, 4>(c, hA, dA, accE, accP);
-      bwd_layer<P, 3>(c, dA, hA, accE, accP);
-      bwd_layer<P, 2>(c, hA, dA, accE, accP);
-      bwd_layer<P, 1>(c, dA, hA, accE, accP);
+      BwdPend pend = {};
+      if (P::DEEP) load_sprime(c, 4, 0, pend.sn);  // slice of the first hidden tile (5, 0)
+      bwd_layer<P, 5>(c, dA, hA, accE, accP, pend);
+      bwd_layer<P, 4>(c, hA, dA, accE, accP, pend);
+      bwd_layer<P, 3>(c, dA, hA, accE, accP, pend);
+      bwd_layer<P, 2>(c, hA, dA, accE, accP, pend);
+      bwd_layer<P, 1>(c, dA, hA, accE, accP, pend);
+      f32x4 Jq[12];  // feature Jacobian: DEEP fetches it under the last chunk
+      if (P::DEEP) {
+#pragma unroll
+        for (int g = 0; g < 12; ++g) Jq[g] = bload(c.sl, c.svoff, SCR_S * 4 + g * 1024);
+      }
       {
-        const BwdPend none = {};
-        accE += bwd_tile<P, 0, 0, false>(c, hA, dA, none);
+        f32x4 unused[4];
+        accE += bwd_tile<P, 0, 0, false>(c, hA, dA, pend, unused);
       }
       SURF_T(3);
       float g3[3] = {0.f, 0.f, 0.f};
@@ -705,7 +765,7 @@ __global__ __launch_bounds__(WPB * 64, P::OCC) void sdf_mlp_split_kernel(SdfArgs
           float Jf[24];
 #pragma unroll
           for (int g = 0; g < 6; ++g) {
-            const f32x4 v = bload(c.sl, c.svoff, SCR_S * 4 + (6 * sl + g) * 1024);
+            const f32x4 v = P::DEEP ? Jq[6 * sl + g] : bload(c.sl, c.svoff, SCR_S * 4 + (6 * sl + g) * 1024);
             Jf[4 * g + 0] = v[0]; Jf[4 * g + 1] = v[1]; Jf[4 * g + 2] = v[2]; Jf[4 * g + 3] = v[3];
           }
 #pragma unroll
@@ -891,6 +951,7 @@ int launch(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n,
     a.tables[s] = s < n_vol ? h_tables[s] : nullptr;
     a.dims[s] = s < n_vol ? h_dims[s] : 0;
     if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
+    if (s < n_vol && h_dims[s] > 1024) return SURF_E_LIMIT;  // 32-bit table indices (gather_features)
   }
   dim3 grid(grid_blocks<P>(n)), block(WPB * 64);
   if (grad)
