@@ -73,6 +73,29 @@ __device__ __forceinline__ f32x4 bload(rsrc_t r, int voff, int soff) {
 // ELU / sigmoid through the raw v_exp_f32 (absolute error <= 1e-7, far inside the 1e-3 colour tolerance)
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
 __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : fexp(x) - 1.0f; }
+// The same function on a pair, written so that the adds and multiplies are packed (v_pk_*) and the select disappears:
+// elu(x) = max(x, 0) + (min(exp(x), 1) - 1); the min is the clamp modifier of v_exp_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 elu2(f32x2 x) {
+  const f32x2 a = x * 1.44269504088896341f;
+  f32x2 e, m;
+  e[0] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(a[0]), 0.0f, 1.0f);
+  e[1] = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(a[1]), 0.0f, 1.0f);
+  m[0] = __builtin_amdgcn_fmed3f(x[0], 0.0f, 3.0e38f);
+  m[1] = __builtin_amdgcn_fmed3f(x[1], 0.0f, 3.0e38f);
+  return m + (e - 1.0f);
+}
+// out[r] = elu(acc[r] + bias[r]) for r < N (N even)
+template <int N>
+__device__ __forceinline__ void elu_rows(const f32x16& acc, const f32x16& bias, float* out) {
+#pragma unroll
+  for (int r = 0; r < N; r += 2) {
+    const f32x2 xa = {acc[r], acc[r + 1]}, xb = {bias[r], bias[r + 1]};
+    const f32x2 y = elu2(xa + xb);
+    out[r] = y[0];
+    out[r + 1] = y[1];
+  }
+}
 __device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + fexp(-x)); }
 
 // Bilinear fetch of a texel4 map with zero padding, branch-free: out-of-range taps read a clamped texel with
@@ -307,14 +330,15 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void blend_kernel(BlendArgs
       f32x16 acc1 = zero16();
       stream_mma<SeqP1, SeqBS, 0, 1>(ring, acc1, bin, lastv, wr, lane16);
       float h8[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) h8[r] = elu(acc1[r] + bias1[r]);
+      elu_rows<8>(acc1, bias1, h8);
       f32x16 acc2 = zero16();
       stream_mma<SeqP1, SeqBS, 1, 2>(ring, acc2, h8, lastv, wr, lane16);
-#pragma unroll
-      for (int r = 0; r < 11; ++r) {
+      {
         // rows of half 1 beyond its 8 channels carry zero weights and zero bias: elu(0) = 0
-        floc[v][r] = g[r] + elu(acc2[r] + bias2[r]);
+        float d12[12];
+        elu_rows<12>(acc2, bias2, d12);
+#pragma unroll
+        for (int r = 0; r < 11; ++r) floc[v][r] = g[r] + d12[r];
       }
       floc[v][11] = 0.f;
       ex[v] = expf(s_abs * (rd[v][3] - 1.0f));
@@ -362,22 +386,22 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void blend_kernel(BlendArgs
       f32x16 a64a = G0a, a64b = G0b;
       stream_mma2<SeqPV, SeqNone, 0, 3>(ring, a64a, a64b, floc[v], lastv, wr, lane16);
       float h32[32];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { h32[r] = elu(a64a[r] + bb0[r]); h32[16 + r] = elu(a64b[r] + bb1[r]); }
+      elu_rows<16>(a64a, bb0, h32);
+      elu_rows<16>(a64b, bb1, h32 + 16);
       // base_fc.2 + ELU : 64 -> 32
       const f32x16 bx = load_row16(wr, h64v, BIAS_OFF + B_B2 * 32);
       f32x16 accx = zero16();
       stream_mma<SeqPV, SeqNone, 6, 8>(ring, accx, h32, lastv, wr, lane16);
       float x[16], xin[16];
+      elu_rows<16>(accx, bx, x);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { x[r] = elu(accx[r] + bx[r]); xin[r] = x[r] * wv[v]; }
+      for (int r = 0; r < 16; ++r) xin[r] = x[r] * wv[v];
       // vis_fc: 32 -> 32 (ELU) -> 33 (ELU)
       const f32x16 bt = load_row16(wr, h64v, BIAS_OFF + B_V0 * 32);
       f32x16 acct = zero16();
       stream_mma<SeqPV, SeqNone, 14, 4>(ring, acct, xin, lastv, wr, lane16);
       float t16[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t16[r] = elu(acct[r] + bt[r]);
+      elu_rows<16>(acct, bt, t16);
       const f32x16 br = load_row16(wr, h64v, BIAS_OFF + B_V2 * 32);
       const f32x16 dvis = load_row16(wr, h64v, DOT_OFF + D_VIS * 32);
       f32x16 accr = zero16();
@@ -387,16 +411,24 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void blend_kernel(BlendArgs
       for (int r = 0; r < 16; ++r) vraw = fmaf(dvis[r], t16[r], vraw);
       vraw += __shfl_xor(vraw, 32);
       const float vis = sigm(elu(vraw + b_vis)) * mk[v];
+      {
+        float d16[16];
+        elu_rows<16>(accr, br, d16);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { x[r] = x[r] + elu(accr[r] + br[r]); xin[r] = x[r] * vis; }
+        for (int r = 0; r < 16; ++r) { x[r] = x[r] + d16[r]; xin[r] = x[r] * vis; }
+      }
       // vis_fc2: 32 -> 32 (ELU) -> 1 (sigmoid)
       const f32x16 bw = load_row16(wr, h64v, BIAS_OFF + B_W0 * 32);
       const f32x16 dvis2 = load_row16(wr, h64v, DOT_OFF + D_VIS2 * 32);
       f32x16 accw = zero16();
       stream_mma<SeqPV, SeqNone, 22, 4>(ring, accw, xin, lastv, wr, lane16);
       float v2 = 0.f;
+      {
+        float d16[16];
+        elu_rows<16>(accw, bw, d16);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v2 = fmaf(dvis2[r], elu(accw[r] + bw[r]), v2);
+        for (int r = 0; r < 16; ++r) v2 = fmaf(dvis2[r], d16[r], v2);
+      }
       v2 += __shfl_xor(v2, 32);
       const float vis2 = sigm(v2 + b_vis2) * mk[v];
       // rgb_fc: [x(32), vis, ray_diff(4)] = 37 -> 16 (ELU) -> 8 (ELU) -> 1
@@ -411,15 +443,18 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void blend_kernel(BlendArgs
       f32x16 acc16 = zero16();
       stream_mma<SeqPV, SeqNone, 26, 5>(ring, acc16, rin, lastv, wr, lane16);
       float r8[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) r8[r] = elu(acc16[r] + b16[r]);
+      elu_rows<8>(acc16, b16, r8);
       const f32x16 b8 = load_row16(wr, h64v, BIAS_OFF + B_R2 * 32);
       const f32x16 drgb4 = load_row16(wr, h64v, DOT_OFF + D_RGB4 * 32);
       f32x16 acc8 = zero16();
       stream_mma<SeqPV, SeqNone, 31, 2>(ring, acc8, r8, lastv, wr, lane16);
       float rr = 0.f;
+      {
+        float d4[4];
+        elu_rows<4>(acc8, b8, d4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) rr = fmaf(drgb4[r], elu(acc8[r] + b8[r]), rr);
+        for (int r = 0; r < 4; ++r) rr = fmaf(drgb4[r], d4[r], rr);
+      }
       rr += __shfl_xor(rr, 32);
       rr += b_rgb4;
       if (mk[v] == 0.f) rr = -1e9f;

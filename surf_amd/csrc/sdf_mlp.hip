@@ -97,13 +97,10 @@ __device__ __forceinline__ f32x4 bload(rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 // gfx950 hazard (observed, not handled by hipcc when soffset is an SGPR): a VALU write to the data VGPRs
-// directly after a buffer_store_dwordx4 corrupts the stored data of some lanes.  Two wait states fix it.
+// directly after a buffer_store_dwordx4 corrupts the stored data of some lanes.  Two wait states fix it; store and
+// pad are one asm statement so that neither the scheduler nor a register-allocator copy can land between them.
 __device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, f32x4 v) {
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
-  asm volatile("s_nop 1");
-  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 
 __device__ __forceinline__ f32x4 wload(rsrc_t r, int voff, int soff) {

@@ -106,8 +106,10 @@ struct FragT { u32x4 p[NP]; };  // B-operand fragments of a 16-wide k-step: NP p
 
 struct PolBf3 {
   // NA: accumulator chains (two independent ones measured no faster); PF: k-steps of LDS read-ahead (2, 3: no faster)
-  static constexpr int NP = 3, NA = 1, OCC = 1, PF = 1;
-  static constexpr bool DEEP = true;  // backward scratch reads two chunks ahead (registers to spare)
+  static constexpr int NP = 3, NA = 1, PF = 1;
+  static constexpr int occ(bool) { return 1; }  // three-piece activations need the whole register file
+  static constexpr bool DEEP = true;   // backward softplus' reads two chunks ahead (registers to spare)
+  static constexpr bool DEEPJ = true;  // feature Jacobian fetched under the last backward chunk
   static constexpr ChunkTable CH = make_chunks(NP);
   struct Acc { f32x16 v[NA]; };
   static __device__ __forceinline__ uint32_t pack2(float a, float b) {
@@ -145,8 +147,13 @@ struct PolBf3 {
 };
 
 struct PolH2 {
-  static constexpr int NP = 2, NA = 1, OCC = 2, PF = 1;
-  static constexpr bool DEEP = false;  // at the 256-register cap: one chunk ahead (the second workgroup hides the rest)
+  static constexpr int NP = 2, NA = 1, PF = 1;
+  // Workgroups per CU.  Forward-only fits 256 registers without spilling and gains from a second workgroup; the
+  // gradient kernel at 256 registers spills ~250 dwords, runs slower than one workgroup with the whole register file
+  // (51.0 vs 49.2 ms) and - with the two-chunk read-ahead enabled - FAILED the race screen (scripts/stress_sdf.py)
+  // in every launch, for a reason not understood; at 512 registers nothing spills and the screen is clean.
+  static constexpr int occ(bool grad) { return grad ? 1 : 2; }
+  static constexpr bool DEEP = true, DEEPJ = true;
   static constexpr ChunkTable CH = make_chunks(NP);
   struct Acc { f32x16 v[NA]; };
   static __device__ __forceinline__ void split(float a, float b, uint32_t (&p)[NP]) {
@@ -175,7 +182,7 @@ template <> struct Scales<PolH2> { static constexpr float W = 256.0f, D = 256.0f
 
 template <class P> constexpr int stream_bytes() { return P::CH.off[N_CHUNKS]; }
 template <class P> constexpr int slot_bytes() { return MAX_KS * P::NP * 1024; }
-template <class P> constexpr int max_blocks() { return 256 * P::OCC; }
+template <class P> constexpr int max_blocks(bool grad) { return 256 * P::occ(grad); }
 
 struct SdfArgs {
   const float* pts;
@@ -194,11 +201,11 @@ struct SdfArgs {
 __device__ __forceinline__ f32x4 bload(rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-__device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, f32x4 v) {  // see sdf_mlp.hip: store-data hazard
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
-  asm volatile("s_nop 1");
-  __builtin_amdgcn_sched_barrier(0);
+// 16-byte scratch store.  gfx950: a VALU write to the data VGPRs right after `buffer_store_dwordx4 ... sN offen` corrupts
+// lanes 12-15 of every 16 (see sdf_mlp.hip).  Store and pad are ONE asm statement so that nothing - not the scheduler,
+// not a register-allocator copy or reload - can land between them.
+__device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, f32x4 v) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 
 template <class P>
@@ -300,7 +307,7 @@ template <class P> constexpr int vm_pre(int ci) {
   if (ci < N_FWD_CHUNKS) return (ci / 4 == 5 && ci % 4 > 0) ? 4 : 0;  // W6 slices
   int l = 5, t = ci - N_FWD_CHUNKS;
   while (t >= BWD_NT[l]) { t -= BWD_NT[l]; --l; }
-  if (l == 0) return P::DEEP ? 12 : 0;  // feature Jacobian for the epilogue
+  if (l == 0) return P::DEEPJ ? 12 : 0;  // feature Jacobian for the epilogue
   return sprime_layer(P::DEEP, l, t) >= 0 ? 4 : 0;
 }
 template <bool GRAD> constexpr int vm_post(int ci) {
@@ -572,7 +579,7 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
   constexpr int CI = bwd_chunk(L, T);
   constexpr int NKS = bwd_ks(L);
   constexpr int SL = sprime_layer(P::DEEP, L, T);
-  static_assert((SL >= 0 ? 4 : 0) + ((L == 0 && P::DEEP) ? 12 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
+  static_assert((SL >= 0 ? 4 : 0) + ((L == 0 && P::DEEPJ) ? 12 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
   if (SL >= 0) load_sprime(c, SL, sprime_tile(P::DEEP, L, T), s_load);
   auto cvt = [&](int q) __attribute__((always_inline)) {
     const int el = 2 * q;
@@ -623,7 +630,7 @@ __device__ __forceinline__ void bwd_layer(const Ctx& c, const FragT<P::NP>* din,
 }
 
 template <class P, bool GRAD>
-__global__ __launch_bounds__(WPB * 64, P::OCC) void sdf_mlp_split_kernel(SdfArgs a) {
+__global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(SdfArgs a) {
   typedef FragT<P::NP> Frag;
   __shared__ __attribute__((aligned(16))) char lds[3 * slot_bytes<P>()];
   static_assert(N_CHUNKS % 3 == 0 && N_FWD_CHUNKS % 3 == 0, "slot of a chunk = index % 3");
@@ -740,7 +747,7 @@ __global__ __launch_bounds__(WPB * 64, P::OCC) void sdf_mlp_split_kernel(SdfArgs
       bwd_layer<P, 2>(c, hA, dA, accE, accP, pend);
       bwd_layer<P, 1>(c, dA, hA, accE, accP, pend);
       f32x4 Jq[12];  // feature Jacobian: DEEP fetches it under the last chunk
-      if (P::DEEP) {
+      if (P::DEEPJ) {
 #pragma unroll
         for (int g = 0; g < 12; ++g) Jq[g] = bload(c.sl, c.svoff, SCR_S * 4 + g * 1024);
       }
@@ -765,7 +772,7 @@ __global__ __launch_bounds__(WPB * 64, P::OCC) void sdf_mlp_split_kernel(SdfArgs
           float Jf[24];
 #pragma unroll
           for (int g = 0; g < 6; ++g) {
-            const f32x4 v = P::DEEP ? Jq[6 * sl + g] : bload(c.sl, c.svoff, SCR_S * 4 + (6 * sl + g) * 1024);
+            const f32x4 v = P::DEEPJ ? Jq[6 * sl + g] : bload(c.sl, c.svoff, SCR_S * 4 + (6 * sl + g) * 1024);
             Jf[4 * g + 0] = v[0]; Jf[4 * g + 1] = v[1]; Jf[4 * g + 2] = v[2]; Jf[4 * g + 3] = v[3];
           }
 #pragma unroll
@@ -793,10 +800,10 @@ __global__ __launch_bounds__(WPB * 64, P::OCC) void sdf_mlp_split_kernel(SdfArgs
 }
 
 template <class P>
-int grid_blocks(int64_t n) {
+int grid_blocks(int64_t n, bool grad) {
   int64_t tiles = (n + TILE - 1) / TILE;
   int64_t rounds = (tiles + WPB - 1) / WPB;
-  return (int)(rounds < max_blocks<P>() ? rounds : max_blocks<P>());
+  return (int)(rounds < max_blocks<P>(grad) ? rounds : max_blocks<P>(grad));
 }
 
 // ---- host packer ------------------------------------------------------------------------------------------------------
@@ -953,7 +960,7 @@ int launch(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n,
     if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
     if (s < n_vol && h_dims[s] > 1024) return SURF_E_LIMIT;  // 32-bit table indices (gather_features)
   }
-  dim3 grid(grid_blocks<P>(n)), block(WPB * 64);
+  dim3 grid(grid_blocks<P>(n, grad != nullptr)), block(WPB * 64);
   if (grad)
     hipLaunchKernelGGL((sdf_mlp_split_kernel<P, true>), grid, block, 0, (hipStream_t)stream, a);
   else
@@ -964,7 +971,7 @@ int launch(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n,
 template <class P>
 int64_t scratch_bytes(int64_t n_points) {
   if (n_points <= 0) return 0;
-  return (int64_t)grid_blocks<P>(n_points) * WPB * SCR_SLOT * sizeof(float);
+  return (int64_t)grid_blocks<P>(n_points, true) * WPB * SCR_SLOT * sizeof(float);
 }
 
 }  // namespace
