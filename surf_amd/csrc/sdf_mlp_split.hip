@@ -450,15 +450,24 @@ __device__ __forceinline__ void gather_features(const SdfArgs& a, const Ctx& c, 
   }
 }
 
-__device__ __forceinline__ void posenc_half(int h, float x, float y, float z, float (&e)[16], float (&je)[14], bool want_j) {
+// Positional encoding of this lane half (14 of the 27 channels + pad) from the three base (sin, cos) pairs: the
+// 2x, 4x, 8x terms by exact double-angle steps.  The base pairs are kept for the epilogue's Jacobian diagonal.
+struct SinCos3 { float s[3], c[3]; };
+__device__ __forceinline__ SinCos3 sincos3(float x, float y, float z) {
+  SinCos3 b;
+  sincosf(x, &b.s[0], &b.c[0]);
+  sincosf(y, &b.s[1], &b.c[1]);
+  sincosf(z, &b.s[2], &b.c[2]);
+  return b;
+}
+__device__ __forceinline__ void posenc_half(int h, float x, float y, float z, const SinCos3& b, float (&e)[16], float (&je)[14],
+                                            bool want_j) {
   float all[28], jall[28];
   all[0] = x; all[1] = y; all[2] = z;
   jall[0] = jall[1] = jall[2] = 1.0f;
-  const float p[3] = {x, y, z};
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    float s, co;
-    sincosf(p[c], &s, &co);
+    float s = b.s[c], co = b.c[c];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float f = (float)(1 << k);
@@ -668,6 +677,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
 
     Frag ef[2], pf[2];
     float y0 = 0.f;
+    const SinCos3 base = sincos3(px, py, pz);
     {
       float phi[16], e[16];
       if (SURF_X_NOGATHER) {
@@ -684,7 +694,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
           if (4 * g + q < 14) y0 = fmaf(w[q], phi[4 * g + q], y0);
       }
       float je_unused[14];
-      posenc_half(c.h, px, py, pz, e, je_unused, false);
+      posenc_half(c.h, px, py, pz, base, e, je_unused, false);
       e[14] = 1.0f;  // bias k-element (weights carry the bias there, lane half 0 only)
       phi[14] = 1.0f;
       local_frags<P>(e, ef);
@@ -759,7 +769,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
       float g3[3] = {0.f, 0.f, 0.f};
       {
         float e2[16], je[14];
-        posenc_half(c.h, px, py, pz, e2, je, true);
+        posenc_half(c.h, px, py, pz, base, e2, je, true);
 #pragma unroll
         for (int s2 = 0; s2 < 14; ++s2) {
           const int c0 = s2 % 3, c1 = (14 + s2) % 3;
