@@ -18,8 +18,20 @@ for s in "${SRCS[@]}"; do
   if [[ ! -f "$o" || "$s" -nt "$o" || "${HERE}/common.h" -nt "$o" || "${HERE}/../../include/surf_hip.h" -nt "$o" ]]; then
     "${HIPCC}" "${FLAGS[@]/-shared/}" -c "$s" -o "$o" &
     pids+=($!)
+    [[ "$(basename "$s")" == "sdf_mlp_split.hip" ]] && check_split=1
   fi
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
+# The split SDF kernels retire their LDS-DMA with counted s_waitcnt vmcnt(N): register-allocator spills to scratch
+# memory would add uncounted (and differently ordered) memory operations inside the chunks.  Refuse such a build.
+if [[ "${check_split:-0}" == 1 ]]; then
+usage="$("${HIPCC}" "${FLAGS[@]/-shared/}" --cuda-device-only -Rpass-analysis=kernel-resource-usage -c "${HERE}/sdf_mlp_split.hip" -o /dev/null 2>&1 | grep -A4 "Function Name: .*sdf_mlp_split_kernel" | grep "ScratchSize" || true)"
+if [[ -z "$usage" ]] || echo "$usage" | grep -qv "ScratchSize \[bytes/lane\]: 0 "; then
+  echo "sdf_mlp_split.hip: a split kernel spills to scratch memory (or its resource usage could not be read):" >&2
+  echo "$usage" >&2
+  rm -f "${HERE}/../_obj/sdf_mlp_split.o"
+  exit 1
+fi
+fi
 "${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${objs[@]}"
 echo "built ${OUT}"
