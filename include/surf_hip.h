@@ -223,10 +223,12 @@ int surf_spconv(const float* in, int cin, const int32_t* in_table, int D_in, con
                 int mode, const float* weight, int cout, const float* bn_scale, const float* bn_shift, const float* skip,
                 float* out, void* stream);
 
+/* bbox (device int32[6]) = [min x, min y, min z, max x, max y, max z] of coords (n,3) */
+int surf_coords_bbox(const int32_t* coords, int64_t n, int32_t* bbox, void* stream);
 /* Output sites of a k3/s2 conv: marks[(D/2+1)^3] |= 1 at q when 2q lies in the 3^3 window of an input voxel and
- * inside the inputs' bounding box h_lo..h_hi (HOST int[3] each).  marks must be zeroed by the caller. */
-int surf_mark_down_sites(const int32_t* coords, int64_t n, int D, const int* h_lo, const int* h_hi, uint8_t* marks,
-                         void* stream);
+ * inside the inputs' bounding box (device int32[6] from surf_coords_bbox: no host round trip).  marks must be zeroed
+ * by the caller. */
+int surf_mark_down_sites(const int32_t* coords, int64_t n, int D, const int32_t* bbox, uint8_t* marks, void* stream);
 /* keys (ascending lattice site numbers, e.g. from surf_compact) -> coords (n,3) and table[key] = rank */
 int surf_sites_from_keys(const int32_t* keys, int64_t n, int D, int32_t* coords, int32_t* table, void* stream);
 /* table[coords[i]] = i (table pre-filled with -1 by the caller) */

@@ -51,7 +51,8 @@ SIGNATURES = {
     "surf_compose_index": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "surf_densify": (c_int, [c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_spconv": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
-    "surf_mark_down_sites": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_coords_bbox": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
+    "surf_mark_down_sites": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
     "surf_sites_from_keys": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr]),
     "surf_table_from_coords": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "surf_row_linear8": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),

@@ -258,9 +258,17 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void blend_kernel(BlendArgs
       ax /= nn; ay /= nn; az /= nn;
     }
     int nvalid = 0;
-    // ------------------------------ pass 1: fetch + direction feature per view -----------------------------
+    // ------------------------------ pass 1a: projections, all texel fetches of all views issued together ------
+    // (one wavefront per SIMD: nothing else hides the fetch latency, so it is exposed once, not once per view;
+    //  with two wavefronts per SIMD (NS <= 2) the register budget still covers 24 fetches)
+    //  with more than four source views the fetches go in groups of three: 36 fetches in flight fit the registers)
+    constexpr int GV = NS <= 4 ? NS : 3;
+    Tap4 qA[NS], qB[NS], qC[NS];
+    bool okv[NS];
 #pragma unroll
-    for (int v = 0; v < NS; ++v) {
+    for (int v0 = 0; v0 < NS; v0 += GV) {
+#pragma unroll
+    for (int v = v0; v < (v0 + GV < NS ? v0 + GV : NS); ++v) {
       const int cam = v + 1;
       // ray_diff (projector.py:485-498)
       float bx = a.cpos[cam][0] - px, by = a.cpos[cam][1] - py, bz = a.cpos[cam][2] - pz;
@@ -281,27 +289,31 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void blend_kernel(BlendArgs
       float qz = K[6] * X + K[7] * Y + K[8] * Z;
       float u0 = qx / qz, v0 = qy / qz;
       bool ok = qz > 0.f;
-      // the three fetches of this half (level A, level B, and the image for half 0) are issued together
-      Tap4 qA, qB, qC;
       {
         float u = u0 * scA, vv = v0 * scA;
         ok = ok && (u >= 0.f) && (u < (float)WA) && (vv >= 0.f) && (vv < (float)HA);
         float nx = u / ((float)(WA - 1) / 2.0f) - 1.0f, ny = vv / ((float)(HA - 1) / 2.0f) - 1.0f;
         float gx = ((nx + 1.0f) * (float)WA - 1.0f) / 2.0f, gy = ((ny + 1.0f) * (float)HA - 1.0f) / 2.0f;
-        tap_issue(qA, mapA + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
+        tap_issue(qA[v], mapA + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
         // half 1 re-reads its level-A taps instead of the image (same addresses: L1 hits), result unused
-        tap_issue(qC, (h == 0 ? a.imgs : mapA) + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
+        tap_issue(qC[v], (h == 0 ? a.imgs : mapA) + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
       }
       {
         float u = u0 * scB, vv = v0 * scB;
         ok = ok && (u >= 0.f) && (u < (float)WB) && (vv >= 0.f) && (vv < (float)HB);
         float nx = u / ((float)(WB - 1) / 2.0f) - 1.0f, ny = vv / ((float)(HB - 1) / 2.0f) - 1.0f;
         float gx = ((nx + 1.0f) * (float)WB - 1.0f) / 2.0f, gy = ((ny + 1.0f) * (float)HB - 1.0f) / 2.0f;
-        tap_issue(qB, mapB + (int64_t)cam * HB * WB * 4, HB, WB, gx, gy);
+        tap_issue(qB[v], mapB + (int64_t)cam * HB * WB * 4, HB, WB, gx, gy);
       }
-      const f32x4 tA = tap_finish(qA), tB = tap_finish(qB);
-      f32x4 tC = tap_finish(qC);
+      okv[v] = ok;
+    }
+    // ------------------------------ pass 1b: direction feature per view ----------------------------------------
+#pragma unroll
+    for (int v = v0; v < (v0 + GV < NS ? v0 + GV : NS); ++v) {
+      const f32x4 tA = tap_finish(qA[v]), tB = tap_finish(qB[v]);
+      f32x4 tC = tap_finish(qC[v]);
       if (h != 0) tC = f32x4{0.f, 0.f, 0.f, 0.f};
+      bool ok = okv[v];
       ok = ok && (__shfl_xor((int)ok, 32) != 0);  // AND over all four levels
       mk[v] = ok ? 1.f : 0.f;
       nvalid += ok ? 1 : 0;
@@ -342,7 +354,8 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void blend_kernel(BlendArgs
       }
       floc[v][11] = 0.f;
       ex[v] = expf(s_abs * (rd[v][3] - 1.0f));
-      __builtin_amdgcn_sched_barrier(0);  // one view's 12 texel loads in flight at a time (register budget)
+      __builtin_amdgcn_sched_barrier(0);
+    }
     }
     if (a.n_valid && active && h == 0) a.n_valid[i] = (uint8_t)nvalid;
 

@@ -90,16 +90,47 @@ __global__ __launch_bounds__(256) void spconv_kernel(SpconvArgs a) {
 // marks[q] = 1 for every coarse site q such that 2q is within the 3^3 window of an input voxel and inside the
 // bounding box of the input coordinates (the output-site rule of a k3/s2 sparse conv, "dilate" in the oracle)
 __global__ __launch_bounds__(256) void mark_down_sites_kernel(const int32_t* __restrict__ coords, int64_t n, int D2,
-                                                              int lox, int loy, int loz, int hix, int hiy, int hiz,
+                                                              const int32_t* __restrict__ bbox,
                                                               uint8_t* __restrict__ marks) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n * 27) return;
+  const int lox = bbox[0], loy = bbox[1], loz = bbox[2], hix = bbox[3], hiy = bbox[4], hiz = bbox[5];
   const int64_t i = t / 27;
   const int k = (int)(t % 27);
   const int x = coords[i * 3 + 0] + (k % 3 - 1), y = coords[i * 3 + 1] + ((k / 3) % 3 - 1), z = coords[i * 3 + 2] + (k / 9 - 1);
   if (((x | y | z) & 1) != 0) return;
   if (x < lox || x > hix || y < loy || y > hiy || z < loz || z > hiz) return;
   marks[((int64_t)(x >> 1) * D2 + (y >> 1)) * D2 + (z >> 1)] = 1;
+}
+
+// bounding box of integer coordinates: bbox = [min x, y, z, max x, y, z] (wave reduce, then six atomics per wave)
+__global__ void bbox_init_kernel(int32_t* __restrict__ bbox) {
+  if (threadIdx.x < 3) bbox[threadIdx.x] = 0x7fffffff;
+  else if (threadIdx.x < 6) bbox[threadIdx.x] = (int32_t)0x80000000;
+}
+__global__ __launch_bounds__(256) void bbox_kernel(const int32_t* __restrict__ coords, int64_t n, int32_t* __restrict__ bbox) {
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int v = coords[i * 3 + a];
+      lo[a] = min(lo[a], v);
+      hi[a] = max(hi[a], v);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lo[a] = wave_min_i(lo[a]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) hi[a] = max(hi[a], __shfl_xor(hi[a], o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      atomicMin(&bbox[a], lo[a]);
+      atomicMax(&bbox[3 + a], hi[a]);
+    }
+  }
 }
 
 // keys (ascending site numbers of a D^3 lattice) -> coords (n,3) and table[key] = rank
@@ -162,12 +193,19 @@ extern "C" int surf_spconv(const float* in, int cin, const int32_t* in_table, in
   return SURF_E_LIMIT;  // channel pair not instantiated (reg_network.py uses d_base = 8 only)
 }
 
-extern "C" int surf_mark_down_sites(const int32_t* coords, int64_t n, int D, const int* h_lo, const int* h_hi,
-                                    uint8_t* marks, void* stream) {
-  if (!coords || !h_lo || !h_hi || !marks || n <= 0 || D < 2) return SURF_E_ARG;
+extern "C" int surf_coords_bbox(const int32_t* coords, int64_t n, int32_t* bbox, void* stream) {
+  if (!coords || !bbox || n <= 0) return SURF_E_ARG;
+  hipLaunchKernelGGL(bbox_init_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, bbox);
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(bbox_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, coords, n, bbox);
+  return surf_check_launch();
+}
+
+extern "C" int surf_mark_down_sites(const int32_t* coords, int64_t n, int D, const int32_t* bbox, uint8_t* marks,
+                                    void* stream) {
+  if (!coords || !bbox || !marks || n <= 0 || D < 2) return SURF_E_ARG;
   const int D2 = D / 2 + 1;
-  hipLaunchKernelGGL(mark_down_sites_kernel, grid1d(n * 27, 256), dim3(256), 0, (hipStream_t)stream, coords, n, D2, h_lo[0],
-                     h_lo[1], h_lo[2], h_hi[0], h_hi[1], h_hi[2], marks);
+  hipLaunchKernelGGL(mark_down_sites_kernel, grid1d(n * 27, 256), dim3(256), 0, (hipStream_t)stream, coords, n, D2, bbox, marks);
   return surf_check_launch();
 }
 

@@ -461,11 +461,10 @@ def down_sites(coords, D):
     D2 = D // 2 + 1
     if coords.shape[0] == 0:
         return (torch.empty(0, 3, dtype=torch.int32, device=dev), torch.full((D2, D2, D2), -1, dtype=torch.int32, device=dev), D2)
-    lo = coords.amin(dim=0).cpu().numpy().astype(np.int32)
-    hi = coords.amax(dim=0).cpu().numpy().astype(np.int32)
+    bbox = torch.empty(6, dtype=torch.int32, device=dev)          # stays on the device: no host round trip
+    _lib.check(_lib.lib().surf_coords_bbox(_p(coords), coords.shape[0], _p(bbox), _stream()), "surf_coords_bbox")
     marks = torch.zeros(D2 * D2 * D2, dtype=torch.uint8, device=dev)
-    lo_c, hi_c = (ctypes.c_int * 3)(*lo.tolist()), (ctypes.c_int * 3)(*hi.tolist())
-    _lib.check(_lib.lib().surf_mark_down_sites(_p(coords), coords.shape[0], int(D), lo_c, hi_c, _p(marks), _stream()),
+    _lib.check(_lib.lib().surf_mark_down_sites(_p(coords), coords.shape[0], int(D), _p(bbox), _p(marks), _stream()),
                "surf_mark_down_sites")
     keys = compact(marks)
     c2 = torch.empty(keys.shape[0], 3, dtype=torch.int32, device=dev)
