@@ -519,11 +519,15 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
     for (int g = 0; g < 4; ++g) w6[g] = bload(c.tr, c.h * 256, (TAIL_W6H * 4) + ((T - 1) * 4 + g) * 16);
   }
   f32x4 sbuf = {0.f, 0.f, 0.f, 0.f};
-  // element pair (2q, 2q+1) of the previous tile
-  auto cvt_pair = [&](int q, Frag* dst, int dst_tile, int s_layer) __attribute__((always_inline)) {
-    f32x2 hv, sv;
+  // element pair (2q, 2q+1) of the previous tile, in two stages so that two independent dependency chains (the
+  // transcendental chain of pair q and the split chain of pair q-1) are available to interleave with each k-step's MFMAs
+  f32x2 pend_h = {0.f, 0.f}, pend_s = {0.f, 0.f};
+  auto stage_a = [&](int q) __attribute__((always_inline)) {
     const f32x2 t2 = {prev[2 * q], prev[2 * q + 1]};
-    softplus_pair<GRAD>(t2, 1.0f / Scales<P>::W, hv, sv);
+    softplus_pair<GRAD>(t2, 1.0f / Scales<P>::W, pend_h, pend_s);
+  };
+  auto stage_b = [&](int q, Frag* dst, int dst_tile, int s_layer) __attribute__((always_inline)) {
+    const f32x2 hv = pend_h, sv = pend_s;
     const int el = 2 * q;
     if (LAST) {
       const float w0 = w6[el >> 2][el & 3], w1 = w6[(el + 1) >> 2][(el + 1) & 3];
@@ -542,11 +546,19 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
     if (L == 0) {
       if (T > 0 && ks < 2) {  // only two k-steps per tile in layer 0: four pairs each
 #pragma unroll
-        for (int u = 0; u < 4; ++u) cvt_pair(4 * ks + u, hout, T - 1, 0);
+        for (int u = 0; u < 4; ++u) {
+          stage_a(4 * ks + u);
+          stage_b(4 * ks + u, hout, T - 1, 0);
+        }
       }
-    } else if (ks < 8) {  // T == 0: tile 3 of the previous layer, first needed by hidden k-step 6 (position >= 8)
-      if (T == 0) cvt_pair(ks, hin, 3, L - 1);
-      else cvt_pair(ks, hout, T - 1, L);
+    } else {
+      // T == 0: tile 3 of the previous layer; its fragments 6 / 7 are complete after k-steps 4 / 8 and first needed
+      // by hidden k-steps 6 / 7 at positions >= 8 / 9
+      if (ks >= 1 && ks <= 8) {
+        if (T == 0) stage_b(ks - 1, hin, 3, L - 1);
+        else stage_b(ks - 1, hout, T - 1, L);
+      }
+      if (ks < 8) stage_a(ks);  // (a third stage - exp | log, rcp | split - measured no faster)
     }
   };
   auto bsel = [&](int ks) __attribute__((always_inline)) -> const Frag& {
@@ -590,17 +602,27 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
   constexpr int SL = sprime_layer(P::DEEP, L, T);
   static_assert((SL >= 0 ? 4 : 0) + ((L == 0 && P::DEEPJ) ? 12 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
   if (SL >= 0) load_sprime(c, SL, sprime_tile(P::DEEP, L, T), s_load);
-  auto cvt = [&](int q) __attribute__((always_inline)) {
+  // two stages, as in the forward tiles: the product of pair q and the split of pair q-1 share a k-step
+  f32x2 pend = {0.f, 0.f};
+  auto mul = [&](int q) __attribute__((always_inline)) {
     const int el = 2 * q;
     constexpr float inv_w = 1.0f / Scales<P>::W;  // G arrives x W_SCALE x D_SCALE, deltas are kept x D_SCALE
-    float d0 = prev.s[el >> 2][el & 3] * prev.G[el], d1 = prev.s[(el + 1) >> 2][(el + 1) & 3] * prev.G[el + 1];
-    if (inv_w != 1.0f) { d0 *= inv_w; d1 *= inv_w; }
-    frag_set_pair<P>(dout[2 * (T - 1) + (el >> 3)], (el & 7) >> 1, d0, d1);
+    pend[0] = prev.s[el >> 2][el & 3] * prev.G[el];
+    pend[1] = prev.s[(el + 1) >> 2][(el + 1) & 3] * prev.G[el + 1];
+    if (inv_w != 1.0f) pend = pend * inv_w;
+  };
+  auto put = [&](int q) __attribute__((always_inline)) {
+    const int el = 2 * q;
+    frag_set_pair<P>(dout[2 * (T - 1) + (el >> 3)], (el & 7) >> 1, pend[0], pend[1]);
   };
   auto fn = [&](int ks) __attribute__((always_inline)) {
     if (CONVERT) {
-      cvt(ks);
-      if (NKS == 7 && ks == 6) cvt(7);
+      if (ks >= 1) put(ks - 1);
+      mul(ks);
+      if (ks == NKS - 1) {  // drain: the last one or two pairs
+        put(ks);
+        if (NKS == 7) { mul(7); put(7); }
+      }
     }
   };
   return run_chunk<P, true, CI, N_CHUNKS>(c, [&](int ks) __attribute__((always_inline)) -> const Frag& { return din[ks]; }, fn);
