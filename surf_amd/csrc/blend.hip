@@ -12,7 +12,11 @@
 // plus 48 per tile for the view-independent [mean | var] part of base_fc.0.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
+
+
 
 namespace {
 
@@ -193,6 +197,45 @@ __device__ __forceinline__ void stream_mma2(WRing& ring, f32x16& acc0, f32x16& a
     for (int i = 0; i < 4; ++i)
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ring.a[(POS + 2 * q + 1) % (RPF + 1)][i], b[q * 4 + i], acc1, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// The same for NV views at once: every weight group is fetched once and used by all of them, and the views' accumulator
+// chains are independent (no dependent-MFMA issue delay).  (Letting VALU work cross the scheduling barrier, so that one
+// view's activations could be scheduled beside another's MFMAs, measured 4-5 % slower than pinning everything.)
+#define SURF_BLEND_SB() __builtin_amdgcn_sched_barrier(0)
+template <class SEQ, class NEXT, int POS, int NQ, int NV>
+__device__ __forceinline__ void stream_mma_v(WRing& ring, f32x16 (&acc)[NV], const float* const (&b)[NV], bool last, rsrc_t wr,
+                                             int lane16) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    ring_prefetch<SEQ, NEXT>(ring, POS + q, last, wr, lane16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int u = 0; u < NV; ++u)
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring.a[(POS + q) % (RPF + 1)][i], b[u][q * 4 + i], acc[u], 0, 0, 0);
+    SURF_BLEND_SB();
+  }
+}
+template <class SEQ, class NEXT, int POS, int NQ, int NV>
+__device__ __forceinline__ void stream_mma2_v(WRing& ring, f32x16 (&acc0)[NV], f32x16 (&acc1)[NV], const float* const (&b)[NV],
+                                              bool last, rsrc_t wr, int lane16) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    ring_prefetch<SEQ, NEXT>(ring, POS + 2 * q, last, wr, lane16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int u = 0; u < NV; ++u)
+        acc0[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring.a[(POS + 2 * q) % (RPF + 1)][i], b[u][q * 4 + i], acc0[u], 0, 0, 0);
+    ring_prefetch<SEQ, NEXT>(ring, POS + 2 * q + 1, last, wr, lane16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int u = 0; u < NV; ++u)
+        acc1[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring.a[(POS + 2 * q + 1) % (RPF + 1)][i], b[u][q * 4 + i], acc1[u], 0, 0, 0);
+    SURF_BLEND_SB();
   }
 }
 
@@ -387,99 +430,142 @@ __global__ __launch_bounds__(256, (NS <= 2 ? 2 : 1)) void blend_kernel(BlendArgs
     // ------------------------------ pass 2: per-view chain, online softmax over views (:88-116) -------------
     const float b_vis = a.w[SCAL_OFF + 1], b_vis2 = a.w[SCAL_OFF + 2], b_rgb4 = a.w[SCAL_OFF + 3];
     float Mx = -INFINITY, Zs = 0.f, o_r = 0.f, o_g = 0.f, o_b = 0.f;
-#pragma unroll
-    for (int v = 0; v < NS; ++v) {
-      const bool lastv = (v == NS - 1);
-      // Per-view copy of the row offset that the compiler cannot see through: otherwise the (identical) bias-row loads
-      // of all views are merged into one set of 160 registers kept live across the whole pass.
+    // NV source views per pass over the weight stream (two at a time, a last single one when NS is odd)
+    auto chain = [&](auto nv_tag, const int v0, const bool lastv) __attribute__((always_inline)) {
+      constexpr int NV = decltype(nv_tag)::value;
+      // Per-chain copy of the row offset that the compiler cannot see through: otherwise the (identical) bias-row loads
+      // of all chains are merged into one set of 160 registers kept live across the whole pass.
       int h64v = h64;
       asm volatile("" : "+v"(h64v));
       // base_fc.0 (view part) + ELU : 57 -> 64
       const f32x16 bb0 = load_row16(wr, h64v, BIAS_OFF + B_B0_T0 * 32), bb1 = load_row16(wr, h64v, BIAS_OFF + B_B0_T1 * 32);
-      f32x16 a64a = G0a, a64b = G0b;
-      stream_mma2<SeqPV, SeqNone, 0, 3>(ring, a64a, a64b, floc[v], lastv, wr, lane16);
-      float h32[32];
-      elu_rows<16>(a64a, bb0, h32);
-      elu_rows<16>(a64b, bb1, h32 + 16);
+      f32x16 a64a[NV], a64b[NV];
+      const float* bp[NV];
+#pragma unroll
+      for (int u = 0; u < NV; ++u) { a64a[u] = G0a; a64b[u] = G0b; bp[u] = floc[v0 + u]; }
+      stream_mma2_v<SeqPV, SeqNone, 0, 3, NV>(ring, a64a, a64b, bp, lastv, wr, lane16);
+      float h32[NV][32];
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        elu_rows<16>(a64a[u], bb0, h32[u]);
+        elu_rows<16>(a64b[u], bb1, h32[u] + 16);
+        bp[u] = h32[u];
+      }
       // base_fc.2 + ELU : 64 -> 32
       const f32x16 bx = load_row16(wr, h64v, BIAS_OFF + B_B2 * 32);
-      f32x16 accx = zero16();
-      stream_mma<SeqPV, SeqNone, 6, 8>(ring, accx, h32, lastv, wr, lane16);
-      float x[16], xin[16];
-      elu_rows<16>(accx, bx, x);
+      f32x16 accx[NV];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xin[r] = x[r] * wv[v];
+      for (int u = 0; u < NV; ++u) accx[u] = zero16();
+      stream_mma_v<SeqPV, SeqNone, 6, 8, NV>(ring, accx, bp, lastv, wr, lane16);
+      float x[NV][16], xin[NV][16];
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        elu_rows<16>(accx[u], bx, x[u]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xin[u][r] = x[u][r] * wv[v0 + u];
+        bp[u] = xin[u];
+      }
       // vis_fc: 32 -> 32 (ELU) -> 33 (ELU)
       const f32x16 bt = load_row16(wr, h64v, BIAS_OFF + B_V0 * 32);
-      f32x16 acct = zero16();
-      stream_mma<SeqPV, SeqNone, 14, 4>(ring, acct, xin, lastv, wr, lane16);
-      float t16[16];
-      elu_rows<16>(acct, bt, t16);
+      f32x16 acct[NV];
+#pragma unroll
+      for (int u = 0; u < NV; ++u) acct[u] = zero16();
+      stream_mma_v<SeqPV, SeqNone, 14, 4, NV>(ring, acct, bp, lastv, wr, lane16);
+      float t16[NV][16];
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        elu_rows<16>(acct[u], bt, t16[u]);
+        bp[u] = t16[u];
+      }
       const f32x16 br = load_row16(wr, h64v, BIAS_OFF + B_V2 * 32);
       const f32x16 dvis = load_row16(wr, h64v, DOT_OFF + D_VIS * 32);
-      f32x16 accr = zero16();
-      stream_mma<SeqPV, SeqNone, 18, 4>(ring, accr, t16, lastv, wr, lane16);
-      float vraw = 0.f;
+      f32x16 accr[NV];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) vraw = fmaf(dvis[r], t16[r], vraw);
-      vraw += __shfl_xor(vraw, 32);
-      const float vis = sigm(elu(vraw + b_vis)) * mk[v];
-      {
+      for (int u = 0; u < NV; ++u) accr[u] = zero16();
+      stream_mma_v<SeqPV, SeqNone, 18, 4, NV>(ring, accr, bp, lastv, wr, lane16);
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        float vraw = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vraw = fmaf(dvis[r], t16[u][r], vraw);
+        vraw += __shfl_xor(vraw, 32);
+        const float vis = sigm(elu(vraw + b_vis)) * mk[v0 + u];
         float d16[16];
-        elu_rows<16>(accr, br, d16);
+        elu_rows<16>(accr[u], br, d16);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { x[r] = x[r] + d16[r]; xin[r] = x[r] * vis; }
+        for (int r = 0; r < 16; ++r) { x[u][r] = x[u][r] + d16[r]; xin[u][r] = x[u][r] * vis; }
+        bp[u] = xin[u];
       }
       // vis_fc2: 32 -> 32 (ELU) -> 1 (sigmoid)
       const f32x16 bw = load_row16(wr, h64v, BIAS_OFF + B_W0 * 32);
       const f32x16 dvis2 = load_row16(wr, h64v, DOT_OFF + D_VIS2 * 32);
-      f32x16 accw = zero16();
-      stream_mma<SeqPV, SeqNone, 22, 4>(ring, accw, xin, lastv, wr, lane16);
-      float v2 = 0.f;
-      {
+      f32x16 accw[NV];
+#pragma unroll
+      for (int u = 0; u < NV; ++u) accw[u] = zero16();
+      stream_mma_v<SeqPV, SeqNone, 22, 4, NV>(ring, accw, bp, lastv, wr, lane16);
+      // rgb_fc: [x(32), vis, ray_diff(4)] = 37 -> 16 (ELU) -> 8 (ELU) -> 1
+      float rin[NV][20];
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int v = v0 + u;
+        float v2 = 0.f;
         float d16[16];
-        elu_rows<16>(accw, bw, d16);
+        elu_rows<16>(accw[u], bw, d16);
 #pragma unroll
         for (int r = 0; r < 16; ++r) v2 = fmaf(dvis2[r], d16[r], v2);
-      }
-      v2 += __shfl_xor(v2, 32);
-      const float vis2 = sigm(v2 + b_vis2) * mk[v];
-      // rgb_fc: [x(32), vis, ray_diff(4)] = 37 -> 16 (ELU) -> 8 (ELU) -> 1
-      float rin[20];
+        v2 += __shfl_xor(v2, 32);
+        const float vis2 = sigm(v2 + b_vis2) * mk[v];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) rin[r] = x[r];
-      rin[16] = h ? rd[v][0] : vis2;
-      rin[17] = h ? rd[v][2] : rd[v][1];
-      rin[18] = h ? 0.f : rd[v][3];
-      rin[19] = 0.f;
+        for (int r = 0; r < 16; ++r) rin[u][r] = x[u][r];
+        rin[u][16] = h ? rd[v][0] : vis2;
+        rin[u][17] = h ? rd[v][2] : rd[v][1];
+        rin[u][18] = h ? 0.f : rd[v][3];
+        rin[u][19] = 0.f;
+        bp[u] = rin[u];
+      }
       const f32x16 b16 = load_row16(wr, h64v, BIAS_OFF + B_R0 * 32);
-      f32x16 acc16 = zero16();
-      stream_mma<SeqPV, SeqNone, 26, 5>(ring, acc16, rin, lastv, wr, lane16);
-      float r8[8];
-      elu_rows<8>(acc16, b16, r8);
+      f32x16 acc16[NV];
+#pragma unroll
+      for (int u = 0; u < NV; ++u) acc16[u] = zero16();
+      stream_mma_v<SeqPV, SeqNone, 26, 5, NV>(ring, acc16, bp, lastv, wr, lane16);
+      float r8[NV][8];
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        elu_rows<8>(acc16[u], b16, r8[u]);
+        bp[u] = r8[u];
+      }
       const f32x16 b8 = load_row16(wr, h64v, BIAS_OFF + B_R2 * 32);
       const f32x16 drgb4 = load_row16(wr, h64v, DOT_OFF + D_RGB4 * 32);
-      f32x16 acc8 = zero16();
-      stream_mma<SeqPV, SeqNone, 31, 2>(ring, acc8, r8, lastv, wr, lane16);
-      float rr = 0.f;
-      {
+      f32x16 acc8[NV];
+#pragma unroll
+      for (int u = 0; u < NV; ++u) acc8[u] = zero16();
+      stream_mma_v<SeqPV, SeqNone, 31, 2, NV>(ring, acc8, bp, lastv, wr, lane16);
+#pragma unroll
+      for (int u = 0; u < NV; ++u) {
+        const int v = v0 + u;
+        float rr = 0.f;
         float d4[4];
-        elu_rows<4>(acc8, b8, d4);
+        elu_rows<4>(acc8[u], b8, d4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) rr = fmaf(drgb4[r], d4[r], rr);
+        rr += __shfl_xor(rr, 32);
+        rr += b_rgb4;
+        if (mk[v] == 0.f) rr = -1e9f;
+        const float Mn = fmaxf(Mx, rr);
+        const float sc = expf(Mx - Mn);  // exp(-inf) = 0 on the first view
+        const float e = expf(rr - Mn);
+        Zs = Zs * sc + e;
+        o_r = o_r * sc + e * rgb[v][0];
+        o_g = o_g * sc + e * rgb[v][1];
+        o_b = o_b * sc + e * rgb[v][2];
+        Mx = Mn;
       }
-      rr += __shfl_xor(rr, 32);
-      rr += b_rgb4;
-      if (mk[v] == 0.f) rr = -1e9f;
-      const float Mn = fmaxf(Mx, rr);
-      const float sc = expf(Mx - Mn);  // exp(-inf) = 0 on the first view
-      const float e = expf(rr - Mn);
-      Zs = Zs * sc + e;
-      o_r = o_r * sc + e * rgb[v][0];
-      o_g = o_g * sc + e * rgb[v][1];
-      o_b = o_b * sc + e * rgb[v][2];
-      Mx = Mn;
-    }
+    };
+    // views per chain: all of them up to four (52.0 ms vs 54.9 one by one at NS = 4); beyond that the split that does not spill
+    constexpr int VPC = NS <= 4 ? NS : (NS == 5 ? 4 : (NS == 6 ? 2 : 3));
+#pragma unroll
+    for (int v = 0; v + VPC <= NS; v += VPC) chain(std::integral_constant<int, VPC>{}, v, v + VPC == NS);
+    if (NS % VPC != 0) chain(std::integral_constant<int, (NS % VPC) ? (NS % VPC) : 1>{}, NS - NS % VPC, true);
     if (active && h == 0) {
       a.color[i * 3 + 0] = o_r / Zs;
       a.color[i * 3 + 1] = o_g / Zs;
