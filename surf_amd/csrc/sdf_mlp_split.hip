@@ -10,13 +10,14 @@
 //           matrix-pipe cycles than fp32.  One wavefront per SIMD (the three-piece activations need the register file).
 //   f16x2   two-way split a ~= a1 + a2 (11 + 11 significant bits; weights and deltas pre-scaled by 2^8 so that the second
 //           piece stays normal); three products a1b1 + a1b2 + a2b1; operand error <= 2^-22 (or 2^-25 absolute).
-//           5.3x fewer matrix-pipe cycles than fp32; two workgroups per CU.  |activations| must stay below 65504 and
-//           |weights| below 255.
+//           5.3x fewer matrix-pipe cycles than fp32.  |activations| must stay below 65504 and |weights| below 255.
 //
 // The weight stream is consumed several times faster than one wavefront could pull it from L2, so the four wavefronts of
-// a workgroup (one per SIMD) run in lockstep over a double-buffered LDS image of it: one chunk = all k-steps x pieces of
-// one 32-row output tile, filled by LDS-DMA (buffer_load ... lds) one chunk ahead, cyclically across rounds.
-// Softplus, operand splitting and scratch stores of output tile t are issued between the MFMAs of tile t+1.
+// a workgroup (one per SIMD) run in lockstep over an LDS image of it: one chunk = all k-steps x pieces of one 32-row
+// output tile, a ring of three slots filled by LDS-DMA (buffer_load ... lds) two chunks ahead, cyclically across rounds
+// and retired by counted s_waitcnt vmcnt(N) (no scratch-memory spills allowed: see build.sh).
+// Softplus, operand splitting and scratch stores of output tile t are issued between the MFMAs of tile t+1, as a
+// two-stage pipeline across k-steps (softplus of pair q beside the split of pair q-1).
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -665,7 +666,6 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
   typedef FragT<P::NP> Frag;
   __shared__ __attribute__((aligned(16))) char lds[3 * slot_bytes<P>()];
   static_assert(N_CHUNKS % 3 == 0 && N_FWD_CHUNKS % 3 == 0, "slot of a chunk = index % 3");
-  constexpr int NCH = GRAD ? N_CHUNKS : N_FWD_CHUNKS;
   Ctx c;
   c.lane = threadIdx.x & 63;
   c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
