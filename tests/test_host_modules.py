@@ -73,3 +73,25 @@ def test_ops_reject_cpu_tensors():
     from surf_amd import ops
     with pytest.raises(TypeError):
         ops.pack_texel4(torch.zeros(1, 3, 4, 4))
+
+
+def test_sdf_precision_conf_key():
+    """render.sdf_precision selects the SDF kernel; absent -> bf16x3 (exact split); unknown values are rejected."""
+    from bench import model_conf
+    from surf_amd import ops
+    from surf_amd.implicit_surface import ImplicitSurface
+    assert ImplicitSurface(model_conf([64, 32, 16, 16])).sdf_precision == "bf16x3"
+    for prec in ops.SDF_PRECISIONS:
+        assert ImplicitSurface(model_conf([8, 8], prec)).sdf_precision == prec
+    with pytest.raises(ValueError):
+        ImplicitSurface(model_conf([8, 8], "fp8"))
+    # the packers of the split kernels run on the host: stream sizes identify the kernel a packed tensor belongs to
+    m = ImplicitSurface(model_conf([8, 8]))
+    layers = ops.sdf_effective_weights({k: v for k, v in m.state_dict().items()}, "sdf_network.")
+    sizes = {p: len(ops.sdf_pack_weights_split_host(layers, p)) for p in ("bf16x3", "f16x2")}
+    assert sizes["bf16x3"] > sizes["f16x2"] > 0
+    for p, n in sizes.items():
+        assert ops.sdf_packed_precision(torch.zeros(n, dtype=torch.uint8)) == p
+    assert ops.sdf_packed_precision(torch.zeros(4, dtype=torch.float32)) == "f32"
+    with pytest.raises(ValueError):
+        ops.sdf_packed_precision(torch.zeros(7, dtype=torch.uint8))
