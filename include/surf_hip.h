@@ -44,20 +44,22 @@ int surf_pack_texel4(const float* src, int n, int C, int H, int W, float* dst, v
 
 /*
  * Ray set-up: z-sampling guided by the matching volume + section mid-points + voxel mask.
- * Replaces ImplicitSurface.render's sampling block (implicit_surface.py:268-311, perturb = 0),
+ * Replaces ImplicitSurface.render's sampling block (implicit_surface.py:268-311),
  * the head of render_core (implicit_surface.py:72-86) and lookup_volume (projector.py:392-420).
  *   rays_o, rays_d (R,3); near, far (R)
  *   mvol        dense matching volume (Dm^3)
  *   lin_depth   device copy of torch.linspace(0,1,n_depth); lin_samples: the n_stage linspaces
  *               torch.linspace(0,1,n_samples[s]) concatenated (S floats)
  *   h_n_samples[n_stage], h_sample_ranges[n_stage]   (confs/surf.conf:118-119)
+ *   jitter      NULL (render.perturb = 0) or device (R, n_stage): the per-ray, per-stage `torch.rand([R,1]) - 0.5`
+ *               draws of render.perturb > 0 (implicit_surface.py:274-277, 304-306)
  *   tables[n_stage] (fine -> coarse, as surf.py:159 passes them), h_dims[n_stage]
  * outputs (any of z_vals may be NULL): z_vals, mid_z, dists (R,S); pts (R*S,3); vmask (R*S) uint8
  */
 int surf_ray_setup(const float* rays_o, const float* rays_d, const float* near, const float* far, int n_rays,
                    const float* mvol, int Dm, const float* lin_depth, int n_depth, const float* lin_samples,
-                   const int* h_n_samples, const float* h_sample_ranges, int n_stage, float sample_dist,
-                   const int32_t* const* h_tables, const int* h_dims, int n_vol,
+                   const int* h_n_samples, const float* h_sample_ranges, int n_stage, const float* jitter,
+                   float sample_dist, const int32_t* const* h_tables, const int* h_dims, int n_vol,
                    float* z_vals, float* mid_z, float* dists, float* pts, uint8_t* vmask, void* stream);
 
 /*

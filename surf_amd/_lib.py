@@ -23,7 +23,7 @@ SIGNATURES = {
     "surf_abi_version": (c_int, []),
     "surf_pack_texel4": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "surf_ray_setup": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr,
-                               c_int, c_float, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+                               c_int, c_ptr, c_float, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_sdf_packed_floats": (c_i64, []),
     "surf_sdf_pack_weights": (c_int, [c_ptr, c_ptr, c_ptr]),
     "surf_sdf_scratch_bytes": (c_i64, [c_i64]),

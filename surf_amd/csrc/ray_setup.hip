@@ -1,7 +1,7 @@
 // K8: per-ray z-sampling guided by the matching volume, section mid-points and voxel mask.
 // One wavefront = one ray; lanes = coarse taps / samples.
 //
-// Restates (perturb = 0): ImplicitSurface.render  implicit_surface.py:268-311
+// Restates: ImplicitSurface.render  implicit_surface.py:268-311 (jitters of render.perturb > 0 supplied by the host)
 //                         render_core head         implicit_surface.py:72-86
 //                         lookup_volume            projector.py:392-420
 #include "common.h"
@@ -19,6 +19,7 @@ struct RaySetupArgs {
   const float* lin_depth;
   int n_depth;
   const float* lin_samples;
+  const float* jitter;  // (n_rays, n_stage) or null
   int n_samples[SURF_MAX_STAGES];
   float ranges[SURF_MAX_STAGES];
   int n_stage;
@@ -94,7 +95,12 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(RaySetupArgs a) {
       lo = fminf(fmaxf(lo, near), far);
       hi = fminf(fmaxf(hi, near), far);
     }
-    s_z[wave][k] = lo + (hi - lo) * a.lin_samples[k];
+    float z = lo + (hi - lo) * a.lin_samples[k];
+    if (a.jitter) {  // t * 2.0 / n (stage 0), t * (far_stage - near_stage) / n (bands): the reference's evaluation order
+      const float t = a.jitter[(int64_t)ray * a.n_stage + s];
+      z = z + (s == 0 ? t * 2.0f / (float)a.n_samples[0] : t * (hi - lo) / (float)a.n_samples[s]);
+    }
+    s_z[wave][k] = z;
   }
   __syncthreads();
 
@@ -144,7 +150,7 @@ __global__ void pack_texel4_kernel(const float* __restrict__ src, int n, int C, 
 
 }  // namespace
 
-extern "C" int surf_abi_version(void) { return 3; }
+extern "C" int surf_abi_version(void) { return 4; }
 
 extern "C" int surf_pack_texel4(const float* src, int n, int C, int H, int W, float* dst, void* stream) {
   if (!src || !dst || n <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return SURF_E_ARG;
@@ -157,7 +163,7 @@ extern "C" int surf_pack_texel4(const float* src, int n, int C, int H, int W, fl
 extern "C" int surf_ray_setup(const float* rays_o, const float* rays_d, const float* near, const float* far, int n_rays,
                               const float* mvol, int Dm, const float* lin_depth, int n_depth,
                               const float* lin_samples, const int* h_n_samples, const float* h_sample_ranges,
-                              int n_stage, float sample_dist, const int32_t* const* h_tables, const int* h_dims,
+                              int n_stage, const float* jitter, float sample_dist, const int32_t* const* h_tables, const int* h_dims,
                               int n_vol, float* z_vals, float* mid_z, float* dists, float* pts, uint8_t* vmask,
                               void* stream) {
   if (!rays_o || !rays_d || !near || !far || !mvol || !lin_depth || !lin_samples || !h_n_samples ||
@@ -169,7 +175,7 @@ extern "C" int surf_ray_setup(const float* rays_o, const float* rays_d, const fl
   RaySetupArgs a;
   a.rays_o = rays_o; a.rays_d = rays_d; a.near = near; a.far = far; a.n_rays = n_rays;
   a.mvol = mvol; a.Dm = Dm; a.lin_depth = lin_depth; a.n_depth = n_depth; a.lin_samples = lin_samples;
-  a.n_stage = n_stage; a.S = 0; a.sample_dist = sample_dist; a.n_vol = n_vol;
+  a.n_stage = n_stage; a.S = 0; a.sample_dist = sample_dist; a.n_vol = n_vol; a.jitter = jitter;
   for (int s = 0; s < SURF_MAX_STAGES; ++s) {
     a.n_samples[s] = s < n_stage ? h_n_samples[s] : 0;
     a.ranges[s] = s < n_stage ? h_sample_ranges[s] : 0.f;

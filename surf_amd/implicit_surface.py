@@ -4,7 +4,7 @@ Same module / parameter names (so reference checkpoints load with ``load_state_d
 ``render`` / ``validate`` / ``extract_geometry`` / ``forward`` entry points and output keys; the
 arithmetic runs in the HIP kernels behind ``surf_amd.ops`` (no PyTorch fallback).
 
-Scope of this mirror (see DESIGN.md): inference (`val`) semantics with ``render.perturb = 0``;
+Scope of this mirror (see DESIGN.md): inference (`val`) semantics, including the ``render.perturb`` jitter;
 the loss-only outputs of ``render_core`` (``ref_gray_val`` / ``sampled_gray_val`` patch warps,
 ``smooth_error``, ``sparse_sdf`` random points) belong to the training row.
 """
@@ -165,12 +165,16 @@ class ImplicitSurface(nn.Module):
         """mask_volumes are redundant with the index tables (mask == table >= 0, volume.py:112-130) and unused."""
         return SceneVolumes(matching_volume, volumes, sparse_idxes, features, imgs, intrs, c2ws)
 
-    def render_scene(self, rays_o, rays_d, near, far, scene, cos_anneal_ratio=1.0, per_sample=True):
-        """render (:268-335) + render_core (:64-266) on prepared SceneVolumes."""
-        if self.perturb > 0:
-            raise NotImplementedError("stochastic sampling (render.perturb > 0) is not implemented: set perturb = 0 "
-                                      "(the reference jitters even in val, implicit_surface.py:274-277)")
+    def render_scene(self, rays_o, rays_d, near, far, scene, cos_anneal_ratio=1.0, per_sample=True, jitter=None):
+        """render (:268-335) + render_core (:64-266) on prepared SceneVolumes.
+        render.perturb > 0 (every shipped conf; the reference jitters even in `val`, :274-277, 304-306): one
+        `torch.rand([R, 1]) - 0.5` per stage drawn on the CPU generator in the reference's order, so that a seeded run
+        reproduces the reference's sample positions for the same ray batch; `jitter` (R, n_stage) overrides the draw."""
         dev = rays_o.device
+        if jitter is None and self.perturb > 0:
+            jitter = torch.cat([torch.rand([rays_o.shape[0], 1]) - 0.5 for _ in self.n_samples], dim=1)
+        if jitter is not None:
+            jitter = jitter.to(dev, torch.float32).contiguous()
         sdf_w, blend_w = self.packed_weights(dev)
         rays_o = rays_o.float().contiguous()
         rays_d = rays_d.float().contiguous()
@@ -187,7 +191,7 @@ class ImplicitSurface(nn.Module):
             return r
 
         st = timed("ray_setup", lambda: ops.ray_setup(rays_o, rays_d, near.float(), far.float(), scene.mvol, scene.sv,
-                                                      self.n_samples, self.sample_ranges, self.n_depth))
+                                                      self.n_samples, self.sample_ranges, self.n_depth, jitter=jitter))
         act = timed("compact", lambda: ops.compact(st["vmask"]))      # masked-in samples, ray-major order
         sdf, grad = timed("sdf_mlp", lambda: ops.sdf_mlp(st["pts"], scene.sv, sdf_w, mask=st["vmask"], active_idx=act))
         col, nvalid = timed("blend", lambda: ops.blend(st["pts"], scene.feats_t4, scene.imgs_t4, scene.cams, blend_w,

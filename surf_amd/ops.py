@@ -184,8 +184,10 @@ def blend_pack_weights(sd, device, prefix="implicit_surface.color_network."):
 # ------------------------------------------------------------------------------------------------
 
 
-def ray_setup(rays_o, rays_d, near, far, mvol, volumes, n_samples, sample_ranges, n_depth, want_z=False):
-    """implicit_surface.py:268-311 (perturb=0) + :72-86.  Returns dict(mid_z, dists, pts, vmask[, z_vals])."""
+def ray_setup(rays_o, rays_d, near, far, mvol, volumes, n_samples, sample_ranges, n_depth, want_z=False, jitter=None):
+    """implicit_surface.py:268-311 + :72-86.  Returns dict(mid_z, dists, pts, vmask[, z_vals]).
+    jitter: None (render.perturb = 0) or (R, n_stage) float32 on the device = the `torch.rand([R, 1]) - 0.5` draws of
+    render.perturb > 0, one column per stage."""
     R = rays_o.shape[0]
     S = int(sum(n_samples))
     dev = rays_o.device
@@ -195,6 +197,9 @@ def ray_setup(rays_o, rays_d, near, far, mvol, volumes, n_samples, sample_ranges
     far = _chk(far.reshape(-1).contiguous(), torch.float32, "far")
     _chk(mvol, torch.float32, "matching volume")
     assert near.numel() == R and far.numel() == R
+    if jitter is not None:
+        _chk(jitter, torch.float32, "jitter")
+        assert tuple(jitter.shape) == (R, len(n_samples)), jitter.shape
     lin_depth = torch.linspace(0.0, 1.0, n_depth, dtype=torch.float32).to(dev)
     lin_s = torch.cat([torch.linspace(0.0, 1.0, int(n), dtype=torch.float32) for n in n_samples]).to(dev)
     out = {
@@ -208,7 +213,7 @@ def ray_setup(rays_o, rays_d, near, far, mvol, volumes, n_samples, sample_ranges
     ns = (ctypes.c_int * len(n_samples))(*[int(n) for n in n_samples])
     rg = (ctypes.c_float * len(sample_ranges))(*[float(r) for r in sample_ranges])
     rc = _lib.lib().surf_ray_setup(_p(rays_o), _p(rays_d), _p(near), _p(far), R, _p(mvol), int(mvol.shape[-1]),
-                                   _p(lin_depth), int(n_depth), _p(lin_s), ns, rg, len(n_samples),
+                                   _p(lin_depth), int(n_depth), _p(lin_s), ns, rg, len(n_samples), _p(jitter),
                                    ctypes.c_float(2.0 / n_samples[0]), volumes._tp, volumes._dp, volumes.n,
                                    _p(out.get("z_vals")), _p(out["mid_z"]), _p(out["dists"]), _p(out["pts"]),
                                    _p(out["vmask"]), _stream())

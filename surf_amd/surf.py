@@ -2,8 +2,9 @@
 step)`` and output keys; every stage runs in the HIP kernels of libsurf_hip.so.
 
 Inference semantics (``mode == "val"`` or a no-grad ``"train"`` forward without the loss-only outputs).  Not
-implemented (they belong to SURVEY rows f2/f3): autograd through the kernels, stochastic sampling
-(``render.perturb > 0``), finetune volumes (``has_vol`` / ``init_volumes`` / ``load_params_vol``).
+implemented (they belong to SURVEY rows f2/f3): autograd through the kernels, the train-mode jitter of the matching
+field (``perturb=True`` in ``build_volumes``), finetune volumes (``has_vol`` / ``init_volumes`` / ``load_params_vol``).
+``render.perturb > 0`` (the per-ray jitter of ``ImplicitSurface.render``, active in ``val`` too) is supported.
 """
 import torch
 import torch.nn as nn

@@ -51,5 +51,10 @@ def golden_render():
 
 
 @pytest.fixture(scope="session")
+def golden_perturb():
+    return load_npz("render_perturb.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_grid():
     return load_npz("sdf_grid.npz")

@@ -148,7 +148,12 @@ def stub_regnet(feats, coords, D, stage):
     return out, torch.tanh(feats @ B)
 
 
+ONLY = set(a for a in sys.argv[1:] if a.endswith(".npz"))   # e.g. `make_golden.py render_perturb.npz`: rewrite just that file
+
+
 def npz(name, **arrs):
+    if ONLY and name not in ONLY:
+        return
     out = {}
     for k, v in arrs.items():
         if torch.is_tensor(v):
@@ -268,6 +273,18 @@ def main():
             rend[tag + k] = outs[k].detach()
         rend[tag + "sdf"] = outs["sparse_sdf"][1024:].detach().reshape(R, -1)
     npz("render.npz", **rend)
+
+    # ---------------- a8 with render.perturb = 1 (every shipped conf sets it; implicit_surface.py:274-277,304-306) ------
+    # The jitters are the first four torch.rand([R, 1]) draws of ImplicitSurface.render on the CPU generator.
+    isurf.perturb = 1.0
+    torch.manual_seed(4321)
+    outs = isurf.render(scene["rays_o"], scene["rays_d"], near, far, mvol, vols_r, tabs_r, masks_r, scene["imgs"],
+                        feats_r, feats_r, intrs, c2ws, 1.0, None)
+    torch.manual_seed(4321)
+    t_rand = torch.cat([torch.rand([R, 1]) - 0.5 for _ in range(4)], dim=1)
+    npz("render_perturb.npz", t_rand=t_rand, mid_z_vals=outs["mid_z_vals"].detach(), color_fine=outs["color_fine"].detach(),
+        render_depth=outs["render_depth"].detach(), weights=outs["weights"].detach())
+    isurf.perturb = 0.0
 
     # ---------------- a16 SDF lattice ----------------
     bmin, bmax = torch.tensor([-0.7, -0.6, -0.65]), torch.tensor([0.7, 0.75, 0.6])

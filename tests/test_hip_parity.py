@@ -162,6 +162,33 @@ def test_render_matches_golden(scene, weights, gpu_scene, golden_render):
         rel_close(eik[0] / (eik[1] + 1e-5), g["gradient_error"], 1e-3, 1e-5)
 
 
+def test_render_with_perturb_matches_golden(scene, weights, gpu_scene, golden_perturb):
+    """render.perturb = 1 (every shipped conf): the kernels, fed the reference's four torch.rand([R, 1]) - 0.5 draws,
+    against the reference's own outputs under the same seed."""
+    from surf_amd import ops
+    d = dev()
+    R = scene["rays_o"].shape[0]
+    near, far = scene["near"].repeat(R, 1), scene["far"].repeat(R, 1)
+    rays_o, rays_d = scene["rays_o"].to(d), scene["rays_d"].to(d)
+    inv_s = float(torch.exp(weights["implicit_surface.deviation_network.variance"] * 10.0).clamp(1e-6, 1e6))
+    g = golden_perturb
+    st = ops.ray_setup(rays_o, rays_d, near.to(d), far.to(d), gpu_scene["mvol"], gpu_scene["sv"], CFG["n_samples"],
+                       CFG["sample_ranges"], CFG["n_depth"], jitter=g["t_rand"].to(d).contiguous())
+    sdf, grad = ops.sdf_mlp(st["pts"], gpu_scene["sv"], gpu_scene["sdf_w"], mask=st["vmask"])
+    col, nvalid = ops.blend(st["pts"], gpu_scene["feats_t4"], gpu_scene["imgs_t4"], gpu_scene["cams"],
+                            gpu_scene["blend_w"], mask=st["vmask"])
+    out = ops.composite(sdf, grad, col, nvalid, st, rays_d, inv_s, 1.0, gpu_scene["cams"])
+    torch.cuda.synchronize()
+    rel_close(st["mid_z"], g["mid_z_vals"], 0, 3e-6)
+    rel_close(out["weights"], g["weights"], 1e-3, 2e-5)
+    rel_close(out["color_fine"], g["color_fine"], 1e-3, 2e-5)
+    rel_close(out["render_depth"].reshape(-1), g["render_depth"].reshape(-1), 1e-3, 5e-5)
+    # without jitter the sample positions differ: the fixture exercises the path
+    st0 = ops.ray_setup(rays_o, rays_d, near.to(d), far.to(d), gpu_scene["mvol"], gpu_scene["sv"], CFG["n_samples"],
+                        CFG["sample_ranges"], CFG["n_depth"])
+    assert float((st0["mid_z"].cpu() - g["mid_z_vals"]).abs().max()) > 1e-3
+
+
 def test_volume_build_matches_golden(scene, weights, golden_fpn, golden_pipe):
     """Rows a2-a4, a6, a7: every stage of the volume build against the reference's own outputs.  The stub
     regulariser's outputs are taken from the fixture so that each stage is compared on equal inputs."""

@@ -95,3 +95,16 @@ def test_sdf_precision_conf_key():
     assert ops.sdf_packed_precision(torch.zeros(4, dtype=torch.float32)) == "f32"
     with pytest.raises(ValueError):
         ops.sdf_packed_precision(torch.zeros(7, dtype=torch.uint8))
+
+
+def test_perturb_draw_order_matches_reference():
+    """ImplicitSurface.render_scene draws one torch.rand([R, 1]) - 0.5 per stage on the CPU generator, stage 0 first
+    (implicit_surface.py:276, 305): under the fixture's seed that reproduces the reference's jitters exactly."""
+    import numpy as np
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "render_perturb.npz"))
+    t_ref = torch.from_numpy(g["t_rand"])
+    R, n_stage = t_ref.shape
+    torch.manual_seed(4321)
+    t = torch.cat([torch.rand([R, 1]) - 0.5 for _ in range(n_stage)], dim=1)      # the expression in render_scene
+    assert torch.equal(t, t_ref)

@@ -127,6 +127,24 @@ def test_a8_a14_render(scene, weights, golden_fpn, golden_pipe, golden_render):
         assert float(g["mid_inside_sphere"].sum()) >= 5
 
 
+def test_a8_render_with_perturb(scene, weights, golden_fpn, golden_pipe, golden_perturb):
+    """render.perturb = 1 (what every shipped conf sets): the reference's output under torch.manual_seed(4321), replayed
+    with the same four torch.rand([R, 1]) - 0.5 jitters."""
+    vols, tabs, masks, mvol = pipeline_views(golden_pipe)
+    feats = [golden_fpn[f"out{i}"] for i in range(4)][::-1]
+    R = scene["rays_o"].shape[0]
+    near, far = scene["near"].repeat(R, 1), scene["far"].repeat(R, 1)
+    g = golden_perturb
+    assert float(g["t_rand"].abs().max()) <= 0.5 and float(g["t_rand"].std()) > 0.2
+    out = O.render(weights, scene["rays_o"], scene["rays_d"], near, far, mvol, vols, tabs, masks, feats,
+                   scene["imgs"], scene["intrs"], scene["c2ws"], CFG["n_samples"], CFG["sample_ranges"],
+                   CFG["n_depth"], 1.0, t_rand=g["t_rand"])
+    close(out["mid_z_vals"], g["mid_z_vals"], atol=2e-6)
+    close(out["weights"], g["weights"], atol=2e-5, rtol=1e-3)
+    close(out["color_fine"], g["color_fine"], atol=2e-5, rtol=1e-4)
+    close(out["render_depth"], g["render_depth"], atol=5e-5, rtol=1e-4)
+
+
 def test_a16_sdf_grid(weights, golden_pipe, golden_grid):
     vols, tabs, _, _ = pipeline_views(golden_pipe)
     u = O.sdf_grid(weights, vols, tabs, golden_grid["bound_min"], golden_grid["bound_max"], 24)

@@ -257,7 +257,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name)
-    assert L.surf_abi_version() == 3
+    assert L.surf_abi_version() == 4
     assert L.surf_sdf_scratch_bytes(1 << 20) > 0
 
 
