@@ -366,3 +366,27 @@ def test_sdf_mlp_split_matches_golden(weights, gpu_scene, golden_render, precisi
     assert gf is None
     m = mask.bool().cpu()
     rel_close(sf.cpu()[m], sa.cpu()[m], 0, 1e-6)
+
+
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_sdf_split_small_and_ragged_sizes(weights, gpu_scene, precision):
+    """One point, partial tiles, one tile more than a workgroup round, forward-only and masked variants: the split kernels
+    against the fp32-MFMA kernel (their weight stream is cyclic across rounds, so every count exercises a different wrap)."""
+    from surf_amd import ops
+    d = dev()
+    w = ops.sdf_pack_weights_split(weights, d, precision=precision)
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 2, 31, 32, 33, 127, 128, 129, 4097):
+        pts = ((torch.rand(n, 3, generator=g) * 2 - 1) * 0.8).to(d).contiguous()
+        s0, g0 = ops.sdf_mlp(pts, gpu_scene["sv"], gpu_scene["sdf_w"])
+        s, gr = ops.sdf_mlp(pts, gpu_scene["sv"], w)
+        sf, _ = ops.sdf_mlp(pts, gpu_scene["sv"], w, want_grad=False)
+        m = torch.zeros(n, dtype=torch.uint8, device=d)
+        m[::2] = 1
+        sm, gm = ops.sdf_mlp(pts, gpu_scene["sv"], w, mask=m)
+        rel_close(s, s0, 0, 1e-5)
+        rel_close(gr, g0, 1e-4, 1e-4)
+        rel_close(sf, s0, 0, 1e-5)
+        rel_close(sm[::2], s0[::2], 0, 1e-5)
+        rel_close(gm[::2], g0[::2], 1e-4, 1e-4)
+        assert bool((sm[1::2] == 100.0).all()) and bool((gm[1::2] == 0).all())
