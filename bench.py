@@ -1,21 +1,34 @@
 #!/usr/bin/env python3
 """Headline benchmark of the SuRF hot path on MI355X: full-image render throughput (rays/s).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload dtu|tnt] [--scenes M]
 
 One "step" = one pass of the render hot path (ray set-up -> SDF MLP + gradient -> multi-view blending ->
-NeuS compositing) over every pixel ray of the 576x800 reference view of a synthetic 5-view scene with
-128 samples per ray (BASELINE.json configs[1]; synthetic sphere pyramid 88^3 -> 704^3).
-Inputs are resident in HBM before the timed region.  With N > 1 every rank renders its own scene
-(seed = rank): scenes are independent, there is no data-path collective (weak scaling).
+NeuS compositing) over every pixel ray of the reference view of a synthetic multi-view scene
+(`--workload dtu`, default: BASELINE.json configs[1], 576x800, 5 views, 128 samples per ray, synthetic sphere pyramid
+88^3 -> 704^3; `--workload tnt`: configs[4], 1080x1920, 7 views, 192 samples per ray).
+Inputs are resident in HBM before the timed region.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (sdf_mlp, fp32 MFMA bound) timed
-with HIP events on the launch stream inside the timed region; `cpu_baseline` is the CPU oracle
-(oracle/surf_oracle.py, a port of the reference algorithm) timed on this host on a bounded ray subset.
+Multi-GPU: scenes are independent, so they shard over ranks with NO data-path collective (weak scaling);
+RCCL only carries the timing barrier, the MAX of the elapsed time and a gather of small per-scene records.
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself (one child process per
+GPU, env:// rendezvous on 127.0.0.1, before this process touches the GPU) and relays rank 0's line; under
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` the ranks are the launcher's.
+`--scenes M` (configs[2]: 15 scans) deals M scenes round-robin over the ranks (scripts/run.sh:3,
+datasets/__init__.py:37-38 of the reference); without it every rank renders one scene (seed = rank).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (sdf_mlp) timed with HIP events on the launch
+stream inside the timed region; `roofline_kernels` lists the other contraction kernels; `cpu_baseline` is the CPU
+oracle (oracle/surf_oracle.py, a port of the reference algorithm) timed on this host on a bounded ray subset.
+`--dry` replaces the kernels by a sleep and RCCL by gloo: it exists so that tests/test_dist_gloo.py can drive this
+file's own N > 1 control flow on a CPU-only host; a dry line says so ("data": "dry-run") and is not a measurement.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,7 +38,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FLOP_PER_SAMPLE_SDF = 2 * (99240 + 99240)          # forward + reverse-mode gradient MACs x 2
+FLOP_PER_SAMPLE_SDF_FWD = 2 * 99240                 # forward only (the 512^3 lattice of extract_geometry)
 FLOP_PER_SAMPLE_BLEND_PER_VIEW = 2 * 9928
+HBM_PEAK = 8.0e12                                   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 CPU_THREADS = min(32, os.cpu_count() or 1)
 # Dominant kernel per SDF precision: (kernel name as the profile summaries spell it, matrix pipe, dense peak of that
 # pipe in TFLOP/s from MI355X_MICROARCH.md, MFMA products issued per fp32-equivalent product).  `roofline.peak` is the
@@ -35,36 +50,95 @@ SDF_KERNELS = {
     "bf16x3": ("sdf_mlp_split_kernel<PolBf3, true>", "v_mfma_f32_32x32x16_bf16", 2500.0, 6),
     "f16x2": ("sdf_mlp_split_kernel<PolH2, true>", "v_mfma_f32_32x32x16_f16", 2500.0, 3),
 }
+BLEND_KERNELS = {
+    "f32": ("blend_kernel<{ns}>", "v_mfma_f32_32x32x2_f32", 157.3, 1),
+    "bf16x3": ("blend_split_kernel<BPolBf3, {ns}>", "v_mfma_f32_32x32x16_bf16", 2500.0, 6),
+    "f16x2": ("blend_split_kernel<BPolH2, {ns}>", "v_mfma_f32_32x32x16_f16", 2500.0, 3),
+}
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "dtu": {"height": 576, "width": 800, "views": 5, "n_samples": "64,32,16,16",
+            "metric": "rays/sec (576x800, 5-view, 128 samp/ray render, whole job)"},
+    # BASELINE.json configs[4]: Tanks&Temples, 7 views 1080p, 192 samples per ray
+    "tnt": {"height": 1080, "width": 1920, "views": 7, "n_samples": "96,48,32,16",
+            "metric": "rays/sec (1080x1920, 7-view, 192 samp/ray render, whole job)"},
+}
+RAY_CHUNK = 1 << 19      # rays per render call (bounds the per-sample buffers; 576x800 fits one call)
 
 
-def model_conf(n_samples, sdf_precision="bf16x3"):
+def model_conf(n_samples, sdf_precision="bf16x3", blend_precision=None):
     from surf_amd import conf
+    render = {"n_samples": n_samples, "sample_ranges": [1.0, 0.4, 0.1, 0.01], "n_depth": 256, "perturb": 0.0,
+              "sdf_precision": sdf_precision}
+    if blend_precision is not None:
+        render["blend_precision"] = blend_precision
     return conf.from_dict({
         "sdf_network": {"d_out": 129, "d_in": 3, "d_hidden": 128, "n_layers": 6, "skip_in": [3], "multires": 4,
                         "bias": 0.5, "scale": 1.0, "geometric_init": True, "weight_norm": True, "feat_channels": 28,
                         "feat_multires": 0},
         "color_network": {"d_feature": 16},
         "variance_network": {"init_val": 0.3},
-        "render": {"n_samples": n_samples, "sample_ranges": [1.0, 0.4, 0.1, 0.01], "n_depth": 256, "perturb": 0.0,
-                   "sdf_precision": sdf_precision},
+        "render": render,
     })
+
+
+def surf_conf(base_dim=88, n_samples=(64, 32, 16, 16)):
+    """The model section of confs/surf.conf:66-124 as a dict (full SuRF: FPN, volume, sparse U-Nets, matching field,
+    implicit surface)."""
+    return {
+        "range_ratios": [1.0, 0.4, 0.1, 0.01],
+        "feature_network": {"d_in": 3, "d_base": 8, "d_out": [4, 4, 4, 4]},
+        "volume": {"base_volume_dim": [base_dim] * 3},
+        "reg_network": {"d_in": [8, 16, 16, 16], "d_base": [8] * 4, "d_out": [8] * 4},
+        "matching_field": {"n_samples_depths": [128, 64, 32, 16], "n_importance_depths": [128, 64, 32, 16],
+                           "up_sample_steps": [4, 4, 4, 4], "depth_res_levels": [4, 2, 2, 1]},
+        "implicit_surface": dict(model_conf(list(n_samples))),
+    }
+
+
+def algorithmic_bytes_per_ray(S, nv, n_depth=256, index_bytes=8):
+    """coarse matching taps + per sample [mask taps + sparse trilinear rows (index + 28 B of features per
+    corner) + per source view 4 levels x 4 taps x 16 B + 4 x 12 B of RGB] + ray in / out.
+    S = 128, nv = 5, 8-byte indices (the reference's int64 tables) -> 313,408 B."""
+    return n_depth * 8 * 4 + S * (4 * 4 + 4 * 8 * (index_bytes + 28) + (nv - 1) * (4 * 4 * 16 + 4 * 12)) + 64
+
+
+def csrc_digest():
+    """sha256 over the kernel sources: ties a committed PMC summary to the code it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "surf_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed PMC summary of this same command
-    (profiles/rNN_bench_pmc.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE is
-    doubled per the gfx950 correction of MI355X_MICROARCH.md section HBM).  None if no profile is committed."""
+    (profiles/rNN_bench_pmc.csv: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE is doubled per the
+    gfx950 correction of MI355X_MICROARCH.md section HBM).  Returns (bytes or None, source note): None when no profile
+    is committed or when the kernel sources have changed since it was taken (`# csrc_sha256:` header line)."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc.csv")), key=os.path.basename)
     if not files:
-        return None
-    with open(files[-1]) as f:
-        rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
+        return None, "no profiles/r*_bench_pmc.csv committed"
+    path = files[-1]
+    sha = None
+    with open(path) as f:
+        lines = f.readlines()
+    for l in lines:
+        if l.startswith("# csrc_sha256:"):
+            sha = l.split(":", 1)[1].strip()
+    name = os.path.relpath(path, ROOT)
+    if sha != csrc_digest():
+        return None, f"{name} was taken on other kernel sources (csrc_sha256 {sha} != {csrc_digest()}): stale, not reported"
+    rows = list(csv.DictReader(l for l in lines if not l.startswith("#")))
     for r in rows:
         if r["kernel"] == kernel and r["FETCH_SIZE"] and r["WRITE_SIZE"]:
-            return (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
-    return None
+            return (2.0 * float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0, f"{name} (csrc_sha256 {sha})"
+    return None, f"{name} has no row for {kernel}"
 
 
 def cpu_baseline(model, cpu_scene, rays_o, rays_d, near, far, n_samples, budget_s, gpu_out, ray_idx):
@@ -90,31 +164,18 @@ def cpu_baseline(model, cpu_scene, rays_o, rays_d, near, far, n_samples, budget_
 
 def volume_build_timing(args, dev):
     """One full-size volume build through surf_amd.surf.SuRF (FPN -> cost volume -> sparsify -> sparse U-Net ->
-    densify -> matching field, rows a1-a7) on the synthetic 5-view scene, reported beside the render metric.
+    densify -> matching field, rows a1-a7) on the synthetic scene, reported beside the render metric.
     Weights are random-init, so the U-Net's matching logit is replaced by the analytic sphere logit
     (-20 | |x| - 0.5 |) to obtain the surface-concentrated pyramid a trained network would produce."""
     from surf_amd import conf, synthetic
     from surf_amd.surf import SuRF
     H, W, nv = args.height, args.width, args.views
-    cfg = {
-        "range_ratios": [1.0, 0.4, 0.1, 0.01],
-        "feature_network": {"d_in": 3, "d_base": 8, "d_out": [4, 4, 4, 4]},
-        "volume": {"base_volume_dim": [args.base_dim] * 3},
-        "reg_network": {"d_in": [8, 16, 16, 16], "d_base": [8] * 4, "d_out": [8] * 4},
-        "matching_field": {"n_samples_depths": [128, 64, 32, 16], "n_importance_depths": [128, 64, 32, 16],
-                           "up_sample_steps": [4, 4, 4, 4], "depth_res_levels": [4, 2, 2, 1]},
-        "implicit_surface": dict(model_conf([64, 32, 16, 16])),
-    }
     torch.manual_seed(0)
-    model = SuRF(conf.from_dict(cfg)).eval().to(dev)
+    model = SuRF(conf.from_dict(surf_conf(args.base_dim))).eval().to(dev)
     intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
     ipts = {"imgs": synthetic.procedural_images(nv, H, W, 0, dev), "intrs": intrs.to(dev), "c2ws": c2ws.to(dev),
             "near_fars": near_fars.to(dev), "near": near_fars[0, 0].reshape(1, 1).to(dev),
             "far": near_fars[0, 1].reshape(1, 1).to(dev)}
-
-    def sphere_logit(coords, D):
-        world = coords.float() * (2.0 / (D - 1)) - 1.0
-        return -20.0 * (world.norm(dim=1) - 0.5).abs()
 
     res = {}
     for it in range(2):                      # first pass warms allocator and code objects
@@ -123,7 +184,7 @@ def volume_build_timing(args, dev):
         e0.record()
         feats = model.feature_network(ipts["imgs"])
         e1.record()
-        model.build_volumes(ipts, feats, logit_override=sphere_logit, timings=timings)
+        model.build_volumes(ipts, feats, logit_override=synthetic.sphere_logit, timings=timings)
         e2.record()
         torch.cuda.synchronize()
         res = {"fpn_ms": e0.elapsed_time(e1), "stages_ms": e1.elapsed_time(e2), "total_ms": e0.elapsed_time(e2), "stages": []}
@@ -135,87 +196,252 @@ def volume_build_timing(args, dev):
     return res
 
 
-def main():
+def mesh_grid_timing(model, scene, dev, resolution):
+    """The lattice of extract_geometry (implicit_surface.py:337-351, row a16): resolution^3 forward-only SDF
+    evaluations, timed end to end and per kernel launch (HIP events)."""
+    bmin, bmax = torch.tensor([-1.0] * 3), torch.tensor([1.0] * 3)
+    model.sdf_grid(scene, bmin, bmax, 64)                    # warms the forward-only code object
+    torch.cuda.synchronize()
+    model.kernel_events = []
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    u = model.sdf_grid(scene, bmin, bmax, resolution)
+    b.record()
+    torch.cuda.synchronize()
+    ev, model.kernel_events = model.kernel_events, None
+    k_ms = sum(x.elapsed_time(y) for name, x, y in ev if name == "sdf_grid")
+    inside = int((u > 0).sum())
+    del u
+    return a.elapsed_time(b), k_ms, inside
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a torch.distributed launcher
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def launch_ranks(n, argv):
+    """Start n ranks of this file as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on
+    127.0.0.1) and relay rank 0's stdout.  Runs before anything in this process has touched the GPU: the parent never
+    initialises HIP and nothing is exec'd from a process that has."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="dtu", choices=sorted(WORKLOADS))
+    ap.add_argument("--scenes", type=int, default=0, help="deal this many scenes round-robin over the ranks "
+                                                          "(BASELINE configs[2]: 15); 0 = one scene per rank")
     ap.add_argument("--base-dim", type=int, default=88)
-    ap.add_argument("--height", type=int, default=576)
-    ap.add_argument("--width", type=int, default=800)
-    ap.add_argument("--views", type=int, default=5)
-    ap.add_argument("--n-samples", type=str, default="64,32,16,16")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--views", type=int, default=None)
+    ap.add_argument("--n-samples", type=str, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline (0 = skip)")
     ap.add_argument("--build", type=int, default=1, help="also time one full volume build (FPN + 4 stages), N=1 only")
+    ap.add_argument("--mesh-grid", type=int, default=512, help="also time the resolution^3 SDF lattice of "
+                                                               "extract_geometry (0 = skip), N=1 only")
     ap.add_argument("--sdf-precision", default="bf16x3", choices=sorted(SDF_KERNELS),
                     help="SDF kernel: f32 MFMA, bf16x3 (exact 3-way bf16 split, fp32-equivalent; default), "
                          "f16x2 (22-bit operands, fastest)")
+    ap.add_argument("--blend-precision", default=None, choices=sorted(BLEND_KERNELS),
+                    help="blending kernel (default: the library's default, see surf_amd.ops.BLEND_DEFAULT)")
     ap.add_argument("--also", default="f16x2", help="comma list of further precisions timed after the headline run "
                                                     "(reported under other_precisions; '' = none)")
-    args = ap.parse_args()
+    ap.add_argument("--dry", action="store_true", help="control-flow test: no GPU, no kernels, gloo instead of RCCL")
+    args = ap.parse_args(argv)
+    wl = WORKLOADS[args.workload]
+    for k in ("height", "width", "views", "n_samples"):
+        if getattr(args, k) is None:
+            setattr(args, k, wl[k])
+    return args
 
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, argv))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with matching values "
+              f"(or leave WORLD_SIZE unset and let bench.py start the ranks)", file=sys.stderr)
+        sys.exit(2)
+    run_rank(args)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one rank
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+class DryScene:
+    """--dry: stands in for a scene and its render call (sleep ~ 2 ms per call)."""
+
+    def __init__(self, seed, R):
+        self.seed, self.R = seed, R
+
+
+def run_rank(args):
+    from surf_amd import dist as D
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    from surf_amd import dist as D
-    D.init_from_env("nccl", dev)          # RCCL; only used for the barrier and the MAX of the elapsed time
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    dry = args.dry
+    if dry:
+        dev = torch.device("cpu")
+        D.init_from_env("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        D.init_from_env("nccl", dev)          # RCCL; only the barrier, the MAX of the elapsed time and the record gather
+    if torch.distributed.is_initialized():
+        assert torch.distributed.get_world_size() == world == args.gpus
 
-    from surf_amd import synthetic
-    from surf_amd.implicit_surface import ImplicitSurface
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
     n_samples = [int(x) for x in args.n_samples.split(",")]
     S = sum(n_samples)
     H, W, nv = args.height, args.width, args.views
-    torch.manual_seed(0)
-    model = ImplicitSurface(model_conf(n_samples, args.sdf_precision)).to(dev)
+    R = H * W
+    my_scenes = D.shard_scenes(args.scenes, rank, world) if args.scenes > 0 else [rank]
 
-    # ---- scene (seed = rank), resident in HBM before the timed region ------------------------------------
-    seed = rank
-    intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
-    imgs = synthetic.procedural_images(nv, H, W, seed, dev)
-    feats = synthetic.feature_pyramid(nv, H, W, seed, dev)                     # fine -> coarse
-    vols, tabs, mvol = synthetic.sphere_pyramid(args.base_dim, dev, seed=seed)  # coarse -> fine
-    scene = model.scene(mvol, vols[::-1], tabs[::-1], None, feats, imgs, intrs.to(dev), c2ws.to(dev))
-    rays_o, rays_d = synthetic.pixel_rays(intrs[0], c2ws[0], H, W, 1, dev)
-    R = rays_o.shape[0]
-    near = near_fars[0, 0].reshape(1, 1).repeat(R, 1).to(dev)
-    far = near_fars[0, 1].reshape(1, 1).repeat(R, 1).to(dev)
+    model = None
+    if not dry:
+        from surf_amd import ops, synthetic
+        from surf_amd.implicit_surface import ImplicitSurface
+        torch.manual_seed(0)
+        model = ImplicitSurface(model_conf(n_samples, args.sdf_precision, args.blend_precision)).to(dev)
+        blend_precision = model.blend_precision
 
-    def step():
-        return model.render_scene(rays_o, rays_d, near, far, scene, 1.0, per_sample=False)
+    # ---- scenes (seed = scene id), resident in HBM before the timed region -------------------------------
+    scenes = []
+    for sid in my_scenes:
+        if dry:
+            scenes.append(DryScene(sid, R))
+            continue
+        intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
+        imgs = synthetic.procedural_images(nv, H, W, sid, dev)
+        feats = synthetic.feature_pyramid(nv, H, W, sid, dev)                     # fine -> coarse
+        vols, tabs, mvol = synthetic.sphere_pyramid(args.base_dim, dev, seed=sid)  # coarse -> fine
+        sc = model.scene(mvol, vols[::-1], tabs[::-1], None, feats, imgs, intrs.to(dev), c2ws.to(dev))
+        rays_o, rays_d = synthetic.pixel_rays(intrs[0], c2ws[0], H, W, 1, dev)
+        near = near_fars[0, 0].reshape(1, 1).repeat(R, 1).to(dev)
+        far = near_fars[0, 1].reshape(1, 1).repeat(R, 1).to(dev)
+        scenes.append({"id": sid, "scene": sc, "rays_o": rays_o, "rays_d": rays_d, "near": near, "far": far,
+                       "cpu": (mvol, vols, tabs, feats, imgs, intrs, c2ws)})
+        if not (rank == 0 and sid == my_scenes[0] and world == 1):
+            scenes[-1]["cpu"] = None
+        del vols, tabs, mvol, feats, imgs
+
+    scene_ms = {}        # scene id -> [ms per step] (HIP events on the launch stream / wall clock when dry)
+
+    def render_scene_once(sc, record):
+        if dry:
+            t = time.perf_counter()
+            time.sleep(0.002)
+            if record:
+                scene_ms.setdefault(sc.seed, []).append((time.perf_counter() - t) * 1e3)
+            return None
+        if record:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        outs = []
+        for s0 in range(0, R, RAY_CHUNK):
+            sl = slice(s0, s0 + RAY_CHUNK)
+            outs.append(model.render_scene(sc["rays_o"][sl], sc["rays_d"][sl], sc["near"][sl], sc["far"][sl], sc["scene"],
+                                           1.0, per_sample=False))
+        if record:
+            b.record()
+            scene_ms.setdefault(sc["id"], []).append((a, b))
+        return outs[0] if len(outs) == 1 else {"color_fine": torch.cat([o["color_fine"] for o in outs])}
+
+    def step(record=False):
+        out = None
+        for sc in scenes:
+            out = render_scene_once(sc, record)
+        return out
 
     for _ in range(args.warmup):
         out = step()
-    torch.cuda.synchronize()
+    sync()
     D.barrier()
-    torch.cuda.synchronize()
-    model.kernel_events = []
+    sync()
+    if model is not None:
+        model.kernel_events = []
+        model.active_samples_log = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
+        out = step(record=True)
+    sync()
     D.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
-    events, model.kernel_events = model.kernel_events, None
+    if model is not None:
+        events, model.kernel_events = model.kernel_events, None
+        active_log, model.active_samples_log = model.active_samples_log, None
     elapsed = D.max_over_ranks(elapsed, dev)
+
+    # ---- per-scene records (gathered: one small object per rank, no tensor traffic) ------------------------
+    my_rec = []
+    for sid, lst in scene_ms.items():
+        ms = [x if dry else x[0].elapsed_time(x[1]) for x in lst]
+        my_rec.append({"scene": sid, "rank": rank, "ms_per_render": sum(ms) / len(ms), "rays_per_s": R / (sum(ms) / len(ms) * 1e-3)})
+    records = D.gather_records(my_rec)
+    n_scenes_total = args.scenes if args.scenes > 0 else world
+    rays_per_step_job = n_scenes_total * R
+
+    if dry:
+        if rank == 0:
+            recs = sorted((r for per_rank in records for r in per_rank), key=lambda r: r["scene"])
+            print(json.dumps({
+                "metric": WORKLOADS[args.workload]["metric"], "value": rays_per_step_job * args.steps / elapsed, "unit": "rays/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none (dry run)",
+                "data": "dry-run", "config": {"workload": f"DRY RUN of the {args.workload} control flow: no kernels executed",
+                                              "scenes": n_scenes_total, "rays_per_step": rays_per_step_job},
+                "scenes": recs}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region -----------------------
     per_kernel = {}
     for name, a, b in events:
         per_kernel.setdefault(name, []).append(a.elapsed_time(b))
-    kernel_ms = {k: sum(v) / len(v) for k, v in per_kernel.items()}
-    active = int(model.last_active_samples)
+    kernel_ms = {k: sum(v) / len(v) for k, v in per_kernel.items()}         # average per launch
+    launches_per_step = {k: len(v) / args.steps for k, v in per_kernel.items()}
+    active = sum(active_log) / len(active_log)                                # active samples per sdf / blend launch
 
     # ---- the other SDF precisions on the same scene (N = 1 only; after the timed region, reported separately) ----
     others = {}
-    if world == 1:
+    if world == 1 and args.scenes == 0:
         for prec in [p for p in args.also.split(",") if p and p != args.sdf_precision]:
             model.sdf_precision = prec
+            if args.blend_precision is None and prec in ops.BLEND_PRECISIONS:
+                model.blend_precision = prec
             out_o = step()
             torch.cuda.synchronize()
             model.kernel_events = []
@@ -226,10 +452,13 @@ def main():
             dt = time.perf_counter() - t1
             ev_o, model.kernel_events = model.kernel_events, None
             sdf_o = [a.elapsed_time(b) for name, a, b in ev_o if name == "sdf_mlp"]
+            bl_o = [a.elapsed_time(b) for name, a, b in ev_o if name == "blend"]
             others[prec] = {"rays_per_s": R * args.steps / dt, "ms_per_step": dt / args.steps * 1e3,
-                            "sdf_mlp_ms": sum(sdf_o) / len(sdf_o),
+                            "sdf_mlp_ms": sum(sdf_o) / len(sdf_o), "blend_ms": sum(bl_o) / len(bl_o),
+                            "blend_precision": model.blend_precision,
                             "max_abs_rgb_diff_vs_headline": float((out_o["color_fine"] - out["color_fine"]).abs().max())}
         model.sdf_precision = args.sdf_precision
+        model.blend_precision = blend_precision
 
     if rank == 0:
         sdf_kernel, sdf_pipe, pipe_peak, n_prod = SDF_KERNELS[args.sdf_precision]
@@ -237,9 +466,23 @@ def main():
         flops = active * FLOP_PER_SAMPLE_SDF
         achieved = flops / (sdf_ms * 1e-3) / 1e12
         peak = pipe_peak / n_prod
+        per_gpu = R * len(scenes) * args.steps / elapsed
+        bytes_per_ray = algorithmic_bytes_per_ray(S, nv)
+        traffic, traffic_src = pmc_traffic(sdf_kernel)
+        bl_kernel, bl_pipe, bl_pipe_peak, bl_prod = BLEND_KERNELS[blend_precision]
+        bl_kernel = bl_kernel.format(ns=nv - 1)
+        bl_ms = kernel_ms["blend"]
+        bl_ach = active * (nv - 1) * FLOP_PER_SAMPLE_BLEND_PER_VIEW / (bl_ms * 1e-3) / 1e12
+        bl_traffic, bl_src = pmc_traffic(bl_kernel)
+        roofline_kernels = [{
+            "kernel": bl_kernel, "bound": "mfma", "achieved": bl_ach, "peak": bl_pipe_peak / bl_prod, "unit": "TFLOP/s",
+            "frac": bl_ach / (bl_pipe_peak / bl_prod), "traffic": bl_traffic, "traffic_source": bl_src,
+            "avg_launch_ms": bl_ms, "flop_per_sample": (nv - 1) * FLOP_PER_SAMPLE_BLEND_PER_VIEW, "samples_per_launch": active,
+            "pipe": bl_pipe, "mfma_products_per_fp32_product": bl_prod, "frac_of_fp32_mfma_peak": bl_ach / 157.3}]
+        recs = sorted((r for per_rank in records for r in per_rank), key=lambda r: r["scene"])
         result = {
-            "metric": "rays/sec (576x800, 5-view, 128 samp/ray render, whole job)",
-            "value": world * R * args.steps / elapsed,
+            "metric": WORKLOADS[args.workload]["metric"],
+            "value": rays_per_step_job * args.steps / elapsed,
             "unit": "rays/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -252,19 +495,47 @@ def main():
                       "f16x2": "f32 accumulate, 22-bit operands (2 fp16 pieces)"}[args.sdf_precision],
             "data": "synthetic",
             "config": {"workload": f"render {H}x{W} ref view, {nv} views, samples {n_samples} (={S}/ray), sphere pyramid "
-                                   f"{args.base_dim}^3->{args.base_dim * 8}^3, one scene per GPU",
-                       "rays_per_step": R, "samples_per_ray": S, "active_samples": active},
-            "per_gpu_rays_per_s": R * args.steps / elapsed,
+                                   f"{args.base_dim}^3->{args.base_dim * 8}^3, "
+                                   + (f"{n_scenes_total} scenes round-robin over {world} GPU(s)" if args.scenes > 0 else "one scene per GPU"),
+                       "rays_per_step": rays_per_step_job, "samples_per_ray": S, "active_samples_per_launch": active,
+                       "scenes": n_scenes_total, "blend_precision": blend_precision},
+            "per_gpu_rays_per_s": per_gpu,
             "kernel_ms": kernel_ms,
+            "kernel_launches_per_step": launches_per_step,
             "roofline": {"kernel": sdf_kernel, "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": pmc_traffic(sdf_kernel), "flop_per_sample": FLOP_PER_SAMPLE_SDF, "samples_per_launch": active,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "flop_per_sample": FLOP_PER_SAMPLE_SDF, "samples_per_launch": active,
                          "avg_launch_ms": sdf_ms, "pipe": sdf_pipe, "pipe_dense_peak": pipe_peak,
-                         "mfma_products_per_fp32_product": n_prod, "frac_of_fp32_mfma_peak": achieved / 157.3},
+                         "mfma_products_per_fp32_product": n_prod, "frac_of_fp32_mfma_peak": achieved / 157.3,
+                         "frac_of_raw_16bit_dense_peak": achieved * n_prod / pipe_peak if n_prod > 1 else None,
+                         # the whole step against the HBM roofline (SURVEY 8d / north_star): algorithmic bytes per ray x
+                         # rays/s per GPU / 8 TB/s
+                         "hbm_frac": bytes_per_ray * per_gpu / HBM_PEAK, "hbm_bytes_per_ray": bytes_per_ray,
+                         "hbm_peak": HBM_PEAK},
+            "roofline_kernels": roofline_kernels,
         }
+        if args.scenes > 0 or world > 1:
+            result["scenes"] = recs
         if others:
             result["other_precisions"] = others
-        if world == 1 and args.cpu_seconds > 0:
+        sc0 = scenes[0]
+        if world == 1 and args.mesh_grid > 0:
+            total_ms, k_ms, inside = mesh_grid_timing(model, sc0["scene"], dev, args.mesh_grid)
+            n_lat = args.mesh_grid ** 3
+            fk, fpipe, fpeak, fprod = SDF_KERNELS[args.sdf_precision]
+            fk = fk.replace("true", "false")
+            ach = n_lat * FLOP_PER_SAMPLE_SDF_FWD / (k_ms * 1e-3) / 1e12
+            result["mesh_grid_ms"] = total_ms
+            result["mesh_grid"] = {"resolution": args.mesh_grid, "points": n_lat, "total_ms": total_ms, "sdf_kernel_ms": k_ms,
+                                   "lattice_points_inside": inside}
+            roofline_kernels.append({"kernel": fk, "bound": "mfma", "achieved": ach, "peak": fpeak / fprod, "unit": "TFLOP/s",
+                                     "frac": ach / (fpeak / fprod), "traffic": None, "avg_launch_ms": k_ms / max(1, -(-n_lat // (1 << 24))),
+                                     "flop_per_sample": FLOP_PER_SAMPLE_SDF_FWD, "samples_per_launch": min(n_lat, 1 << 24),
+                                     "pipe": fpipe, "frac_of_fp32_mfma_peak": ach / 157.3,
+                                     "note": f"{args.mesh_grid}^3 lattice of extract_geometry (row a16), forward only"})
+        if world == 1 and args.cpu_seconds > 0 and sc0["cpu"] is not None:
+            mvol, vols, tabs, feats, imgs, intrs, c2ws = sc0["cpu"]
             n_sub = 8192
             idx = torch.linspace(0, R - 1, n_sub).long()
             cpu_scene = {
@@ -273,13 +544,15 @@ def main():
                 "intrs": intrs, "c2ws": c2ws,
             }
             cpu_scene["masks"] = [(t >= 0).float() for t in cpu_scene["tabs"]]
-            rps, n_done, dt, err = cpu_baseline(model, cpu_scene, rays_o.cpu()[idx], rays_d.cpu()[idx], near.cpu()[idx],
-                                                far.cpu()[idx], n_samples, args.cpu_seconds, out, idx)
+            rps, n_done, dt, err = cpu_baseline(model, cpu_scene, sc0["rays_o"].cpu()[idx], sc0["rays_d"].cpu()[idx],
+                                                sc0["near"].cpu()[idx], sc0["far"].cpu()[idx], n_samples, args.cpu_seconds,
+                                                out, idx)
             result["cpu_baseline"] = {"value": rps, "unit": "rays/s", "cores": CPU_THREADS, "kind": "port",
                                       "sample": f"{n_done} rays (every {R // n_sub}th pixel ray, 256-ray chunks) of the same "
                                                 f"scene in {dt:.1f} s, torch CPU fp32",
                                       "max_abs_rgb_diff_vs_gpu": err}
-        if world == 1 and args.build:
+        if world == 1 and args.build and args.workload == "dtu":
+            sc0["cpu"] = None
             result["volume_build"] = volume_build_timing(args, dev)
         print(json.dumps(result))
     if world > 1:

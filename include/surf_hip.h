@@ -36,8 +36,10 @@ extern "C" {
 #define SURF_E_ARG (-1)      /* null pointer / bad size */
 #define SURF_E_LIMIT (-2)    /* exceeds SURF_MAX_* */
 
-/* ABI version, bumped whenever a signature below changes. */
-int surf_abi_version(void);   /* currently 2 */
+/* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
+ * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
+#define SURF_ABI_VERSION 5
+int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
 int surf_pack_texel4(const float* src, int n, int C, int H, int W, float* dst, void* stream);

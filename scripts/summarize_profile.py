@@ -8,10 +8,12 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+from bench import csrc_digest  # noqa: E402  (ties the summary to the kernel sources it was measured on)
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-OURS = ("sdf_mlp", "blend_kernel", "ray_setup", "composite_kernel", "pack_texel4", "costvol", "densify", "matching_depth",
+OURS = ("sdf_mlp", "blend_kernel", "blend_split", "mcubes", "patch_warp", "ray_setup", "composite_kernel", "pack_texel4", "costvol", "densify", "matching_depth",
         "filter", "spconv", "fpn_", "surf_")
 
 f = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
@@ -42,6 +44,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_mfma"):
 with open(os.path.join(dst, f"{tag}_bench_pmc.csv"), "w") as w:
     w.write("# rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 (one pass per group)\n")
     w.write("# per-launch averages; FETCH_SIZE / WRITE_SIZE in KiB as reported (raw, uncorrected)\n")
+    w.write(f"# csrc_sha256: {csrc_digest()}\n")
     cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]
     cw = csv.writer(w)
     cw.writerow(["kernel", "launches"] + cols)

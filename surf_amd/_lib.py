@@ -12,6 +12,10 @@ import torch  # noqa: F401  (load PyTorch's HIP runtime first: one runtime per p
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
+# must equal SURF_ABI_VERSION of include/surf_hip.h (tests/test_host_modules.py compares the two texts); lib() refuses a
+# library built from another header
+ABI_VERSION = 5
+
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
 c_i64 = ctypes.c_int64
@@ -90,6 +94,11 @@ def lib():
             fn = getattr(_lib, name)  # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
+        got = _lib.surf_abi_version()
+        if got != ABI_VERSION:
+            _lib = None
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {got}, this binding is written for {ABI_VERSION}: "
+                               "rebuild with surf_amd/csrc/build.sh")
     return _lib
 
 

@@ -20,20 +20,21 @@ for s in "${SRCS[@]}"; do
   if [[ ! -f "$o" || "$s" -nt "$o" || "${HERE}/common.h" -nt "$o" || "${HERE}/../../include/surf_hip.h" -nt "$o" ]]; then
     "${HIPCC}" "${FLAGS[@]/-shared/}" -c "$s" -o "$o" &
     pids+=($!)
-    [[ "$(basename "$s")" == "sdf_mlp_split.hip" ]] && check_split=1
+    case "$(basename "$s")" in sdf_mlp_split.hip|blend_split.hip) check_isa="${check_isa:-} $(basename "${s%.hip}")";; esac
   fi
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done
-# The split SDF kernels retire their LDS-DMA with counted s_waitcnt vmcnt(N): register-allocator spills to scratch
-# memory would add uncounted (and differently ordered) memory operations inside the chunks.  Refuse such a build.
-if [[ "${check_split:-0}" == 1 ]]; then
-usage="$("${HIPCC}" "${FLAGS[@]/-shared/}" --cuda-device-only -Rpass-analysis=kernel-resource-usage -c "${HERE}/sdf_mlp_split.hip" -o /dev/null 2>&1 | grep -A4 "Function Name: .*sdf_mlp_split_kernel" | grep "ScratchSize" || true)"
-if [[ -z "$usage" ]] || echo "$usage" | grep -qv "ScratchSize \[bytes/lane\]: 0 "; then
-  echo "sdf_mlp_split.hip: a split kernel spills to scratch memory (or its resource usage could not be read):" >&2
-  echo "$usage" >&2
-  rm -f "${HERE}/../_obj/sdf_mlp_split.o"
-  exit 1
-fi
-fi
+# The split kernels retire their LDS-DMA with counted s_waitcnt vmcnt(N): the count assumes that the compiler emits
+# exactly the vector-memory operations the source issues between two barriers (no scratch spills, no loads removed,
+# duplicated or moved across a barrier).  check_isa.py verifies that on the device assembly of this very compiler.
+for f in ${check_isa:-}; do
+  asm="${HERE}/../_obj/${f}.s"
+  "${HIPCC}" "${FLAGS[@]/-shared/}" --cuda-device-only -S -Rpass-analysis=kernel-resource-usage "${HERE}/${f}.hip" -o "$asm" 2> "${asm%.s}.remarks" || { cat "${asm%.s}.remarks" >&2; exit 1; }
+  if ! python3 "${HERE}/check_isa.py" "$asm" "${asm%.s}.remarks" "${f}_kernel"; then
+    echo "${f}.hip: counted-vmcnt invariant violated (see above); refusing the build" >&2
+    rm -f "${HERE}/../_obj/${f}.o"
+    exit 1
+  fi
+done
 "${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${objs[@]}"
 echo "built ${OUT}"

@@ -150,7 +150,7 @@ __global__ void pack_texel4_kernel(const float* __restrict__ src, int n, int C, 
 
 }  // namespace
 
-extern "C" int surf_abi_version(void) { return 4; }
+extern "C" int surf_abi_version(void) { return SURF_ABI_VERSION; }
 
 extern "C" int surf_pack_texel4(const float* src, int n, int C, int H, int W, float* dst, void* stream) {
   if (!src || !dst || n <= 0 || C <= 0 || C > 4 || H <= 0 || W <= 0) return SURF_E_ARG;

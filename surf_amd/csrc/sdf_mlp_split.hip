@@ -304,12 +304,16 @@ constexpr int sprime_layer(bool deep, int L, int T) {
   return -1;
 }
 constexpr int sprime_tile(bool deep, int L, int T) { return !deep ? T : ((L >= 1 && T < 3) ? T + 1 : 0); }
+// 16-byte groups of a softplus' slice that are read back: layer 2 has 101 rows, so the second half (k-step 7: rows
+// 112..127) of its tile 3 feeds nothing.  Loading it anyway would leave the loads to dead-code elimination, i.e. leave
+// the number of vector-memory operations of that chunk - which stage_barrier's vmcnt counts - to the optimiser.
+constexpr int sprime_groups(int layer, int tile) { return (layer == 2 && tile == 3) ? 2 : 4; }
 template <class P> constexpr int vm_pre(int ci) {
   if (ci < N_FWD_CHUNKS) return (ci / 4 == 5 && ci % 4 > 0) ? 4 : 0;  // W6 slices
   int l = 5, t = ci - N_FWD_CHUNKS;
   while (t >= BWD_NT[l]) { t -= BWD_NT[l]; --l; }
   if (l == 0) return P::DEEPJ ? 12 : 0;  // feature Jacobian for the epilogue
-  return sprime_layer(P::DEEP, l, t) >= 0 ? 4 : 0;
+  return sprime_layer(P::DEEP, l, t) >= 0 ? sprime_groups(sprime_layer(P::DEEP, l, t), sprime_tile(P::DEEP, l, t)) : 0;
 }
 template <bool GRAD> constexpr int vm_post(int ci) {
   if (!GRAD || ci >= N_FWD_CHUNKS) return 0;
@@ -590,9 +594,10 @@ struct BwdPend {
   f32x4 s[4];   // its softplus' slice
   f32x4 sn[4];  // slice of the tile whose G is being computed now
 };
+template <int NG = 4>
 __device__ __forceinline__ void load_sprime(const Ctx& c, int layer, int tile, f32x4 (&dst)[4]) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) dst[g] = bload(c.sl, c.svoff, layer * 16384 + (tile * 4 + g) * 1024);
+  for (int g = 0; g < NG; ++g) dst[g] = bload(c.sl, c.svoff, layer * 16384 + (tile * 4 + g) * 1024);
 }
 template <class P, int L, int T, bool CONVERT>
 __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, const BwdPend& prev,
@@ -601,8 +606,9 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
   constexpr int CI = bwd_chunk(L, T);
   constexpr int NKS = bwd_ks(L);
   constexpr int SL = sprime_layer(P::DEEP, L, T);
-  static_assert((SL >= 0 ? 4 : 0) + ((L == 0 && P::DEEPJ) ? 12 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
-  if (SL >= 0) load_sprime(c, SL, sprime_tile(P::DEEP, L, T), s_load);
+  constexpr int NG = SL >= 0 ? sprime_groups(SL, sprime_tile(P::DEEP, L, T)) : 0;
+  static_assert(NG + ((L == 0 && P::DEEPJ) ? 12 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
+  if (SL >= 0) load_sprime<NG>(c, SL, sprime_tile(P::DEEP, L, T), s_load);
   // two stages, as in the forward tiles: the product of pair q and the split of pair q-1 share a k-step
   f32x2 pend = {0.f, 0.f};
   auto mul = [&](int q) __attribute__((always_inline)) {
@@ -631,7 +637,7 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
 template <class P, int L, int T>
 __device__ __forceinline__ void bwd_hidden_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, BwdPend& pend) {
   const BwdPend prev = pend;
-  f32x4 s_load[4];
+  f32x4 s_load[4] = {};
   const f32x16 G = bwd_tile<P, L, T, (T > 0)>(c, din, dout, prev, s_load);
   pend.G = G;
 #pragma unroll

@@ -130,6 +130,14 @@ class SceneVolumes:
         return self
 
 
+class _LatticeScene:
+    """The part of SceneVolumes the SDF lattice needs (no images / cameras): extract_geometry's reference signature."""
+
+    def __init__(self, volumes, sparse_idxes):
+        self.sv = ops.SparseVolumes([v.detach().float() for v in volumes], list(sparse_idxes))
+        self.device = self.sv.vols[0].device
+
+
 class ImplicitSurface(nn.Module):
     """implicit_surface.py:50-436 (inference semantics)."""
 
@@ -147,11 +155,28 @@ class ImplicitSurface(nn.Module):
         self.sdf_precision = confs.get_string("render.sdf_precision", "bf16x3")
         if self.sdf_precision not in ops.SDF_PRECISIONS:
             raise ValueError(f"render.sdf_precision must be one of {ops.SDF_PRECISIONS}, got {self.sdf_precision!r}")
+        # which blending kernel evaluates color_network (ops.BLEND_PRECISIONS)
+        self.blend_precision = confs.get_string("render.blend_precision", ops.BLEND_DEFAULT)
+        if self.blend_precision not in ops.BLEND_PRECISIONS:
+            raise ValueError(f"render.blend_precision must be one of {ops.BLEND_PRECISIONS}, got {self.blend_precision!r}")
         self._packed = None
-        self.kernel_events = None
+        self.kernel_events = None          # bench.py: list receiving (name, start, end) HIP event triples
+        self.active_samples_log = None     # bench.py: list receiving the active-sample count of every render call
         self.last_active_samples = None
+        # loading a checkpoint or switching train / eval drops the cached weight re-layouts
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_packed())
 
     # ---- weight re-layouts are cached and refreshed whenever parameters change -------------------------
+    def invalidate_packed(self):
+        """Drop the cached MFMA weight re-layouts.  The cache key is (Parameter._version, data_ptr) of every parameter,
+        which optimiser steps, `copy_` on the parameter and `load_state_dict` all change; an in-place write through
+        `param.data` (e.g. `p.data.mul_(2)`) changes neither, so call this after such an edit."""
+        self._packed = None
+
+    def train(self, mode=True):
+        self.invalidate_packed()
+        return super().train(mode)
+
     def packed_weights(self, device):
         ver = tuple((p._version, p.data_ptr()) for p in self.parameters()) + (str(device), self.sdf_precision)
         if self._packed is None or self._packed[0] != ver:
@@ -172,7 +197,7 @@ class ImplicitSurface(nn.Module):
         reproduces the reference's sample positions for the same ray batch; `jitter` (R, n_stage) overrides the draw."""
         dev = rays_o.device
         if jitter is None and self.perturb > 0:
-            jitter = torch.cat([torch.rand([rays_o.shape[0], 1]) - 0.5 for _ in self.n_samples], dim=1)
+            jitter = self.draw_jitter(rays_o.shape[0])
         if jitter is not None:
             jitter = jitter.to(dev, torch.float32).contiguous()
         sdf_w, blend_w = self.packed_weights(dev)
@@ -200,6 +225,8 @@ class ImplicitSurface(nn.Module):
                                                        float(cos_anneal_ratio), scene.cams, per_sample=per_sample))
         if ev is not None:
             self.last_active_samples = int(act.shape[0])
+            if self.active_samples_log is not None:
+                self.active_samples_log.append(int(act.shape[0]))
         R, S = st["mid_z"].shape
         eik = out.pop("eik").sum(dim=0)
         out["gradient_error"] = eik[0] / (eik[1] + 1e-5)
@@ -211,6 +238,19 @@ class ImplicitSurface(nn.Module):
             out["sdf"] = sdf.view(R, S)
         out["s_val"] = torch.full((1, 1), 1.0 / self.deviation_network.inv_s(), device=dev)
         return out
+
+    def draw_jitter(self, n_rays, ref_chunk=None):
+        """The `torch.rand([batch, 1]) - 0.5` draws of ImplicitSurface.render (:274-277, :304-306) on the CPU generator,
+        in the reference's order: per render() call one draw per stage, followed by the `torch.rand([1024, 3])` of
+        render_core (:174), which is drawn and dropped here to keep the generator aligned.  `ref_chunk` = the
+        reference's batch per render() call: None = one call over all rays (train), 256 = validate (:367-370)."""
+        step = n_rays if not ref_chunk else int(ref_chunk)
+        cols = []
+        for s0 in range(0, n_rays, step):
+            b = min(step, n_rays - s0)
+            cols.append(torch.cat([torch.rand([b, 1]) - 0.5 for _ in self.n_samples], dim=1))
+            torch.rand([1024, 3])
+        return torch.cat(cols, dim=0) if cols else torch.zeros(0, len(self.n_samples))
 
     def render(self, rays_o, rays_d, near, far, matching_volume, volumes, sparse_idxes, mask_volumes, imgs, features,
                match_features, intrs, c2ws, cos_anneal_ratio, step):
@@ -230,12 +270,24 @@ class ImplicitSurface(nn.Module):
             xs = axes[0][x0:x0 + slab]
             xx, yy, zz = torch.meshgrid(xs, axes[1], axes[2], indexing="ij")
             pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1).contiguous()
+            if self.kernel_events is not None:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
             sdf, _ = ops.sdf_mlp(pts, scene.sv, sdf_w, want_grad=False)
+            if self.kernel_events is not None:
+                b.record()
+                self.kernel_events.append(("sdf_grid", a, b))
             u[x0:x0 + slab] = -sdf.view(len(xs), resolution, resolution)
         return u
 
     def extract_geometry(self, volumes, sparse_idxes, bound_min, bound_max, resolution, threshold, scene=None):
+        """implicit_surface.py:337-357.  Callable with the reference's signature (volumes: (N_s, 7) rows fine -> coarse,
+        sparse_idxes: their index tables) or with prepared SceneVolumes (`scene=`)."""
         from .marching_cubes import marching_cubes
+        if scene is None:
+            if volumes is None or sparse_idxes is None:
+                raise ValueError("extract_geometry needs either (volumes, sparse_idxes) or scene=SceneVolumes")
+            scene = _LatticeScene(volumes, sparse_idxes)
         u = self.sdf_grid(scene, bound_min, bound_max, resolution)
         vertices, triangles = marching_cubes(u, threshold)
         b_max_np = bound_max.detach().cpu().numpy()
@@ -245,17 +297,20 @@ class ImplicitSurface(nn.Module):
 
     def validate(self, rays_o, rays_d, near, far, scene, bound_min, bound_max, hw, cos_anneal_ratio=1.0, step=None,
                  extract_geometry=True, mesh_resolution=512, threshold=0.0, chunk=65536):
-        """implicit_surface.py:359-402.  The reference's 256-ray chunks exist to bound autograd memory; here
-        rays are independent (perturb = 0), so the chunk is only a scratch-size knob."""
+        """implicit_surface.py:359-402.  The reference's 256-ray chunks exist to bound autograd memory; here rays are
+        independent, so `chunk` is only a scratch-size knob.  With render.perturb > 0 the jitters are drawn in the
+        reference's order (per 256-ray block, stages inner: draw_jitter), so a seeded run reproduces the reference's
+        sample positions whatever `chunk` is."""
         outputs = {}
         if extract_geometry:
             v, t = self.extract_geometry(None, None, bound_min, bound_max, mesh_resolution, threshold, scene=scene)
             outputs["vertices"], outputs["triangles"] = v, t
         height, width = int(hw[0]), int(hw[1])
         cols, nrms, sdeps, rdeps = [], [], [], []
+        jitter = self.draw_jitter(rays_o.shape[0], ref_chunk=256) if self.perturb > 0 else None
         for s in range(0, rays_o.shape[0], chunk):
             o = self.render_scene(rays_o[s:s + chunk], rays_d[s:s + chunk], near[s:s + chunk], far[s:s + chunk], scene,
-                                  cos_anneal_ratio, per_sample=False)
+                                  cos_anneal_ratio, per_sample=False, jitter=None if jitter is None else jitter[s:s + chunk])
             cols.append(o["color_fine"])
             nrms.append(o["normal_val"])
             sdeps.append(o["sdf_depth"])

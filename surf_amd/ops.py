@@ -117,6 +117,8 @@ def sdf_pack_weights_host(layers):
 
 
 SDF_PRECISIONS = ("f32", "bf16x3", "f16x2")
+BLEND_PRECISIONS = ("f32",)     # which blend kernels the library has (render.blend_precision)
+BLEND_DEFAULT = "f32"
 _SPLIT_ABI = {"bf16x3": "bf16", "f16x2": "f16"}   # precision -> infix of the C-ABI entry points
 
 
@@ -426,8 +428,9 @@ def densify(coords, rows, D, prev=None):
     return dense, table
 
 
-def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, ratio_cur=1.0, ratio_prev=1.0):
-    """matching_field.py:73-141 (perturb False).  Returns depth maps (nv,H,W)."""
+def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, ratio_cur=1.0, ratio_prev=1.0, return_lr=False):
+    """matching_field.py:73-141 (perturb False).  Returns depth maps (nv,H,W) (and, with return_lr, the (nv,h,w) maps
+    rendered at the reduced resolution before the bilinear upsample)."""
     _chk(mvol, torch.float32, "matching volume")
     dev = mvol.device
     h, w = H // res_level, W // res_level
@@ -442,7 +445,7 @@ def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, r
                                         _p(pre_depths), ctypes.c_float(float(ratio_cur)), ctypes.c_float(float(ratio_prev)),
                                         _p(lr), _p(full), _stream())
     _lib.check(rc, "surf_matching_depth")
-    return full
+    return (full, lr) if return_lr else full
 
 
 # ------------------------------------------------------------------------------------------------

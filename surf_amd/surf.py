@@ -44,12 +44,12 @@ class SuRF(nn.Module):
         return groups
 
     @torch.no_grad()
-    def build_volumes(self, ipts, features_c2f, cams=None, logit_override=None, timings=None):
+    def build_volumes(self, ipts, features_c2f, cams=None, logit_override=None, timings=None, trace=None):
         """surf.py:80-131 (perturb False).  features_c2f: texel4 maps coarse -> fine.
         Returns (outputs, volumes, tables, matching_volume) with per-stage lists coarse -> fine.
         `logit_override(coords, D) -> (N,)` (bench / tests only) replaces the U-Net's matching logit so that an
         untrained network still produces a realistic, surface-concentrated pyramid; `timings` (dict) receives
-        per-stage HIP-event pairs."""
+        per-stage HIP-event pairs; `trace` (dict, tests only) receives every stage's intermediate tensors."""
         intrs, c2ws = ipts["intrs"], ipts["c2ws"]
         if cams is None:
             cams = ops._cams_ext(ops.Cameras(intrs, c2ws), intrs, c2ws)
@@ -64,6 +64,7 @@ class SuRF(nn.Module):
                 D *= 2
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timings is not None else None
             if ev: ev[0].record()
+            parents, pre_depths = coords, depths
             coords, reg_in = self.volume.stage_inputs(s, D, features_c2f, cams, coords, mid, depths,
                                                       base_range * self.range_ratios[s])
             if ev: ev[1].record()
@@ -74,7 +75,13 @@ class SuRF(nn.Module):
             if ev: ev[2].record()
             mvol, table = ops.densify(coords, out, D, mvol)
             if ev: ev[3].record()
-            depths = self.matching_field(cams, ipts["near_fars"], (H, W), mvol, s, self.range_ratios, depths)
+            depths = self.matching_field(cams, ipts["near_fars"], (H, W), mvol, s, self.range_ratios, depths,
+                                         return_lr=trace is not None)
+            if trace is not None:
+                depths, lr = depths
+                trace[s] = {"D": D, "parents": parents, "pre_depths": pre_depths, "coords": coords, "reg_in": reg_in,
+                            "out": out, "mvol": mvol, "table": table, "depths": depths, "depths_lr": lr,
+                            "depth_range": base_range * self.range_ratios[s]}
             if ev:
                 ev[4].record()
                 timings[s] = {"n_voxels": int(coords.shape[0]), "events": ev}

@@ -94,3 +94,10 @@ def feature_pyramid(nv, H, W, seed=0, device="cpu"):
     """Random 4-level, 4-channel image-feature pyramid, fine -> coarse (stand-in for the FPN output)."""
     g = torch.Generator().manual_seed(1000 + seed)
     return [torch.randn(nv, 4, H >> l, W >> l, generator=g).to(device) for l in range(4)]
+
+
+def sphere_logit(coords, D):
+    """Analytic matching logit of the synthetic scene, -20 | |x| - 0.5 | at the voxel centres of a D^3 lattice: what the
+    (untrained) sparse U-Net's first output channel is replaced by in the full-size volume-build bench / tests."""
+    world = coords.float() * (2.0 / (D - 1)) - 1.0
+    return -20.0 * (world.norm(dim=1) - 0.5).abs()

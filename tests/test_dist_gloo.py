@@ -49,3 +49,52 @@ def test_single_process_helpers():
     assert D.shard_scenes(15, 3, 8) == [3, 11]
     assert D.max_over_ranks(1.5) == 1.5
     assert D.gather_records({"a": 1}) == [{"a": 1}]
+
+
+# ---- bench.py's own N > 1 control flow (kernels stubbed by --dry, gloo instead of RCCL) --------------------------------
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the parent spawns two ranks, rank 0's line says n_gpus 2 and the 5
+    scenes are dealt round-robin (datasets/__init__.py:37-38)."""
+    import json
+    res = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry", "--steps", "3", "--warmup", "1", "--scenes", "5"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["data"] == "dry-run"
+    assert [(x["scene"], x["rank"]) for x in r["scenes"]] == [(0, 0), (1, 1), (2, 0), (3, 1), (4, 0)]
+    assert r["config"]["rays_per_step"] == 5 * 576 * 800
+    # whole-job value = all rays of all ranks / the slowest rank's time; rank 0 renders 3 scenes of >= 2 ms per step
+    assert r["ms_per_step"] >= 6.0
+    assert abs(r["value"] - r["config"]["rays_per_step"] / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+
+
+def test_bench_under_a_launcher_and_world_size_mismatch():
+    """The torch.distributed.run contract: ranks come from the environment; a --gpus that disagrees with WORLD_SIZE is
+    an error, not a silent single-rank run."""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(_clean_env(), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, BENCH, "--gpus", "2", "--dry", "--steps", "2", "--warmup", "0"], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    r = json.loads([l for l in outs[0][0].splitlines() if l.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and [x["scene"] for x in r["scenes"]] == [0, 1]
+    assert not [l for l in outs[1][0].splitlines() if l.startswith("{")]      # only rank 0 prints the line
+    bad = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry"], env=dict(_clean_env(), WORLD_SIZE="1", RANK="0"),
+                         capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 2 and "WORLD_SIZE" in bad.stderr

@@ -390,3 +390,31 @@ def test_sdf_split_small_and_ragged_sizes(weights, gpu_scene, precision):
         rel_close(sm[::2], s0[::2], 0, 1e-5)
         rel_close(gm[::2], g0[::2], 1e-4, 1e-4)
         assert bool((sm[1::2] == 100.0).all()) and bool((gm[1::2] == 0).all())
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
+def test_sdf_grid_matches_golden(weights, golden_pipe, golden_grid, precision):
+    """Row a16: ImplicitSurface.sdf_grid / extract_geometry's lattice (implicit_surface.py:337-351: linspace axes,
+    [x][y][z] order, u = -sdf) against the values the reference handed to mcubes.marching_cubes, all three SDF kernels."""
+    from bench import model_conf
+    from surf_amd.implicit_surface import ImplicitSurface
+    d = dev()
+    model = ImplicitSurface(model_conf(CFG["n_samples"], precision))
+    sd = {k[len("implicit_surface."):]: v for k, v in weights.items() if k.startswith("implicit_surface.")}
+    model.load_state_dict(sd, strict=True)
+    model = model.to(d)
+    vols, tabs, _, _ = pipeline_views(golden_pipe)
+    vols, tabs = [v.to(d) for v in vols], [t.to(d) for t in tabs]
+    scene = type("S", (), {})()
+    from surf_amd import ops
+    scene.sv, scene.device = ops.SparseVolumes(vols, tabs), d
+    bmin, bmax = golden_grid["bound_min"], golden_grid["bound_max"]
+    u = model.sdf_grid(scene, bmin, bmax, 24)
+    torch.cuda.synchronize()
+    assert tuple(u.shape) == (24, 24, 24)
+    rel_close(u, golden_grid["u"], 0, 1e-4)
+    assert float(golden_grid["u"].min()) < 0 < float(golden_grid["u"].max())       # the lattice straddles the surface
+    # the reference's call signature (volumes, sparse_idxes, ...) builds the same lattice and returns a mesh inside the box
+    v, t = model.extract_geometry(vols, tabs, bmin, bmax, 24, 0.0)
+    assert v.shape[1] == 3 and t.shape[1] == 3 and t.shape[0] > 10
+    assert bool((v >= bmin.numpy()[None] - 1e-6).all()) and bool((v <= bmax.numpy()[None] + 1e-6).all())

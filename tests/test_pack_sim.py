@@ -257,7 +257,8 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name)
-    assert L.surf_abi_version() == 4
+    hdr_ver = int(re.search(r"#define\s+SURF_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert L.surf_abi_version() == hdr_ver == _lib.ABI_VERSION
     assert L.surf_sdf_scratch_bytes(1 << 20) > 0
 
 
