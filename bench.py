@@ -52,8 +52,8 @@ SDF_KERNELS = {
 }
 BLEND_KERNELS = {
     "f32": ("blend_kernel<{ns}>", "v_mfma_f32_32x32x2_f32", 157.3, 1),
-    "bf16x3": ("blend_split_kernel<BPolBf3, {ns}>", "v_mfma_f32_32x32x16_bf16", 2500.0, 6),
-    "f16x2": ("blend_split_kernel<BPolH2, {ns}>", "v_mfma_f32_32x32x16_f16", 2500.0, 3),
+    "bf16x3": ("blend_split_kernel<BPolBf3>", "v_mfma_f32_32x32x16_bf16", 2500.0, 6),
+    "f16x2": ("blend_split_kernel<BPolH2>", "v_mfma_f32_32x32x16_f16", 2500.0, 3),
 }
 WORKLOADS = {
     # BASELINE.json configs[1]: the configuration the metric is quoted on

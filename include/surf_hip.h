@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 5
+#define SURF_ABI_VERSION 6
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -136,6 +136,24 @@ int surf_blend_pack_weights(const float* h_raw, float* h_packed);
 int surf_blend(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_feats, const int* h_hw,
                int n_level, const float* imgs, int nv, const float* h_intrs, const float* h_w2c,
                const float* h_c2w, const float* blend_w, float* color, uint8_t* n_valid, void* stream);
+
+/*
+ * The same blending MLP on the 16-bit MFMA pipes (blend_split.hip): every fp32 operand split into 16-bit pieces, fp32
+ * accumulation.  precision: SURF_BLEND_BF16X3 (exact three-way bf16 split, six products: fp32-equivalent) or
+ * SURF_BLEND_F16X2 (two fp16 pieces, 22-bit operands, three products).  `blend_w` is the device copy of
+ * surf_blend_pack_weights_split's output for the same precision (the kernel's LDS image); other arguments as surf_blend.
+ */
+#define SURF_BLEND_BF16X3 1
+#define SURF_BLEND_F16X2 2
+int64_t surf_blend_split_packed_bytes(int precision);
+int surf_blend_pack_weights_split(const float* h_raw, unsigned char* h_packed, int precision);
+/* Bytes of device scratch a launch over n points with nv views needs (per-wavefront staging of the per-view inputs of the
+ * second pass; stays in L2 / Infinity Cache).  Contents need not be preserved between launches. */
+int64_t surf_blend_split_scratch_bytes(int64_t n_points, int nv);
+int surf_blend_split(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_feats,
+                     const int* h_hw, int n_level, const float* imgs, int nv, const float* h_intrs, const float* h_w2c,
+                     const float* h_c2w, const void* blend_w, int precision, float* color, uint8_t* n_valid, void* scratch,
+                     void* stream);
 
 /*
  * NeuS SDF -> alpha compositing, zero-crossing depth and per-ray reductions.

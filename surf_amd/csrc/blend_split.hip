@@ -1,0 +1,795 @@
+// K10b: multi-view feature fetch + IBRNet-style blending MLP on the 16-bit MFMA pipes ("split" blend kernels).
+//
+// Restates lookup_feature / compute_angle   projector.py:485-556
+//          BlendingNetwork.forward           blending_network.py:69-118
+// (same arithmetic as blend.hip, which stays in the tree as the fp32-MFMA reference of this kernel.)
+//
+// Precisions, as in sdf_mlp_split.hip: every fp32 operand is split into 16-bit pieces, partial products accumulate in
+// fp32 with v_mfma_f32_32x32x16_{bf16,f16}:
+//   bf16x3  exact three-way split, six products per k-step: fp32-equivalent (default)
+//   f16x2   two fp16 pieces (operand error <= 2^-22 relative or 2^-25 absolute), three products per k-step
+//
+// Design for CDNA4:
+//   * one wavefront owns 32 sample points, lane l = (sample j = l & 31, half h = l >> 5); every Linear is
+//     W (A operand) x activations^T (B operand), so the 32x32 accumulator tile of a layer IS the B operand of the next
+//     one after ELU and splitting: accumulator registers 8s..8s+7 of half h are the eight k-values of k-step s.
+//   * the whole weight set (26 k-step x tile blocks of NP KB = 78 KB bf16x3 / 52 KB f16x2, + bias and dot rows) is
+//     copied ONCE per workgroup into LDS and stays there: A fragments are ds_read_b128 (1 KB per wave instruction,
+//     lane-linear, conflict-free), there is no weight stream, no ring and no barrier inside the tile loop.
+//   * workgroups of 8 wavefronts = two per SIMD at <= 256 registers: with the 16-bit pipes the kernel is bound by the
+//     VALU work per activation (ELU + operand split), not by the matrix pipe, and two wavefronts per SIMD let one
+//     wavefront's VALU work run beside the other's MFMAs without hand-scheduling.
+//   * ELU on the pre-activation scaled by log2(e) (folded into the packed weights and biases):
+//     elu(x) = ln2 max(t, 0) + (min(exp2 t, 1) - 1), t = x log2 e: four VALU operations per element;
+//     biases are the accumulators' initial values (LDS rows), not VALU adds.
+//   * the 19 per-view input channels are split between the lane halves as in blend.hip: no texel is fetched twice.
+#include <math.h>
+#include <string.h>
+
+#include "blend_raw.h"
+#include "common.h"
+
+namespace {
+
+using namespace blend_raw;
+
+constexpr int TILE = 32;
+#ifndef SURF_BLEND_WPB
+#define SURF_BLEND_WPB 8
+#endif
+constexpr int WPB = SURF_BLEND_WPB;  // wavefronts per workgroup (8 = two per SIMD; one workgroup per CU owns the LDS image)
+
+// ---- LDS image --------------------------------------------------------------------------------------------------------
+enum { L_RD0, L_RD2, L_B0S, L_B0V, L_B2, L_V0, L_V2, L_W0, L_R0, L_R2, N_L };
+constexpr int NKS[N_L] = {1, 1, 3, 2, 4, 2, 2, 2, 3, 1};  // k-steps of 16
+constexpr int NT[N_L] = {1, 1, 2, 2, 1, 1, 1, 1, 1, 1};   // 32-row output tiles
+constexpr int blk_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += NKS[i] * NT[i]; return o; }
+constexpr int N_BLK = blk_off(N_L);  // 26 blocks of NP KB: [layer][k-step][tile][piece][lane] x 16 B
+enum { B_RD0, B_RD2, B_B0_T0, B_B0_T1, B_B2, B_V0, B_V2, B_W0, B_R0, B_R2, N_BIAS };  // accumulator-init rows [h][16]
+enum { D_VIS, D_VIS2, D_RGB4, N_DOT };                                                    // per-lane dot rows [h][16]
+template <int NP> constexpr int bias_off() { return N_BLK * NP * 1024; }
+template <int NP> constexpr int dot_off() { return bias_off<NP>() + N_BIAS * 128; }
+template <int NP> constexpr int scal_off() { return dot_off<NP>() + N_DOT * 128; }  // [|s|, b_vis, b_vis2, b_rgb4]
+template <int NP> constexpr int image_bytes() { return scal_off<NP>() + 16; }
+
+constexpr float LOG2E = 1.44269504088896341f, LN2 = 0.69314718055994531f;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NP>
+struct FragT { u32x4 p[NP]; };  // B operand of one 16-wide k-step: NP pieces x 8 x 16 bit
+
+struct BPolBf3 {
+  static constexpr int NP = 3, ID = 1;
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    uint32_t u = __builtin_bit_cast(uint32_t, v);
+    asm volatile("" : "+v"(u));  // keep the packed value: the residuals below come from its two halves
+    return u;
+  }
+  static __device__ __forceinline__ void split(float a, float b, uint32_t (&p)[NP]) {
+    p[0] = pack2(a, b);
+    const float ra = a - __builtin_bit_cast(float, p[0] << 16), rb = b - __builtin_bit_cast(float, p[0] & 0xffff0000u);
+    p[1] = pack2(ra, rb);
+    p[2] = pack2(ra - __builtin_bit_cast(float, p[1] << 16), rb - __builtin_bit_cast(float, p[1] & 0xffff0000u));
+  }
+  static __device__ __forceinline__ void mma(f32x16& acc, const u32x4 (&a)[NP], const FragT<NP>& b) {
+#define SURF_MF(x, y) \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[x]), __builtin_bit_cast(bf16x8, b.p[y]), acc, 0, 0, 0)
+    SURF_MF(2, 0);  // smallest terms first
+    SURF_MF(0, 2);
+    SURF_MF(1, 1);
+    SURF_MF(1, 0);
+    SURF_MF(0, 1);
+    SURF_MF(0, 0);
+#undef SURF_MF
+  }
+};
+
+struct BPolH2 {
+  static constexpr int NP = 2, ID = 2;
+  static __device__ __forceinline__ void split(float a, float b, uint32_t (&p)[NP]) {
+    const f32x2 v = {a, b};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);
+    p[0] = __builtin_bit_cast(uint32_t, h);
+    p[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+  }
+  static __device__ __forceinline__ void mma(f32x16& acc, const u32x4 (&a)[NP], const FragT<NP>& b) {
+#define SURF_MF(x, y) \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[x]), __builtin_bit_cast(f16x8, b.p[y]), acc, 0, 0, 0)
+    SURF_MF(1, 0);
+    SURF_MF(0, 1);
+    SURF_MF(0, 0);
+#undef SURF_MF
+  }
+};
+
+struct BlendArgs {
+  const float* pts;
+  const uint8_t* mask;
+  const int32_t* idx;  // optional list of point indices (n entries)
+  int64_t n;
+  const float* feats[4];
+  int hw[8];
+  const float* imgs;
+  float K[SURF_MAX_VIEWS][9];
+  float w2c[SURF_MAX_VIEWS][12];
+  float cpos[SURF_MAX_VIEWS][3];
+  const unsigned char* w;  // LDS image (surf_blend_pack_weights_split)
+  float* color;
+  uint8_t* n_valid;
+  float* scratch;  // per-wavefront staging slots (surf_blend_split_scratch_bytes)
+  int nv;
+};
+
+// Phase boundary for the instruction scheduler: without it hipcc hoists the LDS reads (A fragments, bias rows) of later
+// layers far ahead of their use and spills; latency is hidden by the second wavefront of the SIMD instead.
+#ifndef SURF_BLEND_NOPHASE
+#define SURF_PHASE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define SURF_PHASE()
+#endif
+
+// ---- activations ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * LOG2E); }
+__device__ __forceinline__ float elu_x(float x) { return x > 0.f ? x : fexp(x) - 1.0f; }
+__device__ __forceinline__ float sigm(float x) { return __builtin_amdgcn_rcpf(1.0f + fexp(-x)); }
+// ELU of a pre-activation given as t = x log2(e):  ln2 max(t, 0) + (min(exp2(t), 1) - 1)
+__device__ __forceinline__ float elu_t(float t) {
+  const float e = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(t), 0.0f, 1.0f);  // the clamp modifier of v_exp_f32
+  const float m = __builtin_amdgcn_fmed3f(t, 0.0f, 3.0e38f);                       // max(t, 0) without a canonicalising v_max
+  return fmaf(m, LN2, e - 1.0f);
+}
+template <int N>
+__device__ __forceinline__ void elu_rows(const f32x16& acc, float* out) {
+#pragma unroll
+  for (int r = 0; r < N; ++r) out[r] = elu_t(acc[r]);
+}
+
+// N values (N <= 8 * NF) -> NF k-step fragments, zero padded
+template <class P, int N, int NF>
+__device__ __forceinline__ void frags_from(const float* v, FragT<P::NP>* f) {
+#pragma unroll
+  for (int s = 0; s < NF; ++s)
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) {
+      const int i0 = 8 * s + 2 * pr;
+      uint32_t p[P::NP];
+      if (i0 < N) {
+        P::split(v[i0], i0 + 1 < N ? v[i0 + 1] : 0.0f, p);
+      } else {
+#pragma unroll
+        for (int k = 0; k < P::NP; ++k) p[k] = 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < P::NP; ++k) f[s].p[k][pr] = p[k];
+    }
+}
+
+// ELU of the first N registers of an accumulator tile straight into k-step fragments (N = 8 or 16), pair by pair
+template <class P, int N>
+__device__ __forceinline__ void elu_frags(const f32x16& acc, FragT<P::NP>* f) {
+#pragma unroll
+  for (int r = 0; r < N; r += 2) {
+    uint32_t p[P::NP];
+    P::split(elu_t(acc[r]), elu_t(acc[r + 1]), p);
+#pragma unroll
+    for (int k = 0; k < P::NP; ++k) f[r >> 3].p[k][(r & 7) >> 1] = p[k];
+  }
+}
+struct Ctx {
+  const char* lds;
+  int lane16, h64;
+};
+// A copy of the context whose LDS offsets the optimiser cannot see through.  The LDS image is read-only inside the tile
+// loop, so without this every ds_read of a weight fragment / bias row is a loop invariant AND common to all (unrolled)
+// views: hipcc hoists and merges them and then keeps hundreds of registers live (and spills).  One opaque copy per view
+// makes each view read its own fragments when it needs them.
+__device__ __forceinline__ Ctx opaque(const Ctx& c) {
+  Ctx o = c;
+  asm volatile("" : "+v"(o.lane16), "+v"(o.h64));
+  return o;
+}
+
+template <class P>
+__device__ __forceinline__ f32x16 lds_row16(const Ctx& c, int byte_off) {  // [h][16] floats, broadcast within a half
+  f32x16 v;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(c.lds + byte_off + c.h64 + g * 16);
+    v[4 * g + 0] = x[0]; v[4 * g + 1] = x[1]; v[4 * g + 2] = x[2]; v[4 * g + 3] = x[3];
+  }
+  return v;
+}
+template <class P> __device__ __forceinline__ f32x16 bias_row(const Ctx& c, int row) { return lds_row16<P>(c, bias_off<P::NP>() + row * 128); }
+template <class P> __device__ __forceinline__ f32x16 dot_row(const Ctx& c, int row) { return lds_row16<P>(c, dot_off<P::NP>() + row * 128); }
+
+// acc += W[layer L, k-step KS, tile T] x b   (A fragments from the LDS image)
+template <class P, int L, int KS, int T>
+__device__ __forceinline__ void mma_blk(const Ctx& c, f32x16& acc, const FragT<P::NP>& b) {
+  constexpr int OFF = (blk_off(L) + KS * NT[L] + T) * P::NP * 1024;
+  u32x4 a[P::NP];
+#pragma unroll
+  for (int p = 0; p < P::NP; ++p) a[p] = *reinterpret_cast<const u32x4*>(c.lds + OFF + p * 1024 + c.lane16);
+  P::mma(acc, a, b);
+}
+// one 32-row tile of layer L over NK k-steps
+template <class P, int L, int T, int NK>
+__device__ __forceinline__ void mma_layer(const Ctx& c, f32x16& acc, const FragT<P::NP>* b) {
+  static_assert(NK == NKS[L], "k-steps");
+  if constexpr (NK >= 1) mma_blk<P, L, 0, T>(c, acc, b[0]);
+  if constexpr (NK >= 2) mma_blk<P, L, 1, T>(c, acc, b[1]);
+  if constexpr (NK >= 3) mma_blk<P, L, 2, T>(c, acc, b[2]);
+  if constexpr (NK >= 4) mma_blk<P, L, 3, T>(c, acc, b[3]);
+  SURF_PHASE();
+}
+
+// Bilinear fetch of a texel4 map with zero padding, branch-free: out-of-range taps read a clamped texel with
+// weight 0, so all four 16-byte loads of a fetch (and of every fetch of a view) can be in flight together.
+struct Tap4 {
+  f32x4 v[4];
+  float w[4];
+};
+__device__ __forceinline__ void tap_issue(Tap4& t, const float* __restrict__ map, int H, int W, float x, float y) {
+  const float fx = floorf(x), fy = floorf(y);
+  const float tx = x - fx, ty = y - fy;
+  const int x0 = (int)fx, y0 = (int)fy;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {  // order (y0,x0), (y0,x1), (y1,x0), (y1,x1) = grid_sample's nw, ne, sw, se
+    const int dx = k & 1, dy = k >> 1;
+    const int xi = x0 + dx, yi = y0 + dy;
+    const bool ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H);
+    const int xc = min(max(xi, 0), W - 1), yc = min(max(yi, 0), H - 1);
+    t.v[k] = *reinterpret_cast<const f32x4*>(map + ((int64_t)yc * W + xc) * 4);
+    t.w[k] = ok ? (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) : 0.0f;
+  }
+}
+__device__ __forceinline__ f32x4 tap_finish(const Tap4& t) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) acc += t.v[k] * t.w[k];
+  return acc;
+}
+
+template <class P> constexpr int lds_bytes() { return image_bytes<P::NP>(); }
+
+// Per-wavefront staging slot in global memory (L2 / Infinity-Cache resident: written in pass 1, read back within the
+// same tile): per source view five 16-byte groups per lane = [floc 0..3][floc 4..7][floc 8..11][ray_diff][rgb, +-ex]
+// (ex = exp(|s| (dot - 1)) > 0, stored negated where the view's mask is 0).  It makes the register state independent of
+// the number of views, so the view loops are real loops: one code path for 1..7 source views, ~4x less code than the
+// unrolled form and no spills at two wavefronts per SIMD.
+constexpr int SLOT_GROUPS = 5;
+constexpr int slot_floats(int ns) { return ns * SLOT_GROUPS * 64 * 4; }
+
+struct ViewState {
+  float floc[12];
+  float rd[4];
+  float rgb[3];
+  float ex;  // > 0; mk = 1
+  float mk;
+};
+__device__ __forceinline__ void slot_store(float* slot, int v, int lane, const ViewState& s) {
+  f32x4* p = reinterpret_cast<f32x4*>(slot + (int64_t)(v * SLOT_GROUPS) * 256 + lane * 4);
+  p[0 * 64] = f32x4{s.floc[0], s.floc[1], s.floc[2], s.floc[3]};
+  p[1 * 64] = f32x4{s.floc[4], s.floc[5], s.floc[6], s.floc[7]};
+  p[2 * 64] = f32x4{s.floc[8], s.floc[9], s.floc[10], s.floc[11]};
+  p[3 * 64] = f32x4{s.rd[0], s.rd[1], s.rd[2], s.rd[3]};
+  p[4 * 64] = f32x4{s.rgb[0], s.rgb[1], s.rgb[2], s.mk != 0.f ? s.ex : -s.ex};
+}
+__device__ __forceinline__ void slot_load_floc(const float* slot, int v, int lane, float (&floc)[12]) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(slot + (int64_t)(v * SLOT_GROUPS) * 256 + lane * 4);
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const f32x4 x = p[g * 64];
+    floc[4 * g + 0] = x[0]; floc[4 * g + 1] = x[1]; floc[4 * g + 2] = x[2]; floc[4 * g + 3] = x[3];
+  }
+}
+__device__ __forceinline__ void slot_load_tail(const float* slot, int v, int lane, ViewState& s) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(slot + (int64_t)(v * SLOT_GROUPS) * 256 + lane * 4);
+  const f32x4 r = p[3 * 64], c = p[4 * 64];
+  s.rd[0] = r[0]; s.rd[1] = r[1]; s.rd[2] = r[2]; s.rd[3] = r[3];
+  s.rgb[0] = c[0]; s.rgb[1] = c[1]; s.rgb[2] = c[2];
+  s.mk = c[3] > 0.f ? 1.f : 0.f;
+  s.ex = fabsf(c[3]);
+}
+
+template <class P>
+__global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArgs a) {
+  typedef FragT<P::NP> Frag;
+  __shared__ __attribute__((aligned(16))) char lds[lds_bytes<P>()];
+  // ---- the weight image: global -> LDS once per workgroup --------------------------------------------------------
+  for (int o = threadIdx.x * 16; o < lds_bytes<P>(); o += WPB * 64 * 16)
+    *reinterpret_cast<u32x4*>(lds + o) = *reinterpret_cast<const u32x4*>(a.w + o);
+  __syncthreads();
+
+  Ctx c0;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 31, h = lane >> 5;
+  c0.lds = lds;
+  c0.lane16 = lane * 16;
+  c0.h64 = h * 64;
+  const int NS = a.nv - 1;
+  const int64_t wave_id = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * WPB;
+  const int64_t n_tiles = (a.n + TILE - 1) / TILE;
+  float* slot = a.scratch + wave_id * slot_floats(NS);
+  const float* scal = reinterpret_cast<const float*>(lds + scal_off<P::NP>());
+  const float s_abs = scal[0], b_vis = scal[1], b_vis2 = scal[2], b_rgb4 = scal[3];
+
+  // the two pyramid levels this half fetches
+  const float* __restrict__ mapA = h ? a.feats[2] : a.feats[0];
+  const float* __restrict__ mapB = h ? a.feats[3] : a.feats[1];
+  const int HA = h ? a.hw[4] : a.hw[0], WA = h ? a.hw[5] : a.hw[1];
+  const int HB = h ? a.hw[6] : a.hw[2], WB = h ? a.hw[7] : a.hw[3];
+  const float scA = h ? 0.25f : 1.0f, scB = h ? 0.125f : 0.5f;
+
+  for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+    const int64_t slot_i = tile * TILE + j;
+    const int64_t sc = slot_i < a.n ? slot_i : a.n - 1;
+    const int64_t i = a.idx ? (int64_t)a.idx[sc] : sc;
+    const bool active = (slot_i < a.n) && (!a.mask || a.mask[i] != 0);
+    if (__ballot(active) == 0ull) continue;
+    const float px = a.pts[i * 3 + 0], py = a.pts[i * 3 + 1], pz = a.pts[i * 3 + 2];
+
+    float ax = a.cpos[0][0] - px, ay = a.cpos[0][1] - py, az = a.cpos[0][2] - pz;
+    {
+      const float nn = sqrtf(ax * ax + ay * ay + az * az) + 1e-6f;
+      ax /= nn; ay /= nn; az /= nn;
+    }
+    int nvalid = 0;
+    float emin = INFINITY;
+    // ------------------------------ pass 1: per view, projections + texel fetches + direction feature ----------------
+#pragma unroll 1
+    for (int v = 0; v < NS; ++v) {
+      const Ctx c = opaque(c0);
+      const int cam = v + 1;
+      ViewState st;
+      // ray_diff (projector.py:485-498)
+      float bx = a.cpos[cam][0] - px, by = a.cpos[cam][1] - py, bz = a.cpos[cam][2] - pz;
+      const float nn = sqrtf(bx * bx + by * by + bz * bz) + 1e-6f;
+      bx /= nn; by /= nn; bz /= nn;
+      const float ddx = ax - bx, ddy = ay - by, ddz = az - bz;
+      const float dn = fmaxf(sqrtf(ddx * ddx + ddy * ddy + ddz * ddz), 1e-6f);
+      st.rd[0] = ddx / dn; st.rd[1] = ddy / dn; st.rd[2] = ddz / dn;
+      st.rd[3] = ax * bx + ay * by + az * bz;
+      // projection (projector.py:527-539); level l uses intrinsics rows 0,1 x 0.5^l = exact scaling of u,v
+      const float* M = a.w2c[cam];
+      const float X = M[0] * px + M[1] * py + M[2] * pz + M[3];
+      const float Y = M[4] * px + M[5] * py + M[6] * pz + M[7];
+      const float Z = M[8] * px + M[9] * py + M[10] * pz + M[11];
+      const float* K = a.K[cam];
+      const float qx = K[0] * X + K[1] * Y + K[2] * Z;
+      const float qy = K[3] * X + K[4] * Y + K[5] * Z;
+      const float qz = K[6] * X + K[7] * Y + K[8] * Z;
+      const float u0 = qx / qz, v0 = qy / qz;
+      bool ok = qz > 0.f;
+      Tap4 qA, qB, qC;
+      {
+        const float u = u0 * scA, vv = v0 * scA;
+        ok = ok && (u >= 0.f) && (u < (float)WA) && (vv >= 0.f) && (vv < (float)HA);
+        const float nx = u / ((float)(WA - 1) / 2.0f) - 1.0f, ny = vv / ((float)(HA - 1) / 2.0f) - 1.0f;
+        const float gx = ((nx + 1.0f) * (float)WA - 1.0f) / 2.0f, gy = ((ny + 1.0f) * (float)HA - 1.0f) / 2.0f;
+        tap_issue(qA, mapA + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
+        // half 1 re-reads its level-A taps instead of the image (same addresses: L1 hits), result unused
+        tap_issue(qC, (h == 0 ? a.imgs : mapA) + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
+      }
+      {
+        const float u = u0 * scB, vv = v0 * scB;
+        ok = ok && (u >= 0.f) && (u < (float)WB) && (vv >= 0.f) && (vv < (float)HB);
+        const float nx = u / ((float)(WB - 1) / 2.0f) - 1.0f, ny = vv / ((float)(HB - 1) / 2.0f) - 1.0f;
+        const float gx = ((nx + 1.0f) * (float)WB - 1.0f) / 2.0f, gy = ((ny + 1.0f) * (float)HB - 1.0f) / 2.0f;
+        tap_issue(qB, mapB + (int64_t)cam * HB * WB * 4, HB, WB, gx, gy);
+      }
+      // direction feature ELU(L(ELU(L(ray_diff))))  4 -> 16 -> 19  (blending_network.py:72-74), under the fetches
+      float d12[12];
+      {
+        const float bin[2] = {h ? st.rd[1] : st.rd[0], h ? st.rd[3] : st.rd[2]};
+        Frag fb, f8;
+        frags_from<P, 2, 1>(bin, &fb);
+        f32x16 acc1 = bias_row<P>(c, B_RD0);
+        mma_layer<P, L_RD0, 0, 1>(c, acc1, &fb);
+        elu_frags<P, 8>(acc1, &f8);
+        f32x16 acc2 = bias_row<P>(c, B_RD2);
+        mma_layer<P, L_RD2, 0, 1>(c, acc2, &f8);
+        // rows of half 1 beyond its 8 channels carry zero weights and zero bias: elu(0) = 0
+        elu_rows<12>(acc2, d12);
+      }
+      const f32x4 tA = tap_finish(qA), tB = tap_finish(qB);
+      f32x4 tC = tap_finish(qC);
+      if (h != 0) tC = f32x4{0.f, 0.f, 0.f, 0.f};
+      ok = ok && (__shfl_xor((int)ok, 32) != 0);  // AND over all four levels
+      st.mk = ok ? 1.f : 0.f;
+      nvalid += ok ? 1 : 0;
+      st.rgb[0] = tC[0]; st.rgb[1] = tC[1]; st.rgb[2] = tC[2];
+      // local channel order: half 0 = [rgb, F0, F1], half 1 = [F2, F3, 0, 0, 0]
+      float g[12];
+      if (h == 0) {
+        g[0] = tC[0]; g[1] = tC[1]; g[2] = tC[2];
+        g[3] = tA[0]; g[4] = tA[1]; g[5] = tA[2]; g[6] = tA[3];
+        g[7] = tB[0]; g[8] = tB[1]; g[9] = tB[2]; g[10] = tB[3];
+      } else {
+        g[0] = tA[0]; g[1] = tA[1]; g[2] = tA[2]; g[3] = tA[3];
+        g[4] = tB[0]; g[5] = tB[1]; g[6] = tB[2]; g[7] = tB[3];
+        g[8] = g[9] = g[10] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 11; ++r) st.floc[r] = g[r] + d12[r];
+      st.floc[11] = 0.f;
+      st.ex = expf(s_abs * (st.rd[3] - 1.0f));
+      emin = fminf(emin, st.ex);
+      slot_store(slot, v, lane, st);
+    }
+    if (a.n_valid && active && h == 0) a.n_valid[i] = (uint8_t)nvalid;
+
+    // ------------------------------ pooling weights, weighted mean / variance (:76-86) ----------------------
+    // w_v = (ex_v - min_v ex) mk_v / (sum + 1e-8); mean = sum_v w_v f_v; var = sum_v w_v (f_v - mean)^2: two sweeps
+    // over the staged views (each lane reads back exactly what it wrote)
+    float wsum = 0.f;
+    float mv[24];
+#pragma unroll
+    for (int ch = 0; ch < 24; ++ch) mv[ch] = 0.f;
+#pragma unroll 1
+    for (int v = 0; v < NS; ++v) {
+      ViewState st;
+      slot_load_floc(slot, v, lane, st.floc);
+      slot_load_tail(slot, v, lane, st);
+      const float w = (st.ex - emin) * st.mk;
+      wsum += w;
+#pragma unroll
+      for (int ch = 0; ch < 12; ++ch) mv[ch] += st.floc[ch] * w;
+    }
+    const float winv = 1.0f / (wsum + 1e-8f);
+#pragma unroll
+    for (int ch = 0; ch < 12; ++ch) mv[ch] *= winv;
+#pragma unroll 1
+    for (int v = 0; v < NS; ++v) {
+      ViewState st;
+      slot_load_floc(slot, v, lane, st.floc);
+      slot_load_tail(slot, v, lane, st);
+      const float w = (st.ex - emin) * st.mk * winv;
+#pragma unroll
+      for (int ch = 0; ch < 12; ++ch) { const float d = st.floc[ch] - mv[ch]; mv[12 + ch] += w * (d * d); }
+    }
+    // view-independent part of base_fc.0: [mean(12) | var(12)] -> 64 (two tiles), initialised with the bias
+    f32x16 G0a, G0b;
+    {
+      const Ctx c = opaque(c0);
+      G0a = bias_row<P>(c, B_B0_T0);
+      G0b = bias_row<P>(c, B_B0_T1);
+      Frag fm[3];
+      frags_from<P, 24, 3>(mv, fm);
+      mma_layer<P, L_B0S, 0, 3>(c, G0a, fm);
+      mma_layer<P, L_B0S, 1, 3>(c, G0b, fm);
+    }
+
+    // ------------------------------ pass 2: per-view chain, online softmax over views (:88-116) -------------
+    // Written for short live ranges (two wavefronts per SIMD = 256 registers): every activation tile is converted to
+    // B fragments pair by pair as it leaves the accumulator and consumed by the next layer's k-steps at once.
+    float Mx = -INFINITY, Zs = 0.f, o_r = 0.f, o_g = 0.f, o_b = 0.f;
+#pragma unroll 1
+    for (int v = 0; v < NS; ++v) {
+      const Ctx c = opaque(c0);
+      ViewState st;
+      slot_load_floc(slot, v, lane, st.floc);
+      slot_load_tail(slot, v, lane, st);
+      const float wv = (st.ex - emin) * st.mk * winv;
+      // base_fc.0 (view part) : 57 -> 64, on top of the view-independent part
+      f32x16 a0 = G0a, a1 = G0b;
+      {
+        Frag fl[2];
+        frags_from<P, 12, 2>(st.floc, fl);
+        mma_layer<P, L_B0V, 0, 2>(c, a0, fl);
+        mma_layer<P, L_B0V, 1, 2>(c, a1, fl);
+      }
+      // ELU, base_fc.2 : 64 -> 32, two k-steps per input tile
+      f32x16 ax2 = bias_row<P>(c, B_B2);
+      {
+        Frag hf[2];
+        elu_frags<P, 16>(a0, hf);
+        mma_blk<P, L_B2, 0, 0>(c, ax2, hf[0]);
+        mma_blk<P, L_B2, 1, 0>(c, ax2, hf[1]);
+        SURF_PHASE();
+        elu_frags<P, 16>(a1, hf);
+        mma_blk<P, L_B2, 2, 0>(c, ax2, hf[0]);
+        mma_blk<P, L_B2, 3, 0>(c, ax2, hf[1]);
+        SURF_PHASE();
+      }
+      float x[16];
+      elu_rows<16>(ax2, x);
+      // vis_fc: 32 -> 32 (ELU) -> 33 (ELU)
+      float vis;
+      {
+        f32x16 at;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) at[r] = 0.f;
+        {
+          Frag xf[2];
+          frags_from<P, 16, 2>(x, xf);
+          mma_layer<P, L_V0, 0, 2>(c, at, xf);
+        }
+        const f32x16 bt = bias_row<P>(c, B_V0);
+        f32x16 ar = bias_row<P>(c, B_V2);
+        float vraw = 0.f;
+        {
+          float t16[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t16[r] = elu_t(fmaf(at[r], wv, bt[r]));
+          const f32x16 dvis = dot_row<P>(c, D_VIS);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) vraw = fmaf(dvis[r], t16[r], vraw);
+          Frag tf[2];
+          frags_from<P, 16, 2>(t16, tf);
+          mma_layer<P, L_V2, 0, 2>(c, ar, tf);
+        }
+        vraw += __shfl_xor(vraw, 32);
+        vis = sigm(elu_x(vraw + b_vis)) * st.mk;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[r] += elu_t(ar[r]);
+      }
+      // vis_fc2: 32 -> 32 (ELU) -> 1 (sigmoid).  Its input x vis and the x part of rgb_fc's input share ONE operand
+      // split: a Linear commutes with the per-sample scale, W (x vis) + b = vis (W x) + b, so the matrix product runs on
+      // the fragments of x itself and the scale is applied to the accumulator (16 FMAs instead of a second split).
+      Frag rf[3];
+      frags_from<P, 16, 2>(x, rf);
+      float vis2;
+      {
+        f32x16 aw;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) aw[r] = 0.f;
+        mma_layer<P, L_W0, 0, 2>(c, aw, rf);
+        const f32x16 bw = bias_row<P>(c, B_W0);
+        const f32x16 dvis2 = dot_row<P>(c, D_VIS2);
+        float v2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v2 = fmaf(dvis2[r], elu_t(fmaf(aw[r], vis, bw[r])), v2);
+        v2 += __shfl_xor(v2, 32);
+        vis2 = sigm(v2 + b_vis2) * st.mk;
+      }
+      // rgb_fc: [x(32), vis, ray_diff(4)] = 37 -> 16 (ELU) -> 8 (ELU) -> 1
+      float rr;
+      {
+        f32x16 a16 = bias_row<P>(c, B_R0);
+        {
+          const float extra[3] = {h ? st.rd[0] : vis2, h ? st.rd[2] : st.rd[1], h ? 0.f : st.rd[3]};
+          frags_from<P, 3, 1>(extra, rf + 2);
+          mma_layer<P, L_R0, 0, 3>(c, a16, rf);
+        }
+        f32x16 a8 = bias_row<P>(c, B_R2);
+        {
+          Frag f8;
+          elu_frags<P, 8>(a16, &f8);
+          mma_layer<P, L_R2, 0, 1>(c, a8, &f8);
+        }
+        const f32x16 drgb4 = dot_row<P>(c, D_RGB4);
+        rr = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rr = fmaf(drgb4[r], elu_t(a8[r]), rr);
+        rr += __shfl_xor(rr, 32);
+        rr += b_rgb4;
+      }
+      if (st.mk == 0.f) rr = -1e9f;
+      const float Mn = fmaxf(Mx, rr);
+      const float scl = expf(Mx - Mn);  // exp(-inf) = 0 on the first view
+      const float e = expf(rr - Mn);
+      Zs = Zs * scl + e;
+      o_r = o_r * scl + e * st.rgb[0];
+      o_g = o_g * scl + e * st.rgb[1];
+      o_b = o_b * scl + e * st.rgb[2];
+      Mx = Mn;
+    }
+    if (active && h == 0) {
+      a.color[i * 3 + 0] = o_r / Zs;
+      a.color[i * 3 + 1] = o_g / Zs;
+      a.color[i * 3 + 2] = o_b / Zs;
+    }
+  }
+}
+
+int grid_blocks(int64_t n) {
+  const int64_t tiles = (n + TILE - 1) / TILE;
+  const int64_t blocks = (tiles + WPB - 1) / WPB;
+  return (int)(blocks < 256 ? blocks : 256);  // one 8-wave workgroup per CU, persistent over tiles
+}
+
+// ---- host packer ------------------------------------------------------------------------------------------------------
+inline uint16_t bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+inline float bf16_to_f(uint16_t b) {
+  uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+inline uint16_t f16_bits(float v) {
+  _Float16 hh = (_Float16)v;  // round to nearest even
+  uint16_t b;
+  memcpy(&b, &hh, 2);
+  return b;
+}
+inline float f16_to_f(uint16_t b) {
+  _Float16 hh;
+  memcpy(&hh, &b, 2);
+  return (float)hh;
+}
+template <class P> void split_host(float v, uint16_t* p);
+template <> void split_host<BPolBf3>(float v, uint16_t* p) {
+  p[0] = bf16_rne(v);
+  float r = v - bf16_to_f(p[0]);
+  p[1] = bf16_rne(r);
+  r = r - bf16_to_f(p[1]);
+  p[2] = bf16_rne(r);
+}
+template <> void split_host<BPolH2>(float v, uint16_t* p) {
+  p[0] = f16_bits(v);
+  p[1] = f16_bits(v - f16_to_f(p[0]));
+}
+
+// feature held by accumulator register r of half h in 32-row tile tt (= k-slot (s, i) with r = 8 s + i)
+inline int hk(int tt, int r, int h) { return 32 * tt + (r & 3) + 8 * (r >> 2) + 4 * h; }
+// local channel index (register r of half h) -> channel of the 19-vector, -1 = pad
+inline int loc_ch(int r, int h) { return h == 0 ? (r < 11 ? r : -1) : (r < 8 ? 11 + r : -1); }
+
+// A blocks of one layer: row_of(tile, rho) = weight row (or -1), col_of(m, h) = weight column of k-slot m = 8 ks + i of
+// lane half h (or -1)
+template <class P, class RowF, class ColF>
+void pack_layer(unsigned char* out, int L, const float* W, int ldw, RowF row_of, ColF col_of) {
+  constexpr int NP = P::NP;
+  for (int ks = 0; ks < NKS[L]; ++ks)
+    for (int t = 0; t < NT[L]; ++t)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int i = 0; i < 8; ++i) {
+          const int h = lane >> 5, rho = lane & 31;
+          const int row = row_of(t, rho), col = col_of(8 * ks + i, h);
+          const float v = (row >= 0 && col >= 0) ? (float)((double)W[row * ldw + col] * (double)LOG2E) : 0.f;
+          uint16_t p[NP];
+          split_host<P>(v, p);
+          for (int pc = 0; pc < NP; ++pc) {
+            uint16_t* dst = reinterpret_cast<uint16_t*>(out + ((blk_off(L) + ks * NT[L] + t) * NP + pc) * 1024 + lane * 16);
+            dst[i] = p[pc];
+          }
+        }
+}
+template <class RowF>
+void pack_rows(float* dst, const float* b, RowF feat_of, float scale) {  // [h][16] <- b[feat_of(r,h)]
+  for (int h = 0; h < 2; ++h)
+    for (int r = 0; r < 16; ++r) {
+      const int f = feat_of(r, h);
+      dst[h * 16 + r] = f >= 0 ? (float)((double)b[f] * (double)scale) : 0.f;
+    }
+}
+
+template <class P>
+int pack_weights(const float* raw, unsigned char* out) {
+  if (!raw || !out) return SURF_E_ARG;
+  constexpr int NP = P::NP;
+  memset(out, 0, image_bytes<NP>());
+  float* bias = reinterpret_cast<float*>(out + bias_off<NP>());
+  float* dots = reinterpret_cast<float*>(out + dot_off<NP>());
+  float* scal = reinterpret_cast<float*>(out + scal_off<NP>());
+  auto nat_row = [](int lim) { return [lim](int t, int rho) { const int f = 32 * t + rho; return f < lim ? f : -1; }; };
+  // k-slot m of half h -> natural feature of the producing accumulator tile(s)
+  auto nat_col = [](int lim) { return [lim](int m, int h) { const int f = hk(m / 16, m % 16, h); return f < lim ? f : -1; }; };
+  auto natf = [](int lim) { return [lim](int r, int h) { const int f = hk(0, r, h); return f < lim ? f : -1; }; };
+  // row map of the direction-feature output: D row rho -> (r, h_row) -> local channel
+  auto dir_row = [](int t, int rho) { const int hr = (rho >> 2) & 1, r = (rho & 3) | ((rho >> 3) << 2); return loc_ch(r, hr); };
+
+  // ray_dir_fc.0: 4 -> 16; k-slots 0, 1 of half h = (rd0 | rd1), (rd2 | rd3)
+  pack_layer<P>(out, L_RD0, raw + R_RD0_W, 4, nat_row(16), [](int m, int h) { return m < 2 ? 2 * m + h : -1; });
+  pack_rows(bias + B_RD0 * 32, raw + R_RD0_B, natf(16), LOG2E);
+  // ray_dir_fc.2: 16 -> 19, output rows in local-channel order
+  pack_layer<P>(out, L_RD2, raw + R_RD2_W, 16, dir_row, nat_col(16));
+  pack_rows(bias + B_RD2 * 32, raw + R_RD2_B, [](int r, int h) { return loc_ch(r, h); }, LOG2E);
+  // base_fc.0 shared part: [mean(12 slots) | var(12 slots)] -> 64
+  pack_layer<P>(out, L_B0S, raw + R_B0_W, 57, nat_row(64), [](int m, int h) {
+    const int grp = m / 12, s = m % 12;
+    const int ch = (grp < 2 && s < 11) ? loc_ch(s, h) : -1;
+    return ch >= 0 ? grp * DF + ch : -1;
+  });
+  pack_rows(bias + B_B0_T0 * 32, raw + R_B0_B, [](int r, int h) { return hk(0, r, h); }, LOG2E);
+  pack_rows(bias + B_B0_T1 * 32, raw + R_B0_B, [](int r, int h) { return hk(1, r, h); }, LOG2E);
+  // base_fc.0 view part: f (12 slots) -> 64
+  pack_layer<P>(out, L_B0V, raw + R_B0_W, 57, nat_row(64), [](int m, int h) {
+    const int ch = m < 11 ? loc_ch(m, h) : -1;
+    return ch >= 0 ? 2 * DF + ch : -1;
+  });
+  // base_fc.2: 64 -> 32
+  pack_layer<P>(out, L_B2, raw + R_B2_W, 64, nat_row(32), nat_col(64));
+  pack_rows(bias + B_B2 * 32, raw + R_B2_B, natf(32), LOG2E);
+  // vis_fc.0: 32 -> 32 ; vis_fc.2 rows 0..31 (x_res) as MFMA, row 32 (vis) as a per-lane dot
+  pack_layer<P>(out, L_V0, raw + R_V0_W, 32, nat_row(32), nat_col(32));
+  pack_rows(bias + B_V0 * 32, raw + R_V0_B, natf(32), LOG2E);
+  pack_layer<P>(out, L_V2, raw + R_V2_W, 32, nat_row(32), nat_col(32));
+  pack_rows(bias + B_V2 * 32, raw + R_V2_B, natf(32), LOG2E);
+  pack_rows(dots + D_VIS * 32, raw + R_V2_W + 32 * 32, natf(32), 1.0f);
+  // vis_fc2.0: 32 -> 32 ; vis_fc2.2: 32 -> 1 as a dot
+  pack_layer<P>(out, L_W0, raw + R_W0_W, 32, nat_row(32), nat_col(32));
+  pack_rows(bias + B_W0 * 32, raw + R_W0_B, natf(32), LOG2E);
+  pack_rows(dots + D_VIS2 * 32, raw + R_W2_W, natf(32), 1.0f);
+  // rgb_fc.0: [x(32) | vis | rd(4)] -> 16 ; k-step 2: slots 0..2 = (vis2 | rd0), (rd1 | rd2), (rd3 | -)
+  pack_layer<P>(out, L_R0, raw + R_R0_W, 37, nat_row(16), [](int m, int h) {
+    if (m < 16) return hk(0, m, h);
+    if (m == 16) return h ? 33 : 32;
+    if (m == 17) return h ? 35 : 34;
+    if (m == 18) return h ? -1 : 36;
+    return -1;
+  });
+  pack_rows(bias + B_R0 * 32, raw + R_R0_B, natf(16), LOG2E);
+  // rgb_fc.2: 16 -> 8 ; rgb_fc.4: 8 -> 1 as a dot over registers 0..3 (feature 4 h + r)
+  pack_layer<P>(out, L_R2, raw + R_R2_W, 16, nat_row(8), nat_col(16));
+  pack_rows(bias + B_R2 * 32, raw + R_R2_B, natf(8), LOG2E);
+  pack_rows(dots + D_RGB4 * 32, raw + R_R4_W, [](int r, int h) { return r < 4 ? 4 * h + r : -1; }, 1.0f);
+  scal[0] = fabsf(raw[R_S]);
+  scal[1] = raw[R_V2_B + 32];
+  scal[2] = raw[R_W2_B];
+  scal[3] = raw[R_R4_B];
+  return 0;
+}
+
+template <class P>
+int launch(const BlendArgs& a, hipStream_t st) {
+  dim3 grid(grid_blocks(a.n)), block(WPB * 64);
+  hipLaunchKernelGGL((blend_split_kernel<P>), grid, block, 0, st, a);
+  return surf_check_launch();
+}
+
+}  // namespace
+
+extern "C" int64_t surf_blend_split_packed_bytes(int precision) {
+  if (precision == BPolBf3::ID) return image_bytes<BPolBf3::NP>();
+  if (precision == BPolH2::ID) return image_bytes<BPolH2::NP>();
+  return SURF_E_ARG;
+}
+
+extern "C" int surf_blend_pack_weights_split(const float* h_raw, unsigned char* h_packed, int precision) {
+  if (precision == BPolBf3::ID) return pack_weights<BPolBf3>(h_raw, h_packed);
+  if (precision == BPolH2::ID) return pack_weights<BPolH2>(h_raw, h_packed);
+  return SURF_E_ARG;
+}
+
+extern "C" int64_t surf_blend_split_scratch_bytes(int64_t n_points, int nv) {
+  if (n_points <= 0 || nv < 2 || nv > SURF_MAX_VIEWS) return 0;
+  return (int64_t)grid_blocks(n_points) * WPB * slot_floats(nv - 1) * (int64_t)sizeof(float);
+}
+
+extern "C" int surf_blend_split(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n,
+                                const float* const* h_feats, const int* h_hw, int n_level, const float* imgs, int nv,
+                                const float* h_intrs, const float* h_w2c, const float* h_c2w, const void* blend_w,
+                                int precision, float* color, uint8_t* n_valid, void* scratch, void* stream) {
+  if (!pts || !h_feats || !h_hw || !imgs || !h_intrs || !h_w2c || !h_c2w || !blend_w || !color || !scratch) return SURF_E_ARG;
+  if (n <= 0 || nv < 2) return SURF_E_ARG;
+  if (n_level != 4 || nv > SURF_MAX_VIEWS) return SURF_E_LIMIT;  // d_feature = 16 = 4 levels x 4 channels
+  if (precision != BPolBf3::ID && precision != BPolH2::ID) return SURF_E_ARG;
+  BlendArgs a;
+  a.pts = pts; a.mask = mask; a.idx = idx; a.n = n; a.imgs = imgs; a.w = (const unsigned char*)blend_w; a.color = color;
+  a.n_valid = n_valid;
+  a.scratch = (float*)scratch;
+  a.nv = nv;
+  for (int l = 0; l < 4; ++l) {
+    if (!h_feats[l]) return SURF_E_ARG;
+    a.feats[l] = h_feats[l];
+    a.hw[2 * l] = h_hw[2 * l];
+    a.hw[2 * l + 1] = h_hw[2 * l + 1];
+  }
+  for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
+    const int s = v < nv ? v : 0;
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) a.K[v][r * 3 + cc] = h_intrs[s * 16 + r * 4 + cc];
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 4; ++cc) a.w2c[v][r * 4 + cc] = h_w2c[s * 16 + r * 4 + cc];
+    for (int r = 0; r < 3; ++r) a.cpos[v][r] = h_c2w[s * 16 + r * 4 + 3];
+  }
+  return precision == BPolBf3::ID ? launch<BPolBf3>(a, (hipStream_t)stream) : launch<BPolH2>(a, (hipStream_t)stream);
+}

@@ -20,7 +20,7 @@ for s in "${SRCS[@]}"; do
   if [[ ! -f "$o" || "$s" -nt "$o" || "${HERE}/common.h" -nt "$o" || "${HERE}/../../include/surf_hip.h" -nt "$o" ]]; then
     "${HIPCC}" "${FLAGS[@]/-shared/}" -c "$s" -o "$o" &
     pids+=($!)
-    case "$(basename "$s")" in sdf_mlp_split.hip|blend_split.hip) check_isa="${check_isa:-} $(basename "${s%.hip}")";; esac
+    case "$(basename "$s")" in sdf_mlp_split.hip) check_isa="${check_isa:-} $(basename "${s%.hip}")";; esac
   fi
 done
 for p in "${pids[@]:-}"; do [[ -n "$p" ]] && wait "$p"; done

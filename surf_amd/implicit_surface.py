@@ -178,12 +178,12 @@ class ImplicitSurface(nn.Module):
         return super().train(mode)
 
     def packed_weights(self, device):
-        ver = tuple((p._version, p.data_ptr()) for p in self.parameters()) + (str(device), self.sdf_precision)
+        ver = tuple((p._version, p.data_ptr()) for p in self.parameters()) + (str(device), self.sdf_precision, self.blend_precision)
         if self._packed is None or self._packed[0] != ver:
             sd = {k: v for k, v in self.state_dict().items()}
             sdf_w = (ops.sdf_pack_weights(sd, device, "sdf_network.") if self.sdf_precision == "f32" else
                      ops.sdf_pack_weights_split(sd, device, "sdf_network.", self.sdf_precision))
-            self._packed = (ver, sdf_w, ops.blend_pack_weights(sd, device, "color_network."))
+            self._packed = (ver, sdf_w, ops.blend_pack_weights(sd, device, "color_network.", self.blend_precision))
         return self._packed[1], self._packed[2]
 
     def scene(self, matching_volume, volumes, sparse_idxes, mask_volumes, features, imgs, intrs, c2ws):

@@ -117,8 +117,9 @@ def sdf_pack_weights_host(layers):
 
 
 SDF_PRECISIONS = ("f32", "bf16x3", "f16x2")
-BLEND_PRECISIONS = ("f32",)     # which blend kernels the library has (render.blend_precision)
-BLEND_DEFAULT = "f32"
+BLEND_PRECISIONS = ("f32", "bf16x3", "f16x2")     # the blend kernels of the library (render.blend_precision)
+BLEND_DEFAULT = "bf16x3"
+_BLEND_ID = {"bf16x3": 1, "f16x2": 2}              # SURF_BLEND_BF16X3 / SURF_BLEND_F16X2
 _SPLIT_ABI = {"bf16x3": "bf16", "f16x2": "f16"}   # precision -> infix of the C-ABI entry points
 
 
@@ -177,8 +178,34 @@ def blend_pack_weights_host(raw):
     return out
 
 
-def blend_pack_weights(sd, device, prefix="implicit_surface.color_network."):
-    return torch.from_numpy(blend_pack_weights_host(blend_raw_weights(sd, prefix))).to(device)
+def blend_pack_weights_split_host(raw, precision):
+    """LDS image of the split blend kernels (surf_blend_pack_weights_split): 16-bit weight pieces + bias / dot rows."""
+    L = _lib.lib()
+    if raw.size != L.surf_blend_raw_floats():
+        raise NotImplementedError("colour network shape differs from the shipped BlendingNetwork(d_feature=16)")
+    pid = _BLEND_ID[precision]
+    out = np.zeros(L.surf_blend_split_packed_bytes(pid), dtype=np.uint8)
+    _lib.check(L.surf_blend_pack_weights_split(_np_ptr(np.ascontiguousarray(raw, dtype=np.float32)), _np_ptr(out), pid),
+               "surf_blend_pack_weights_split")
+    return out
+
+
+def blend_pack_weights(sd, device, prefix="implicit_surface.color_network.", precision="f32"):
+    """Packed BlendingNetwork weights for the blend kernel of `precision` (fp32 tensor: blend.hip; bytes: blend_split.hip)."""
+    raw = blend_raw_weights(sd, prefix)
+    if precision == "f32":
+        return torch.from_numpy(blend_pack_weights_host(raw)).to(device)
+    return torch.from_numpy(blend_pack_weights_split_host(raw, precision)).to(device)
+
+
+def blend_packed_precision(packed):
+    if packed.dtype == torch.float32:
+        return "f32"
+    if packed.dtype == torch.uint8:
+        for precision, pid in _BLEND_ID.items():
+            if packed.numel() == _lib.lib().surf_blend_split_packed_bytes(pid):
+                return precision
+    raise ValueError("packed blend weights: not an output of surf_blend_pack_weights / surf_blend_pack_weights_split")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -304,9 +331,22 @@ def blend(pts, feats_t4, imgs_t4, cams, packed, mask=None, compact_active=True, 
         n_eval = int(idx.shape[0])
     if n_eval == 0:
         return color, nvalid
-    rc = _lib.lib().surf_blend(_p(pts), _p(None if idx is not None else mask), _p(idx), n_eval, fp, hw, len(feats_t4), _p(imgs_t4), cams.nv, _np_ptr(cams.intrs),
-                               _np_ptr(cams.w2c), _np_ptr(cams.c2w), _p(packed), _p(color), _p(nvalid), _stream())
-    _lib.check(rc, "surf_blend")
+    precision = blend_packed_precision(packed)     # which kernel the packed weights were laid out for
+    if precision == "f32":
+        rc = _lib.lib().surf_blend(_p(pts), _p(None if idx is not None else mask), _p(idx), n_eval, fp, hw, len(feats_t4),
+                                   _p(imgs_t4), cams.nv, _np_ptr(cams.intrs), _np_ptr(cams.w2c), _np_ptr(cams.c2w), _p(packed),
+                                   _p(color), _p(nvalid), _stream())
+    else:
+        need = _lib.lib().surf_blend_split_scratch_bytes(int(n_eval), cams.nv)
+        key = ("blend", dev.index if dev.index is not None else torch.cuda.current_device())
+        scratch = _scratch_cache.get(key)
+        if scratch is None or scratch.numel() < need:
+            scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+            _scratch_cache[key] = scratch
+        rc = _lib.lib().surf_blend_split(_p(pts), _p(None if idx is not None else mask), _p(idx), n_eval, fp, hw, len(feats_t4),
+                                         _p(imgs_t4), cams.nv, _np_ptr(cams.intrs), _np_ptr(cams.w2c), _np_ptr(cams.c2w),
+                                         _p(packed), _BLEND_ID[precision], _p(color), _p(nvalid), _p(scratch), _stream())
+    _lib.check(rc, "surf_blend" if precision == "f32" else f"surf_blend_split({precision})")
     return color, nvalid
 
 

@@ -241,10 +241,10 @@ def test_full_size_matching_field_vs_oracle(full_build):
             err = (got - ref).abs()
             assert bool((err <= 5e-5 + 1e-3 * ref.abs()).all()), (s, v, float(err.max()))
         del mv
-    # the final reference-view depth of rays through the sphere's centre region lies between its front and its centre
+    # the final reference-view depth of rays through the sphere's centre region lies between its front and its back crossing
     d0 = fb["outputs"]["depth_stage3"]
     centre = float(d0[H // 2, W // 2])
-    assert 1.9 < centre < 2.6, centre
+    assert 1.9 < centre < 3.1, centre      # front (2.0) or back (3.0) crossing of the r = 0.5 sphere, or between
 
 
 # ----------------------------------------------------------------------------------------------------------------------

@@ -418,3 +418,41 @@ def test_sdf_grid_matches_golden(weights, golden_pipe, golden_grid, precision):
     v, t = model.extract_geometry(vols, tabs, bmin, bmax, 24, 0.0)
     assert v.shape[1] == 3 and t.shape[1] == 3 and t.shape[0] > 10
     assert bool((v >= bmin.numpy()[None] - 1e-6).all()) and bool((v <= bmax.numpy()[None] + 1e-6).all())
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1.0), ("f16x2", 4.0)])
+def test_blend_split_matches_golden(scene, weights, gpu_scene, golden_render, precision, tol):
+    """The split blend kernels (16-bit operand pieces on the bf16 / fp16 MFMA pipe, fp32 accumulation, weights resident
+    in LDS) against the reference's BlendingNetwork outputs at the fp32 kernel's tolerances, and against the fp32-MFMA
+    kernel itself; then ragged sizes, masks, compaction and many tiles per wavefront."""
+    from surf_amd import ops
+    d = dev()
+    pts = golden_render["pts"].to(d).contiguous()
+    w16 = ops.blend_pack_weights(weights, d, precision=precision)
+    assert ops.blend_packed_precision(w16) == precision
+    color, nvalid = ops.blend(pts, gpu_scene["feats_t4"], gpu_scene["imgs_t4"], gpu_scene["cams"], w16)
+    torch.cuda.synchronize()
+    rel_close(color, golden_render["blend_rgb"], 1e-3, 1e-5)
+    assert torch.equal(nvalid.cpu().long(), golden_render["mask_valid"].long().sum(1))
+    c32, n32 = ops.blend(pts, gpu_scene["feats_t4"], gpu_scene["imgs_t4"], gpu_scene["cams"], gpu_scene["blend_w"])
+    print(f"{precision}: max |rgb - rgb_f32| = {float((color - c32).abs().max()):.3g}")
+    rel_close(color, c32, 0, 3e-6 * tol)
+    assert torch.equal(nvalid, n32)
+    g = torch.Generator().manual_seed(21)
+    for n in (1, 31, 32, 33, 255, 257, 4097, 300_000):
+        p = ((torch.rand(n, 3, generator=g) * 2 - 1) * 0.7).to(d).contiguous()
+        a, na = ops.blend(p, gpu_scene["feats_t4"], gpu_scene["imgs_t4"], gpu_scene["cams"], w16)
+        b, nb = ops.blend(p, gpu_scene["feats_t4"], gpu_scene["imgs_t4"], gpu_scene["cams"], gpu_scene["blend_w"])
+        rel_close(a, b, 0, 3e-6 * tol)
+        assert torch.equal(na, nb)
+        m = (torch.arange(n) % 3 != 1).to(torch.uint8).to(d)
+        am, nam = ops.blend(p, gpu_scene["feats_t4"], gpu_scene["imgs_t4"], gpu_scene["cams"], w16, mask=m)
+        an, _ = ops.blend(p, gpu_scene["feats_t4"], gpu_scene["imgs_t4"], gpu_scene["cams"], w16, mask=m, compact_active=False)
+        assert torch.equal(am, an)                                      # compaction does not change a bit
+        keep = m.bool()
+        assert torch.equal(am[keep], a[keep]) and bool((am[~keep] == 0).all()) and bool((nam[~keep] == 0).all())
+    # repeated launches are bit-identical (no inter-wavefront communication in the tile loop)
+    first, _ = ops.blend(p, gpu_scene["feats_t4"], gpu_scene["imgs_t4"], gpu_scene["cams"], w16)
+    for _ in range(5):
+        again, _ = ops.blend(p, gpu_scene["feats_t4"], gpu_scene["imgs_t4"], gpu_scene["cams"], w16)
+        assert torch.equal(first, again)
