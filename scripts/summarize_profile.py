@@ -19,7 +19,7 @@ OURS = ("sdf_mlp", "blend_kernel", "blend_split", "mcubes", "patch_warp", "ray_s
 f = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w") as w:
-    w.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-seconds 0   (MI355X, {tag})\n")
+    w.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-seconds 0   (= the default bench command without its CPU-baseline leg; MI355X, {tag})\n")
     w.write("# surf_amd kernels verbatim; torch helper kernels (synthetic scene construction) summed in the last row\n")
     w.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
     other = 0
@@ -42,7 +42,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_mfma"):
             short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             agg[short].setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 with open(os.path.join(dst, f"{tag}_bench_pmc.csv"), "w") as w:
-    w.write("# rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 (one pass per group)\n")
+    w.write("# rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps 1 --warmup 0 --cpu-seconds 0 --mesh-grid 0 (one pass per group)\n")
     w.write("# per-launch averages; FETCH_SIZE / WRITE_SIZE in KiB as reported (raw, uncorrected)\n")
     w.write(f"# csrc_sha256: {csrc_digest()}\n")
     cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]

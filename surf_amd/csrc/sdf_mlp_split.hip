@@ -104,6 +104,15 @@ struct FragT { u32x4 p[NP]; };  // B-operand fragments of a 16-wide k-step: NP p
 #ifndef SURF_X_NOSOFTPLUS
 #define SURF_X_NOSOFTPLUS 0
 #endif
+#ifndef SURF_SDF_SGB  // > 0: sched_group_barrier pattern of the k-steps (VALU operations per MFMA)
+#define SURF_SDF_SGB 0
+#endif
+#ifndef SURF_X_NODMA  // no LDS-DMA inside the chunks (the ring keeps whatever the prologue loaded)
+#define SURF_X_NODMA 0
+#endif
+#ifndef SURF_X_NOSPLIT  // activations "split" by plain bit copies (no conversion arithmetic)
+#define SURF_X_NOSPLIT 0
+#endif
 
 struct PolBf3 {
   // NA: accumulator chains (two independent ones measured no faster); PF: k-steps of LDS read-ahead (2, 3: no faster)
@@ -212,7 +221,12 @@ __device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, f32x4 v) {
 template <class P>
 __device__ __forceinline__ void frag_set_pair(FragT<P::NP>& f, int pair /*0..3*/, float a, float b) {
   uint32_t p[P::NP];
-  P::split(a, b, p);
+  if (SURF_X_NOSPLIT) {
+#pragma unroll
+    for (int k = 0; k < P::NP; ++k) p[k] = __builtin_bit_cast(uint32_t, k & 1 ? a : b);
+  } else {
+    P::split(a, b, p);
+  }
 #pragma unroll
   for (int k = 0; k < P::NP; ++k) f.p[k][pair] = p[k];
 }
@@ -364,7 +378,18 @@ __device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F fn) {
     fn(ks);
 #pragma unroll
     for (int k = 0; k < ND; ++k)  // this wave's DMA pieces of chunk CI+2, spread over the k-steps behind their MFMAs
-      if (k * NKS / ND == ks) stage_dma_piece<P, NXT>(c, k);
+      if (!SURF_X_NODMA && k * NKS / ND == ks) stage_dma_piece<P, NXT>(c, k);
+#if SURF_SDF_SGB > 0
+    // order of this k-step's instructions: every MFMA is followed by SURF_SDF_SGB VALU operations (conversion work of
+    // the previous tile) and the LDS reads of the next k-step's A pieces, so that the matrix pipe never waits behind a
+    // run of VALU work and the VALU never idles behind a run of dependent MFMAs
+#pragma unroll
+    for (int m = 0; m < (NP == 3 ? 6 : 3); ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, SURF_SDF_SGB, 0);
+      if (m < NP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
   }
   SURF_T(CI < N_FWD_CHUNKS ? 1 : 3);
