@@ -211,8 +211,18 @@ def mesh_grid_timing(model, scene, dev, resolution):
     ev, model.kernel_events = model.kernel_events, None
     k_ms = sum(x.elapsed_time(y) for name, x, y in ev if name == "sdf_grid")
     inside = int((u > 0).sum())
-    del u
-    return a.elapsed_time(b), k_ms, inside
+    # marching cubes on that lattice (row f1; mcubes.marching_cubes at implicit_surface.py:353), device side only
+    from surf_amd import ops
+    ops.marching_cubes(u[:64, :64, :64].contiguous(), 0.0)
+    torch.cuda.synchronize()
+    c, d = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c.record()
+    v, t = ops.marching_cubes(u, 0.0)
+    d.record()
+    torch.cuda.synchronize()
+    mc = {"marching_cubes_ms": c.elapsed_time(d), "vertices": int(v.shape[0]), "triangles": int(t.shape[0])}
+    del u, v, t
+    return a.elapsed_time(b), k_ms, inside, mc
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -521,14 +531,14 @@ def run_rank(args):
             result["other_precisions"] = others
         sc0 = scenes[0]
         if world == 1 and args.mesh_grid > 0:
-            total_ms, k_ms, inside = mesh_grid_timing(model, sc0["scene"], dev, args.mesh_grid)
+            total_ms, k_ms, inside, mc = mesh_grid_timing(model, sc0["scene"], dev, args.mesh_grid)
             n_lat = args.mesh_grid ** 3
             fk, fpipe, fpeak, fprod = SDF_KERNELS[args.sdf_precision]
             fk = fk.replace("true", "false")
             ach = n_lat * FLOP_PER_SAMPLE_SDF_FWD / (k_ms * 1e-3) / 1e12
             result["mesh_grid_ms"] = total_ms
             result["mesh_grid"] = {"resolution": args.mesh_grid, "points": n_lat, "total_ms": total_ms, "sdf_kernel_ms": k_ms,
-                                   "lattice_points_inside": inside}
+                                   "lattice_points_inside": inside, **mc}
             roofline_kernels.append({"kernel": fk, "bound": "mfma", "achieved": ach, "peak": fpeak / fprod, "unit": "TFLOP/s",
                                      "frac": ach / (fpeak / fprod), "traffic": None, "avg_launch_ms": k_ms / max(1, -(-n_lat // (1 << 24))),
                                      "flop_per_sample": FLOP_PER_SAMPLE_SDF_FWD, "samples_per_launch": min(n_lat, 1 << 24),

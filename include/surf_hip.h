@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 6
+#define SURF_ABI_VERSION 7
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -272,6 +272,25 @@ int surf_deconv3x3_s2(const float* in, const float* weight, int N, int H, int W,
  * workspace: surf_inorm_workspace_doubles(N,H,W,C) doubles; stats (N,C,2) receives mean and 1/sqrt(var+1e-5). */
 int64_t surf_inorm_workspace_doubles(int N, int H, int W, int C);
 int surf_inorm_relu(float* x, int N, int H, int W, int C, const float* skip, double* workspace, float* stats, void* stream);
+
+/*
+ * Marching cubes on a (nx, ny, nz) fp32 lattice u[x][y][z] (z fastest).  Replaces mcubes.marching_cubes(u, isovalue)
+ * (PyMCubes 0.1.4, called at models/modules/implicit_surface.py:353): classic 256-case table, `u <= isovalue` inside
+ * test, one vertex per sign-changing lattice edge by linear interpolation in double precision, lattice-index units.
+ * Call sequence (the host sizes the outputs between the steps):
+ *   surf_mc_classify  -> flags (nx*ny*nz bytes): bits 0-2 sign change along x/y/z from the point, bits 3-5 triangles of
+ *                        the cell whose origin it is
+ *   surf_compact(flags) -> active (ascending lattice indices of the non-zero flags)
+ *   surf_mc_count     -> workspace (surf_mc_workspace_ints(n_active) int32), totals[0] = vertices, totals[1] = triangles
+ *   surf_mc_emit      -> vertices (totals[0], 3) double, triangles (totals[1], 3) int32 vertex ids; vbase: scratch of
+ *                        nx*ny*nz int32 (first vertex id of every active point)
+ * Vertex order: (owner lattice point, axis); triangle order: cell (x outermost) then table order.
+ */
+int surf_mc_classify(const float* u, int nx, int ny, int nz, double isovalue, uint8_t* flags, void* stream);
+int64_t surf_mc_workspace_ints(int64_t n_active);
+int surf_mc_count(const uint8_t* flags, const int32_t* active, int64_t n_active, int32_t* workspace, int32_t* totals, void* stream);
+int surf_mc_emit(const float* u, int nx, int ny, int nz, double isovalue, const uint8_t* flags, const int32_t* active,
+                 int64_t n_active, const int32_t* workspace, int32_t* vbase, double* vertices, int32_t* triangles, void* stream);
 
 #ifdef __cplusplus
 }

@@ -488,6 +488,34 @@ def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, r
     return (full, lr) if return_lr else full
 
 
+def marching_cubes(u, isovalue=0.0):
+    """mcubes.marching_cubes(u, isovalue) (implicit_surface.py:353) on a device lattice u (nx, ny, nz) fp32.
+    Returns (vertices (nv, 3) float64, triangles (nt, 3) int32) device tensors, vertices in lattice-index units.
+    Two host syncs size the outputs (number of active lattice points, then vertex / triangle totals)."""
+    _chk(u, torch.float32, "u")
+    assert u.dim() == 3
+    nx, ny, nz = (int(v) for v in u.shape)
+    dev = u.device
+    L = _lib.lib()
+    flags = torch.empty(nx * ny * nz, dtype=torch.uint8, device=dev)
+    iso = ctypes.c_double(float(isovalue))       # PyMCubes takes the isovalue as a double
+    _lib.check(L.surf_mc_classify(_p(u), nx, ny, nz, iso, _p(flags), _stream()), "surf_mc_classify")
+    active = compact(flags)
+    m = int(active.shape[0])
+    if m == 0:
+        return torch.zeros(0, 3, dtype=torch.float64, device=dev), torch.zeros(0, 3, dtype=torch.int32, device=dev)
+    ws = torch.empty(L.surf_mc_workspace_ints(m), dtype=torch.int32, device=dev)
+    totals = torch.empty(2, dtype=torch.int32, device=dev)
+    _lib.check(L.surf_mc_count(_p(flags), _p(active), m, _p(ws), _p(totals), _stream()), "surf_mc_count")
+    n_v, n_t = (int(v) for v in totals.tolist())
+    vertices = torch.empty(n_v, 3, dtype=torch.float64, device=dev)
+    triangles = torch.empty(n_t, 3, dtype=torch.int32, device=dev)
+    vbase = torch.empty(nx * ny * nz, dtype=torch.int32, device=dev)
+    _lib.check(L.surf_mc_emit(_p(u), nx, ny, nz, iso, _p(flags), _p(active), m, _p(ws), _p(vbase), _p(vertices), _p(triangles),
+                              _stream()), "surf_mc_emit")
+    return vertices, triangles
+
+
 # ------------------------------------------------------------------------------------------------
 # sparse 3D U-Net pieces (reg_network.py)
 # ------------------------------------------------------------------------------------------------
