@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 7
+#define SURF_ABI_VERSION 8
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -247,10 +247,14 @@ int surf_spconv(const float* in, int cin, const int32_t* in_table, int D_in, con
 
 /* bbox (device int32[6]) = [min x, min y, min z, max x, max y, max z] of coords (n,3) */
 int surf_coords_bbox(const int32_t* coords, int64_t n, int32_t* bbox, void* stream);
-/* Output sites of a k3/s2 conv: marks[(D/2+1)^3] |= 1 at q when 2q lies in the 3^3 window of an input voxel and
- * inside the inputs' bounding box (device int32[6] from surf_coords_bbox: no host round trip).  marks must be zeroed
- * by the caller. */
-int surf_mark_down_sites(const int32_t* coords, int64_t n, int D, const int32_t* bbox, uint8_t* marks, void* stream);
+/* Output sites of a k3/s2 conv, marks[(D/2+1)^3] |= 1 (marks zeroed by the caller).  torchsparse 2.1 is absent, which of its
+ * down-sampling rules the authors' checkpoint was trained with is unknown, so both are offered:
+ *   SURF_DOWN_DILATE  q is an output site when 2q lies in the 3^3 window of an input voxel and inside the inputs'
+ *                     bounding box (device int32[6] from surf_coords_bbox: no host round trip)        [default]
+ *   SURF_DOWN_FLOOR   q = floor(c / 2) for every input voxel c (bbox unused, may be NULL) */
+#define SURF_DOWN_DILATE 0
+#define SURF_DOWN_FLOOR 1
+int surf_mark_down_sites(const int32_t* coords, int64_t n, int D, const int32_t* bbox, uint8_t* marks, int rule, void* stream);
 /* keys (ascending lattice site numbers, e.g. from surf_compact) -> coords (n,3) and table[key] = rank */
 int surf_sites_from_keys(const int32_t* keys, int64_t n, int D, int32_t* coords, int32_t* table, void* stream);
 /* table[coords[i]] = i (table pre-filled with -1 by the caller) */

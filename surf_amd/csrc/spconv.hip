@@ -89,6 +89,14 @@ __global__ __launch_bounds__(256) void spconv_kernel(SpconvArgs a) {
 
 // marks[q] = 1 for every coarse site q such that 2q is within the 3^3 window of an input voxel and inside the
 // bounding box of the input coordinates (the output-site rule of a k3/s2 sparse conv, "dilate" in the oracle)
+// 'floor' rule: the output sites of a k3/s2 conv are unique(floor(c / 2)) (MinkowskiEngine-style)
+__global__ __launch_bounds__(256) void mark_down_sites_floor_kernel(const int32_t* __restrict__ coords, int64_t n, int D2,
+                                                                    uint8_t* __restrict__ marks) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  marks[((int64_t)(coords[i * 3 + 0] >> 1) * D2 + (coords[i * 3 + 1] >> 1)) * D2 + (coords[i * 3 + 2] >> 1)] = 1;
+}
+
 __global__ __launch_bounds__(256) void mark_down_sites_kernel(const int32_t* __restrict__ coords, int64_t n, int D2,
                                                               const int32_t* __restrict__ bbox,
                                                               uint8_t* __restrict__ marks) {
@@ -201,11 +209,17 @@ extern "C" int surf_coords_bbox(const int32_t* coords, int64_t n, int32_t* bbox,
   return surf_check_launch();
 }
 
-extern "C" int surf_mark_down_sites(const int32_t* coords, int64_t n, int D, const int32_t* bbox, uint8_t* marks,
+extern "C" int surf_mark_down_sites(const int32_t* coords, int64_t n, int D, const int32_t* bbox, uint8_t* marks, int rule,
                                     void* stream) {
-  if (!coords || !bbox || !marks || n <= 0 || D < 2) return SURF_E_ARG;
+  if (!coords || !marks || n <= 0 || D < 2) return SURF_E_ARG;
+  if (rule != SURF_DOWN_DILATE && rule != SURF_DOWN_FLOOR) return SURF_E_ARG;
   const int D2 = D / 2 + 1;
-  hipLaunchKernelGGL(mark_down_sites_kernel, grid1d(n * 27, 256), dim3(256), 0, (hipStream_t)stream, coords, n, D2, bbox, marks);
+  if (rule == SURF_DOWN_FLOOR) {
+    hipLaunchKernelGGL(mark_down_sites_floor_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, coords, n, D2, marks);
+  } else {
+    if (!bbox) return SURF_E_ARG;
+    hipLaunchKernelGGL(mark_down_sites_kernel, grid1d(n * 27, 256), dim3(256), 0, (hipStream_t)stream, coords, n, D2, bbox, marks);
+  }
   return surf_check_launch();
 }
 

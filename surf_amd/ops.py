@@ -530,8 +530,12 @@ def table_from_coords(coords, D):
     return table
 
 
-def down_sites(coords, D):
-    """Output sites of a k3/s2 sparse conv on the (D//2+1)^3 lattice: (coords2 (M,3) int32, table2, D2)."""
+DOWN_RULES = {"dilate": 0, "floor": 1}     # SURF_DOWN_DILATE / SURF_DOWN_FLOOR
+
+
+def down_sites(coords, D, rule="dilate"):
+    """Output sites of a k3/s2 sparse conv on the (D//2+1)^3 lattice: (coords2 (M,3) int32, table2, D2).
+    rule: "dilate" (torchsparse-2.1 spconv-style, default) or "floor" (unique(floor(c/2))): SURVEY App. C."""
     _chk(coords, torch.int32, "coords")
     dev = coords.device
     D2 = D // 2 + 1
@@ -540,8 +544,8 @@ def down_sites(coords, D):
     bbox = torch.empty(6, dtype=torch.int32, device=dev)          # stays on the device: no host round trip
     _lib.check(_lib.lib().surf_coords_bbox(_p(coords), coords.shape[0], _p(bbox), _stream()), "surf_coords_bbox")
     marks = torch.zeros(D2 * D2 * D2, dtype=torch.uint8, device=dev)
-    _lib.check(_lib.lib().surf_mark_down_sites(_p(coords), coords.shape[0], int(D), _p(bbox), _p(marks), _stream()),
-               "surf_mark_down_sites")
+    _lib.check(_lib.lib().surf_mark_down_sites(_p(coords), coords.shape[0], int(D), _p(bbox), _p(marks), DOWN_RULES[rule],
+                                               _stream()), "surf_mark_down_sites")
     keys = compact(marks)
     c2 = torch.empty(keys.shape[0], 3, dtype=torch.int32, device=dev)
     t2 = torch.full((D2, D2, D2), -1, dtype=torch.int32, device=dev)

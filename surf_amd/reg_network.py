@@ -40,8 +40,11 @@ class _Block(nn.Module):
 
 
 class SparseCostRegNet(nn.Module):
-    def __init__(self, d_in, d_out=8, d_base=8):
+    def __init__(self, d_in, d_out=8, d_base=8, down_rule="dilate"):
         super().__init__()
+        if down_rule not in ops.DOWN_RULES:
+            raise ValueError(f"reg_network.down_rule must be one of {sorted(ops.DOWN_RULES)}, got {down_rule!r}")
+        self.down_rule = down_rule
         if d_base != 8 or d_out != 8 or d_in not in (8, 16):
             raise NotImplementedError("surf_spconv is instantiated for d_base = d_out = 8, d_in in {8, 16} (confs/*.conf)")
         b = d_base
@@ -67,13 +70,13 @@ class SparseCostRegNet(nn.Module):
         """feats (N, d_in) fp32, coords (N,3) int32 on the D lattice -> (out (N,8), mid (N,8))  (reg_network.py:69-88)"""
         t0 = table if table is not None else ops.table_from_coords(coords, D)
         c0 = self._conv(self.conv0, feats, t0, coords, ops.SUBM)
-        cd1, t1, D1 = ops.down_sites(coords, D)
+        cd1, t1, D1 = ops.down_sites(coords, D, self.down_rule)
         x = self._conv(self.conv1, c0, t0, cd1, ops.DOWN)
         c2 = self._conv(self.conv2, x, t1, cd1, ops.SUBM)
-        cd2, t2, D2 = ops.down_sites(cd1, D1)
+        cd2, t2, D2 = ops.down_sites(cd1, D1, self.down_rule)
         x = self._conv(self.conv3, c2, t1, cd2, ops.DOWN)
         c4 = self._conv(self.conv4, x, t2, cd2, ops.SUBM)
-        cd3, t3, D3 = ops.down_sites(cd2, D2)
+        cd3, t3, D3 = ops.down_sites(cd2, D2, self.down_rule)
         x = self._conv(self.conv5, c4, t2, cd3, ops.DOWN)
         x = self._conv(self.conv6, x, t3, cd3, ops.SUBM)
         x = self._conv(self.conv7, x, t3, cd2, ops.UP, skip=c4)
@@ -88,7 +91,9 @@ class SparseCostRegNetList(nn.Module):
         super().__init__()
         d_in, d_out, d_base = confs.get_list("d_in"), confs.get_list("d_out"), confs.get_list("d_base")
         self.num_stages = len(d_in)
-        self.nets = nn.ModuleList([SparseCostRegNet(d_in[i], d_out[i], d_base[i]) for i in range(self.num_stages)])
+        # optional key (ours): which stride-2 output-site rule of torchsparse the checkpoint was trained with
+        rule = confs.get_string("down_rule", "dilate")
+        self.nets = nn.ModuleList([SparseCostRegNet(d_in[i], d_out[i], d_base[i], rule) for i in range(self.num_stages)])
 
     def forward(self, feats, coords, D, stage_idx, table=None):
         return self.nets[stage_idx](feats, coords, D, table)

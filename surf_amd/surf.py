@@ -2,9 +2,11 @@
 step)`` and output keys; every stage runs in the HIP kernels of libsurf_hip.so.
 
 Inference semantics (``mode == "val"`` or a no-grad ``"train"`` forward without the loss-only outputs).  Not
-implemented (they belong to SURVEY rows f2/f3): autograd through the kernels, the train-mode jitter of the matching
-field (``perturb=True`` in ``build_volumes``), finetune volumes (``has_vol`` / ``init_volumes`` / ``load_params_vol``).
-``render.perturb > 0`` (the per-ray jitter of ``ImplicitSurface.render``, active in ``val`` too) is supported.
+implemented (they belong to SURVEY row f2): autograd through the kernels and the train-mode jitter of the matching
+field (``perturb=True`` in ``build_volumes``).  ``render.perturb > 0`` (the per-ray jitter of ``ImplicitSurface.render``,
+active in ``val`` too) is supported, and so is the per-scene volume API of finetuning (``has_vol`` / ``init_volumes`` /
+``get_params_vol`` / ``load_params_vol``, surf.py:47-78): the volumes are frozen once and every later forward renders from
+them without touching the FPN or the sparse U-Nets (their optimisation itself is row f2).
 """
 import torch
 import torch.nn as nn
@@ -21,27 +23,88 @@ class SuRF(nn.Module):
     def __init__(self, confs):
         super().__init__()
         self.has_vol = confs.get_bool("has_vol", default=False)
-        if self.has_vol:
-            raise NotImplementedError("has_vol (per-scene finetuning, surf.py:47-78) is not implemented")
         self.range_ratios = [float(r) for r in confs.get_list("range_ratios")]
         self.num_stage = len(self.range_ratios)
         if self.num_stage != 4:
             raise NotImplementedError("the kernels are built for the 4-stage pyramid of confs/*.conf")
-        self.feature_network = FeatureNetwork(confs["feature_network"])
-        self.volume = Volume(confs["volume"])
-        self.reg_network = SparseCostRegNetList(confs["reg_network"])
-        self.matching_field = MatchingField(confs["matching_field"])
-        self.match_feature_network = FeatureNetwork(confs["feature_network"])
-        for p in self.match_feature_network.parameters():
-            p.requires_grad = False
+        if not self.has_vol:                       # surf.py:24-32: a has_vol model carries only the implicit surface
+            self.feature_network = FeatureNetwork(confs["feature_network"])
+            self.volume = Volume(confs["volume"])
+            self.reg_network = SparseCostRegNetList(confs["reg_network"])
+            self.matching_field = MatchingField(confs["matching_field"])
+            self.match_feature_network = FeatureNetwork(confs["feature_network"])
+            for p in self.match_feature_network.parameters():
+                p.requires_grad = False
         self.implicit_surface = ImplicitSurface(confs["implicit_surface"])
+        self._vol_scene = None                     # kernel-layout copy of the frozen volumes (per view subset)
 
     def get_optim_params(self, lr_conf):
         """surf.py:36-45 (parameter groups; training itself is row f2)."""
         groups = [{"params": list(self.implicit_surface.parameters()), "lr": lr_conf["mlp_lr"]}]
-        feat = list(self.feature_network.parameters()) + list(self.reg_network.parameters()) + list(self.volume.parameters())
-        groups.append({"params": feat, "lr": lr_conf["feat_lr"]})
+        if not self.has_vol:
+            feat = list(self.feature_network.parameters()) + list(self.reg_network.parameters()) + list(self.volume.parameters())
+            groups.append({"params": feat, "lr": lr_conf["feat_lr"]})
+        else:
+            for v_lr, volume_param in zip(lr_conf["vol_lr"], self.volumes):
+                groups.append({"params": volume_param, "lr": v_lr})
         return groups
+
+    # ---- per-scene volumes (finetuning API, surf.py:47-78) ----------------------------------------------------------
+    @torch.no_grad()
+    def init_volumes(self, ipts):
+        """surf.py:65-78: run the FPN and the 4-stage build once and keep the results as (frozen-structure) parameters:
+        `volumes` = the (N_s, 7) feature rows (trainable in the reference), `sparse_idxes` = the index tables,
+        `matching_volume`, `features` = the FPN maps (nv, 4, h, w) coarse -> fine.  `mask_volmes` (the reference's dense
+        0/1 volumes, 1.4 GB at 704^3) are implied by the tables (mask == table >= 0) and materialised only on demand."""
+        feats_t4 = self.feature_network(ipts["imgs"])
+        _, volumes, tables, mvol = self.build_volumes(ipts, feats_t4)
+        self.volumes = nn.ParameterList([nn.Parameter(v[:, 1:].contiguous(), requires_grad=True) for v in volumes])
+        self.sparse_idxes = nn.ParameterList([nn.Parameter(t, requires_grad=False) for t in tables])
+        self.matching_volume = nn.Parameter(mvol[None, None], requires_grad=False)
+        self.features = [f.permute(0, 3, 1, 2).contiguous() for f in feats_t4]
+        self.has_vol = True
+        self._vol_scene = None
+
+    @property
+    def mask_volmes(self):
+        """The reference's dense mask volumes (1,1,D,D,D), built from the index tables when somebody asks for them."""
+        return [(t.detach() >= 0).float()[None, None] for t in self.sparse_idxes]
+
+    def get_params_vol(self):
+        """surf.py:56-63, plus the two entries the reference forgets (`sparse_idxes`, `matching_volume`: without them
+        its own load_params_vol cannot render)."""
+        return {"volumes": self.volumes, "mask_volmes": self.mask_volmes, "features": self.features,
+                "implicit_surface": self.implicit_surface.state_dict(),
+                "sparse_idxes": [t.detach() for t in self.sparse_idxes], "matching_volume": self.matching_volume.detach()}
+
+    def load_params_vol(self, path, device):
+        """surf.py:47-54.  Accepts this class's get_params_vol files; a file written by the reference lacks the index
+        tables and the matching volume (its loader has the same gap) and is refused with an explanation."""
+        model = torch.load(path, map_location="cpu", weights_only=False)["model"]
+        missing = [k for k in ("sparse_idxes", "matching_volume") if k not in model]
+        if missing:
+            raise KeyError(f"{path}: no {missing} in the saved volumes.  The reference's get_params_vol (surf.py:56-63) does not "
+                           "save them and its load_params_vol cannot render either; re-save with surf_amd's get_params_vol")
+        self.volumes = nn.ParameterList([nn.Parameter(v.detach().to(device).float(), requires_grad=True) for v in model["volumes"]])
+        self.sparse_idxes = nn.ParameterList([nn.Parameter(t.to(device).to(torch.int32), requires_grad=False)
+                                              for t in model["sparse_idxes"]])
+        self.matching_volume = nn.Parameter(model["matching_volume"].to(device).float(), requires_grad=False)
+        self.features = [f.to(device).float() for f in model["features"]]
+        self.implicit_surface.load_state_dict(model["implicit_surface"])
+        self.has_vol = True
+        self._vol_scene = None
+
+    def _frozen_scene(self, ipts):
+        """SceneVolumes of the frozen volumes for the views of this call (surf.py:150-156: features[view_ids])."""
+        view_ids = [int(v) for v in ipts["view_ids"]] if "view_ids" in ipts else list(range(ipts["imgs"].shape[0]))
+        key = (tuple(view_ids), tuple((p._version, p.data_ptr()) for p in self.volumes))
+        if self._vol_scene is None or self._vol_scene[0] != key:
+            feats = [f[view_ids].contiguous() for f in self.features]
+            scene = SceneVolumes(self.matching_volume, [v.detach() for v in self.volumes][::-1],
+                                 [t.detach() for t in self.sparse_idxes][::-1], feats[::-1], ipts["imgs"], ipts["intrs"],
+                                 ipts["c2ws"])
+            self._vol_scene = (key, scene)
+        return self._vol_scene[1]
 
     @torch.no_grad()
     def build_volumes(self, ipts, features_c2f, cams=None, logit_override=None, timings=None, trace=None):
@@ -95,12 +158,15 @@ class SuRF(nn.Module):
     def forward(self, mode, ipts, cos_anneal_ratio=1.0, step=None):
         imgs = ipts["imgs"]
         intrs, c2ws = ipts["intrs"], ipts["c2ws"]
-        cams = ops._cams_ext(ops.Cameras(intrs, c2ws), intrs, c2ws)
-        features = self.feature_network(imgs)                                   # texel4, coarse -> fine
-        outputs, volumes, tables, mvol = self.build_volumes(ipts, features, cams)
-        # the second (frozen) FPN pass of surf.py:147-148 only feeds the loss-only patch warp: skipped
-        scene = SceneVolumes.from_device_layouts(mvol, [v[:, 1:] for v in volumes[::-1]], tables[::-1], features[::-1],
-                                                 ops.pack_texel4(imgs.detach().float().contiguous()), cams)
+        if self.has_vol:                                                        # surf.py:149-156
+            outputs, scene = {}, self._frozen_scene(ipts)
+        else:
+            cams = ops._cams_ext(ops.Cameras(intrs, c2ws), intrs, c2ws)
+            features = self.feature_network(imgs)                               # texel4, coarse -> fine
+            outputs, volumes, tables, mvol = self.build_volumes(ipts, features, cams)
+            # the second (frozen) FPN pass of surf.py:147-148 only feeds the loss-only patch warp: skipped
+            scene = SceneVolumes.from_device_layouts(mvol, [v[:, 1:] for v in volumes[::-1]], tables[::-1], features[::-1],
+                                                     ops.pack_texel4(imgs.detach().float().contiguous()), cams)
         isurf = self.implicit_surface
         rays_o, rays_d = ipts["rays_o"], ipts["rays_d"]
         near, far = ipts["near"], ipts["far"]

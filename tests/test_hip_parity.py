@@ -246,14 +246,18 @@ def test_compact_large_and_edge_cases():
         assert torch.equal(idx.cpu().long(), flags.nonzero().view(-1))
 
 
-def test_sparse_unet_matches_oracle(golden_pipe):
+@pytest.mark.parametrize("rule", ["dilate", "floor"])
+def test_sparse_unet_matches_oracle(golden_pipe, rule):
     """Row a5 (parity unpinned vs torchsparse): the HIP sparse U-Net against the oracle's restatement, on the
-    stage-1 and stage-2 voxel sets of the pipeline fixture with seeded weights and non-trivial BN statistics."""
+    stage-1 and stage-2 voxel sets of the pipeline fixture with seeded weights and non-trivial BN statistics, for both
+    candidate stride-2 output-site rules (reg_network.down_rule)."""
     from surf_amd import conf
     from surf_amd.reg_network import SparseCostRegNetList
+    from surf_amd.ops import down_sites as ops_down
     d = dev()
     torch.manual_seed(3)
-    net = SparseCostRegNetList(conf.from_dict({"d_in": [8, 16, 16, 16], "d_out": [8] * 4, "d_base": [8] * 4})).eval()
+    net = SparseCostRegNetList(conf.from_dict({"d_in": [8, 16, 16, 16], "d_out": [8] * 4, "d_base": [8] * 4,
+                                               "down_rule": rule})).eval()
     g = torch.Generator().manual_seed(4)
     for m in net.modules():
         if isinstance(m, torch.nn.BatchNorm1d):
@@ -268,7 +272,10 @@ def test_sparse_unet_matches_oracle(golden_pipe):
     for s, D in ((1, 16), (2, 32)):
         coords = golden_pipe[f"s{s}_coords"].to(torch.int32)
         feats = golden_pipe[f"s{s}_reg_in"].contiguous()
-        out_ref, mid_ref = O.sparse_unet(sd, feats, coords.long(), D, s)
+        out_ref, mid_ref = O.sparse_unet(sd, feats, coords.long(), D, s, rule=rule)
+        cd_ref, D1 = O.down_coords(coords.long(), D, rule)
+        cd, _, D1g = ops_down(coords.to(d).contiguous(), D, rule)
+        assert D1g == D1 and torch.equal(cd.cpu().long(), cd_ref)
         out, mid = net(feats.to(d), coords.to(d).contiguous(), D, s)
         rel_close(mid, mid_ref, 1e-3, 1e-4)
         rel_close(out, out_ref, 1e-3, 1e-4)
@@ -456,3 +463,48 @@ def test_blend_split_matches_golden(scene, weights, gpu_scene, golden_render, pr
     for _ in range(5):
         again, _ = ops.blend(p, gpu_scene["feats_t4"], gpu_scene["imgs_t4"], gpu_scene["cams"], w16)
         assert torch.equal(first, again)
+
+
+def test_finetune_volume_api_round_trip(scene, tmp_path):
+    """surf.py:47-78: init_volumes freezes the scene's volumes, a has_vol forward renders from them (identical to the
+    build-every-call forward), get_params_vol / load_params_vol round trip through a file into a model constructed with
+    has_vol = True (no FPN / U-Net parameters), and a reference-style file without the index tables is refused."""
+    from surf_amd import conf
+    from surf_amd.surf import SuRF
+    from tests.golden.make_golden import MODEL_CONF
+    d = dev()
+    cfg = {k: v for k, v in MODEL_CONF.items()}
+    cfg["reg_network"] = {"d_in": [8, 16, 16, 16], "d_base": [8] * 4, "d_out": [8] * 4}
+    torch.manual_seed(1)
+    model = SuRF(conf.from_dict(cfg)).eval()
+    with torch.no_grad():
+        model.implicit_surface.deviation_network.variance.fill_(0.45)
+        for net in model.reg_network.nets:
+            net.out_lin.weight.mul_(4.0)
+    model = model.to(d)
+    ipts = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    out_a = model("train", ipts, 1.0)
+    model.init_volumes(ipts)
+    assert model.has_vol and len(model.volumes) == 4 and model.volumes[0].shape[1] == 7
+    assert tuple(model.features[-1].shape) == tuple(scene["imgs"].shape[:1]) + (4,) + tuple(scene["imgs"].shape[2:])
+    groups = model.get_optim_params({"mlp_lr": 1e-3, "vol_lr": [1e-2, 1e-2, 1e-3, 1e-3]})
+    assert len(groups) == 5 and groups[1]["params"] is model.volumes[0]
+    out_b = model("train", dict(ipts, view_ids=[0, 1, 2]), 1.0)
+    for k in ("color_fine", "render_depth", "sdf_depth", "weights"):
+        assert torch.equal(out_a[k], out_b[k]), k
+    assert "depth_stage0" in out_a and "depth_stage0" not in out_b          # a has_vol forward builds nothing
+    path = tmp_path / "vol.ckpt"
+    torch.save({"model": model.get_params_vol()}, path)
+    cfg2 = dict(cfg, has_vol=True)
+    m2 = SuRF(conf.from_dict(cfg2)).to(d)
+    assert not hasattr(m2, "feature_network") and [n for n, _ in m2.named_children()] == ["implicit_surface"]
+    m2.load_params_vol(str(path), d)
+    out_c = m2("train", dict(ipts, view_ids=[0, 1, 2]), 1.0)
+    for k in ("color_fine", "render_depth", "sdf_depth", "weights"):
+        assert torch.equal(out_a[k], out_c[k]), k
+    mv = model.mask_volmes
+    assert tuple(mv[0].shape) == (1, 1, 8, 8, 8) and float(mv[3].sum()) == model.volumes[3].shape[0]
+    ref_style = {k: v for k, v in model.get_params_vol().items() if k not in ("sparse_idxes", "matching_volume")}
+    torch.save({"model": ref_style}, tmp_path / "ref.ckpt")
+    with pytest.raises(KeyError):
+        m2.load_params_vol(str(tmp_path / "ref.ckpt"), d)
