@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 8
+#define SURF_ABI_VERSION 9
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -162,14 +162,15 @@ int surf_blend_split(const float* pts, const uint8_t* mask, const int32_t* idx, 
  *   h_rot_ref: inverse(c2w[0][:3,:3]) row-major (9 floats, HOST)
  * outputs (R rows each; any may be NULL): color(3), render_depth, sdf_depth, normal(3) (camera frame),
  *   normal_val(3) = sum_k grad*w*inside (world frame, for validate), valid_mask u8, mid_inside u8,
- *   weights (R,S), inside (R,S), eik (R,2) = per-ray [sum relax*(|g|-1)^2, sum relax]
+ *   weights (R,S), inside (R,S), eik (R,2) = per-ray [sum relax*(|g|-1)^2, sum relax],
+ *   z_sdf0 (R) = the zero crossing's ray parameter before the validity factor and the cosine (feeds surf_surface_points)
  */
 int surf_composite(const float* sdf, const float* grad, const float* color, const uint8_t* n_valid,
                    const float* mid_z, const float* dists, const float* pts, const uint8_t* vmask,
                    const float* rays_d, int n_rays, int S, float inv_s, float cos_anneal_ratio,
                    const float* h_rot_ref, float* out_color, float* out_depth, float* out_sdf_depth,
                    float* out_normal, float* out_normal_val, uint8_t* out_valid, uint8_t* out_mid_inside,
-                   float* out_weights, float* out_inside, float* out_eik, void* stream);
+                   float* out_weights, float* out_inside, float* out_eik, float* out_z_sdf0, void* stream);
 
 /* =====================================================================================================
  * Volume build (surf.py:80-131).  Voxel coordinates are int32 triples; voxel_size = 2/(D-1), origin -1.
@@ -276,6 +277,23 @@ int surf_deconv3x3_s2(const float* in, const float* weight, int N, int H, int W,
  * workspace: surf_inorm_workspace_doubles(N,H,W,C) doubles; stats (N,C,2) receives mean and 1/sqrt(var+1e-5). */
 int64_t surf_inorm_workspace_doubles(int N, int H, int W, int C);
 int surf_inorm_relu(float* x, int N, int H, int W, int C, const float* skip, double* workspace, float* stats, void* stream);
+
+/*
+ * Surface patches for the LNCC loss (training outputs ref_gray_val / sampled_gray_val).  Replaces render_core's tail
+ * (implicit_surface.py:217-245), surface_patch_warp2 (projector.py:560-627) and patch_homography (:630-645).
+ *   surf_upsample_bilinear_t4  F.interpolate(bilinear, align_corners=False) of a texel4 map (n,h,w,4) -> (n,H,W,4)
+ *   surf_surface_points        pts = rays_o + rays_d * z with z = z_sdf0 zeroed outside [0, max(z_vals)] (:217-220);
+ *                              workspace: one device uint32
+ *   surf_patch_warp            maps: the three finest FPN levels as texel4 (nv,H,W,4) at FULL resolution (levels 1, 2
+ *                              upsampled); h_intrs / h_c2w (nv,4,4) HOST; h_kinv_ref = inverse(intrs)[0][:3,:3] (9 floats);
+ *                              grads = raw SDF gradients at pts; ref_out (1,R,p*p,12), src_out (nv-1,R,p*p,12)
+ */
+int surf_upsample_bilinear_t4(const float* src, int n, int h, int w, int H, int W, float* dst, void* stream);
+int surf_surface_points(const float* rays_o, const float* rays_d, const float* z_sdf0, int n_rays, const float* z_vals,
+                        int64_t n_z, unsigned* workspace, float* pts, void* stream);
+int surf_patch_warp(const float* pts, const float* grads, int n_rays, const float* const* h_maps, int nv, int H, int W,
+                    const float* h_intrs, const float* h_kinv_ref, const float* h_c2w, int patch_size, float* ref_out,
+                    float* src_out, void* stream);
 
 /*
  * Marching cubes on a (nx, ny, nz) fp32 lattice u[x][y][z] (z fastest).  Replaces mcubes.marching_cubes(u, isovalue)

@@ -32,6 +32,7 @@ struct CompositeArgs {
   float* out_weights;
   float* out_inside;
   float* out_eik;
+  float* out_z_sdf0;  // (R) zero crossing ray parameter, before validity / cosine
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(256) void composite_kernel(CompositeArgs a) {
     if (!(cosd > 0.5f)) mis = 0.f;
     float z0 = (s[0] * z[1] - s[1] * z[0]) / (s[0] - s[1] + 1e-10f);
     if (a.out_sdf_depth) a.out_sdf_depth[ray] = z0 * cz * mis;
+    if (a.out_z_sdf0) a.out_z_sdf0[ray] = z0;
     if (a.out_mid_inside) a.out_mid_inside[ray] = mis > 0.f ? 1 : 0;
   }
 }
@@ -181,7 +183,7 @@ extern "C" int surf_composite(const float* sdf, const float* grad, const float* 
                               const float* h_rot_ref, float* out_color, float* out_depth, float* out_sdf_depth,
                               float* out_normal, float* out_normal_val, uint8_t* out_valid,
                               uint8_t* out_mid_inside, float* out_weights, float* out_inside, float* out_eik,
-                              void* stream) {
+                              float* out_z_sdf0, void* stream) {
   if (!sdf || !grad || !color || !n_valid || !mid_z || !dists || !pts || !vmask || !rays_d || !h_rot_ref)
     return SURF_E_ARG;
   if (n_rays <= 0 || S < 2) return SURF_E_ARG;
@@ -193,7 +195,7 @@ extern "C" int surf_composite(const float* sdf, const float* grad, const float* 
   for (int i = 0; i < 9; ++i) a.rot[i] = h_rot_ref[i];
   a.out_color = out_color; a.out_depth = out_depth; a.out_sdf_depth = out_sdf_depth; a.out_normal = out_normal;
   a.out_normal_val = out_normal_val; a.out_valid = out_valid; a.out_mid_inside = out_mid_inside;
-  a.out_weights = out_weights; a.out_inside = out_inside; a.out_eik = out_eik;
+  a.out_weights = out_weights; a.out_inside = out_inside; a.out_eik = out_eik; a.out_z_sdf0 = out_z_sdf0;
   hipLaunchKernelGGL(composite_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
   return surf_check_launch();
 }

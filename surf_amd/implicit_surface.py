@@ -116,6 +116,18 @@ class SceneVolumes:
         self.imgs_t4 = ops.pack_texel4(imgs.detach().float().contiguous())
         self.cams = ops.Cameras(intrs, c2ws)
         self.device = dev
+        self.match_feats_t4 = None
+        self._warp_maps = {}
+
+    def warp_maps(self, use_match=False):
+        """implicit_surface.py:229-241: FPN levels 0, 1, 2 at the finest level's size (texel4), from `features` or - once
+        training is past step 2 - from the frozen `match_features`; built on first use."""
+        key = bool(use_match and self.match_feats_t4 is not None)
+        if key not in self._warp_maps:
+            f = self.match_feats_t4 if key else self.feats_t4
+            H, W = f[0].shape[1:3]
+            self._warp_maps[key] = [f[0], ops.upsample_bilinear_t4(f[1], H, W), ops.upsample_bilinear_t4(f[2], H, W)]
+        return self._warp_maps[key]
 
     @classmethod
     def from_device_layouts(cls, mvol, volumes, tables, feats_t4, imgs_t4, cams):
@@ -127,6 +139,8 @@ class SceneVolumes:
         self.imgs_t4 = imgs_t4
         self.cams = cams
         self.device = mvol.device
+        self.match_feats_t4 = None
+        self._warp_maps = {}
         return self
 
 
@@ -190,11 +204,14 @@ class ImplicitSurface(nn.Module):
         """mask_volumes are redundant with the index tables (mask == table >= 0, volume.py:112-130) and unused."""
         return SceneVolumes(matching_volume, volumes, sparse_idxes, features, imgs, intrs, c2ws)
 
-    def render_scene(self, rays_o, rays_d, near, far, scene, cos_anneal_ratio=1.0, per_sample=True, jitter=None):
+    def render_scene(self, rays_o, rays_d, near, far, scene, cos_anneal_ratio=1.0, per_sample=True, jitter=None,
+                     patch_warp=False, step=None):
         """render (:268-335) + render_core (:64-266) on prepared SceneVolumes.
         render.perturb > 0 (every shipped conf; the reference jitters even in `val`, :274-277, 304-306): one
         `torch.rand([R, 1]) - 0.5` per stage drawn on the CPU generator in the reference's order, so that a seeded run
-        reproduces the reference's sample positions for the same ray batch; `jitter` (R, n_stage) overrides the draw."""
+        reproduces the reference's sample positions for the same ray batch; `jitter` (R, n_stage) overrides the draw.
+        patch_warp: also the training outputs ref_gray_val / sampled_gray_val (:217-245, row a15): the 11x11 homography
+        patches of the stacked feature maps around every ray's SDF zero crossing (from match_features once step >= 2)."""
         dev = rays_o.device
         if jitter is None and self.perturb > 0:
             jitter = self.draw_jitter(rays_o.shape[0])
@@ -216,13 +233,15 @@ class ImplicitSurface(nn.Module):
             return r
 
         st = timed("ray_setup", lambda: ops.ray_setup(rays_o, rays_d, near.float(), far.float(), scene.mvol, scene.sv,
-                                                      self.n_samples, self.sample_ranges, self.n_depth, jitter=jitter))
+                                                      self.n_samples, self.sample_ranges, self.n_depth, jitter=jitter,
+                                                      want_z=patch_warp))
         act = timed("compact", lambda: ops.compact(st["vmask"]))      # masked-in samples, ray-major order
         sdf, grad = timed("sdf_mlp", lambda: ops.sdf_mlp(st["pts"], scene.sv, sdf_w, mask=st["vmask"], active_idx=act))
         col, nvalid = timed("blend", lambda: ops.blend(st["pts"], scene.feats_t4, scene.imgs_t4, scene.cams, blend_w,
                                                        mask=st["vmask"], active_idx=act))
         out = timed("composite", lambda: ops.composite(sdf, grad, col, nvalid, st, rays_d, self.deviation_network.inv_s(),
-                                                       float(cos_anneal_ratio), scene.cams, per_sample=per_sample))
+                                                       float(cos_anneal_ratio), scene.cams, per_sample=per_sample,
+                                                       want_z0=patch_warp))
         if ev is not None:
             self.last_active_samples = int(act.shape[0])
             if self.active_samples_log is not None:
@@ -237,6 +256,12 @@ class ImplicitSurface(nn.Module):
             out["gradients"] = grad.view(R, S, 3)
             out["sdf"] = sdf.view(R, S)
         out["s_val"] = torch.full((1, 1), 1.0 / self.deviation_network.inv_s(), device=dev)
+        if patch_warp:
+            pts0 = ops.surface_points(rays_o, rays_d, out.pop("z_sdf0"), st["z_vals"])
+            _, g0 = ops.sdf_mlp(pts0, scene.sv, sdf_w)                           # :221: gradient at the crossing, unmasked
+            maps = scene.warp_maps(use_match=not (step is None or step < 2))
+            out["ref_gray_val"], out["sampled_gray_val"] = ops.patch_warp(pts0, g0, maps, scene.cams)
+            out["pts_sdf0"], out["gradients_sdf0"] = pts0, g0
         return out
 
     def draw_jitter(self, n_rays, ref_chunk=None):

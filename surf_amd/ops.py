@@ -350,8 +350,9 @@ def blend(pts, feats_t4, imgs_t4, cams, packed, mask=None, compact_active=True, 
     return color, nvalid
 
 
-def composite(sdf, grad, color, n_valid, setup, rays_d, inv_s, cos_anneal_ratio, cams, per_sample=True):
-    """implicit_surface.py:126-166,181-216.  Returns the per-ray dict (+ weights / inside_sphere if per_sample)."""
+def composite(sdf, grad, color, n_valid, setup, rays_d, inv_s, cos_anneal_ratio, cams, per_sample=True, want_z0=False):
+    """implicit_surface.py:126-166,181-216.  Returns the per-ray dict (+ weights / inside_sphere if per_sample;
+    + z_sdf0, the zero crossing's ray parameter, if want_z0)."""
     R, S = setup["mid_z"].shape
     dev = sdf.device
     f32 = dict(dtype=torch.float32, device=dev)
@@ -364,14 +365,66 @@ def composite(sdf, grad, color, n_valid, setup, rays_d, inv_s, cos_anneal_ratio,
     if per_sample:
         out["weights"] = torch.empty(R, S, **f32)
         out["inside_sphere"] = torch.empty(R, S, **f32)
+    if want_z0:
+        out["z_sdf0"] = torch.empty(R, **f32)
     rc = _lib.lib().surf_composite(_p(sdf), _p(grad), _p(color), _p(n_valid), _p(setup["mid_z"]), _p(setup["dists"]),
                                    _p(setup["pts"]), _p(setup["vmask"]), _p(rays_d), R, S, ctypes.c_float(inv_s),
                                    ctypes.c_float(cos_anneal_ratio), _np_ptr(cams.rot_ref), _p(out["color_fine"]),
                                    _p(out["render_depth"]), _p(out["sdf_depth"]), _p(out["normal"]),
                                    _p(out["normal_val"]), _p(out["valid_mask"]), _p(out["mid_inside_sphere"]),
-                                   _p(out.get("weights")), _p(out.get("inside_sphere")), _p(out["eik"]), _stream())
+                                   _p(out.get("weights")), _p(out.get("inside_sphere")), _p(out["eik"]), _p(out.get("z_sdf0")),
+                                   _stream())
     _lib.check(rc, "surf_composite")
     return out
+
+
+def upsample_bilinear_t4(x, H, W):
+    """F.interpolate(x, size=(H, W), mode="bilinear", align_corners=False) on a texel4 map (n,h,w,4)."""
+    _chk(x, torch.float32, "x")
+    n, h, w, c = x.shape
+    assert c == 4
+    out = torch.empty(n, H, W, 4, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().surf_upsample_bilinear_t4(_p(x), n, h, w, int(H), int(W), _p(out), _stream()), "surf_upsample_bilinear_t4")
+    return out
+
+
+def surface_points(rays_o, rays_d, z_sdf0, z_vals):
+    """implicit_surface.py:217-220: the zero crossing's ray parameter zeroed outside [0, max(z_vals)], then o + d z."""
+    _chk(rays_o, torch.float32, "rays_o")
+    _chk(rays_d, torch.float32, "rays_d")
+    _chk(z_sdf0, torch.float32, "z_sdf0")
+    _chk(z_vals, torch.float32, "z_vals")
+    R = rays_o.shape[0]
+    ws = torch.empty(1, dtype=torch.int32, device=rays_o.device)
+    pts = torch.empty(R, 3, dtype=torch.float32, device=rays_o.device)
+    _lib.check(_lib.lib().surf_surface_points(_p(rays_o), _p(rays_d), _p(z_sdf0), R, _p(z_vals), z_vals.numel(), _p(ws), _p(pts),
+                                              _stream()), "surf_surface_points")
+    return pts
+
+
+def patch_warp(pts, grads, maps_t4, cams, patch_size=11):
+    """projector.py:560-645 (+ the normal's normalisation and rotation of implicit_surface.py:224-228).
+    maps_t4: the three finest feature levels as texel4 (nv,H,W,4) at full resolution; cams: ops.Cameras.
+    Returns (ref_gray_val (1,R,p*p,12), sampled_gray_val (nv-1,R,p*p,12))."""
+    _chk(pts, torch.float32, "pts")
+    _chk(grads, torch.float32, "grads")
+    for m in maps_t4:
+        _chk(m, torch.float32, "feature map")
+    nv, H, W, _ = maps_t4[0].shape
+    assert len(maps_t4) == 3 and all(tuple(m.shape) == (nv, H, W, 4) for m in maps_t4)
+    R = pts.shape[0]
+    dev = pts.device
+    if not hasattr(cams, "kinv_ref"):
+        cams.kinv_ref = np.ascontiguousarray(torch.inverse(torch.from_numpy(cams.intrs))[0, :3, :3].contiguous().numpy())
+    K, kinv, c2w = cams.intrs, cams.kinv_ref, cams.c2w
+    assert cams.nv == nv
+    P = patch_size * patch_size
+    ref = torch.empty(1, R, P, 12, dtype=torch.float32, device=dev)
+    src = torch.empty(nv - 1, R, P, 12, dtype=torch.float32, device=dev)
+    rc = _lib.lib().surf_patch_warp(_p(pts), _p(grads), R, _ptr_array(list(maps_t4)), nv, H, W, _np_ptr(K), _np_ptr(kinv),
+                                    _np_ptr(c2w), int(patch_size), _p(ref), _p(src), _stream())
+    _lib.check(rc, "surf_patch_warp")
+    return ref, src
 
 
 # ------------------------------------------------------------------------------------------------

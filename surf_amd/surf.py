@@ -164,9 +164,14 @@ class SuRF(nn.Module):
             cams = ops._cams_ext(ops.Cameras(intrs, c2ws), intrs, c2ws)
             features = self.feature_network(imgs)                               # texel4, coarse -> fine
             outputs, volumes, tables, mvol = self.build_volumes(ipts, features, cams)
-            # the second (frozen) FPN pass of surf.py:147-148 only feeds the loss-only patch warp: skipped
             scene = SceneVolumes.from_device_layouts(mvol, [v[:, 1:] for v in volumes[::-1]], tables[::-1], features[::-1],
                                                      ops.pack_texel4(imgs.detach().float().contiguous()), cams)
+            if mode != "val":                                                   # surf.py:141-148 (loss-only inputs)
+                if step is not None and step % 2 == 0:                          # refresh the frozen matching FPN
+                    self.match_feature_network.load_state_dict(self.feature_network.state_dict(), strict=True)
+                    for p in self.match_feature_network.parameters():
+                        p.requires_grad = False
+                scene.match_feats_t4 = self.match_feature_network(imgs)[::-1]
         isurf = self.implicit_surface
         rays_o, rays_d = ipts["rays_o"], ipts["rays_d"]
         near, far = ipts["near"], ipts["far"]
@@ -177,6 +182,6 @@ class SuRF(nn.Module):
             surface = isurf.validate(rays_o, rays_d, near, far, scene, ipts["bound_min"], ipts["bound_max"], ipts["hw"],
                                      cos_anneal_ratio, step, mesh_resolution=int(ipts.get("mesh_resolution", 512)))
         else:
-            surface = isurf.render_scene(rays_o, rays_d, near, far, scene, cos_anneal_ratio)
+            surface = isurf.render_scene(rays_o, rays_d, near, far, scene, cos_anneal_ratio, patch_warp=True, step=step)
         outputs.update(surface)
         return outputs

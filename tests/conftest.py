@@ -58,3 +58,8 @@ def golden_perturb():
 @pytest.fixture(scope="session")
 def golden_grid():
     return load_npz("sdf_grid.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_train():
+    return load_npz("train_outputs.npz")

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Golden vectors of the training-only outputs of the hot path (SURVEY rows a15, a11 smooth term), generated in the build
+container by importing the reference's own modules from /root/reference (same shims as make_golden.py, whose fixtures
+this script READS and does not rewrite).  Only data is committed.
+
+  train_outputs.npz
+    unit level  surface_patch_warp2 (projector.py:560-645) on given surface points / gradients / the stacked feature maps
+                (implicit_surface.py:231-235: FPN levels 0, 1, 2, the coarser two F.interpolate'd to full resolution)
+    chain       ImplicitSurface.render (perturb = 0, cos_anneal_ratio = 1): ref_gray_val, sampled_gray_val, smooth_error
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from tests.golden import make_golden as G  # noqa: E402
+
+
+def load(name):
+    z = np.load(os.path.join(HERE, name))
+    return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+def main():
+    FeatureNetwork, Volume, MatchingField, ImplicitSurface, projector = G.import_reference()
+    conf = G.Conf(G.MODEL_CONF)
+    scene, weights, fpn, pipe = load("scene.npz"), load("weights.npz"), load("fpn.npz"), load("pipeline.npz")
+    isurf = ImplicitSurface(conf["implicit_surface"]).eval()
+    isurf.load_state_dict({k[len("implicit_surface."):]: v for k, v in weights.items() if k.startswith("implicit_surface.")})
+    feats = [fpn[f"out{i}"] for i in range(4)]                     # coarse -> fine
+    feats_r = feats[::-1]
+    vols_r, tabs_r, masks_r = [], [], []
+    for s in range(4):
+        table = pipe[f"s{s}_table"].long()
+        vols_r.append(pipe[f"s{s}_reg_out"][:, 1:].contiguous())
+        tabs_r.append(table)
+        masks_r.append((table >= 0).float()[None, None])
+    vols_r, tabs_r, masks_r = vols_r[::-1], tabs_r[::-1], masks_r[::-1]
+    mvol = pipe["s3_mvol"][None, None]
+    intrs, c2ws = scene["intrs"], scene["c2ws"]
+    out = {}
+    # ---- unit level: points near the r = 0.5 surface seen by all cameras, arbitrary (non-unit) gradients
+    g = torch.Generator().manual_seed(11)
+    n = 40
+    dirs = F.normalize(torch.randn(n, 3, generator=g) * torch.tensor([0.6, 0.6, 1.0]) + torch.tensor([0.0, 0.0, -1.2]), dim=1)
+    pts = dirs * (0.5 + 0.05 * torch.randn(n, 1, generator=g))
+    grads = dirs * (0.5 + torch.rand(n, 1, generator=g)) + 0.1 * torch.randn(n, 3, generator=g)
+    grads[0] = 0.0                                                  # the |g| <= 0 -> 1e-8 branch (implicit_surface.py:226)
+    with torch.no_grad():
+        w0 = feats_r[0]
+        w1 = F.interpolate(feats_r[1], size=w0.shape[-2:], mode="bilinear")
+        w2 = F.interpolate(feats_r[2], size=w0.shape[-2:], mode="bilinear")
+        warp_feats = torch.cat([w0, w1, w2], dim=1)
+        gn = torch.linalg.norm(grads.reshape(n, 1, 3), ord=2, dim=-1, keepdim=True)
+        gn = torch.where(gn <= 0, torch.ones_like(gn) * 1e-8, gn)
+        g_cam = grads.reshape(n, 1, 3) / gn
+        g_cam = torch.matmul(c2ws[0, :3, :3].permute(1, 0).contiguous()[None, ...], g_cam.permute(0, 2, 1).contiguous())
+        g_cam = g_cam.permute(0, 2, 1).contiguous()
+        ref, src = projector.surface_patch_warp2(pts.reshape(n, 1, 3), g_cam, warp_feats, intrs, c2ws)
+    out.update(unit_pts=pts, unit_grads=grads, unit_warp_feats=warp_feats, unit_ref=ref, unit_src=src)
+    # ---- chain: the reference's own render
+    R = scene["rays_o"].shape[0]
+    near, far = scene["near"].repeat(R, 1), scene["far"].repeat(R, 1)
+    torch.manual_seed(0)
+    outs = isurf.render(scene["rays_o"], scene["rays_d"], near, far, mvol, vols_r, tabs_r, masks_r, scene["imgs"], feats_r,
+                        feats_r, intrs, c2ws, 1.0, None)
+    out.update(ref_gray_val=outs["ref_gray_val"].detach(), sampled_gray_val=outs["sampled_gray_val"].detach(),
+               smooth_error=outs["smooth_error"].detach(), mid_inside_sphere=outs["mid_inside_sphere"].detach(),
+               sdf_depth=outs["sdf_depth"].detach())
+    G.ONLY.clear()
+    G.npz("train_outputs.npz", **out)
+
+
+if __name__ == "__main__":
+    main()

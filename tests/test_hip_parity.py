@@ -508,3 +508,47 @@ def test_finetune_volume_api_round_trip(scene, tmp_path):
     torch.save({"model": ref_style}, tmp_path / "ref.ckpt")
     with pytest.raises(KeyError):
         m2.load_params_vol(str(tmp_path / "ref.ckpt"), d)
+
+
+def test_patch_warp_matches_golden(scene, weights, gpu_scene, golden_fpn, golden_train):
+    """Row a15: the feature stack (F.interpolate of FPN levels 1, 2), the homography patches on given points, and the whole
+    chain of a training forward (zero crossing -> surface point -> SDF gradient -> patches) against the reference's outputs."""
+    from bench import model_conf
+    from surf_amd import ops
+    from surf_amd.implicit_surface import ImplicitSurface, SceneVolumes
+    d = dev()
+    gt = golden_train
+    f_t4 = gpu_scene["feats_t4"]                                     # fine -> coarse
+    H, W = f_t4[0].shape[1:3]
+    maps = [f_t4[0], ops.upsample_bilinear_t4(f_t4[1], H, W), ops.upsample_bilinear_t4(f_t4[2], H, W)]
+    stack = torch.cat([m.permute(0, 3, 1, 2) for m in maps], dim=1)
+    rel_close(stack, gt["unit_warp_feats"], 0, 2e-6)
+    ref, src = ops.patch_warp(gt["unit_pts"].to(d).contiguous(), gt["unit_grads"].to(d).contiguous(), maps, gpu_scene["cams"])
+    torch.cuda.synchronize()
+    rel_close(ref, gt["unit_ref"], 1e-4, 2e-5)
+    rel_close(src, gt["unit_src"], 1e-3, 2e-4)
+    # chain through ImplicitSurface.render_scene(patch_warp=True)
+    model = ImplicitSurface(model_conf(CFG["n_samples"], "f32"))
+    model.load_state_dict({k[len("implicit_surface."):]: v for k, v in weights.items() if k.startswith("implicit_surface.")})
+    model = model.to(d)
+    sc = SceneVolumes.from_device_layouts(gpu_scene["mvol"], gpu_scene["sv"].vols, gpu_scene["sv"].tables, f_t4,
+                                          gpu_scene["imgs_t4"], gpu_scene["cams"])
+    R = scene["rays_o"].shape[0]
+    near, far = scene["near"].repeat(R, 1).to(d), scene["far"].repeat(R, 1).to(d)
+    out = model.render_scene(scene["rays_o"].to(d), scene["rays_d"].to(d), near, far, sc, 1.0, patch_warp=True)
+    torch.cuda.synchronize()
+    rel_close(out["sdf_depth"], gt["sdf_depth"], 1e-3, 2e-5)
+    hit = (gt["mid_inside_sphere"].reshape(-1) > 0).to(d)
+    rel_close(out["ref_gray_val"], gt["ref_gray_val"], 1e-3, 2e-4)
+    err = (out["sampled_gray_val"][:, hit].cpu() - gt["sampled_gray_val"][:, hit.cpu()]).abs()
+    # source patches go through the homography of the fitted plane (ill-conditioned in the normal): outlier allowance here,
+    # the tight comparison is the unit-level one above
+    assert float(err.max()) < 2e-2 and float((err < 2e-3).float().mean()) > 0.99, (float(err.max()), float((err < 2e-3).float().mean()))
+    # ... and the chain's intermediate quantities against the (golden-pinned) oracle: surface points and their gradients
+    c = gpu_scene["cpu"]
+    oref = O.render(weights, scene["rays_o"], scene["rays_d"], scene["near"].repeat(R, 1), scene["far"].repeat(R, 1), c["mvol"],
+                    c["vols"], c["tabs"], c["masks"], c["feats"], scene["imgs"], scene["intrs"], scene["c2ws"], CFG["n_samples"],
+                    CFG["sample_ranges"], CFG["n_depth"], 1.0, patch_warp=True)
+    rel_close(out["pts_sdf0"], oref["pts_sdf0"], 0, 2e-5)
+    rel_close(out["gradients_sdf0"], oref["gradients_sdf0"], 1e-3, 3e-4)
+    assert tuple(out["sampled_gray_val"].shape) == (2, R, 121, 12) and tuple(out["ref_gray_val"].shape) == (1, R, 121, 12)
