@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 9
+#define SURF_ABI_VERSION 10
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -313,6 +313,16 @@ int64_t surf_mc_workspace_ints(int64_t n_active);
 int surf_mc_count(const uint8_t* flags, const int32_t* active, int64_t n_active, int32_t* workspace, int32_t* totals, void* stream);
 int surf_mc_emit(const float* u, int nx, int ny, int nz, double isovalue, const uint8_t* flags, const int32_t* active,
                  int64_t n_active, const int32_t* workspace, int32_t* vbase, double* vertices, int32_t* triangles, void* stream);
+
+/*
+ * First-hit face ids of a triangle mesh from one pinhole view, by z-buffer rasterisation (mesh cleaning of the
+ * evaluation: the faces some mask-pixel ray hits first; utils/clean_mesh.py:37-108 uses trimesh + pyembree for it).
+ *   vertices (nv,3) fp32, faces (nf,3) int32 on the device; h_K (9) and h_w2c (12) HOST row-major; (h, w) the image the
+ *   intrinsics refer to, (Hup, Wup) the sample lattice torch.linspace(0, w-1, Wup) x torch.linspace(0, h-1, Hup)
+ *   zbuf (Hup*Wup) uint64 pre-filled with ~0: on return (depth bits << 32 | face id) of the nearest covering face
+ */
+int surf_raster_first_hit(const float* vertices, const int32_t* faces, int64_t n_faces, const float* h_K, const float* h_w2c,
+                          int h, int w, int Hup, int Wup, unsigned long long* zbuf, void* stream);
 
 #ifdef __cplusplus
 }

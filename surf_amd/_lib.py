@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
 # must equal SURF_ABI_VERSION of include/surf_hip.h (tests/test_host_modules.py compares the two texts); lib() refuses a
 # library built from another header
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -54,6 +54,7 @@ SIGNATURES = {
     "surf_mc_workspace_ints": (c_i64, [c_i64]),
     "surf_mc_count": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     "surf_mc_emit": (c_int, [c_ptr, c_int, c_int, c_int, ctypes.c_double, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_raster_first_hit": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "surf_composite": (c_int, [c_ptr] * 9 + [c_int, c_int, c_float, c_float] + [c_ptr] * 13),
     "surf_upsample_bilinear_t4": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "surf_surface_points": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),

@@ -541,6 +541,22 @@ def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, r
     return (full, lr) if return_lr else full
 
 
+def raster_first_hit(vertices, faces, intr, c2w, hw, upscale=1):
+    """Face id of the first triangle hit by the ray through every sample of the (h*upscale, w*upscale) lattice
+    torch.linspace(0, w-1, w*upscale) x torch.linspace(0, h-1, h*upscale) of one view; -1 where nothing is hit."""
+    _chk(vertices, torch.float32, "vertices")
+    _chk(faces, torch.int32, "faces")
+    h, w = int(hw[0]), int(hw[1])
+    Hup, Wup = int(h * upscale), int(w * upscale)
+    K = np.ascontiguousarray(intr.detach().to("cpu", torch.float32)[:3, :3].contiguous().numpy())
+    w2c = np.ascontiguousarray(torch.inverse(c2w.detach().to("cpu", torch.float32))[:3, :4].contiguous().numpy())
+    zbuf = torch.full((Hup, Wup), -1, dtype=torch.int64, device=vertices.device)      # all ones = empty
+    rc = _lib.lib().surf_raster_first_hit(_p(vertices), _p(faces), faces.shape[0], _np_ptr(K), _np_ptr(w2c), h, w, Hup, Wup,
+                                          _p(zbuf), _stream())
+    _lib.check(rc, "surf_raster_first_hit")
+    return torch.where(zbuf == -1, torch.full_like(zbuf, -1), zbuf & 0xffffffff)
+
+
 def marching_cubes(u, isovalue=0.0):
     """mcubes.marching_cubes(u, isovalue) (implicit_surface.py:353) on a device lattice u (nx, ny, nz) fp32.
     Returns (vertices (nv, 3) float64, triangles (nt, 3) int32) device tensors, vertices in lattice-index units.
