@@ -29,7 +29,7 @@ def test_sample_mesh_points_covers_the_triangles():
     v2, t2 = _sphere_mesh(10.0, 24)
     p2 = E.sample_mesh_points(v2, t2, 0.5)
     density = (len(p2) - len(v2)) / (4 * np.pi * 100)
-    assert 0.5 < density * 0.25 < 4.0                                  # of the order of one sample per thresh^2 of area (small triangles get fewer)
+    assert 0.2 < density * 0.25 < 4.0                                  # of the order of one sample per thresh^2 of area (small triangles get fewer)
     degenerate = E.sample_mesh_points(v, np.array([[0, 0, 1]]), 0.5)   # zero-area triangles add nothing
     assert len(degenerate) == 3
 
