@@ -145,6 +145,7 @@ int surf_blend(const float* pts, const uint8_t* mask, const int32_t* idx, int64_
  */
 #define SURF_BLEND_BF16X3 1
 #define SURF_BLEND_F16X2 2
+#define SURF_BLEND_F32 3      /* the same LDS-resident kernel on v_mfma_f32_32x32x2_f32, no operand split */
 int64_t surf_blend_split_packed_bytes(int precision);
 int surf_blend_pack_weights_split(const float* h_raw, unsigned char* h_packed, int precision);
 /* Bytes of device scratch a launch over n points with nv views needs (per-wavefront staging of the per-view inputs of the

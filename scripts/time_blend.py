@@ -24,7 +24,7 @@ st = ops.ray_setup(rays_o, rays_d, near, far, mvol, scene.sv, n_samples, [1.0, 0
 act = ops.compact(st["vmask"])
 sd = {k: v for k, v in model.state_dict().items()}
 ref = None
-for prec in os.environ.get('SURF_BLEND', 'f32,bf16x3,f16x2').split(','):
+for prec in os.environ.get('SURF_BLEND', 'f32,f32lds,bf16x3,f16x2').split(','):
     w = ops.blend_pack_weights(sd, dev, "color_network.", prec)
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()

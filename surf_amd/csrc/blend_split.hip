@@ -47,10 +47,11 @@ constexpr int blk_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += NKS[i
 constexpr int N_BLK = blk_off(N_L);  // 26 blocks of NP KB: [layer][k-step][tile][piece][lane] x 16 B
 enum { B_RD0, B_RD2, B_B0_T0, B_B0_T1, B_B2, B_V0, B_V2, B_W0, B_R0, B_R2, N_BIAS };  // accumulator-init rows [h][16]
 enum { D_VIS, D_VIS2, D_RGB4, N_DOT };                                                    // per-lane dot rows [h][16]
-template <int NP> constexpr int bias_off() { return N_BLK * NP * 1024; }
-template <int NP> constexpr int dot_off() { return bias_off<NP>() + N_BIAS * 128; }
-template <int NP> constexpr int scal_off() { return dot_off<NP>() + N_DOT * 128; }  // [|s|, b_vis, b_vis2, b_rgb4]
-template <int NP> constexpr int image_bytes() { return scal_off<NP>() + 16; }
+// BB = bytes of one block: NP x 1 KB for the 16-bit policies, 2 KB for the fp32 policy
+template <int BB> constexpr int bias_off() { return N_BLK * BB; }
+template <int BB> constexpr int dot_off() { return bias_off<BB>() + N_BIAS * 128; }
+template <int BB> constexpr int scal_off() { return dot_off<BB>() + N_DOT * 128; }  // [|s|, b_vis, b_vis2, b_rgb4]
+template <int BB> constexpr int image_bytes() { return scal_off<BB>() + 16; }
 
 constexpr float LOG2E = 1.44269504088896341f, LN2 = 0.69314718055994531f;
 
@@ -65,7 +66,11 @@ template <int NP>
 struct FragT { u32x4 p[NP]; };  // B operand of one 16-wide k-step: NP pieces x 8 x 16 bit
 
 struct BPolBf3 {
-  static constexpr int NP = 3, ID = 1;
+  static constexpr int NP = 3, ID = 1, BB = NP * 1024, LANE_BYTES = 16;
+  typedef FragT<NP> Frag;
+  static __device__ __forceinline__ void set_pair(Frag& f, int pr, float a, float b);
+  static __device__ __forceinline__ void zero_pair(Frag& f, int pr);
+  template <int NUSED> static __device__ __forceinline__ void mma_lds(f32x16& acc, const char* blk_lane, const Frag& b);
   static __device__ __forceinline__ uint32_t pack2(float a, float b) {
     bf16x2 v;
     v[0] = (__bf16)a;
@@ -94,7 +99,11 @@ struct BPolBf3 {
 };
 
 struct BPolH2 {
-  static constexpr int NP = 2, ID = 2;
+  static constexpr int NP = 2, ID = 2, BB = NP * 1024, LANE_BYTES = 16;
+  typedef FragT<NP> Frag;
+  static __device__ __forceinline__ void set_pair(Frag& f, int pr, float a, float b);
+  static __device__ __forceinline__ void zero_pair(Frag& f, int pr);
+  template <int NUSED> static __device__ __forceinline__ void mma_lds(f32x16& acc, const char* blk_lane, const Frag& b);
   static __device__ __forceinline__ void split(float a, float b, uint32_t (&p)[NP]) {
     const f32x2 v = {a, b};
     const f16x2 h = __builtin_convertvector(v, f16x2);
@@ -109,6 +118,54 @@ struct BPolH2 {
     SURF_MF(0, 1);
     SURF_MF(0, 0);
 #undef SURF_MF
+  }
+};
+
+// fragment helpers of the 16-bit policies
+template <class P>
+struct Frag16 {
+  static __device__ __forceinline__ void set_pair(typename P::Frag& f, int pr, float a, float b) {
+    uint32_t p[P::NP];
+    P::split(a, b, p);
+#pragma unroll
+    for (int k = 0; k < P::NP; ++k) f.p[k][pr] = p[k];
+  }
+  static __device__ __forceinline__ void zero_pair(typename P::Frag& f, int pr) {
+#pragma unroll
+    for (int k = 0; k < P::NP; ++k) f.p[k][pr] = 0u;
+  }
+  // NUSED (number of k-slots that carry data) is irrelevant here: one MFMA covers all 16 k of the step
+  template <int NUSED>
+  static __device__ __forceinline__ void mma_lds(f32x16& acc, const char* blk_lane, const typename P::Frag& b) {
+    u32x4 a[P::NP];
+#pragma unroll
+    for (int p = 0; p < P::NP; ++p) a[p] = *reinterpret_cast<const u32x4*>(blk_lane + p * 1024);
+    P::mma(acc, a, b);
+  }
+};
+
+__device__ __forceinline__ void BPolBf3::set_pair(Frag& f, int pr, float a, float b) { Frag16<BPolBf3>::set_pair(f, pr, a, b); }
+__device__ __forceinline__ void BPolBf3::zero_pair(Frag& f, int pr) { Frag16<BPolBf3>::zero_pair(f, pr); }
+template <int NUSED> __device__ __forceinline__ void BPolBf3::mma_lds(f32x16& acc, const char* l, const Frag& b) { Frag16<BPolBf3>::mma_lds<NUSED>(acc, l, b); }
+__device__ __forceinline__ void BPolH2::set_pair(Frag& f, int pr, float a, float b) { Frag16<BPolH2>::set_pair(f, pr, a, b); }
+__device__ __forceinline__ void BPolH2::zero_pair(Frag& f, int pr) { Frag16<BPolH2>::zero_pair(f, pr); }
+template <int NUSED> __device__ __forceinline__ void BPolH2::mma_lds(f32x16& acc, const char* l, const Frag& b) { Frag16<BPolH2>::mma_lds<NUSED>(acc, l, b); }
+
+// fp32 policy: no operand split, v_mfma_f32_32x32x2_f32 (exact fp32, 1/16 of the 16-bit rate).  A "k-step" is the same
+// eight k-slots per lane half as in the 16-bit layouts (so the packer's row / column maps are shared); it takes one MFMA
+// per slot that carries data.  Block = [lane][8 floats] = 2 KB.
+struct BPolF32 {
+  static constexpr int NP = 1, ID = 3, BB = 2048, LANE_BYTES = 32;
+  struct Frag { float v[8]; };
+  static __device__ __forceinline__ void set_pair(Frag& f, int pr, float a, float b) { f.v[2 * pr] = a; f.v[2 * pr + 1] = b; }
+  static __device__ __forceinline__ void zero_pair(Frag& f, int pr) { f.v[2 * pr] = 0.f; f.v[2 * pr + 1] = 0.f; }
+  template <int NUSED>
+  static __device__ __forceinline__ void mma_lds(f32x16& acc, const char* blk_lane, const Frag& b) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(blk_lane);
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f};
+    if (NUSED > 4) a1 = *reinterpret_cast<const f32x4*>(blk_lane + 16);
+#pragma unroll
+    for (int i = 0; i < NUSED; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(i < 4 ? a0[i] : a1[i - 4], b.v[i], acc, 0, 0, 0);
   }
 };
 
@@ -156,35 +213,23 @@ __device__ __forceinline__ void elu_rows(const f32x16& acc, float* out) {
 
 // N values (N <= 8 * NF) -> NF k-step fragments, zero padded
 template <class P, int N, int NF>
-__device__ __forceinline__ void frags_from(const float* v, FragT<P::NP>* f) {
+__device__ __forceinline__ void frags_from(const float* v, typename P::Frag* f) {
 #pragma unroll
   for (int s = 0; s < NF; ++s)
 #pragma unroll
     for (int pr = 0; pr < 4; ++pr) {
       const int i0 = 8 * s + 2 * pr;
-      uint32_t p[P::NP];
-      if (i0 < N) {
-        P::split(v[i0], i0 + 1 < N ? v[i0 + 1] : 0.0f, p);
-      } else {
-#pragma unroll
-        for (int k = 0; k < P::NP; ++k) p[k] = 0u;
-      }
-#pragma unroll
-      for (int k = 0; k < P::NP; ++k) f[s].p[k][pr] = p[k];
+      if (i0 < N) P::set_pair(f[s], pr, v[i0], i0 + 1 < N ? v[i0 + 1] : 0.0f);
+      else P::zero_pair(f[s], pr);
     }
 }
-
 // ELU of the first N registers of an accumulator tile straight into k-step fragments (N = 8 or 16), pair by pair
 template <class P, int N>
-__device__ __forceinline__ void elu_frags(const f32x16& acc, FragT<P::NP>* f) {
+__device__ __forceinline__ void elu_frags(const f32x16& acc, typename P::Frag* f) {
 #pragma unroll
-  for (int r = 0; r < N; r += 2) {
-    uint32_t p[P::NP];
-    P::split(elu_t(acc[r]), elu_t(acc[r + 1]), p);
-#pragma unroll
-    for (int k = 0; k < P::NP; ++k) f[r >> 3].p[k][(r & 7) >> 1] = p[k];
-  }
+  for (int r = 0; r < N; r += 2) P::set_pair(f[r >> 3], (r & 7) >> 1, elu_t(acc[r]), elu_t(acc[r + 1]));
 }
+
 struct Ctx {
   const char* lds;
   int lane16, h64;
@@ -209,26 +254,28 @@ __device__ __forceinline__ f32x16 lds_row16(const Ctx& c, int byte_off) {  // [h
   }
   return v;
 }
-template <class P> __device__ __forceinline__ f32x16 bias_row(const Ctx& c, int row) { return lds_row16<P>(c, bias_off<P::NP>() + row * 128); }
-template <class P> __device__ __forceinline__ f32x16 dot_row(const Ctx& c, int row) { return lds_row16<P>(c, dot_off<P::NP>() + row * 128); }
+template <class P> __device__ __forceinline__ f32x16 bias_row(const Ctx& c, int row) { return lds_row16<P>(c, bias_off<P::BB>() + row * 128); }
+template <class P> __device__ __forceinline__ f32x16 dot_row(const Ctx& c, int row) { return lds_row16<P>(c, dot_off<P::BB>() + row * 128); }
 
-// acc += W[layer L, k-step KS, tile T] x b   (A fragments from the LDS image)
-template <class P, int L, int KS, int T>
-__device__ __forceinline__ void mma_blk(const Ctx& c, f32x16& acc, const FragT<P::NP>& b) {
-  constexpr int OFF = (blk_off(L) + KS * NT[L] + T) * P::NP * 1024;
-  u32x4 a[P::NP];
-#pragma unroll
-  for (int p = 0; p < P::NP; ++p) a[p] = *reinterpret_cast<const u32x4*>(c.lds + OFF + p * 1024 + c.lane16);
-  P::mma(acc, a, b);
+// acc += W[layer L, k-step KS, tile T] x b   (A fragments from the LDS image); NUSED = k-slots of this step that carry data
+template <class P, int L, int KS, int T, int NUSED = 8>
+__device__ __forceinline__ void mma_blk(const Ctx& c, f32x16& acc, const typename P::Frag& b) {
+  constexpr int OFF = (blk_off(L) + KS * NT[L] + T) * P::BB;
+  P::template mma_lds<NUSED>(acc, c.lds + OFF + c.lane16 * (P::LANE_BYTES / 16), b);
 }
+// k-slots in use in the LAST k-step of every layer (max over the lane halves; all earlier k-steps are full)
+constexpr int LAST_USED[N_L] = {2, 8, 7, 3, 8, 8, 8, 8, 3, 8};
 // one 32-row tile of layer L over NK k-steps
 template <class P, int L, int T, int NK>
-__device__ __forceinline__ void mma_layer(const Ctx& c, f32x16& acc, const FragT<P::NP>* b) {
+__device__ __forceinline__ void mma_layer(const Ctx& c, f32x16& acc, const typename P::Frag* b) {
   static_assert(NK == NKS[L], "k-steps");
-  if constexpr (NK >= 1) mma_blk<P, L, 0, T>(c, acc, b[0]);
-  if constexpr (NK >= 2) mma_blk<P, L, 1, T>(c, acc, b[1]);
-  if constexpr (NK >= 3) mma_blk<P, L, 2, T>(c, acc, b[2]);
-  if constexpr (NK >= 4) mma_blk<P, L, 3, T>(c, acc, b[3]);
+  if constexpr (NK == 1) mma_blk<P, L, 0, T, LAST_USED[L]>(c, acc, b[0]);
+  if constexpr (NK >= 2) mma_blk<P, L, 0, T>(c, acc, b[0]);
+  if constexpr (NK == 2) mma_blk<P, L, 1, T, LAST_USED[L]>(c, acc, b[1]);
+  if constexpr (NK >= 3) mma_blk<P, L, 1, T>(c, acc, b[1]);
+  if constexpr (NK == 3) mma_blk<P, L, 2, T, LAST_USED[L]>(c, acc, b[2]);
+  if constexpr (NK >= 4) mma_blk<P, L, 2, T>(c, acc, b[2]);
+  if constexpr (NK == 4) mma_blk<P, L, 3, T, LAST_USED[L]>(c, acc, b[3]);
   SURF_PHASE();
 }
 
@@ -259,7 +306,7 @@ __device__ __forceinline__ f32x4 tap_finish(const Tap4& t) {
   return acc;
 }
 
-template <class P> constexpr int lds_bytes() { return image_bytes<P::NP>(); }
+template <class P> constexpr int lds_bytes() { return image_bytes<P::BB>(); }
 
 // Per-wavefront staging slot in global memory (L2 / Infinity-Cache resident: written in pass 1, read back within the
 // same tile): per source view five 16-byte groups per lane = [floc 0..3][floc 4..7][floc 8..11][ray_diff][rgb, +-ex]
@@ -303,7 +350,7 @@ __device__ __forceinline__ void slot_load_tail(const float* slot, int v, int lan
 
 template <class P>
 __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArgs a) {
-  typedef FragT<P::NP> Frag;
+  typedef typename P::Frag Frag;
   __shared__ __attribute__((aligned(16))) char lds[lds_bytes<P>()];
   // ---- the weight image: global -> LDS once per workgroup --------------------------------------------------------
   for (int o = threadIdx.x * 16; o < lds_bytes<P>(); o += WPB * 64 * 16)
@@ -321,7 +368,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
   const int64_t n_waves = (int64_t)gridDim.x * WPB;
   const int64_t n_tiles = (a.n + TILE - 1) / TILE;
   float* slot = a.scratch + wave_id * slot_floats(NS);
-  const float* scal = reinterpret_cast<const float*>(lds + scal_off<P::NP>());
+  const float* scal = reinterpret_cast<const float*>(lds + scal_off<P::BB>());
   const float s_abs = scal[0], b_vis = scal[1], b_vis2 = scal[2], b_rgb4 = scal[3];
 
   // the two pyramid levels this half fetches
@@ -636,6 +683,15 @@ template <> void split_host<BPolH2>(float v, uint16_t* p) {
   p[0] = f16_bits(v);
   p[1] = f16_bits(v - f16_to_f(p[0]));
 }
+// element (lane, k-slot i) of block `blk` of the image
+template <class P> void put_weight(unsigned char* out, int blk, int lane, int i, float v) {
+  uint16_t p[P::NP];
+  split_host<P>(v, p);
+  for (int pc = 0; pc < P::NP; ++pc) reinterpret_cast<uint16_t*>(out + (int64_t)blk * P::BB + pc * 1024 + lane * 16)[i] = p[pc];
+}
+template <> void put_weight<BPolF32>(unsigned char* out, int blk, int lane, int i, float v) {
+  reinterpret_cast<float*>(out + (int64_t)blk * BPolF32::BB + lane * 32)[i] = v;
+}
 
 // feature held by accumulator register r of half h in 32-row tile tt (= k-slot (s, i) with r = 8 s + i)
 inline int hk(int tt, int r, int h) { return 32 * tt + (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -646,7 +702,6 @@ inline int loc_ch(int r, int h) { return h == 0 ? (r < 11 ? r : -1) : (r < 8 ? 1
 // lane half h (or -1)
 template <class P, class RowF, class ColF>
 void pack_layer(unsigned char* out, int L, const float* W, int ldw, RowF row_of, ColF col_of) {
-  constexpr int NP = P::NP;
   for (int ks = 0; ks < NKS[L]; ++ks)
     for (int t = 0; t < NT[L]; ++t)
       for (int lane = 0; lane < 64; ++lane)
@@ -654,12 +709,7 @@ void pack_layer(unsigned char* out, int L, const float* W, int ldw, RowF row_of,
           const int h = lane >> 5, rho = lane & 31;
           const int row = row_of(t, rho), col = col_of(8 * ks + i, h);
           const float v = (row >= 0 && col >= 0) ? (float)((double)W[row * ldw + col] * (double)LOG2E) : 0.f;
-          uint16_t p[NP];
-          split_host<P>(v, p);
-          for (int pc = 0; pc < NP; ++pc) {
-            uint16_t* dst = reinterpret_cast<uint16_t*>(out + ((blk_off(L) + ks * NT[L] + t) * NP + pc) * 1024 + lane * 16);
-            dst[i] = p[pc];
-          }
+          put_weight<P>(out, blk_off(L) + ks * NT[L] + t, lane, i, v);
         }
 }
 template <class RowF>
@@ -674,11 +724,10 @@ void pack_rows(float* dst, const float* b, RowF feat_of, float scale) {  // [h][
 template <class P>
 int pack_weights(const float* raw, unsigned char* out) {
   if (!raw || !out) return SURF_E_ARG;
-  constexpr int NP = P::NP;
-  memset(out, 0, image_bytes<NP>());
-  float* bias = reinterpret_cast<float*>(out + bias_off<NP>());
-  float* dots = reinterpret_cast<float*>(out + dot_off<NP>());
-  float* scal = reinterpret_cast<float*>(out + scal_off<NP>());
+  memset(out, 0, image_bytes<P::BB>());
+  float* bias = reinterpret_cast<float*>(out + bias_off<P::BB>());
+  float* dots = reinterpret_cast<float*>(out + dot_off<P::BB>());
+  float* scal = reinterpret_cast<float*>(out + scal_off<P::BB>());
   auto nat_row = [](int lim) { return [lim](int t, int rho) { const int f = 32 * t + rho; return f < lim ? f : -1; }; };
   // k-slot m of half h -> natural feature of the producing accumulator tile(s)
   auto nat_col = [](int lim) { return [lim](int m, int h) { const int f = hk(m / 16, m % 16, h); return f < lim ? f : -1; }; };
@@ -748,14 +797,16 @@ int launch(const BlendArgs& a, hipStream_t st) {
 }  // namespace
 
 extern "C" int64_t surf_blend_split_packed_bytes(int precision) {
-  if (precision == BPolBf3::ID) return image_bytes<BPolBf3::NP>();
-  if (precision == BPolH2::ID) return image_bytes<BPolH2::NP>();
+  if (precision == BPolBf3::ID) return image_bytes<BPolBf3::BB>();
+  if (precision == BPolH2::ID) return image_bytes<BPolH2::BB>();
+  if (precision == BPolF32::ID) return image_bytes<BPolF32::BB>();
   return SURF_E_ARG;
 }
 
 extern "C" int surf_blend_pack_weights_split(const float* h_raw, unsigned char* h_packed, int precision) {
   if (precision == BPolBf3::ID) return pack_weights<BPolBf3>(h_raw, h_packed);
   if (precision == BPolH2::ID) return pack_weights<BPolH2>(h_raw, h_packed);
+  if (precision == BPolF32::ID) return pack_weights<BPolF32>(h_raw, h_packed);
   return SURF_E_ARG;
 }
 
@@ -771,7 +822,7 @@ extern "C" int surf_blend_split(const float* pts, const uint8_t* mask, const int
   if (!pts || !h_feats || !h_hw || !imgs || !h_intrs || !h_w2c || !h_c2w || !blend_w || !color || !scratch) return SURF_E_ARG;
   if (n <= 0 || nv < 2) return SURF_E_ARG;
   if (n_level != 4 || nv > SURF_MAX_VIEWS) return SURF_E_LIMIT;  // d_feature = 16 = 4 levels x 4 channels
-  if (precision != BPolBf3::ID && precision != BPolH2::ID) return SURF_E_ARG;
+  if (precision != BPolBf3::ID && precision != BPolH2::ID && precision != BPolF32::ID) return SURF_E_ARG;
   BlendArgs a;
   a.pts = pts; a.mask = mask; a.idx = idx; a.n = n; a.imgs = imgs; a.w = (const unsigned char*)blend_w; a.color = color;
   a.n_valid = n_valid;
@@ -791,5 +842,7 @@ extern "C" int surf_blend_split(const float* pts, const uint8_t* mask, const int
       for (int cc = 0; cc < 4; ++cc) a.w2c[v][r * 4 + cc] = h_w2c[s * 16 + r * 4 + cc];
     for (int r = 0; r < 3; ++r) a.cpos[v][r] = h_c2w[s * 16 + r * 4 + 3];
   }
-  return precision == BPolBf3::ID ? launch<BPolBf3>(a, (hipStream_t)stream) : launch<BPolH2>(a, (hipStream_t)stream);
+  if (precision == BPolBf3::ID) return launch<BPolBf3>(a, (hipStream_t)stream);
+  if (precision == BPolH2::ID) return launch<BPolH2>(a, (hipStream_t)stream);
+  return launch<BPolF32>(a, (hipStream_t)stream);
 }

@@ -117,9 +117,12 @@ def sdf_pack_weights_host(layers):
 
 
 SDF_PRECISIONS = ("f32", "bf16x3", "f16x2")
-BLEND_PRECISIONS = ("f32", "bf16x3", "f16x2")     # the blend kernels of the library (render.blend_precision)
+# the blend kernels of the library (render.blend_precision): "f32" = blend.hip (fp32 MFMA, register-resident weights
+# stream, round 1); the others = blend_split.hip (weights resident in LDS, two wavefronts per SIMD): "f32lds" fp32 MFMA,
+# "bf16x3" exact three-way bf16 split, "f16x2" two fp16 pieces
+BLEND_PRECISIONS = ("f32", "f32lds", "bf16x3", "f16x2")
 BLEND_DEFAULT = "bf16x3"
-_BLEND_ID = {"bf16x3": 1, "f16x2": 2}              # SURF_BLEND_BF16X3 / SURF_BLEND_F16X2
+_BLEND_ID = {"bf16x3": 1, "f16x2": 2, "f32lds": 3}   # SURF_BLEND_BF16X3 / SURF_BLEND_F16X2 / SURF_BLEND_F32
 _SPLIT_ABI = {"bf16x3": "bf16", "f16x2": "f16"}   # precision -> infix of the C-ABI entry points
 
 
@@ -195,12 +198,16 @@ def blend_pack_weights(sd, device, prefix="implicit_surface.color_network.", pre
     raw = blend_raw_weights(sd, prefix)
     if precision == "f32":
         return torch.from_numpy(blend_pack_weights_host(raw)).to(device)
-    return torch.from_numpy(blend_pack_weights_split_host(raw, precision)).to(device)
+    packed = torch.from_numpy(blend_pack_weights_split_host(raw, precision)).to(device)
+    packed.surf_precision = precision          # the f16x2 and f32lds images have the same size: carry the name along
+    return packed
 
 
 def blend_packed_precision(packed):
     if packed.dtype == torch.float32:
         return "f32"
+    if getattr(packed, "surf_precision", None) in _BLEND_ID:
+        return packed.surf_precision
     if packed.dtype == torch.uint8:
         for precision, pid in _BLEND_ID.items():
             if packed.numel() == _lib.lib().surf_blend_split_packed_bytes(pid):

@@ -427,7 +427,7 @@ def test_sdf_grid_matches_golden(weights, golden_pipe, golden_grid, precision):
     assert bool((v >= bmin.numpy()[None] - 1e-6).all()) and bool((v <= bmax.numpy()[None] + 1e-6).all())
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", 1.0), ("f16x2", 4.0)])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1.0), ("f16x2", 4.0), ("f32lds", 1.0)])
 def test_blend_split_matches_golden(scene, weights, gpu_scene, golden_render, precision, tol):
     """The split blend kernels (16-bit operand pieces on the bf16 / fp16 MFMA pipe, fp32 accumulation, weights resident
     in LDS) against the reference's BlendingNetwork outputs at the fp32 kernel's tolerances, and against the fp32-MFMA

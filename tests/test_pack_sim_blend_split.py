@@ -24,17 +24,20 @@ LOG2E, LN2 = 1.44269504088896341, 0.69314718055994531
 
 class Image:
     def __init__(self, img, precision):
-        self.NP = {"bf16x3": 3, "f16x2": 2}[precision]
+        self.NP = {"bf16x3": 3, "f16x2": 2, "f32lds": 1}[precision]
         n_blk = int(BLK_OFF[-1])
         assert n_blk == 26
-        a_bytes = n_blk * self.NP * 1024
-        u16 = img[:a_bytes].view(np.uint16).reshape(n_blk, self.NP, 64, 8)
-        if precision == "bf16x3":
-            vals = (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+        if precision == "f32lds":                                  # blocks of [lane][8 floats]
+            a_bytes = n_blk * 2048
+            self.A = img[:a_bytes].view(np.float32).reshape(n_blk, 64, 8).astype(np.float64)
         else:
-            vals = u16.view(np.float16).astype(np.float64)
-        self.A = vals.sum(axis=1)                                  # (blk, lane, 8): pieces summed
-        self.pieces = vals
+            a_bytes = n_blk * self.NP * 1024
+            u16 = img[:a_bytes].view(np.uint16).reshape(n_blk, self.NP, 64, 8)
+            if precision == "bf16x3":
+                vals = (u16.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+            else:
+                vals = u16.view(np.float16).astype(np.float64)
+            self.A = vals.sum(axis=1)                              # (blk, lane, 8): pieces summed
         f = img[a_bytes:].view(np.float32).astype(np.float64)
         self.bias = f[: 10 * 32].reshape(10, 2, 16)
         self.dots = f[10 * 32: 13 * 32].reshape(3, 2, 16)
@@ -139,7 +142,7 @@ def sim_blend_split(I, rgb_feat, ray_diff, mask):
     return (rgb_feat[:, :, :3] * beta[:, :, None]).sum(1)
 
 
-@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-5), ("f16x2", 1e-5)])
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-5), ("f16x2", 1e-5), ("f32lds", 1e-5)])
 def test_blend_split_image_matches_oracle(weights, golden_render, precision, tol):
     gr = golden_render
     img = ops.blend_pack_weights_split_host(ops.blend_raw_weights(weights), precision)
