@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 10
+#define SURF_ABI_VERSION 11
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -115,6 +115,19 @@ int surf_sdf_pack_weights_f16(const float* const* h_W, const float* const* h_b, 
 int surf_sdf_mlp_f16x2(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_vols,
                        const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* sdf,
                        float* grad, void* scratch, void* stream);
+
+/*
+ * Second-order term of the SDF network (training): grad (n,3) (optional) and smooth (n,3) = H.1, the row sums of the
+ * Hessian of the SDF wrt the point.  Replaces the two chained torch.autograd.grad calls of SDFNetworkSparse.gradient
+ * (models/modules/sdf_network.py:129-152; `smooth` feeds smooth_error, implicit_surface.py:172) by their closed form
+ * in plain fp32.  idx (optional): compacted list of the n point indices to evaluate; other rows are left untouched.
+ * surf_sdf_smooth_pack_weights takes the same host matrices as surf_sdf_pack_weights.
+ */
+int64_t surf_sdf_smooth_packed_floats(void);
+int surf_sdf_smooth_pack_weights(const float* const* h_W, const float* const* h_b, float* h_packed);
+int surf_sdf_smooth(const float* pts, const int32_t* idx, int64_t n, const float* const* h_vols,
+                    const int32_t* const* h_tables, const int* h_dims, int n_vol, const float* packed, float* grad,
+                    float* smooth, void* stream);
 
 /*
  * Multi-view feature fetch + blending MLP.

@@ -4,9 +4,10 @@ Same module / parameter names (so reference checkpoints load with ``load_state_d
 ``render`` / ``validate`` / ``extract_geometry`` / ``forward`` entry points and output keys; the
 arithmetic runs in the HIP kernels behind ``surf_amd.ops`` (no PyTorch fallback).
 
-Scope of this mirror (see DESIGN.md): inference (`val`) semantics, including the ``render.perturb`` jitter;
-the loss-only outputs of ``render_core`` (``ref_gray_val`` / ``sampled_gray_val`` patch warps,
-``smooth_error``, ``sparse_sdf`` random points) belong to the training row.
+Scope of this mirror: inference (`val`) semantics, including the ``render.perturb`` jitter, and the
+forward side of a training step: ``render_scene(patch_warp=True)`` adds the loss-only outputs of ``render_core``
+(``ref_gray_val`` / ``sampled_gray_val`` patch warps, ``smooth_error``, ``sparse_sdf``).  Nothing here is differentiable
+(backward kernels are not built).
 """
 import math
 
@@ -119,6 +120,18 @@ class SceneVolumes:
         self.match_feats_t4 = None
         self._warp_maps = {}
 
+    def occupied_any(self, pts):
+        """lookup_volume(pts, mask_volumes, 'nearest').any(-1) (implicit_surface.py:175): is the nearest voxel of any
+        level occupied; the mask volume is 1 exactly where the index table is >= 0 (volume.py:112-130)."""
+        occ = torch.zeros(pts.shape[0], dtype=torch.bool, device=pts.device)
+        for table in self.sv.tables:
+            D = table.shape[0]
+            g = torch.round(((pts + 1.0) * D - 1.0) / 2.0).long()      # align_corners=False, half-to-even like grid_sample
+            ok = ((g >= 0) & (g < D)).all(dim=-1)
+            g = g.clamp(0, D - 1)
+            occ |= ok & (table[g[:, 0], g[:, 1], g[:, 2]] >= 0)
+        return occ
+
     def warp_maps(self, use_match=False):
         """implicit_surface.py:229-241: FPN levels 0, 1, 2 at the finest level's size (texel4), from `features` or - once
         training is past step 2 - from the frozen `match_features`; built on first use."""
@@ -200,6 +213,14 @@ class ImplicitSurface(nn.Module):
             self._packed = (ver, sdf_w, ops.blend_pack_weights(sd, device, "color_network.", self.blend_precision))
         return self._packed[1], self._packed[2]
 
+    def smooth_weights(self, device):
+        """fp32 image of sdf_network for the second-order kernel (training only), cached with the other re-layouts."""
+        self.packed_weights(device)                  # refreshes self._packed when parameters changed
+        if len(self._packed) == 3:
+            sd = {k: v for k, v in self.state_dict().items()}
+            self._packed = self._packed + (ops.sdf_smooth_pack_weights(sd, device, "sdf_network."),)
+        return self._packed[3]
+
     def scene(self, matching_volume, volumes, sparse_idxes, mask_volumes, features, imgs, intrs, c2ws):
         """mask_volumes are redundant with the index tables (mask == table >= 0, volume.py:112-130) and unused."""
         return SceneVolumes(matching_volume, volumes, sparse_idxes, features, imgs, intrs, c2ws)
@@ -213,6 +234,7 @@ class ImplicitSurface(nn.Module):
         patch_warp: also the training outputs ref_gray_val / sampled_gray_val (:217-245, row a15): the 11x11 homography
         patches of the stacked feature maps around every ray's SDF zero crossing (from match_features once step >= 2)."""
         dev = rays_o.device
+        self._random_pts = None
         if jitter is None and self.perturb > 0:
             jitter = self.draw_jitter(rays_o.shape[0])
         if jitter is not None:
@@ -262,6 +284,16 @@ class ImplicitSurface(nn.Module):
             maps = scene.warp_maps(use_match=not (step is None or step < 2))
             out["ref_gray_val"], out["sampled_gray_val"] = ops.patch_warp(pts0, g0, maps, scene.cams)
             out["pts_sdf0"], out["gradients_sdf0"] = pts0, g0
+            # smooth_error (:100-103, :172): |H.1| of the SDF averaged over the masked-in samples inside the unit sphere
+            smooth, _ = ops.sdf_smooth(st["pts"], scene.sv, self.smooth_weights(dev), active_idx=act)
+            inside = ((torch.linalg.norm(st["pts"], ord=2, dim=-1) < 1.0) & st["vmask"].bool()).float()
+            out["smooth_error"] = (torch.linalg.norm(smooth, ord=2, dim=-1) * inside).sum() / (inside.sum() + 1e-5)
+            # sparse_sdf (:174-178, :255): the SDF at 1024 uniform points (zero where no level is occupied) + at the samples
+            pr = self._random_pts if self._random_pts is not None else torch.rand([1024, 3]) * 2 - 1
+            pr = pr.to(dev, torch.float32).contiguous()
+            occ = scene.occupied_any(pr)
+            sdf_r, _ = ops.sdf_mlp(pr, scene.sv, sdf_w, mask=occ.to(torch.uint8), want_grad=False)
+            out["sparse_sdf"] = torch.cat([torch.where(occ, sdf_r, torch.zeros_like(sdf_r)), sdf]).view(-1, 1)
         return out
 
     def draw_jitter(self, n_rays, ref_chunk=None):
@@ -274,7 +306,7 @@ class ImplicitSurface(nn.Module):
         for s0 in range(0, n_rays, step):
             b = min(step, n_rays - s0)
             cols.append(torch.cat([torch.rand([b, 1]) - 0.5 for _ in self.n_samples], dim=1))
-            torch.rand([1024, 3])
+            self._random_pts = torch.rand([1024, 3]) * 2 - 1          # sparse_sdf's points of a training forward
         return torch.cat(cols, dim=0) if cols else torch.zeros(0, len(self.n_samples))
 
     def render(self, rays_o, rays_d, near, far, matching_volume, volumes, sparse_idxes, mask_volumes, imgs, features,

@@ -305,6 +305,42 @@ def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True, compact_active=True
     return sdf, grad
 
 
+def sdf_smooth_pack_weights(sd, device, prefix="implicit_surface.sdf_network."):
+    """fp32 image of the SDF network for surf_sdf_smooth (both orientations of every matrix)."""
+    layers = sdf_effective_weights(sd, prefix)
+    sdf_pack_weights_host(layers)  # shape validation only
+    Ws = [_host_f32(W) for W, _ in layers]
+    bs = [_host_f32(b) for _, b in layers]
+    L = _lib.lib()
+    out = np.zeros(L.surf_sdf_smooth_packed_floats(), dtype=np.float32)
+    wp = (ctypes.c_void_p * 7)(*[w.ctypes.data for w in Ws])
+    bp = (ctypes.c_void_p * 7)(*[b.ctypes.data for b in bs])
+    _lib.check(L.surf_sdf_smooth_pack_weights(wp, bp, _np_ptr(out)), "surf_sdf_smooth_pack_weights")
+    return torch.from_numpy(out).to(device)
+
+
+def sdf_smooth(pts, volumes, packed, active_idx=None, want_grad=False):
+    """sdf_network.py:143-152: smooth = d/dx sum_a (d sdf/d x_a) at n points.  Returns (smooth (n,3), grad (n,3) or
+    None); rows not in active_idx stay zero (implicit_surface.py:100-103)."""
+    _chk(pts, torch.float32, "pts")
+    _chk(packed, torch.float32, "packed weights")
+    n = pts.shape[0]
+    if active_idx is not None:
+        smooth = torch.zeros(n, 3, dtype=torch.float32, device=pts.device)
+        grad = torch.zeros(n, 3, dtype=torch.float32, device=pts.device) if want_grad else None
+        n_eval = int(active_idx.shape[0])
+        if n_eval == 0:
+            return smooth, grad
+    else:
+        smooth = torch.empty(n, 3, dtype=torch.float32, device=pts.device)
+        grad = torch.empty(n, 3, dtype=torch.float32, device=pts.device) if want_grad else None
+        n_eval = n
+    rc = _lib.lib().surf_sdf_smooth(_p(pts), _p(active_idx), n_eval, volumes._vp, volumes._tp, volumes._dp, volumes.n,
+                                    _p(packed), _p(grad), _p(smooth), _stream())
+    _lib.check(rc, "surf_sdf_smooth")
+    return smooth, grad
+
+
 class Cameras:
     """Host copies of the 4x4 camera matrices the kernels take by value."""
 

@@ -99,6 +99,35 @@ def test_sdf_mlp_matches_oracle_and_golden(weights, gpu_scene, golden_render):
     rel_close(sdf2, exp, 0, 1e-4)
 
 
+def test_sdf_smooth_matches_golden(weights, gpu_scene, golden_render):
+    """sdf_network.py:143-152: the second autograd.grad (H.1, |values| up to ~2e2) and the first, against the reference's own
+    outputs and the oracle's closed form; ragged counts, the compacted index list, untouched rows."""
+    from surf_amd import ops
+    d = dev()
+    pts = golden_render["pts"]
+    w = ops.sdf_smooth_pack_weights(weights, d)
+    smooth, grad = ops.sdf_smooth(pts.to(d).contiguous(), gpu_scene["sv"], w, want_grad=True)
+    torch.cuda.synchronize()
+    rel_close(grad, golden_render["sdf_grad"], 1e-4, 1e-4)
+    rel_close(smooth, golden_render["sdf_smooth"], 2e-3, 1e-3)
+    c = gpu_scene["cpu"]
+    g = torch.Generator().manual_seed(17)
+    for n in (1, 3, 4, 5, 1023):
+        p = (torch.rand(n, 3, generator=g) * 2 - 1) * 0.9
+        phi, jphi, mphi = O.lookup_sparse_volume(p, c["vols"], c["tabs"], with_mixed=True)
+        g_o, s_o = O.sdf_mlp_smooth(O.sdf_weights(weights), p, phi, jphi, mphi)
+        s_k, g_k = ops.sdf_smooth(p.to(d).contiguous(), gpu_scene["sv"], w, want_grad=True)
+        rel_close(g_k, g_o, 1e-4, 1e-4)
+        rel_close(s_k, s_o, 2e-3, 1e-3)
+    idx = torch.arange(0, 1023, 3, dtype=torch.int32)
+    s_i, _ = ops.sdf_smooth(p.to(d).contiguous(), gpu_scene["sv"], w, active_idx=idx.to(d))
+    s_i = s_i.cpu()
+    keep = torch.zeros(1023, dtype=torch.bool)
+    keep[idx.long()] = True
+    assert torch.equal(s_i[keep], s_k.cpu()[keep])
+    assert (s_i[~keep] == 0).all()
+
+
 def test_sdf_mlp_many_tiles_consistent(weights, gpu_scene):
     """More tiles than resident waves: every wave loops; results must not depend on the tile -> wave map."""
     from surf_amd import ops
@@ -535,9 +564,23 @@ def test_patch_warp_matches_golden(scene, weights, gpu_scene, golden_fpn, golden
                                           gpu_scene["imgs_t4"], gpu_scene["cams"])
     R = scene["rays_o"].shape[0]
     near, far = scene["near"].repeat(R, 1).to(d), scene["far"].repeat(R, 1).to(d)
+    torch.manual_seed(21)
     out = model.render_scene(scene["rays_o"].to(d), scene["rays_d"].to(d), near, far, sc, 1.0, patch_warp=True)
     torch.cuda.synchronize()
     rel_close(out["sdf_depth"], gt["sdf_depth"], 1e-3, 2e-5)
+    # smooth_error (implicit_surface.py:172) against the reference's scalar
+    rel_close(out["smooth_error"], gt["smooth_error"], 1e-3, 1e-4)
+    # sparse_sdf (:174-178, :255): 1024 uniform points (perturb = 0: drawn inside render_scene) + the ray samples
+    torch.manual_seed(21)
+    pr = torch.rand([1024, 3]) * 2 - 1
+    c = gpu_scene["cpu"]
+    occ = torch.stack([O.lookup_volume_nearest(pr, mk) for mk in c["masks"]], dim=-1).any(dim=-1)
+    assert 50 < int(occ.sum()) < 1000
+    phi = O.lookup_sparse_volume(pr, c["vols"], c["tabs"])
+    sdf_r = O.sdf_mlp(O.sdf_weights(weights), pr, phi)[0] * occ.float()
+    assert tuple(out["sparse_sdf"].shape) == (1024 + R * sum(CFG["n_samples"]), 1)
+    rel_close(out["sparse_sdf"][:1024, 0], sdf_r, 0, 1e-4)
+    assert torch.equal(out["sparse_sdf"][1024:, 0], out["sdf"].reshape(-1))
     hit = (gt["mid_inside_sphere"].reshape(-1) > 0).to(d)
     rel_close(out["ref_gray_val"], gt["ref_gray_val"], 1e-3, 2e-4)
     err = (out["sampled_gray_val"][:, hit].cpu() - gt["sampled_gray_val"][:, hit.cpu()]).abs()

@@ -88,6 +88,16 @@ def test_a11_sdf_mlp_and_gradient(weights, golden_pipe, golden_render):
     close(grad, gr["sdf_grad"], atol=2e-5, rtol=1e-4)
 
 
+def test_a11_sdf_smooth_hessian_row_sums(weights, golden_pipe, golden_render):
+    """sdf_network.py:143-150: the second autograd.grad = H.1; values reach ~2e2 at the golden points."""
+    vols, tabs, _, _ = pipeline_views(golden_pipe)
+    gr = golden_render
+    phi, jphi, mphi = O.lookup_sparse_volume(gr["pts"], vols, tabs, with_mixed=True)
+    grad, smooth = O.sdf_mlp_smooth(O.sdf_weights(weights), gr["pts"], phi, jphi, mphi)
+    close(grad, gr["sdf_grad"], atol=2e-5, rtol=1e-4)
+    close(smooth, gr["sdf_smooth"], atol=5e-4, rtol=1e-4)
+
+
 def test_a12_a13_feature_lookup_and_blending(scene, weights, golden_fpn, golden_render):
     feats = [golden_fpn[f"out{i}"] for i in range(4)][::-1]
     gr = golden_render
