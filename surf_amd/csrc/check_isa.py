@@ -5,11 +5,12 @@ the vector-memory operations the source issues between two workgroup barriers.  
 (hipcc --cuda-device-only -S) and the resource-usage remarks of the same compile and refuses the build when
 
   * a checked kernel spills to scratch memory (spill loads / stores are uncounted, FLAT-class operations), or
-  * any `s_waitcnt vmcnt(N)` that directly precedes an `s_barrier` has FEWER than N vector-memory instructions between
-    it and the previous barrier: the wait would then leave operations of the previous chunk - possibly the DMA of the
-    chunk about to be read - in flight (more than N is stricter than needed and allowed at the few seams where the
-    source says so - the prologue, the first chunk of a round (which follows the gather) and the forward -> backward seam:
-    at most `--max-loose` (default 3) barriers per kernel).
+  * any `s_waitcnt vmcnt(N)` that directly precedes an `s_barrier` has FEWER than N vector-memory instructions in the
+    W barrier intervals before it (W = the `; surf_ring_window W` comment stage_barrier emits with the wait: ring length
+    - 2; 1 when absent): the wait would then leave operations of an older chunk - possibly the DMA of the chunk about to
+    be read - in flight (more than N is stricter than needed and allowed at the few seams where the source says so - the
+    prologue, the first chunk of a round (which follows the gather) and the forward -> backward seam, each of which
+    falls into W windows: at most `--max-loose` (default 3 W) barriers per kernel).
 
 usage: check_isa.py <file.s> <remarks.txt> <kernel name substring> [--max-loose K]
 """
@@ -19,7 +20,7 @@ import sys
 
 def main():
     asm_path, remarks_path, needle = sys.argv[1:4]
-    max_loose = int(sys.argv[sys.argv.index("--max-loose") + 1]) if "--max-loose" in sys.argv else 3
+    max_loose_arg = int(sys.argv[sys.argv.index("--max-loose") + 1]) if "--max-loose" in sys.argv else None
     lines = open(asm_path).read().split("\n")
     heads = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
     heads.append(len(lines))
@@ -31,17 +32,26 @@ def main():
         if needle not in name:
             continue
         n_kernels += 1
-        cnt, last_wait, pairs = 0, None, []
+        cnt, last_wait, pairs, window, hist, max_w = 0, None, [], 1, [], 1
         for i in range(heads[k], heads[k + 1]):
             l = lines[i]
             if vm.match(l):
                 cnt += 1
+            m = re.search(r"surf_ring_window (\d+)", l)
+            if m:
+                window = int(m.group(1))
+                max_w = max(max_w, window)
             m = re.search(r"s_waitcnt vmcnt\((\d+)\)", l)
             if m:
                 last_wait = (int(m.group(1)), i)
             if re.match(r"^\s+s_barrier", l):
-                pairs.append((last_wait[0] if last_wait and last_wait[1] == i - 1 else None, cnt, i + 1))
-                cnt = 0
+                hist.append(cnt)
+                counted_wait = last_wait is not None and last_wait[1] == i - 1
+                # straight-line position only: the round loop's back edge (first chunks of a round) sees the prologue's
+                # intervals here, which hold no fewer operations than the tail of a round - those barriers are "loose"
+                pairs.append((last_wait[0] if counted_wait else None, sum(hist[-window:]), i + 1))
+                cnt, window = 0, 1
+        max_loose = max_loose_arg if max_loose_arg is not None else 3 * max_w
         counted = [p for p in pairs if p[0] is not None]
         under = [p for p in counted if p[1] < p[0]]
         loose = [p for p in counted if p[1] > p[0]]
@@ -50,8 +60,8 @@ def main():
             print(f"check_isa: {name}: no `s_waitcnt vmcnt(N); s_barrier` pair found (was the kernel restructured?)", file=sys.stderr)
             ok = False
         for n, c, ln in under:
-            print(f"check_isa: {name}: line {ln}: vmcnt({n}) but only {c} vector-memory instructions since the previous "
-                  f"barrier", file=sys.stderr)
+            print(f"check_isa: {name}: line {ln}: vmcnt({n}) but only {c} vector-memory instructions in the barrier "
+                  f"intervals it spans", file=sys.stderr)
             ok = False
         if len(loose) > max_loose:
             print(f"check_isa: {name}: {len(loose)} barriers wait for more than they need (allowed: {max_loose}): "

@@ -45,9 +45,10 @@ constexpr int n_bwd_chunks() { int n = 0; for (int l = 0; l < 6; ++l) n += BWD_N
 constexpr int N_BWD_CHUNKS = n_bwd_chunks();
 constexpr int N_CHUNKS = N_FWD_CHUNKS + N_BWD_CHUNKS;
 
+constexpr int MAX_PAD = 4;  // empty chunks that round the gradient stream up to a multiple of the ring length
 struct ChunkTable {
-  int off[N_CHUNKS + 1];  // byte offset into the packed stream
-  int ks[N_CHUNKS + 1];
+  int off[N_CHUNKS + MAX_PAD + 1];  // byte offset into the packed stream
+  int ks[N_CHUNKS + MAX_PAD + 1];
 };
 constexpr ChunkTable make_chunks(int np) {  // one k-step = np pieces x 64 lanes x 16 B
   ChunkTable c{};
@@ -56,8 +57,7 @@ constexpr ChunkTable make_chunks(int np) {  // one k-step = np pieces x 64 lanes
     for (int t = 0; t < 4; ++t) { c.off[n] = o; c.ks[n] = fwd_ks(l); o += fwd_ks(l) * np * 1024; ++n; }
   for (int l = 5; l >= 0; --l)
     for (int t = 0; t < BWD_NT[l]; ++t) { c.off[n] = o; c.ks[n] = bwd_ks(l); o += bwd_ks(l) * np * 1024; ++n; }
-  c.off[n] = o;
-  c.ks[n] = 0;
+  for (; n <= N_CHUNKS + MAX_PAD; ++n) { c.off[n] = o; c.ks[n] = 0; }
   return c;
 }
 constexpr int fwd_chunk(int l, int t) { return l * 4 + t; }
@@ -114,10 +114,21 @@ struct FragT { u32x4 p[NP]; };  // B-operand fragments of a 16-wide k-step: NP p
 #define SURF_X_NOSPLIT 0
 #endif
 
+// LDS ring length of the gradient kernels (chunks in flight + the one being read), per policy.  Measured (round 2, f16x2,
+// half image): a fourth slot (one more chunk of slack before the counted vmcnt) is SLOWER, 47.4-48.6 vs 46.3-46.5 ms, and
+// costs ~30-40 registers (bf16x3 then spills): the barrier wait is not store-acknowledge latency.  3 is the default.
+#ifndef SURF_SDF_NSLOT_BF3
+#define SURF_SDF_NSLOT_BF3 3
+#endif
+#ifndef SURF_SDF_NSLOT_H2
+#define SURF_SDF_NSLOT_H2 3
+#endif
+
 struct PolBf3 {
   // NA: accumulator chains (two independent ones measured no faster); PF: k-steps of LDS read-ahead (2, 3: no faster)
   static constexpr int NP = 3, NA = 1, PF = 1;
   static constexpr int occ(bool) { return 1; }  // three-piece activations need the whole register file
+  static constexpr int nslot(bool) { return SURF_SDF_NSLOT_BF3; }  // LDS ring length (36 KB slots)
   static constexpr bool DEEP = true;   // backward softplus' reads two chunks ahead (registers to spare)
   static constexpr bool DEEPJ = true;  // feature Jacobian fetched under the last backward chunk
   static constexpr ChunkTable CH = make_chunks(NP);
@@ -163,6 +174,7 @@ struct PolH2 {
   // (51.0 vs 49.2 ms) and - with the two-chunk read-ahead enabled - FAILED the race screen (scripts/stress_sdf.py)
   // in every launch, for a reason not understood; at 512 registers nothing spills and the screen is clean.
   static constexpr int occ(bool grad) { return grad ? 1 : 2; }
+  static constexpr int nslot(bool grad) { return grad ? SURF_SDF_NSLOT_H2 : 3; }  // 24 KB slots; two workgroups per CU forward-only
   static constexpr bool DEEP = true, DEEPJ = true;
   static constexpr ChunkTable CH = make_chunks(NP);
   struct Acc { f32x16 v[NA]; };
@@ -193,6 +205,11 @@ template <> struct Scales<PolH2> { static constexpr float W = 256.0f, D = 256.0f
 template <class P> constexpr int stream_bytes() { return P::CH.off[N_CHUNKS]; }
 template <class P> constexpr int slot_bytes() { return MAX_KS * P::NP * 1024; }
 template <class P> constexpr int max_blocks(bool grad) { return 256 * P::occ(grad); }
+// chunks per round: the gradient stream is padded with empty chunks to a multiple of the ring length, so that the slot of
+// a chunk (index % ring length) continues across rounds
+template <class P> constexpr int n_chunks(bool grad) {
+  return grad ? (N_CHUNKS + P::nslot(true) - 1) / P::nslot(true) * P::nslot(true) : N_FWD_CHUNKS;
+}
 
 struct SdfArgs {
   const float* pts;
@@ -288,25 +305,26 @@ struct Ctx {
 };
 
 // ---- staging ------------------------------------------------------------------------------------------------------------
-// The chunk stream is cyclic over rounds and lives in a ring of three LDS slots (chunk CI in slot CI % 3; both stream
-// lengths are multiples of 3).  While chunk CI is consumed, chunk CI+2 is in flight by LDS-DMA (buffer_load ... lds,
-// 1 KB per instruction, lane-linear image) and chunk CI+1 is retired at the end of chunk CI by a counted vmcnt.
-// vmcnt retires in issue order, so everything older than that DMA has to be complete too: two chunks of slack keep the
-// softplus' stores of the previous chunk (acknowledged late by L2) out of that wait.
+// The chunk stream is cyclic over rounds and lives in a ring of NS = P::nslot LDS slots (chunk CI in slot CI % NS; the
+// stream lengths are multiples of NS).  While chunk CI is consumed, chunks CI+2 .. CI+NS-1 are in flight by LDS-DMA
+// (buffer_load ... lds, 1 KB per instruction, lane-linear image; chunk CI+NS-1 is issued during chunk CI) and chunk CI+1
+// is retired at the end of chunk CI by a counted vmcnt.  vmcnt retires in issue order, so everything older than that DMA
+// has to be complete too: NS-1 chunks of slack keep the softplus' stores of the chunks before (acknowledged late by L2)
+// out of that wait.
 template <class P> constexpr int n_dma(int ci) { return (P::CH.ks[ci] * P::NP + 3) / 4; }
-template <class P, int CI>
+template <class P, int NS, int CI>
 __device__ __forceinline__ void stage_dma_piece(const Ctx& c, int k) {  // blocks wave + 4 k of chunk CI
   constexpr int OFF = P::CH.off[CI];
   // blocks past the end of a chunk read into the next one / out of range (= 0) and land in the unused tail of the slot
   const int blk = c.wave + 4 * k;
   __builtin_amdgcn_raw_ptr_buffer_load_lds(
-      c.wr, (__attribute__((address_space(3))) void*)(c.lds + (CI % 3) * slot_bytes<P>() + blk * 1024), 16, c.lane16,
+      c.wr, (__attribute__((address_space(3))) void*)(c.lds + (CI % NS) * slot_bytes<P>() + blk * 1024), 16, c.lane16,
       OFF + blk * 1024, 0, 0);
 }
-template <class P, int CI>
+template <class P, int NS, int CI>
 __device__ __forceinline__ void stage_dma(const Ctx& c) {
 #pragma unroll
-  for (int k = 0; k < n_dma<P>(CI); ++k) stage_dma_piece<P, CI>(c, k);
+  for (int k = 0; k < n_dma<P>(CI); ++k) stage_dma_piece<P, NS, CI>(c, k);
 }
 // vector-memory operations a chunk issues by itself, in order: [pre: loads before its DMA] [DMA] [post: stores in fn]
 // which softplus' slice the backward chunk (L, T) loads (layer < 0: none): DEEP: that of the hidden tile computed by the
@@ -324,6 +342,7 @@ constexpr int sprime_tile(bool deep, int L, int T) { return !deep ? T : ((L >= 1
 constexpr int sprime_groups(int layer, int tile) { return (layer == 2 && tile == 3) ? 2 : 4; }
 template <class P> constexpr int vm_pre(int ci) {
   if (ci < N_FWD_CHUNKS) return (ci / 4 == 5 && ci % 4 > 0) ? 4 : 0;  // W6 slices
+  if (ci >= N_CHUNKS) return 0;                                        // padding chunk
   int l = 5, t = ci - N_FWD_CHUNKS;
   while (t >= BWD_NT[l]) { t -= BWD_NT[l]; --l; }
   if (l == 0) return P::DEEPJ ? 12 : 0;  // feature Jacobian for the epilogue
@@ -334,16 +353,25 @@ template <bool GRAD> constexpr int vm_post(int ci) {
   const int l = ci / 4, t = ci % 4;
   return ((l == 0 && t == 0) || (l == 5 && t > 0)) ? 0 : 4;
 }
-// Retire the DMA of chunk CI+1, issued at the top of chunk CI-1: everything this wave issued after it may stay in flight
-// (operations between rounds are not counted, which only makes the wait stricter).  Then the LDS-only workgroup barrier.
+// Retire the DMA of chunk CI+1, issued during chunk CI-(NS-2): everything this wave issued in the chunks after that one
+// may stay in flight (operations between rounds are not counted, which only makes the wait stricter; that DMA's pieces are
+// spread over the k-steps of their chunk, so that chunk's own stores are not counted either).  Then the LDS-only
+// workgroup barrier.  The `surf_ring_window` comment tells check_isa.py how many barrier intervals the count spans.
+template <class P, bool GRAD, int CI, int NCH>
+constexpr int barrier_vmcnt() {
+  constexpr int DIST = P::nslot(GRAD) - 1;
+  int n = 0;
+  for (int j = 0; j + 1 < DIST; ++j) {
+    const int cj = (CI - j + NCH) % NCH;
+    n += vm_pre<P>(cj) + n_dma<P>((cj + DIST) % NCH) + vm_post<GRAD>(cj);
+  }
+  return n;
+}
 template <class P, bool GRAD, int CI, int NCH>
 __device__ __forceinline__ void stage_barrier() {
-  constexpr int PREV = (CI + NCH - 1) % NCH;
-  // (that DMA's pieces are spread over the k-steps of chunk CI-1, so that chunk's own stores are not counted)
-  constexpr int N = vm_pre<P>(CI) + n_dma<P>((CI + 2) % NCH) + vm_post<GRAD>(CI);
-  (void)PREV;
+  constexpr int N = barrier_vmcnt<P, GRAD, CI, NCH>();
   static_assert(N >= 0 && N < 64, "vmcnt");
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+  asm volatile("; surf_ring_window %1\n\ts_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N), "n"(P::nslot(GRAD) - 2) : "memory");
 }
 
 // One chunk: NKS k-steps read from its LDS slot; B fragments come from bsel(ks); fn(ks) = VALU work to interleave.
@@ -351,7 +379,8 @@ template <class P, bool GRAD, int CI, int NCH, class BSel, class F>
 __device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F fn) {
   constexpr int NKS = P::CH.ks[CI];
   constexpr int NP = P::NP;
-  const char* rd = c.lds + (CI % 3) * slot_bytes<P>() + c.lane16;
+  constexpr int NS = P::nslot(GRAD);
+  const char* rd = c.lds + (CI % NS) * slot_bytes<P>() + c.lane16;
   typename P::Acc acc;
 #pragma unroll
   for (int q = 0; q < P::NA; ++q)
@@ -364,7 +393,8 @@ __device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F fn) {
 #pragma unroll
     for (int p = 0; p < NP; ++p)
       if (d < NKS) a_q[d][p] = *reinterpret_cast<const u32x4*>(rd + (d * NP + p) * 1024);
-  constexpr int NXT = (CI + 2) % NCH, ND = n_dma<P>(NXT);
+  constexpr int NXT = (CI + NS - 1) % NCH, ND = n_dma<P>(NXT);
+  if (NKS == 0 && !SURF_X_NODMA) stage_dma<P, NS, NXT>(c);  // padding chunk: nothing to hide the DMA issue behind
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) {
@@ -378,7 +408,7 @@ __device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F fn) {
     fn(ks);
 #pragma unroll
     for (int k = 0; k < ND; ++k)  // this wave's DMA pieces of chunk CI+2, spread over the k-steps behind their MFMAs
-      if (!SURF_X_NODMA && k * NKS / ND == ks) stage_dma_piece<P, NXT>(c, k);
+      if (!SURF_X_NODMA && k * NKS / (ND > 0 ? ND : 1) == ks) stage_dma_piece<P, NS, NXT>(c, k);
 #if SURF_SDF_SGB > 0
     // order of this k-step's instructions: every MFMA is followed by SURF_SDF_SGB VALU operations (conversion work of
     // the previous tile) and the LDS reads of the next k-step's A pieces, so that the matrix pipe never waits behind a
@@ -597,7 +627,7 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
     return hin[ks - NL];
   };
   static_assert(STORES == vm_post<GRAD>(CI) && (LAST ? 4 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
-  raw = run_chunk<P, GRAD, CI, GRAD ? N_CHUNKS : N_FWD_CHUNKS>(c, bsel, fn);
+  raw = run_chunk<P, GRAD, CI, n_chunks<P>(GRAD)>(c, bsel, fn);
 }
 
 template <class P, bool GRAD, int L>
@@ -657,7 +687,7 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
       }
     }
   };
-  return run_chunk<P, true, CI, N_CHUNKS>(c, [&](int ks) __attribute__((always_inline)) -> const Frag& { return din[ks]; }, fn);
+  return run_chunk<P, true, CI, n_chunks<P>(true)>(c, [&](int ks) __attribute__((always_inline)) -> const Frag& { return din[ks]; }, fn);
 }
 template <class P, int L, int T>
 __device__ __forceinline__ void bwd_hidden_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, BwdPend& pend) {
@@ -692,11 +722,22 @@ __device__ __forceinline__ void bwd_layer(const Ctx& c, const FragT<P::NP>* din,
   }
 }
 
+// empty chunks at the end of the gradient stream (n_chunks): their only content is the DMA issue and the barrier
+template <class P, int CI>
+__device__ __forceinline__ void pad_chunks(const Ctx& c, const FragT<P::NP>* any) {
+  if constexpr (CI < n_chunks<P>(true)) {
+    run_chunk<P, true, CI, n_chunks<P>(true)>(
+        c, [&](int ks) __attribute__((always_inline)) -> const FragT<P::NP>& { return any[0]; }, [&](int) __attribute__((always_inline)) {});
+    pad_chunks<P, CI + 1>(c, any);
+  }
+}
+
 template <class P, bool GRAD>
 __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(SdfArgs a) {
   typedef FragT<P::NP> Frag;
-  __shared__ __attribute__((aligned(16))) char lds[3 * slot_bytes<P>()];
-  static_assert(N_CHUNKS % 3 == 0 && N_FWD_CHUNKS % 3 == 0, "slot of a chunk = index % 3");
+  constexpr int NS = P::nslot(GRAD), NCH = n_chunks<P>(GRAD);
+  __shared__ __attribute__((aligned(16))) char lds[NS * slot_bytes<P>()];
+  static_assert(NCH % NS == 0 && NCH - N_CHUNKS <= MAX_PAD && NS >= 3, "slot of a chunk = index % ring length");
   Ctx c;
   c.lane = threadIdx.x & 63;
   c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -712,9 +753,11 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
   const int64_t n_tiles = (a.n + TILE - 1) / TILE;
   const int64_t n_rounds = (n_tiles + WPB - 1) / WPB;
 
-  // stream prologue: chunks 0 and 1 (later rounds inherit them from the last two chunks of the round before)
-  stage_dma<P, 0>(c);
-  stage_dma<P, 1>(c);
+  // stream prologue: chunks 0 .. NS-2 (later rounds inherit them from the last chunks of the round before)
+  stage_dma<P, NS, 0>(c);
+  stage_dma<P, NS, 1>(c);
+  if (NS > 3) stage_dma<P, NS, 2>(c);
+  if (NS > 4) stage_dma<P, NS, 3>(c);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #ifdef SURF_SDF_TIMING
   c.tprev = __builtin_readcyclecounter();
@@ -818,6 +861,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
         f32x4 unused[4];
         accE += bwd_tile<P, 0, 0, false>(c, hA, dA, pend, unused);
       }
+      pad_chunks<P, N_CHUNKS>(c, hA);
       SURF_T(3);
       float g3[3] = {0.f, 0.f, 0.f};
       {
