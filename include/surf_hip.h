@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 11
+#define SURF_ABI_VERSION 12
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -259,6 +259,17 @@ int surf_matching_depth(const float* mvol, int D, int nv, const float* h_kinv, c
 int surf_spconv(const float* in, int cin, const int32_t* in_table, int D_in, const int32_t* out_coords, int64_t n_out,
                 int mode, const float* weight, int cout, const float* bn_scale, const float* bn_shift, const float* skip,
                 float* out, void* stream);
+/*
+ * The same convolution on the matrix cores for the wide layers (C_in, C_out in {16, 32, 64}): per-offset gather-GEMM,
+ * fp32 operands split exactly into three bf16 pieces (fp32-equivalent results).  surf_spconv_packed_bytes returns 0 for a
+ * channel pair without such a kernel (use surf_spconv); surf_spconv_pack_weights (a device kernel on `stream`) turns the
+ * (27, C_in, C_out) kernel into the split operand image `packed` once per model.
+ */
+int64_t surf_spconv_packed_bytes(int cin, int cout);
+int surf_spconv_pack_weights(const float* weight, int cin, int cout, void* packed, void* stream);
+int surf_spconv_mfma(const float* in, int cin, const int32_t* in_table, int D_in, const int32_t* out_coords, int64_t n_out,
+                     int mode, const void* packed, int cout, const float* bn_scale, const float* bn_shift,
+                     const float* skip, float* out, void* stream);
 
 /* bbox (device int32[6]) = [min x, min y, min z, max x, max y, max z] of coords (n,3) */
 int surf_coords_bbox(const int32_t* coords, int64_t n, int32_t* bbox, void* stream);

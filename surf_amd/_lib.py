@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
 # must equal SURF_ABI_VERSION of include/surf_hip.h (tests/test_host_modules.py compares the two texts); lib() refuses a
 # library built from another header
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -71,6 +71,9 @@ SIGNATURES = {
     "surf_compose_index": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "surf_densify": (c_int, [c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_spconv": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_spconv_packed_bytes": (c_i64, [c_int, c_int]),
+    "surf_spconv_pack_weights": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr]),
+    "surf_spconv_mfma": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_coords_bbox": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     "surf_mark_down_sites": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_int, c_ptr]),
     "surf_sites_from_keys": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr]),

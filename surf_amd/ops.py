@@ -667,8 +667,22 @@ def down_sites(coords, D, rule="dilate"):
     return c2, t2, D2
 
 
-def spconv(x, in_table, out_coords, mode, weight, bn_scale=None, bn_shift=None, skip=None):
-    """One sparse conv + BN(eval) + ReLU (+ skip).  x (n_in, Cin); weight (27, Cin, Cout); returns (n_out, Cout)."""
+def spconv_pack_weights(weight):
+    """(27, Cin, Cout) fp32 device kernel -> split bf16 operand image of surf_spconv_mfma, or None when the channel pair
+    has no matrix-core kernel (Cin or Cout < 16)."""
+    _chk(weight, torch.float32, "weight")
+    cin, cout = int(weight.shape[1]), int(weight.shape[2])
+    nbytes = _lib.lib().surf_spconv_packed_bytes(cin, cout)
+    if nbytes == 0:
+        return None
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    _lib.check(_lib.lib().surf_spconv_pack_weights(_p(weight), cin, cout, _p(packed), _stream()), "surf_spconv_pack_weights")
+    return packed
+
+
+def spconv(x, in_table, out_coords, mode, weight, bn_scale=None, bn_shift=None, skip=None, packed=None):
+    """One sparse conv + BN(eval) + ReLU (+ skip).  x (n_in, Cin); weight (27, Cin, Cout); returns (n_out, Cout).
+    packed (spconv_pack_weights(weight)): run the matrix-core kernel instead of the per-voxel one."""
     _chk(x, torch.float32, "x")
     _chk(in_table, torch.int32, "in_table")
     _chk(out_coords, torch.int32, "out_coords")
@@ -680,6 +694,13 @@ def spconv(x, in_table, out_coords, mode, weight, bn_scale=None, bn_shift=None, 
         return out
     if x.shape[0] == 0:             # no input rows: every lookup misses, the output is relu(bn_shift) (+ skip)
         x = torch.zeros(1, cin, dtype=torch.float32, device=x.device)
+    if packed is not None:
+        _chk(packed, torch.uint8, "packed weights")
+        assert packed.numel() == _lib.lib().surf_spconv_packed_bytes(cin, cout)
+        rc = _lib.lib().surf_spconv_mfma(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords), out_coords.shape[0],
+                                         int(mode), _p(packed), cout, _p(bn_scale), _p(bn_shift), _p(skip), _p(out), _stream())
+        _lib.check(rc, "surf_spconv_mfma")
+        return out
     rc = _lib.lib().surf_spconv(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords), out_coords.shape[0], int(mode),
                                 _p(weight), cout, _p(bn_scale), _p(bn_shift), _p(skip), _p(out), _stream())
     _lib.check(rc, "surf_spconv")

@@ -38,6 +38,18 @@ class _Block(nn.Module):
         shift = bn.bias.detach() - bn.running_mean * scale
         return scale.float().contiguous(), shift.float().contiguous()
 
+    def prepared(self, use_mfma=True):
+        """(kernel, bn scale, bn shift, split-bf16 operand image or None), cached until a parameter or buffer changes
+        (optimiser step, load_state_dict, .to(device)): saves five small launches per convolution and the repacking."""
+        conv, bn = self.net[0], self.net[1]
+        ts = (conv.kernel, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        key = tuple((t._version, t.data_ptr()) for t in ts) + (bool(use_mfma),)
+        if getattr(self, "_prep", None) is None or self._prep[0] != key:
+            w = conv.kernel.detach().float().contiguous()
+            scale, shift = self.bn_affine()
+            self._prep = (key, w, scale, shift, ops.spconv_pack_weights(w) if use_mfma else None)
+        return self._prep[1:]
+
 
 class SparseCostRegNet(nn.Module):
     def __init__(self, d_in, d_out=8, d_base=8, down_rule="dilate"):
@@ -45,6 +57,7 @@ class SparseCostRegNet(nn.Module):
         if down_rule not in ops.DOWN_RULES:
             raise ValueError(f"reg_network.down_rule must be one of {sorted(ops.DOWN_RULES)}, got {down_rule!r}")
         self.down_rule = down_rule
+        self.use_mfma = True      # wide layers on the matrix cores (spconv_mfma.hip); False: every layer on spconv.hip
         if d_base != 8 or d_out != 8 or d_in not in (8, 16):
             raise NotImplementedError("surf_spconv is instantiated for d_base = d_out = 8, d_in in {8, 16} (confs/*.conf)")
         b = d_base
@@ -63,8 +76,8 @@ class SparseCostRegNet(nn.Module):
     def _conv(self, blk, x, table, out_coords, mode, skip=None):
         if self.training:
             raise NotImplementedError("BatchNorm batch statistics (train mode) are not implemented: call .eval()")
-        scale, shift = blk.bn_affine()
-        return ops.spconv(x, table, out_coords, mode, blk.net[0].kernel.detach().float().contiguous(), scale, shift, skip)
+        w, scale, shift, packed = blk.prepared(self.use_mfma)
+        return ops.spconv(x, table, out_coords, mode, w, scale, shift, skip, packed=packed)
 
     def forward(self, feats, coords, D, table=None):
         """feats (N, d_in) fp32, coords (N,3) int32 on the D lattice -> (out (N,8), mid (N,8))  (reg_network.py:69-88)"""

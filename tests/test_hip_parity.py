@@ -309,6 +309,43 @@ def test_sparse_unet_matches_oracle(golden_pipe, rule):
         rel_close(mid, mid_ref, 1e-3, 1e-4)
         rel_close(out, out_ref, 1e-3, 1e-4)
         assert float(mid_ref.abs().max()) > 0.05
+        # the wide layers ran on the matrix cores (spconv_mfma.hip); the per-voxel fp32 kernels give the same network
+        for sub in net.nets:
+            sub.use_mfma = False
+        out_v, mid_v = net(feats.to(d), coords.to(d).contiguous(), D, s)
+        for sub in net.nets:
+            sub.use_mfma = True
+        rel_close(mid, mid_v, 1e-5, 2e-6)
+        rel_close(out, out_v, 1e-5, 2e-6)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 32), (32, 16)])
+def test_spconv_mfma_matches_per_voxel_kernel(cin, cout):
+    """surf_spconv_mfma (bf16x3 split on the matrix cores) against surf_spconv (fp32 FMAs) on a random sparse lattice:
+    the three modes, skip / no skip, BN / no BN, a voxel count that leaves a partial wavefront tile."""
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    D = 24
+    occ = torch.rand(D, D, D, generator=g) < 0.3
+    coords = occ.nonzero().to(torch.int32)
+    coords = coords[: coords.shape[0] - (coords.shape[0] % 128) + 37].contiguous().to(d)
+    table = ops.table_from_coords(coords, D)
+    cd, tcd, D2 = ops.down_sites(coords, D, "dilate")
+    w = (torch.randn(27, cin, cout, generator=g) / (27 * cin) ** 0.5).to(d)
+    packed = ops.spconv_pack_weights(w)
+    assert packed is not None and ops.spconv_pack_weights(torch.zeros(27, 8, 16, device=d)) is None
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(d), (torch.randn(cout, generator=g) * 0.1).to(d)
+    x_f = torch.randn(coords.shape[0], cin, generator=g).to(d)
+    x_c = torch.randn(cd.shape[0], cin, generator=g).to(d)
+    cases = [(x_f, table, coords, ops.SUBM), (x_f, table, cd, ops.DOWN), (x_c, tcd, coords, ops.UP)]
+    for x, tab, oc, mode in cases:
+        skip = torch.randn(oc.shape[0], cout, generator=g).to(d)
+        for sc, sh, sk in ((scale, shift, skip), (scale, shift, None), (None, None, None)):
+            ref = ops.spconv(x, tab, oc, mode, w, sc, sh, sk)
+            out = ops.spconv(x, tab, oc, mode, w, sc, sh, sk, packed=packed)
+            rel_close(out, ref, 1e-5, 1e-5)      # two fp32 summation orders of up to 27 x 64 terms
+            assert float(ref.abs().max()) > 0.1
 
 
 def test_fpn_matches_golden(scene, weights, golden_fpn):
