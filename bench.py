@@ -141,6 +141,26 @@ def pmc_traffic(kernel):
     return None, f"{name} has no row for {kernel}"
 
 
+def pmc_mfma_busy(kernel):
+    """Matrix-pipe utilisation of `kernel` from the same committed PMC summary: SQ_VALU_MFMA_BUSY_CYCLES /
+    (GRBM_GUI_ACTIVE per XCD x 256 CUs x 4 SIMDs) (GRBM_GUI_ACTIVE is summed over the 8 XCDs).  None when stale / absent."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_pmc.csv")), key=os.path.basename)
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        lines = f.readlines()
+    sha = [l.split(":", 1)[1].strip() for l in lines if l.startswith("# csrc_sha256:")]
+    if not sha or sha[-1] != csrc_digest():
+        return None
+    for r in csv.DictReader(l for l in lines if not l.startswith("#")):
+        if r["kernel"] == kernel and r.get("SQ_VALU_MFMA_BUSY_CYCLES") and r.get("GRBM_GUI_ACTIVE"):
+            gui = float(r["GRBM_GUI_ACTIVE"]) / 8.0
+            return float(r["SQ_VALU_MFMA_BUSY_CYCLES"]) / (gui * 256 * 4) if gui > 0 else None
+    return None
+
+
 def cpu_baseline(model, cpu_scene, rays_o, rays_d, near, far, n_samples, budget_s, gpu_out, ray_idx):
     """Time the CPU oracle on 256-ray chunks (implicit_surface.py:367) of a strided ray subset."""
     from oracle import surf_oracle as O
@@ -487,6 +507,7 @@ def run_rank(args):
         roofline_kernels = [{
             "kernel": bl_kernel, "bound": "mfma", "achieved": bl_ach, "peak": bl_pipe_peak / bl_prod, "unit": "TFLOP/s",
             "frac": bl_ach / (bl_pipe_peak / bl_prod), "traffic": bl_traffic, "traffic_source": bl_src,
+            "mfma_busy": pmc_mfma_busy(bl_kernel),
             "avg_launch_ms": bl_ms, "flop_per_sample": (nv - 1) * FLOP_PER_SAMPLE_BLEND_PER_VIEW, "samples_per_launch": active,
             "pipe": bl_pipe, "mfma_products_per_fp32_product": bl_prod, "frac_of_fp32_mfma_peak": bl_ach / 157.3}]
         recs = sorted((r for per_rank in records for r in per_rank), key=lambda r: r["scene"])
@@ -515,6 +536,8 @@ def run_rank(args):
             "roofline": {"kernel": sdf_kernel, "bound": "mfma", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": traffic, "traffic_source": traffic_src,
+                         # matrix-pipe busy fraction from the PMC pass of the same profile (None when stale)
+                         "mfma_busy": pmc_mfma_busy(sdf_kernel),
                          "flop_per_sample": FLOP_PER_SAMPLE_SDF, "samples_per_launch": active,
                          "avg_launch_ms": sdf_ms, "pipe": sdf_pipe, "pipe_dense_peak": pipe_peak,
                          "mfma_products_per_fp32_product": n_prod, "frac_of_fp32_mfma_peak": achieved / 157.3,
