@@ -13,8 +13,10 @@ from bench import csrc_digest  # noqa: E402  (ties the summary to the kernel sou
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-OURS = ("sdf_mlp", "blend_kernel", "blend_split", "mcubes", "patch_warp", "ray_setup", "composite_kernel", "pack_texel4", "costvol", "densify", "matching_depth",
-        "filter", "spconv", "fpn_", "surf_")
+def ours(name):
+    """every kernel of libsurf_hip.so lives in an anonymous namespace; torch's own kernels are at::native::..."""
+    return "(anonymous namespace)::" in name and "at::" not in name and "rocprim" not in name
+
 
 f = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(f)))
@@ -24,7 +26,7 @@ with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w") as w:
     w.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
     other = 0
     for r in rows:
-        if any(s in r["Name"] for s in OURS) and "at::native" not in r["Name"]:
+        if ours(r["Name"]):
             w.write(",".join('"%s"' % r[k] if k == "Name" else r[k]
                              for k in ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"]) + "\n")
         else:
@@ -38,7 +40,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_mfma"):
         continue
     for row in csv.DictReader(open(fs[0])):
         k = row["Kernel_Name"]
-        if any(s in k for s in OURS) and "at::native" not in k:
+        if ours(k):
             short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
             agg[short].setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 with open(os.path.join(dst, f"{tag}_bench_pmc.csv"), "w") as w:

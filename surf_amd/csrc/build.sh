@@ -17,7 +17,9 @@ pids=()
 for s in "${SRCS[@]}"; do
   o="${HERE}/../_obj/$(basename "${s%.hip}").o"
   objs+=("$o")
-  if [[ ! -f "$o" || "$s" -nt "$o" || "${HERE}/common.h" -nt "$o" || "${HERE}/../../include/surf_hip.h" -nt "$o" ]]; then
+  stale=0
+  for hdr in "${HERE}"/*.h "${HERE}/../../include/surf_hip.h"; do [[ "$hdr" -nt "$o" ]] && stale=1; done
+  if [[ ! -f "$o" || "$s" -nt "$o" || $stale == 1 ]]; then
     "${HIPCC}" "${FLAGS[@]/-shared/}" -c "$s" -o "$o" &
     pids+=($!)
     case "$(basename "$s")" in sdf_mlp_split.hip) check_isa="${check_isa:-} $(basename "${s%.hip}")";; esac

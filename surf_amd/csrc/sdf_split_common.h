@@ -1,0 +1,400 @@
+// Shared pieces of the split-operand SDF kernels (sdf_mlp_split.hip, sdf_mlp_v2.hip): network shape and weight-stream
+// tables, precision policies, scratch layout, softplus, sparse gather and positional encoding.  Included once per
+// translation unit (everything lives in an anonymous namespace).
+#pragma once
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+
+constexpr int HID = 128, NE = 27, H2 = 101, TILE = 32;
+constexpr int BWD_NT[6] = {1, 5, 5, 6, 5, 5};
+constexpr int WPB = 4;
+constexpr int MAX_KS = 12;
+
+// ---- chunk stream ------------------------------------------------------------------------------------------------
+// forward chunk (l, t): k-steps = [e s=0,1 (l = 0, 3)][phi s=0,1 (l >= 1)][hidden (tt, s) ...]: the hidden fragments of
+// the previous layer's last tile are still being converted during the first k-steps of tile 0
+constexpr int fwd_nh(int l) { return l == 0 ? 0 : (l == 3 ? 7 : 8); }
+constexpr int fwd_ne(int l) { return (l == 0 || l == 3) ? 2 : 0; }
+constexpr int fwd_np(int l) { return l == 0 ? 0 : 2; }
+constexpr int fwd_nl(int l) { return fwd_ne(l) + fwd_np(l); }
+constexpr int fwd_ks(int l) { return fwd_nh(l) + fwd_nl(l); }
+constexpr int bwd_ks(int l) { return l == 2 ? 7 : 8; }
+constexpr int N_FWD_CHUNKS = 24;
+constexpr int n_bwd_chunks() { int n = 0; for (int l = 0; l < 6; ++l) n += BWD_NT[l]; return n; }
+constexpr int N_BWD_CHUNKS = n_bwd_chunks();
+constexpr int N_CHUNKS = N_FWD_CHUNKS + N_BWD_CHUNKS;
+
+constexpr int MAX_PAD = 4;  // empty chunks that round the gradient stream up to a multiple of the ring length
+struct ChunkTable {
+  int off[N_CHUNKS + MAX_PAD + 1];  // byte offset into the packed stream
+  int ks[N_CHUNKS + MAX_PAD + 1];
+};
+constexpr ChunkTable make_chunks(int np) {  // one k-step = np pieces x 64 lanes x 16 B
+  ChunkTable c{};
+  int n = 0, o = 0;
+  for (int l = 0; l < 6; ++l)
+    for (int t = 0; t < 4; ++t) { c.off[n] = o; c.ks[n] = fwd_ks(l); o += fwd_ks(l) * np * 1024; ++n; }
+  for (int l = 5; l >= 0; --l)
+    for (int t = 0; t < BWD_NT[l]; ++t) { c.off[n] = o; c.ks[n] = bwd_ks(l); o += bwd_ks(l) * np * 1024; ++n; }
+  for (; n <= N_CHUNKS + MAX_PAD; ++n) { c.off[n] = o; c.ks[n] = 0; }
+  return c;
+}
+constexpr int fwd_chunk(int l, int t) { return l * 4 + t; }
+constexpr int bwd_chunk(int l, int t) {
+  int n = N_FWD_CHUNKS;
+  for (int i = 5; i > l; --i) n += BWD_NT[i];
+  return n + t;
+}
+// fp32 tail of the packed buffer (floats): W6[0] in lane order, b6
+constexpr int TAIL_W6H = 0;               // [h][64]
+constexpr int TAIL_W6P = TAIL_W6H + 128;  // [h][16]
+constexpr int TAIL_B6 = TAIL_W6P + 32;
+constexpr int TAIL_FLOATS = TAIL_B6 + 4;
+
+// per-wave scratch slot (floats): softplus' of layers 0..4 + feature Jacobian (same layout as sdf_mlp.hip)
+constexpr int SCR_S = 5 * 16 * 64 * 4;
+constexpr int SCR_J = 12 * 64 * 4;
+constexpr int SCR_SLOT = SCR_S + SCR_J;
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NP>
+struct FragT { u32x4 p[NP]; };  // B-operand fragments of a 16-wide k-step: NP pieces x 4 dwords (8 x 16 bit)
+
+// ---- precision policies ----------------------------------------------------------------------------------------------
+#ifndef SURF_X_NOGATHER  // timing experiments only (wrong results)
+#define SURF_X_NOGATHER 0
+#endif
+#ifndef SURF_X_NOSCRATCH
+#define SURF_X_NOSCRATCH 0
+#endif
+#ifndef SURF_X_NOMMA
+#define SURF_X_NOMMA 0
+#endif
+#ifndef SURF_X_NOLDS
+#define SURF_X_NOLDS 0
+#endif
+#ifndef SURF_X_NOSOFTPLUS
+#define SURF_X_NOSOFTPLUS 0
+#endif
+#ifndef SURF_SDF_SGB  // > 0: sched_group_barrier pattern of the k-steps (VALU operations per MFMA)
+#define SURF_SDF_SGB 0
+#endif
+#ifndef SURF_X_NODMA  // no LDS-DMA inside the chunks (the ring keeps whatever the prologue loaded)
+#define SURF_X_NODMA 0
+#endif
+#ifndef SURF_X_NOSPLIT  // activations "split" by plain bit copies (no conversion arithmetic)
+#define SURF_X_NOSPLIT 0
+#endif
+
+// LDS ring length of the gradient kernels (chunks in flight + the one being read), per policy.  Measured (round 2, f16x2,
+// half image): a fourth slot (one more chunk of slack before the counted vmcnt) is SLOWER, 47.4-48.6 vs 46.3-46.5 ms, and
+// costs ~30-40 registers (bf16x3 then spills): the barrier wait is not store-acknowledge latency.  3 is the default.
+#ifndef SURF_SDF_NSLOT_BF3
+#define SURF_SDF_NSLOT_BF3 3
+#endif
+#ifndef SURF_SDF_NSLOT_H2
+#define SURF_SDF_NSLOT_H2 3
+#endif
+
+struct PolBf3 {
+  // NA: accumulator chains (two independent ones measured no faster); PF: k-steps of LDS read-ahead (2, 3: no faster)
+  static constexpr int NP = 3, NA = 1, PF = 1;
+  static constexpr int occ(bool) { return 1; }  // three-piece activations need the whole register file
+  static constexpr int nslot(bool) { return SURF_SDF_NSLOT_BF3; }  // LDS ring length (36 KB slots)
+  static constexpr bool DEEP = true;   // backward softplus' reads two chunks ahead (registers to spare)
+  static constexpr bool DEEPJ = true;  // feature Jacobian fetched under the last backward chunk
+  static constexpr ChunkTable CH = make_chunks(NP);
+  struct Acc { f32x16 v[NA]; };
+  static __device__ __forceinline__ uint32_t pack2(float a, float b) {
+    bf16x2 v;
+    v[0] = (__bf16)a;
+    v[1] = (__bf16)b;
+    uint32_t u = __builtin_bit_cast(uint32_t, v);
+    asm volatile("" : "+v"(u));  // keep the packed value: the residuals below come from its two halves
+    return u;
+  }
+  static __device__ __forceinline__ void split(float a, float b, uint32_t (&p)[NP]) {
+    p[0] = pack2(a, b);
+    const float ra = a - __builtin_bit_cast(float, p[0] << 16), rb = b - __builtin_bit_cast(float, p[0] & 0xffff0000u);
+    p[1] = pack2(ra, rb);
+    p[2] = pack2(ra - __builtin_bit_cast(float, p[1] << 16), rb - __builtin_bit_cast(float, p[1] & 0xffff0000u));
+  }
+  static __device__ __forceinline__ void mma(Acc& acc, const u32x4 (&a)[NP], const FragT<NP>& b) {
+#define SURF_MF(q, x, y) \
+  acc.v[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[x]), __builtin_bit_cast(bf16x8, b.p[y]), acc.v[q], 0, 0, 0)
+    SURF_MF(0, 2, 0);  // smallest terms first
+    SURF_MF(NA - 1, 0, 2);
+    SURF_MF(0, 1, 1);
+    SURF_MF(NA - 1, 1, 0);
+    SURF_MF(0, 0, 1);
+    SURF_MF(NA - 1, 0, 0);
+#undef SURF_MF
+  }
+  static __device__ __forceinline__ f32x16 finish(const Acc& acc) {
+    if (NA == 1) return acc.v[0];
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = acc.v[0][i] + acc.v[NA - 1][i];
+    return r;
+  }
+};
+
+struct PolH2 {
+  static constexpr int NP = 2, NA = 1, PF = 1;
+  // Workgroups per CU.  Forward-only fits 256 registers without spilling and gains from a second workgroup; the
+  // gradient kernel at 256 registers spills ~250 dwords, runs slower than one workgroup with the whole register file
+  // (51.0 vs 49.2 ms) and - with the two-chunk read-ahead enabled - FAILED the race screen (scripts/stress_sdf.py)
+  // in every launch, for a reason not understood; at 512 registers nothing spills and the screen is clean.
+  static constexpr int occ(bool grad) { return grad ? 1 : 2; }
+  static constexpr int nslot(bool grad) { return grad ? SURF_SDF_NSLOT_H2 : 3; }  // 24 KB slots; two workgroups per CU forward-only
+  static constexpr bool DEEP = true, DEEPJ = true;
+  static constexpr ChunkTable CH = make_chunks(NP);
+  struct Acc { f32x16 v[NA]; };
+  static __device__ __forceinline__ void split(float a, float b, uint32_t (&p)[NP]) {
+    const f32x2 v = {a, b};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);
+    p[0] = __builtin_bit_cast(uint32_t, h);
+    p[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
+  }
+  static __device__ __forceinline__ void mma(Acc& acc, const u32x4 (&a)[NP], const FragT<NP>& b) {
+#define SURF_MF(x, y) \
+  acc.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[x]), __builtin_bit_cast(f16x8, b.p[y]), acc.v[0], 0, 0, 0)
+    SURF_MF(1, 0);
+    SURF_MF(0, 1);
+    SURF_MF(0, 0);
+#undef SURF_MF
+  }
+  static __device__ __forceinline__ f32x16 finish(const Acc& acc) { return acc.v[0]; }
+};
+
+// Power-of-two operand scales (exact): weights and back-propagated deltas are stored x 2^8 so that their second fp16
+// piece stays a normal number down to |v| ~ 5e-4 (activations are O(1) and stay unscaled; their second piece carries an
+// absolute error <= 2^-25).  Accumulators therefore come out x W_SCALE (forward) and x W_SCALE x D_SCALE (backward).
+template <class P> struct Scales { static constexpr float W = 1.0f, D = 1.0f; };
+template <> struct Scales<PolH2> { static constexpr float W = 256.0f, D = 256.0f; };
+
+template <class P> constexpr int stream_bytes() { return P::CH.off[N_CHUNKS]; }
+template <class P> constexpr int slot_bytes() { return MAX_KS * P::NP * 1024; }
+template <class P> constexpr int max_blocks(bool grad) { return 256 * P::occ(grad); }
+// chunks per round: the gradient stream is padded with empty chunks to a multiple of the ring length, so that the slot of
+// a chunk (index % ring length) continues across rounds
+template <class P> constexpr int n_chunks(bool grad) {
+  return grad ? (N_CHUNKS + P::nslot(true) - 1) / P::nslot(true) * P::nslot(true) : N_FWD_CHUNKS;
+}
+
+struct SdfArgs {
+  const float* pts;
+  const uint8_t* mask;
+  const int32_t* idx;
+  int64_t n;
+  const float* vols[SURF_MAX_STAGES];
+  const int32_t* tables[SURF_MAX_STAGES];
+  int dims[SURF_MAX_STAGES];
+  const unsigned char* packed;
+  float* sdf;
+  float* grad;
+  float* scratch;
+};
+
+__device__ __forceinline__ f32x4 bload(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+// 16-byte scratch store.  gfx950: a VALU write to the data VGPRs right after `buffer_store_dwordx4 ... sN offen` corrupts
+// lanes 12-15 of every 16 (see sdf_mlp.hip).  Store and pad are ONE asm statement so that nothing - not the scheduler,
+// not a register-allocator copy or reload - can land between them.
+__device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, f32x4 v) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
+template <class P>
+__device__ __forceinline__ void frag_set_pair(FragT<P::NP>& f, int pair /*0..3*/, float a, float b) {
+  uint32_t p[P::NP];
+  if (SURF_X_NOSPLIT) {
+#pragma unroll
+    for (int k = 0; k < P::NP; ++k) p[k] = __builtin_bit_cast(uint32_t, k & 1 ? a : b);
+  } else {
+    P::split(a, b, p);
+  }
+#pragma unroll
+  for (int k = 0; k < P::NP; ++k) f.p[k][pair] = p[k];
+}
+
+// softplus(beta = 100, threshold = 20) and its derivative for a pair of pre-activations given x ACC_SCALE, in the
+// overflow-free form  h = max(t, 0) + log(1 + exp(-|100 t|)) / 100,  h' = (t >= 0 ? 1 : exp(-|100 t|)) / (1 + exp(-|100 t|)),
+// which equals torch's thresholded softplus to fp32 rounding (the linear branch differs from it by < 2^-33 relative).
+template <bool WANT_S>
+__device__ __forceinline__ void softplus_pair(f32x2 acc, float acc_scale_inv, f32x2& hv, f32x2& sv) {
+  if (SURF_X_NOSOFTPLUS) {
+    hv = acc * acc_scale_inv;
+    sv = acc * 0.5f;
+    return;
+  }
+  const f32x2 arg = acc * (144.269504088896341f * acc_scale_inv);  // 100 log2(e) t
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(-__builtin_fabsf(arg[0]));
+  e[1] = __builtin_amdgcn_exp2f(-__builtin_fabsf(arg[1]));
+  const f32x2 d = e + 1.0f;
+  f32x2 l;
+  l[0] = __builtin_amdgcn_logf(d[0]);
+  l[1] = __builtin_amdgcn_logf(d[1]);
+  f32x2 m;
+  m[0] = __builtin_amdgcn_fmed3f(acc[0], 0.0f, 3.0e38f);  // max(acc, 0) without the canonicalising extra v_max
+  m[1] = __builtin_amdgcn_fmed3f(acc[1], 0.0f, 3.0e38f);
+  if (acc_scale_inv != 1.0f) m = m * acc_scale_inv;
+  hv[0] = fmaf(l[0], 0.69314718055994531f * 0.01f, m[0]);
+  hv[1] = fmaf(l[1], 0.69314718055994531f * 0.01f, m[1]);
+  if (WANT_S) {
+    f32x2 r, sel;
+    r[0] = __builtin_amdgcn_rcpf(d[0]);
+    r[1] = __builtin_amdgcn_rcpf(d[1]);
+    sel[0] = acc[0] >= 0.0f ? 1.0f : e[0];
+    sel[1] = acc[1] >= 0.0f ? 1.0f : e[1];
+    sv = sel * r;
+  }
+}
+
+// ---- gather / posenc (identical arithmetic to sdf_mlp.hip) -------------------------------------------------------------
+// Sparse trilinear gather of this lane half's two pyramid levels: phi[7 sl + ch], and (GRAD) the feature Jacobian of each
+// level straight to the wave's scratch slot (6 x 16 B per level: [ch][axis], 21 values + pad) to keep registers free.
+template <bool GRAD, class Ctx>
+__device__ __forceinline__ void gather_features(const SdfArgs& a, const Ctx& c, float px, float py, float pz, float (&phi)[16]) {
+#pragma unroll
+  for (int ch = 0; ch < 16; ++ch) phi[ch] = 0.f;
+  int rows[2][8];
+  float tx[2], ty[2], tz[2], inv_vs[2];
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const int st = 2 * c.h + sl;
+    const int D = a.dims[st];
+    const int32_t* __restrict__ table = a.tables[st];
+    const float vs = 2.0f / ((float)D - 1.0f);
+    inv_vs[sl] = 1.0f / vs;
+    const float gx = (px + 1.0f) / vs, gy = (py + 1.0f) / vs, gz = (pz + 1.0f) / vs;
+    const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+    tx[sl] = gx - fx; ty[sl] = gy - fy; tz[sl] = gz - fz;
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    // clamped corner coordinates; D <= 1024 (checked at launch), so 24-bit multiplies and 32-bit indices are exact
+    int xs[2], ys[2], zs[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      xs[d] = min(max(x0 + d, 0), D - 1);
+      ys[d] = min(max(y0 + d, 0), D - 1);
+      zs[d] = min(max(z0 + d, 0), D - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const unsigned xy = __umul24(__umul24(xs[k >> 2], D) + ys[(k >> 1) & 1], D);
+      rows[sl][k] = D > 0 ? table[xy + zs[k & 1]] : -1;
+    }
+  }
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+    const float* __restrict__ vol = a.vols[2 * c.h + sl];
+    f32x4 f0[8], f1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const f32x4* fr = reinterpret_cast<const f32x4*>(vol + (int64_t)max(rows[sl][k], 0) * 8);
+      f0[k] = fr[0];
+      f1[k] = fr[1];
+    }
+    float Jl[24];
+#pragma unroll
+    for (int q = 0; q < 24; ++q) Jl[q] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int dx = k >> 2, dy = (k >> 1) & 1, dz = k & 1;
+      const float ok = rows[sl][k] >= 0 ? 1.0f : 0.0f;
+      const float wx = dx ? tx[sl] : 1.0f - tx[sl];
+      const float wy = dy ? ty[sl] : 1.0f - ty[sl];
+      const float wz = dz ? tz[sl] : 1.0f - tz[sl];
+      const float w = wx * wy * wz * ok;
+      const float f[7] = {f0[k][0], f0[k][1], f0[k][2], f0[k][3], f1[k][0], f1[k][1], f1[k][2]};
+      float cx = 0.f, cy = 0.f, cz = 0.f;
+      if (GRAD) {
+        cx = ((dx ? 1.0f : -1.0f) * wy * wz) * (inv_vs[sl] * ok);
+        cy = ((dy ? 1.0f : -1.0f) * wx * wz) * (inv_vs[sl] * ok);
+        cz = ((dz ? 1.0f : -1.0f) * wx * wy) * (inv_vs[sl] * ok);
+      }
+#pragma unroll
+      for (int ch = 0; ch < 7; ++ch) {
+        phi[7 * sl + ch] += f[ch] * w;
+        if (GRAD) {
+          Jl[3 * ch + 0] += f[ch] * cx;
+          Jl[3 * ch + 1] += f[ch] * cy;
+          Jl[3 * ch + 2] += f[ch] * cz;
+        }
+      }
+    }
+    if (GRAD) {
+#pragma unroll
+      for (int g = 0; g < 6; ++g) {
+        const f32x4 v = {Jl[4 * g], Jl[4 * g + 1], Jl[4 * g + 2], Jl[4 * g + 3]};
+        bstore(c.sr, c.svoff, SCR_S * 4 + (6 * sl + g) * 1024, v);
+      }
+    }
+  }
+}
+
+// Positional encoding of this lane half (14 of the 27 channels + pad) from the three base (sin, cos) pairs: the
+// 2x, 4x, 8x terms by exact double-angle steps.  The base pairs are kept for the epilogue's Jacobian diagonal.
+struct SinCos3 { float s[3], c[3]; };
+__device__ __forceinline__ SinCos3 sincos3(float x, float y, float z) {
+  SinCos3 b;
+  sincosf(x, &b.s[0], &b.c[0]);
+  sincosf(y, &b.s[1], &b.c[1]);
+  sincosf(z, &b.s[2], &b.c[2]);
+  return b;
+}
+__device__ __forceinline__ void posenc_half(int h, float x, float y, float z, const SinCos3& b, float (&e)[16], float (&je)[14],
+                                            bool want_j) {
+  float all[28], jall[28];
+  all[0] = x; all[1] = y; all[2] = z;
+  jall[0] = jall[1] = jall[2] = 1.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float s = b.s[c], co = b.c[c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float f = (float)(1 << k);
+      all[3 + 6 * k + c] = s;
+      all[3 + 6 * k + 3 + c] = co;
+      jall[3 + 6 * k + c] = f * co;
+      jall[3 + 6 * k + 3 + c] = -f * s;
+      const float s2 = 2.0f * s * co;
+      const float c2 = fmaf(-2.0f * s, s, 1.0f);
+      s = s2;
+      co = c2;
+    }
+  }
+  all[27] = 0.f; jall[27] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    e[s] = h ? all[14 + s] : all[s];
+    if (want_j) je[s] = h ? jall[14 + s] : jall[s];
+  }
+  e[14] = e[15] = 0.f;
+}
+
+// 16 local channels (14 data + the bias one + pad) -> two k-step fragments
+template <class P>
+__device__ __forceinline__ void local_frags(const float (&v)[16], FragT<P::NP> (&f)[2]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int pr = 0; pr < 4; ++pr) frag_set_pair<P>(f[s], pr, v[8 * s + 2 * pr], v[8 * s + 2 * pr + 1]);
+}
+}  // namespace
