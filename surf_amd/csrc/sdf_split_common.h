@@ -303,6 +303,9 @@ __device__ __forceinline__ void gather_features(const SdfArgs& a, const Ctx& c, 
   }
 #pragma unroll
   for (int sl = 0; sl < 2; ++sl) {
+#ifdef SURF_GATHER_SEQUENTIAL  // one level's 16 row loads in flight at a time (kernels compiled for 256 registers)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     const float* __restrict__ vol = a.vols[2 * c.h + sl];
     f32x4 f0[8], f1[8];
 #pragma unroll
