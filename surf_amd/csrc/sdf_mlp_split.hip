@@ -47,7 +47,8 @@ struct Ctx {
 #endif
   rsrc_t wr, sr, sl, tr;  // packed stream, scratch (stores / loads), fp32 tail
   int lane, lane16, h, svoff, wave;
-  char* lds;  // three slots
+  char* lds;    // the ring
+  char* lds_s;  // this wavefront's softplus' slices + lane * 16
 };
 
 // ---- staging ------------------------------------------------------------------------------------------------------------
@@ -82,6 +83,13 @@ constexpr int sprime_layer(bool deep, int L, int T) {
   return -1;
 }
 constexpr int sprime_tile(bool deep, int L, int T) { return !deep ? T : ((L >= 1 && T < 3) ? T + 1 : 0); }
+// softplus' slices kept in the workgroup's spare LDS instead of the scratch buffer (P::LDS_SLICES per wavefront, 4 KB each:
+// layer 4 tiles first, then layer 3): the CU executes ~90 clocks per vector-memory wave-instruction in this kernel
+// (SQ_INSTS_VMEM / time) and softplus' is a quarter of them; an LDS slice costs eight ds_* instead.
+template <class P> constexpr int lds_slice(int layer, int tile) {  // index in the wavefront's LDS area or -1
+  const int k = (4 - layer) * 4 + tile;
+  return (layer <= 4 && layer >= 0 && k < P::LDS_SLICES) ? k : -1;
+}
 // 16-byte groups of a softplus' slice that are read back: layer 2 has 101 rows, so the second half (k-step 7: rows
 // 112..127) of its tile 3 feeds nothing.  Loading it anyway would leave the loads to dead-code elimination, i.e. leave
 // the number of vector-memory operations of that chunk - which stage_barrier's vmcnt counts - to the optimiser.
@@ -92,12 +100,15 @@ template <class P> constexpr int vm_pre(int ci) {
   int l = 5, t = ci - N_FWD_CHUNKS;
   while (t >= BWD_NT[l]) { t -= BWD_NT[l]; --l; }
   if (l == 0) return P::DEEPJ ? 12 : 0;  // feature Jacobian for the epilogue
-  return sprime_layer(P::DEEP, l, t) >= 0 ? sprime_groups(sprime_layer(P::DEEP, l, t), sprime_tile(P::DEEP, l, t)) : 0;
+  if (sprime_layer(P::DEEP, l, t) < 0 || lds_slice<P>(sprime_layer(P::DEEP, l, t), sprime_tile(P::DEEP, l, t)) >= 0) return 0;
+  return sprime_groups(sprime_layer(P::DEEP, l, t), sprime_tile(P::DEEP, l, t));
 }
-template <bool GRAD> constexpr int vm_post(int ci) {
+template <class P, bool GRAD> constexpr int vm_post(int ci) {
   if (!GRAD || ci >= N_FWD_CHUNKS) return 0;
   const int l = ci / 4, t = ci % 4;
-  return ((l == 0 && t == 0) || (l == 5 && t > 0)) ? 0 : 4;
+  if ((l == 0 && t == 0) || (l == 5 && t > 0)) return 0;
+  // the slice stored under chunk (l, t): tile 3 of the layer below for t = 0, else (l, t - 1)
+  return lds_slice<P>(t == 0 ? l - 1 : l, t == 0 ? 3 : t - 1) >= 0 ? 0 : 4;
 }
 // Retire the DMA of chunk CI+1, issued during chunk CI-(NS-2): everything this wave issued in the chunks after that one
 // may stay in flight (operations between rounds are not counted, which only makes the wait stricter; that DMA's pieces are
@@ -109,7 +120,7 @@ constexpr int barrier_vmcnt() {
   int n = 0;
   for (int j = 0; j + 1 < DIST; ++j) {
     const int cj = (CI - j + NCH) % NCH;
-    n += vm_pre<P>(cj) + n_dma<P>((cj + DIST) % NCH) + vm_post<GRAD>(cj);
+    n += vm_pre<P>(cj) + n_dma<P>((cj + DIST) % NCH) + vm_post<P, GRAD>(cj);
   }
   return n;
 }
@@ -215,7 +226,11 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
       frag_set_pair<P>(dst[2 * dst_tile + (el >> 3)], (el & 7) >> 1, hv[0], hv[1]);
       sbuf[el & 3] = sv[0];
       sbuf[(el & 3) + 1] = sv[1];
-      if (GRAD && (el & 3) == 2) bstore(c.sr, c.svoff, s_layer * 16384 + (dst_tile * 4 + (el >> 2)) * 1024, sbuf);
+      if (GRAD && (el & 3) == 2) {
+        const int ls = lds_slice<P>(s_layer, dst_tile);  // (compile-time at every call site)
+        if (ls >= 0) *reinterpret_cast<f32x4*>(c.lds_s + ls * 4096 + (el >> 2) * 1024) = sbuf;
+        else bstore(c.sr, c.svoff, s_layer * 16384 + (dst_tile * 4 + (el >> 2)) * 1024, sbuf);
+      }
     }
   };
   auto fn = [&](int ks) __attribute__((always_inline)) {
@@ -242,7 +257,7 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
     if (ks < NL) return pf[ks - NEk];
     return hin[ks - NL];
   };
-  static_assert(STORES == vm_post<GRAD>(CI) && (LAST ? 4 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
+  static_assert((lds_slice<P>(T == 0 ? L - 1 : L, T == 0 ? 3 : T - 1) >= 0 ? 0 : STORES) == vm_post<P, GRAD>(CI) && (LAST ? 4 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
   raw = run_chunk<P, GRAD, CI, n_chunks<P>(GRAD)>(c, bsel, fn);
 }
 
@@ -265,10 +280,14 @@ struct BwdPend {
   f32x4 s[4];   // its softplus' slice
   f32x4 sn[4];  // slice of the tile whose G is being computed now
 };
-template <int NG = 4>
+template <class P, int NG = 4>
 __device__ __forceinline__ void load_sprime(const Ctx& c, int layer, int tile, f32x4 (&dst)[4]) {
+  const int ls = lds_slice<P>(layer, tile);
 #pragma unroll
-  for (int g = 0; g < NG; ++g) dst[g] = bload(c.sl, c.svoff, layer * 16384 + (tile * 4 + g) * 1024);
+  for (int g = 0; g < NG; ++g) {
+    if (ls >= 0) dst[g] = *reinterpret_cast<const f32x4*>(c.lds_s + ls * 4096 + g * 1024);
+    else dst[g] = bload(c.sl, c.svoff, layer * 16384 + (tile * 4 + g) * 1024);
+  }
 }
 template <class P, int L, int T, bool CONVERT>
 __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, const BwdPend& prev,
@@ -278,8 +297,9 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
   constexpr int NKS = bwd_ks(L);
   constexpr int SL = sprime_layer(P::DEEP, L, T);
   constexpr int NG = SL >= 0 ? sprime_groups(SL, sprime_tile(P::DEEP, L, T)) : 0;
-  static_assert(NG + ((L == 0 && P::DEEPJ) ? 12 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
-  if (SL >= 0) load_sprime<NG>(c, SL, sprime_tile(P::DEEP, L, T), s_load);
+  static_assert((SL >= 0 && lds_slice<P>(SL, sprime_tile(P::DEEP, L, T)) >= 0 ? 0 : NG) + ((L == 0 && P::DEEPJ) ? 12 : 0) == vm_pre<P>(CI),
+                "vmcnt bookkeeping");
+  if (SL >= 0) load_sprime<P, NG>(c, SL, sprime_tile(P::DEEP, L, T), s_load);
   // two stages, as in the forward tiles: the product of pair q and the split of pair q-1 share a k-step
   f32x2 pend = {0.f, 0.f};
   auto mul = [&](int q) __attribute__((always_inline)) {
@@ -352,7 +372,10 @@ template <class P, bool GRAD>
 __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(SdfArgs a) {
   typedef FragT<P::NP> Frag;
   constexpr int NS = P::nslot(GRAD), NCH = n_chunks<P>(GRAD);
-  __shared__ __attribute__((aligned(16))) char lds[NS * slot_bytes<P>()];
+  constexpr int NSL = GRAD ? P::LDS_SLICES : 0;
+  // ONE LDS object (ring + softplus' slices): with a second __shared__ array the compiler's LDS-DMA alias tracking falls
+  // back to `s_waitcnt vmcnt(0)` in front of every ds_read (311 of them, kernel 64 -> 98 ms)
+  __shared__ __attribute__((aligned(16))) char lds[NS * slot_bytes<P>() + WPB * NSL * 4096];
   static_assert(NCH % NS == 0 && NCH - N_CHUNKS <= MAX_PAD && NS >= 3, "slot of a chunk = index % ring length");
   Ctx c;
   c.lane = threadIdx.x & 63;
@@ -360,6 +383,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
   c.h = c.lane >> 5;
   c.lane16 = c.lane * 16;
   c.lds = lds;
+  c.lds_s = lds + NS * slot_bytes<P>() + c.wave * (NSL * 4096) + c.lane16;
   c.wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, stream_bytes<P>(), 0x00020000);
   c.tr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.packed + stream_bytes<P>()), 0, TAIL_FLOATS * 4, 0x00020000);
   c.sr = __builtin_amdgcn_make_buffer_rsrc((void*)a.scratch, 0, (GRAD && !(SURF_X_NOSCRATCH & 1)) ? 0x7fffffff : 0, 0x00020000);
@@ -462,7 +486,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
         for (int q = 0; q < 4; ++q) accP[4 * g + q] = w[q] * (Scales<P>::W * Scales<P>::D);
       }
       BwdPend pend = {};
-      if (P::DEEP) load_sprime(c, 4, 0, pend.sn);  // slice of the first hidden tile (5, 0)
+      if (P::DEEP) load_sprime<P>(c, 4, 0, pend.sn);  // slice of the first hidden tile (5, 0)
       bwd_layer<P, 5>(c, dA, hA, accE, accP, pend);
       bwd_layer<P, 4>(c, hA, dA, accE, accP, pend);
       bwd_layer<P, 3>(c, dA, hA, accE, accP, pend);

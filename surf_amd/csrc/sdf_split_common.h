@@ -109,11 +109,19 @@ struct FragT { u32x4 p[NP]; };  // B-operand fragments of a 16-wide k-step: NP p
 #define SURF_SDF_NSLOT_H2 3
 #endif
 
+#ifndef SURF_SDF_LDS_SLICES_BF3
+#define SURF_SDF_LDS_SLICES_BF3 3
+#endif
+#ifndef SURF_SDF_LDS_SLICES_H2
+#define SURF_SDF_LDS_SLICES_H2 5
+#endif
+
 struct PolBf3 {
   // NA: accumulator chains (two independent ones measured no faster); PF: k-steps of LDS read-ahead (2, 3: no faster)
   static constexpr int NP = 3, NA = 1, PF = 1;
   static constexpr int occ(bool) { return 1; }  // three-piece activations need the whole register file
   static constexpr int nslot(bool) { return SURF_SDF_NSLOT_BF3; }  // LDS ring length (36 KB slots)
+  static constexpr int LDS_SLICES = SURF_SDF_LDS_SLICES_BF3;       // softplus' slices per wavefront in the spare LDS (3 x 36 + 4 x 3 x 4 KB = 156 KB)
   static constexpr bool DEEP = true;   // backward softplus' reads two chunks ahead (registers to spare)
   static constexpr bool DEEPJ = true;  // feature Jacobian fetched under the last backward chunk
   static constexpr ChunkTable CH = make_chunks(NP);
@@ -159,7 +167,8 @@ struct PolH2 {
   // (51.0 vs 49.2 ms) and - with the two-chunk read-ahead enabled - FAILED the race screen (scripts/stress_sdf.py)
   // in every launch, for a reason not understood; at 512 registers nothing spills and the screen is clean.
   static constexpr int occ(bool grad) { return grad ? 1 : 2; }
-  static constexpr int nslot(bool grad) { return grad ? SURF_SDF_NSLOT_H2 : 3; }  // 24 KB slots; two workgroups per CU forward-only
+  static constexpr int nslot(bool grad) { return grad ? SURF_SDF_NSLOT_H2 : 3; }
+  static constexpr int LDS_SLICES = SURF_SDF_LDS_SLICES_H2;        // 3 x 24 + 4 x 5 x 4 KB = 152 KB (gradient kernel: one workgroup per CU)  // 24 KB slots; two workgroups per CU forward-only
   static constexpr bool DEEP = true, DEEPJ = true;
   static constexpr ChunkTable CH = make_chunks(NP);
   struct Acc { f32x16 v[NA]; };
