@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 12
+#define SURF_ABI_VERSION 13
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -128,6 +128,15 @@ int surf_sdf_smooth_pack_weights(const float* const* h_W, const float* const* h_
 int surf_sdf_smooth(const float* pts, const int32_t* idx, int64_t n, const float* const* h_vols,
                     const int32_t* const* h_tables, const int* h_dims, int n_vol, const float* packed, float* grad,
                     float* smooth, void* stream);
+
+/*
+ * Local normalised cross-correlation of the surface patches: out (n_rays) = mean of the two smallest per-view values of
+ * mean_c clamp(1 - cov^2 / (var_ref var_src + 1e-5), 0, 2).  Replaces compute_LNCC2 (models/losses/ncc.py:7-51), the
+ * multi-view feature-consistency term of Loss.forward (losses/loss.py:43-45).  ref (1, n_rays, P, C), src (n_src, n_rays, P, C)
+ * as written by surf_patch_warp; n_src >= 2.
+ */
+int surf_lncc(const float* ref, const float* src, int64_t n_rays, int n_src, int patch_elems, int channels, float* out,
+              void* stream);
 
 /*
  * Multi-view feature fetch + blending MLP.

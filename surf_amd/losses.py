@@ -1,0 +1,73 @@
+"""Host-side mirror of the reference's training loss (models/losses/loss.py:10-111), forward values only.
+
+Same constructor keys (`confs/surf.conf:49-63`), same `forward(preds, targets, step, mode)` and the same output dictionary.
+The terms are scalar reductions of the hot path's outputs; the one with real work, the local NCC of the surface patches
+(`compute_LNCC2`, losses/ncc.py:7-51), runs in `surf_lncc` (csrc/lncc.hip).  NOT built: the per-stage photometric term
+(`compute_ptloss`, losses/photometric_loss.py:54-125: inverse warping of the source images by the matching-field depths,
+SSIM + L1 + gradient), which `mode == "train"` needs when `ptloss_weight != 0`, and every backward pass:
+nothing here is differentiable.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Loss(nn.Module):
+    KEYS = ("color_weight", "sparse_scale_factor", "sparse_weight", "igr_weight", "mfc_weight", "smooth_weight", "depth_weight",
+            "ptloss_weight", "pseudo_auxi_depth_weight", "pseudo_sdf_weight", "pseudo_depth_weight")
+
+    def __init__(self, confs):
+        super().__init__()
+        for k in self.KEYS:
+            setattr(self, k, confs.get_float(k))
+        self.stage_weights = confs.get_list("stage_weights")
+
+    @staticmethod
+    def _masked_l1(pred, target, mask):
+        mask = mask.float()
+        return ((pred - target).abs() * mask).sum() / (mask.sum() + 1e-8)
+
+    def forward(self, preds, targets, step=None, mode="train"):
+        valid_mask = preds["valid_mask"]
+        if "mask" in targets:
+            valid_mask = valid_mask * targets["mask"].reshape(-1, 1)
+        vm = valid_mask.float()
+        color_loss = ((preds["color_fine"] - targets["color"]).abs() * vm).sum() / (vm.sum() + 1e-5)       # loss.py:32-33
+        eikonal_loss = preds["gradient_error"].mean()
+        anneal = min(1.0, step / 2)                                                                          # loss.py:37
+        sparse_loss = torch.exp(-preds["sparse_sdf"].abs() * self.sparse_scale_factor).mean() * anneal
+        smooth_loss = preds["smooth_error"].mean()
+        ncc = ops.lncc(preds["ref_gray_val"].contiguous(), preds["sampled_gray_val"].contiguous())          # (R,1)
+        ncc_mask = vm * preds["mid_inside_sphere"]
+        mfc_loss = 0.5 * ((ncc * ncc_mask).sum(dim=0) / (ncc_mask.sum(dim=0) + 1e-8)).squeeze(-1)
+
+        zero = 0.0
+        photo_loss = pseudo_auxi = auxi = auxi0 = src_auxi = src_auxi0 = zero
+        if mode == "train":
+            if self.ptloss_weight != 0:
+                raise NotImplementedError("compute_ptloss (per-stage photometric term) is not built: SURVEY 8f-f2")
+            n = len(self.stage_weights)
+            for i in range(n):
+                pa = self._masked_l1(preds[f"depth_stage{i}"], targets["pseudo_depth_ref"], targets["pseudo_depth_ref"] > 0)
+                spa = self._masked_l1(preds[f"depth_src_stage{i}"], targets["pseudo_depth_src"], targets["pseudo_depth_src"] > 0)
+                pseudo_auxi = pseudo_auxi + (pa + spa) * self.stage_weights[i]
+            auxi = self._masked_l1(preds[f"depth_stage{n - 1}"], targets["depth_ref"], targets["mask_ref"])
+            src_auxi = self._masked_l1(preds[f"depth_src_stage{n - 1}"], targets["depth_src"], targets["mask_src"])
+            auxi0 = self._masked_l1(preds["depth_stage0"], targets["depth_ref"], targets["mask_ref"])
+            src_auxi0 = self._masked_l1(preds["depth_src_stage0"], targets["depth_src"], targets["mask_src"])
+
+        pseudo_sdf_loss = preds["pseudo_sdf"].abs().mean() if "pseudo_sdf" in preds else zero
+        pseudo_depth_loss = (self._masked_l1(preds["render_depth"], targets["pseudo_depth"], targets["pseudo_depth"] > 0)
+                             if "pseudo_depth" in targets else zero)
+        depth_loss = (self._masked_l1(preds["render_depth"], targets["depth"], targets["depth"] > 0)
+                      if "depth" in targets else zero)
+        loss = (color_loss * self.color_weight + eikonal_loss * self.igr_weight + sparse_loss * self.sparse_weight
+                + mfc_loss * self.mfc_weight + smooth_loss * self.smooth_weight + depth_loss * self.depth_weight
+                + photo_loss * self.ptloss_weight + pseudo_auxi * self.pseudo_auxi_depth_weight
+                + pseudo_sdf_loss * self.pseudo_sdf_weight + pseudo_depth_loss * self.pseudo_depth_weight)
+        return {"loss": loss, "color_loss": color_loss, "eikonal_loss": eikonal_loss, "sparse_loss": sparse_loss,
+                "mfc_loss": mfc_loss, "smooth_loss": smooth_loss, "depth_loss": depth_loss, "photo_loss": photo_loss,
+                "auxi_depth_loss": auxi, "pseudo_auxi_depth_loss": pseudo_auxi, "src_auxi_depth_loss": src_auxi,
+                "pseudo_sdf_loss": pseudo_sdf_loss, "auxi_depth_loss0": auxi0, "src_auxi_depth_loss0": src_auxi0,
+                "pseudo_depth_loss": pseudo_depth_loss}

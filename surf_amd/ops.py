@@ -470,6 +470,19 @@ def patch_warp(pts, grads, maps_t4, cams, patch_size=11):
     return ref, src
 
 
+def lncc(ref_gray_val, sampled_gray_val):
+    """compute_LNCC2 (losses/ncc.py:7-51): ref (1,R,P,C), src (nsrc,R,P,C) -> (R,1)."""
+    _chk(ref_gray_val, torch.float32, "ref_gray_val")
+    _chk(sampled_gray_val, torch.float32, "sampled_gray_val")
+    nsrc, R, P, C = sampled_gray_val.shape
+    assert tuple(ref_gray_val.shape) == (1, R, P, C)
+    out = torch.empty(R, 1, dtype=torch.float32, device=ref_gray_val.device)
+    if R > 0:
+        _lib.check(_lib.lib().surf_lncc(_p(ref_gray_val), _p(sampled_gray_val), R, int(nsrc), int(P), int(C), _p(out), _stream()),
+                   "surf_lncc")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # volume build (surf.py:80-131)
 # ------------------------------------------------------------------------------------------------

@@ -7,6 +7,8 @@ this script READS and does not rewrite).  Only data is committed.
     unit level  surface_patch_warp2 (projector.py:560-645) on given surface points / gradients / the stacked feature maps
                 (implicit_surface.py:231-235: FPN levels 0, 1, 2, the coarser two F.interpolate'd to full resolution)
     chain       ImplicitSurface.render (perturb = 0, cos_anneal_ratio = 1): ref_gray_val, sampled_gray_val, smooth_error
+    losses      compute_LNCC2 (losses/ncc.py:7-51) on the chain's patches and Loss.forward (losses/loss.py:27-111, mode "val":
+                every term but the per-stage photometric ones) on the chain's outputs with seeded targets
 """
 import os
 import sys
@@ -23,6 +25,11 @@ from tests.golden import make_golden as G  # noqa: E402
 def load(name):
     z = np.load(os.path.join(HERE, name))
     return {k: torch.from_numpy(z[k]) for k in z.files}
+
+
+LOSS_CONF = {"color_weight": 1.0, "sparse_weight": 0.02, "igr_weight": 0.1, "sparse_scale_factor": 100, "mfc_weight": 1.0,
+             "smooth_weight": 0.0001, "tv_weight": 0.0, "depth_weight": 0.5, "ptloss_weight": 1.0, "pseudo_auxi_depth_weight": 1.0,
+             "pseudo_sdf_weight": 1.0, "stage_weights": [0.25, 0.5, 0.75, 1.0], "pseudo_depth_weight": 1.0}   # confs/surf.conf:49-63 (depth_weight raised from 0 so that the term is exercised)
 
 
 def main():
@@ -71,6 +78,26 @@ def main():
     out.update(ref_gray_val=outs["ref_gray_val"].detach(), sampled_gray_val=outs["sampled_gray_val"].detach(),
                smooth_error=outs["smooth_error"].detach(), mid_inside_sphere=outs["mid_inside_sphere"].detach(),
                sdf_depth=outs["sdf_depth"].detach())
+    # ---- losses on the chain's outputs
+    from models.losses.loss import Loss
+    from models.losses.ncc import compute_LNCC2
+    out["ncc"] = compute_LNCC2(outs["ref_gray_val"].detach(), outs["sampled_gray_val"].detach())
+    out["unit_ncc"] = compute_LNCC2(out["unit_ref"], out["unit_src"])
+    g = torch.Generator().manual_seed(23)
+    targets = {"color": torch.rand(R, 3, generator=g), "mask": (torch.rand(R, generator=g) > 0.2).float(),
+               "pseudo_depth": torch.rand(R, generator=g) * (torch.rand(R, generator=g) > 0.3).float() * 3.0,
+               "depth": torch.rand(R, generator=g) * (torch.rand(R, generator=g) > 0.5).float() * 3.0}
+    loss_fn = Loss(G.Conf(LOSS_CONF))
+    preds = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in outs.items()}
+    preds["pseudo_sdf"] = torch.randn(64, 1, generator=g) * 0.05
+    lo = loss_fn(preds, targets, step=1, mode="val")
+    for k, v in targets.items():
+        out["loss_target_" + k] = v
+    out["loss_pred_pseudo_sdf"] = preds["pseudo_sdf"]
+    for k in ("color_fine", "valid_mask", "gradient_error", "sparse_sdf", "render_depth"):
+        out["loss_pred_" + k] = preds[k].float() if preds[k].dtype == torch.bool else preds[k]
+    for k, v in lo.items():
+        out["loss_out_" + k] = torch.as_tensor(v, dtype=torch.float32).reshape(-1)
     G.ONLY.clear()
     G.npz("train_outputs.npz", **out)
 

@@ -632,3 +632,27 @@ def test_patch_warp_matches_golden(scene, weights, gpu_scene, golden_fpn, golden
     rel_close(out["pts_sdf0"], oref["pts_sdf0"], 0, 2e-5)
     rel_close(out["gradients_sdf0"], oref["gradients_sdf0"], 1e-3, 3e-4)
     assert tuple(out["sampled_gray_val"].shape) == (2, R, 121, 12) and tuple(out["ref_gray_val"].shape) == (1, R, 121, 12)
+
+
+def test_lncc_and_loss_match_golden(golden_train):
+    """Row f2 (forward values): surf_lncc against compute_LNCC2's outputs and Loss.forward (mode "val") against the
+    reference's Loss on the same predictions / targets (losses/loss.py:27-111; the per-stage photometric term is not built)."""
+    from surf_amd import conf, ops
+    from surf_amd.losses import Loss
+    from tests.golden.make_golden_train import LOSS_CONF
+    d = dev()
+    gt = golden_train
+    ncc = ops.lncc(gt["unit_ref"].to(d).contiguous(), gt["unit_src"].to(d).contiguous())
+    rel_close(ncc, gt["unit_ncc"], 1e-5, 2e-6)
+    rel_close(ops.lncc(gt["ref_gray_val"].to(d).contiguous(), gt["sampled_gray_val"].to(d).contiguous()), gt["ncc"], 1e-5, 2e-6)
+    preds = {k[len("loss_pred_"):]: v.to(d) for k, v in gt.items() if k.startswith("loss_pred_")}
+    preds["valid_mask"] = preds["valid_mask"] > 0
+    for k in ("ref_gray_val", "sampled_gray_val", "smooth_error", "mid_inside_sphere"):
+        preds[k] = gt[k].to(d)
+    targets = {k[len("loss_target_"):]: v.to(d) for k, v in gt.items() if k.startswith("loss_target_")}
+    out = Loss(conf.from_dict(LOSS_CONF))(preds, targets, step=1, mode="val")
+    for k, v in out.items():
+        got = torch.as_tensor(v, dtype=torch.float32).reshape(-1)
+        rel_close(got, gt["loss_out_" + k], 1e-5, 1e-6)
+    with pytest.raises(NotImplementedError):
+        Loss(conf.from_dict(LOSS_CONF))(preds, targets, step=1, mode="train")

@@ -186,3 +186,11 @@ def test_a15_surface_patch_warp(scene, weights, golden_fpn, golden_pipe, golden_
     #  pixel, so the chain is compared with a small allowance for outliers; the unit-level comparison above is tight)
     err = (out["sampled_gray_val"][:, hit] - gt["sampled_gray_val"][:, hit]).abs()
     assert float(err.max()) < 5e-3 and float((err < 5e-4).float().mean()) > 0.995, (float(err.max()), float((err < 5e-4).float().mean()))
+
+
+def test_f2_lncc(golden_train):
+    """losses/ncc.py:7-51 on the reference's own patches (unit level and the render chain)."""
+    gt = golden_train
+    close(O.lncc(gt["unit_ref"], gt["unit_src"]), gt["unit_ncc"], atol=2e-6, rtol=1e-5)
+    close(O.lncc(gt["ref_gray_val"], gt["sampled_gray_val"]), gt["ncc"], atol=2e-6, rtol=1e-5)
+    assert float(gt["unit_ncc"].min()) < 0.7 and float(gt["unit_ncc"].max()) > 0.95
