@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 13
+#define SURF_ABI_VERSION 14
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -279,6 +279,19 @@ int surf_spconv_pack_weights(const float* weight, int cin, int cout, void* packe
 int surf_spconv_mfma(const float* in, int cin, const int32_t* in_table, int D_in, const int32_t* out_coords, int64_t n_out,
                      int mode, const void* packed, int cout, const float* bn_scale, const float* bn_shift,
                      const float* skip, float* out, void* stream);
+
+/*
+ * BatchNorm with BATCH statistics over the voxel rows x (n, C) (train mode of spnn.BatchNorm, reg_network.py:14-15,28-29;
+ * C in {8, 16, 32, 64}): scale = gamma / sqrt(var + eps), shift = beta - mean scale (device, C floats each), fp64 reduction;
+ * running_mean / running_var (may both be NULL) are updated in place as torch.nn.BatchNorm1d does (momentum, unbiased
+ * variance).  surf_bn_relu_apply: out = relu(x scale + shift) (+ skip).  workspace: surf_bn_workspace_bytes(C) device bytes.
+ */
+int64_t surf_bn_workspace_bytes(int channels);
+int surf_bn_train_affine(const float* x, int64_t n, int channels, const float* gamma, const float* beta, float eps,
+                         float momentum, float* running_mean, float* running_var, float* scale, float* shift, void* workspace,
+                         void* stream);
+int surf_bn_relu_apply(const float* x, int64_t n, int channels, const float* scale, const float* shift, const float* skip,
+                       float* out, void* stream);
 
 /* bbox (device int32[6]) = [min x, min y, min z, max x, max y, max z] of coords (n,3) */
 int surf_coords_bbox(const int32_t* coords, int64_t n, int32_t* bbox, void* stream);

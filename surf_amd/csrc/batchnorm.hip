@@ -1,0 +1,103 @@
+// BatchNorm over the voxel rows of a sparse tensor with BATCH statistics (train mode of spnn.BatchNorm = nn.BatchNorm1d on
+// the feature rows, reg_network.py:14-15,28-29; eval mode is folded into the convolution epilogues, spconv.hip).
+//   surf_bn_train_affine: per-channel mean / biased variance of x (n, C) -> scale = gamma / sqrt(var + eps),
+//                         shift = beta - mean scale; running_mean / running_var updated as torch does (momentum, unbiased var)
+//   surf_bn_relu_apply:   out = relu(x scale + shift) (+ skip)
+// Statistics are reduced deterministically in fp64: per-workgroup partials, then a serial finalise (as the FPN's
+// InstanceNorm, fpn.hip).  Byte-bound: x is read twice, written once.
+#include "common.h"
+
+namespace {
+
+constexpr int BN_BLOCKS = 512;
+
+template <int C>
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ part) {
+  constexpr int G = 256 / C;                       // row groups per workgroup
+  __shared__ double sh[2][256];
+  const int c = threadIdx.x % C, g = threadIdx.x / C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * G + g; r < n; r += (int64_t)gridDim.x * G) {
+    const double v = (double)x[r * C + c];
+    s1 += v;
+    s2 += v * v;
+  }
+  sh[0][threadIdx.x] = s1;
+  sh[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < G; ++k) { a += sh[0][k * C + threadIdx.x]; b += sh[1][k * C + threadIdx.x]; }
+    part[((int64_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = a;
+    part[((int64_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = b;
+  }
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ part, int blocks, int C, int64_t n, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < blocks; ++b) { s1 += part[((int64_t)b * 2 + 0) * C + c]; s2 += part[((int64_t)b * 2 + 1) * C + c]; }
+  const double mean = s1 / (double)n;
+  double var = s2 / (double)n - mean * mean;      // biased (what the normalisation uses)
+  if (var < 0.0) var = 0.0;
+  const float sc = gamma[c] / sqrtf((float)var + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - (float)mean * sc;
+  if (running_mean) {
+    const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int64_t n4, int C4, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ skip,
+                                                       float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 4-channel group
+  if (i >= n4) return;
+  const int c = (int)(i % C4) * 4;
+  const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c), sh = *reinterpret_cast<const f32x4*>(shift + c);
+  f32x4 y;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) y[q] = fmaxf(v[q] * sc[q] + sh[q], 0.f);
+  if (skip) y += reinterpret_cast<const f32x4*>(skip)[i];
+  reinterpret_cast<f32x4*>(out)[i] = y;
+}
+
+}  // namespace
+
+extern "C" int64_t surf_bn_workspace_bytes(int channels) { return (int64_t)BN_BLOCKS * 2 * channels * sizeof(double); }
+
+extern "C" int surf_bn_train_affine(const float* x, int64_t n, int channels, const float* gamma, const float* beta, float eps,
+                                    float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                                    void* workspace, void* stream) {
+  if (!x || !gamma || !beta || !scale || !shift || !workspace || n <= 0) return SURF_E_ARG;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return SURF_E_ARG;
+  const int64_t want = (n * channels + 255) / 256;
+  const int blocks = (int)(want < BN_BLOCKS ? want : BN_BLOCKS);
+  double* part = (double*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  switch (channels) {
+    case 8: hipLaunchKernelGGL(bn_partial_kernel<8>, dim3(blocks), dim3(256), 0, s, x, n, part); break;
+    case 16: hipLaunchKernelGGL(bn_partial_kernel<16>, dim3(blocks), dim3(256), 0, s, x, n, part); break;
+    case 32: hipLaunchKernelGGL(bn_partial_kernel<32>, dim3(blocks), dim3(256), 0, s, x, n, part); break;
+    case 64: hipLaunchKernelGGL(bn_partial_kernel<64>, dim3(blocks), dim3(256), 0, s, x, n, part); break;
+    default: return SURF_E_LIMIT;
+  }
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, part, blocks, channels, n, gamma, beta, eps, momentum,
+                     running_mean, running_var, scale, shift);
+  return surf_check_launch();
+}
+
+extern "C" int surf_bn_relu_apply(const float* x, int64_t n, int channels, const float* scale, const float* shift,
+                                  const float* skip, float* out, void* stream) {
+  if (!x || !scale || !shift || !out || n <= 0 || channels < 4 || channels % 4) return SURF_E_ARG;
+  const int64_t n4 = n * (channels / 4);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n4, channels / 4,
+                     scale, shift, skip, out);
+  return surf_check_launch();
+}

@@ -720,6 +720,30 @@ def spconv(x, in_table, out_coords, mode, weight, bn_scale=None, bn_shift=None, 
     return out
 
 
+def bn_train_relu(x, bn, skip=None):
+    """spnn.BatchNorm in train mode + ReLU (+ skip) on raw convolution outputs x (n, C): batch statistics, running
+    statistics updated in place like torch (reg_network.py:14-15,28-29).  bn: the block's nn.BatchNorm1d."""
+    _chk(x, torch.float32, "x")
+    n, C = x.shape
+    dev = x.device
+    out = torch.empty_like(x)
+    if n == 0:
+        return out
+    scale = torch.empty(C, dtype=torch.float32, device=dev)
+    shift = torch.empty(C, dtype=torch.float32, device=dev)
+    ws = torch.empty(_lib.lib().surf_bn_workspace_bytes(C), dtype=torch.uint8, device=dev)
+    momentum = 0.1 if bn.momentum is None else float(bn.momentum)
+    track = bn.track_running_stats and bn.running_mean is not None
+    rc = _lib.lib().surf_bn_train_affine(_p(x), n, C, _p(bn.weight.detach()), _p(bn.bias.detach()), float(bn.eps), momentum,
+                                         _p(bn.running_mean if track else None), _p(bn.running_var if track else None),
+                                         _p(scale), _p(shift), _p(ws), _stream())
+    _lib.check(rc, "surf_bn_train_affine")
+    if track:
+        bn.num_batches_tracked += 1
+    _lib.check(_lib.lib().surf_bn_relu_apply(_p(x), n, C, _p(scale), _p(shift), _p(skip), _p(out), _stream()), "surf_bn_relu_apply")
+    return out
+
+
 def row_linear8(x, weight):
     _chk(x, torch.float32, "x")
     _chk(weight, torch.float32, "weight")

@@ -5,7 +5,8 @@ checkpoints load: ``nets.{s}.conv{i}.net.0.kernel`` (27, C_in, C_out), ``nets.{s
 running_mean,running_var,num_batches_tracked}``, ``nets.{s}.out_lin.weight``.  The arithmetic runs in
 ``surf_spconv`` (csrc/spconv.hip).  torchsparse itself is absent here (third party): the convolution
 semantics are those documented in ``oracle.surf_oracle.sparse_unet`` -- PARITY UNPINNED.
-Only eval-mode BatchNorm (running statistics) is implemented; batch statistics belong to the training row.
+Eval-mode BatchNorm (running statistics) is folded into the convolution epilogues; train mode uses batch statistics
+(`surf_bn_train_affine`, forward only) and updates the running ones like torch.
 """
 import math
 
@@ -40,15 +41,20 @@ class _Block(nn.Module):
 
     def prepared(self, use_mfma=True):
         """(kernel, bn scale, bn shift, split-bf16 operand image or None), cached until a parameter or buffer changes
-        (optimiser step, load_state_dict, .to(device)): saves five small launches per convolution and the repacking."""
+        (optimiser step, load_state_dict, .to(device)): saves five small launches per convolution and the repacking.
+        The running statistics are also written by surf_bn_train_affine through raw pointers, which torch's version
+        counters do not see: the train path sets `_bn_dirty`."""
         conv, bn = self.net[0], self.net[1]
-        ts = (conv.kernel, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-        key = tuple((t._version, t.data_ptr()) for t in ts) + (bool(use_mfma),)
-        if getattr(self, "_prep", None) is None or self._prep[0] != key:
+        wkey = (conv.kernel._version, conv.kernel.data_ptr(), bool(use_mfma))
+        if getattr(self, "_wprep", None) is None or self._wprep[0] != wkey:
             w = conv.kernel.detach().float().contiguous()
-            scale, shift = self.bn_affine()
-            self._prep = (key, w, scale, shift, ops.spconv_pack_weights(w) if use_mfma else None)
-        return self._prep[1:]
+            self._wprep = (wkey, w, ops.spconv_pack_weights(w) if use_mfma else None)
+        ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+        bkey = tuple((t._version, t.data_ptr()) for t in ts)
+        if getattr(self, "_bprep", None) is None or self._bprep[0] != bkey or getattr(self, "_bn_dirty", False):
+            self._bprep = (bkey,) + self.bn_affine()
+            self._bn_dirty = False
+        return self._wprep[1], self._bprep[1], self._bprep[2], self._wprep[2]
 
 
 class SparseCostRegNet(nn.Module):
@@ -74,9 +80,11 @@ class SparseCostRegNet(nn.Module):
         self.out_lin = nn.Linear(b, d_out, bias=False)
 
     def _conv(self, blk, x, table, out_coords, mode, skip=None):
-        if self.training:
-            raise NotImplementedError("BatchNorm batch statistics (train mode) are not implemented: call .eval()")
         w, scale, shift, packed = blk.prepared(self.use_mfma)
+        if self.training:   # batch statistics (forward only: nothing here is differentiable), running statistics updated
+            raw = ops.spconv(x, table, out_coords, mode, w, None, None, None, packed=packed)
+            blk._bn_dirty = True
+            return ops.bn_train_relu(raw, blk.net[1], skip)
         return ops.spconv(x, table, out_coords, mode, w, scale, shift, skip, packed=packed)
 
     def forward(self, feats, coords, D, table=None):

@@ -656,3 +656,36 @@ def test_lncc_and_loss_match_golden(golden_train):
         rel_close(got, gt["loss_out_" + k], 1e-5, 1e-6)
     with pytest.raises(NotImplementedError):
         Loss(conf.from_dict(LOSS_CONF))(preds, targets, step=1, mode="train")
+
+
+def test_sparse_unet_train_mode_batch_statistics(golden_pipe):
+    """spnn.BatchNorm in train mode (reg_network.py:14-15): batch statistics in the forward, running statistics updated like
+    torch.nn.BatchNorm1d (momentum 0.1, unbiased variance), and the eval path picking the new statistics up."""
+    from surf_amd import conf
+    from surf_amd.reg_network import SparseCostRegNetList
+    d = dev()
+    torch.manual_seed(5)
+    net = SparseCostRegNetList(conf.from_dict({"d_in": [8, 16, 16, 16], "d_out": [8] * 4, "d_base": [8] * 4}))
+    sd = {"reg_network." + k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(d).train()
+    s, D = 2, 32
+    coords = golden_pipe[f"s{s}_coords"].to(torch.int32)
+    feats = golden_pipe[f"s{s}_reg_in"].contiguous()
+    out_ref, mid_ref = O.sparse_unet(sd, feats, coords.long(), D, s, training=True)
+    out, mid = net(feats.to(d), coords.to(d).contiguous(), D, s)
+    rel_close(mid, mid_ref, 1e-3, 1e-4)
+    rel_close(out, out_ref, 1e-3, 1e-4)
+    # running statistics of the first block: conv0's raw output through torch's own BatchNorm1d
+    raw0 = O.spconv_subm(feats, coords.long(), D, sd[f"reg_network.nets.{s}.conv0.net.0.kernel"])
+    bn = torch.nn.BatchNorm1d(8).train()
+    bn(raw0)
+    blk = net.nets[s].conv0.net[1]
+    rel_close(blk.running_mean, bn.running_mean, 1e-4, 1e-6)
+    rel_close(blk.running_var, bn.running_var, 1e-4, 1e-6)
+    assert int(blk.num_batches_tracked) == 1
+    # eval after the update uses the new running statistics (the cached affine is refreshed)
+    net.eval()
+    sd2 = {"reg_network." + k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    out_e, mid_e = net(feats.to(d), coords.to(d).contiguous(), D, s)
+    out_eref, mid_eref = O.sparse_unet(sd2, feats, coords.long(), D, s)
+    rel_close(mid_e, mid_eref, 1e-3, 1e-4)
