@@ -246,12 +246,14 @@ int surf_densify(const int32_t* coords, const float* rows, int row_stride, int64
  *   h_kinv (nv,3,3) = inverse(intrs)[:, :3, :3]; h_c2w (nv,4,4); h_rinv (nv,3,3) = inverse(c2w[:, :3, :3]);
  *   h_near_fars (nv,2) -- HOST.  lin_x/lin_y/lin_n: device copies of torch.linspace(0,W-1,w), (0,H-1,h), (0,1,n).
  *   pre_depths (nv,H,W) or NULL (stage 0); ratio_cur/ratio_prev = range_ratios[stage], [stage-1]
+ * jitter (optional, device, (nv, h*w, 2)): the train-mode `torch.rand([batch, 1]) - 0.5` of every ray and band
+ * (matching_field.py:33-35; zeros for the views rendered without it, :129-133)
  * outputs: depth_lr (nv,h,w) and depth_full (nv,H,W) = bilinear upsample (align_corners=False)
  */
 int surf_matching_depth(const float* mvol, int D, int nv, const float* h_kinv, const float* h_c2w, const float* h_rinv,
                         const float* h_near_fars, int H, int W, int h, int w, const float* lin_x, const float* lin_y,
                         const float* lin_n, int n, const float* pre_depths, float ratio_cur, float ratio_prev,
-                        float* depth_lr, float* depth_full, void* stream);
+                        const float* jitter, float* depth_lr, float* depth_full, void* stream);
 
 /* =====================================================================================================
  * Sparse 3D U-Net pieces (reg_network.py:38-88 over torchsparse 2.1.0 -- third party, PARITY UNPINNED).

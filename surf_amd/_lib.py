@@ -88,7 +88,7 @@ SIGNATURES = {
     "surf_inorm_workspace_doubles": (c_i64, [c_int, c_int, c_int, c_int]),
     "surf_inorm_relu": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_matching_depth": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr,
-                                    c_ptr, c_int, c_ptr, c_float, c_float, c_ptr, c_ptr, c_ptr]),
+                                    c_ptr, c_int, c_ptr, c_float, c_float, c_ptr, c_ptr, c_ptr, c_ptr]),
 }
 
 _lib = None

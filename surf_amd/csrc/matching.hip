@@ -25,6 +25,7 @@ struct MatchArgs {
   int n;
   const float* pre;    // (nv,H,W) previous-stage depths or null
   float ratio_cur, ratio_prev;
+  const float* jitter; // (nv, h*w, 2) train-mode `rand - 0.5` per ray and band, or null (matching_field.py:33-35)
   float* out;          // (nv,h,w)
 };
 
@@ -72,8 +73,10 @@ __global__ __launch_bounds__(256) void matching_depth_kernel(MatchArgs a) {
   float m = -INFINITY, den = 0.f, num = 0.f;
   for (int b = 0; b < nb; ++b) {
     const float rng = hi[b] - lo[b];
+    const float shift = a.jitter ? a.jitter[i * 2 + b] * rng / (float)a.n : 0.f;
     for (int k = 0; k < a.n; ++k) {
-      const float z = lo[b] + rng * a.lin_n[k];
+      float z = lo[b] + rng * a.lin_n[k];
+      if (a.jitter) z = z + shift;
       const float qx = ox + dx * z, qy = oy + dy * z, qz = oz + dz * z;
       const float rho = trilinear_zeros(a.mvol, a.D, unnorm_acf(qx, a.D), unnorm_acf(qy, a.D), unnorm_acf(qz, a.D));
       const float mn = fmaxf(m, rho);
@@ -111,14 +114,15 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
 extern "C" int surf_matching_depth(const float* mvol, int D, int nv, const float* h_kinv, const float* h_c2w,
                                    const float* h_rinv, const float* h_near_fars, int H, int W, int h, int w,
                                    const float* lin_x, const float* lin_y, const float* lin_n, int n, const float* pre_depths,
-                                   float ratio_cur, float ratio_prev, float* depth_lr, float* depth_full, void* stream) {
+                                   float ratio_cur, float ratio_prev, const float* jitter, float* depth_lr, float* depth_full,
+                                   void* stream) {
   if (!mvol || !h_kinv || !h_c2w || !h_rinv || !h_near_fars || !lin_x || !lin_y || !lin_n || !depth_lr || !depth_full)
     return SURF_E_ARG;
   if (D < 2 || H < 1 || W < 1 || h < 1 || w < 1 || n < 1) return SURF_E_ARG;
   if (nv < 1 || nv > SURF_MAX_VIEWS) return SURF_E_LIMIT;
   MatchArgs a;
   a.mvol = mvol; a.D = D; a.nv = nv; a.H = H; a.W = W; a.h = h; a.w = w; a.lin_x = lin_x; a.lin_y = lin_y; a.lin_n = lin_n;
-  a.n = n; a.pre = pre_depths; a.ratio_cur = ratio_cur; a.ratio_prev = ratio_prev; a.out = depth_lr;
+  a.n = n; a.pre = pre_depths; a.ratio_cur = ratio_cur; a.ratio_prev = ratio_prev; a.jitter = jitter; a.out = depth_lr;
   for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
     const int s = v < nv ? v : 0;
     for (int r = 0; r < 3; ++r)

@@ -1,4 +1,5 @@
 """Host-side mirror of models/modules/matching_field.py MatchingField (no parameters)."""
+import torch
 import torch.nn as nn
 
 from . import ops
@@ -12,9 +13,26 @@ class MatchingField(nn.Module):
         self.up_sample_steps = confs.get_list("up_sample_steps")
         self.depth_res_levels = [int(v) for v in confs.get_list("depth_res_levels")]
 
-    def forward(self, cams, near_fars, hw, matching_volume, stage_idx, range_ratios, pre_depths=None, return_lr=False):
-        """matching_field.py:73-141 with perturb False -> depth maps (nv,H,W)."""
+    def draw_jitter(self, nv, n_rays, n_bands, src_idx=0):
+        """The train-mode draws of depth_render (:33-35) on the CPU generator, in the reference's order: views in order, only
+        the reference view and `src_idx` are perturbed (:129-133), one `torch.rand([batch, 1]) - 0.5` per band."""
+        jit = torch.zeros(nv, n_rays, 2)
+        for i in range(nv):
+            if i == 0 or i == src_idx:
+                for b in range(n_bands):
+                    jit[i, :, b] = (torch.rand([n_rays, 1]) - 0.5)[:, 0]
+        return jit
+
+    def forward(self, cams, near_fars, hw, matching_volume, stage_idx, range_ratios, pre_depths=None, return_lr=False,
+                perturb=False, src_idx=0):
+        """matching_field.py:73-141 -> depth maps (nv,H,W).  perturb (train mode, surf.py:139): the per-ray z jitter of the
+        reference and source views; `occ_reg` (unused by the loss) is not produced."""
         H, W = hw
+        jitter = None
+        if perturb:
+            lvl = self.depth_res_levels[stage_idx]
+            jitter = self.draw_jitter(cams.nv, (H // lvl) * (W // lvl), 1 if pre_depths is None else 2, src_idx)
+            jitter = jitter.to(matching_volume.device).contiguous()
         return ops.matching_depth(matching_volume, cams, near_fars, H, W, self.depth_res_levels[stage_idx],
                                   self.n_samples_depths[stage_idx], pre_depths, range_ratios[stage_idx],
-                                  range_ratios[stage_idx - 1] if stage_idx > 0 else 1.0, return_lr=return_lr)
+                                  range_ratios[stage_idx - 1] if stage_idx > 0 else 1.0, return_lr=return_lr, jitter=jitter)

@@ -577,9 +577,10 @@ def densify(coords, rows, D, prev=None):
     return dense, table
 
 
-def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, ratio_cur=1.0, ratio_prev=1.0, return_lr=False):
-    """matching_field.py:73-141 (perturb False).  Returns depth maps (nv,H,W) (and, with return_lr, the (nv,h,w) maps
-    rendered at the reduced resolution before the bilinear upsample)."""
+def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, ratio_cur=1.0, ratio_prev=1.0, return_lr=False,
+                   jitter=None):
+    """matching_field.py:73-141.  Returns depth maps (nv,H,W) (and, with return_lr, the (nv,h,w) maps rendered at the
+    reduced resolution before the bilinear upsample).  jitter (nv, h*w, 2): the train-mode per-ray, per-band z shifts."""
     _chk(mvol, torch.float32, "matching volume")
     dev = mvol.device
     h, w = H // res_level, W // res_level
@@ -589,10 +590,13 @@ def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, r
     nf = np.ascontiguousarray(near_fars.detach().to("cpu", torch.float32).numpy())
     lr = torch.empty(cams.nv, h, w, dtype=torch.float32, device=dev)
     full = torch.empty(cams.nv, H, W, dtype=torch.float32, device=dev)
+    if jitter is not None:
+        _chk(jitter, torch.float32, "jitter")
+        assert tuple(jitter.shape) == (cams.nv, h * w, 2)
     rc = _lib.lib().surf_matching_depth(_p(mvol), int(mvol.shape[0]), cams.nv, _np_ptr(cams.kinv), _np_ptr(cams.c2w),
                                         _np_ptr(cams.rinv), _np_ptr(nf), H, W, h, w, _p(lin_x), _p(lin_y), _p(lin_n), int(n),
                                         _p(pre_depths), ctypes.c_float(float(ratio_cur)), ctypes.c_float(float(ratio_prev)),
-                                        _p(lr), _p(full), _stream())
+                                        _p(jitter), _p(lr), _p(full), _stream())
     _lib.check(rc, "surf_matching_depth")
     return (full, lr) if return_lr else full
 

@@ -107,8 +107,8 @@ class SuRF(nn.Module):
         return self._vol_scene[1]
 
     @torch.no_grad()
-    def build_volumes(self, ipts, features_c2f, cams=None, logit_override=None, timings=None, trace=None):
-        """surf.py:80-131 (perturb False).  features_c2f: texel4 maps coarse -> fine.
+    def build_volumes(self, ipts, features_c2f, cams=None, logit_override=None, timings=None, trace=None, perturb=False):
+        """surf.py:80-131 (perturb = the train-mode z jitter of the matching field, surf.py:139).  features_c2f: texel4 maps coarse -> fine.
         Returns (outputs, volumes, tables, matching_volume) with per-stage lists coarse -> fine.
         `logit_override(coords, D) -> (N,)` (bench / tests only) replaces the U-Net's matching logit so that an
         untrained network still produces a realistic, surface-concentrated pyramid; `timings` (dict) receives
@@ -139,7 +139,8 @@ class SuRF(nn.Module):
             mvol, table = ops.densify(coords, out, D, mvol)
             if ev: ev[3].record()
             depths = self.matching_field(cams, ipts["near_fars"], (H, W), mvol, s, self.range_ratios, depths,
-                                         return_lr=trace is not None)
+                                         return_lr=trace is not None, perturb=perturb,
+                                         src_idx=int(ipts["src_idx"]) if "src_idx" in ipts else 0)
             if trace is not None:
                 depths, lr = depths
                 trace[s] = {"D": D, "parents": parents, "pre_depths": pre_depths, "coords": coords, "reg_in": reg_in,
@@ -163,7 +164,7 @@ class SuRF(nn.Module):
         else:
             cams = ops._cams_ext(ops.Cameras(intrs, c2ws), intrs, c2ws)
             features = self.feature_network(imgs)                               # texel4, coarse -> fine
-            outputs, volumes, tables, mvol = self.build_volumes(ipts, features, cams)
+            outputs, volumes, tables, mvol = self.build_volumes(ipts, features, cams, perturb=(mode == "train"))   # surf.py:139
             scene = SceneVolumes.from_device_layouts(mvol, [v[:, 1:] for v in volumes[::-1]], tables[::-1], features[::-1],
                                                      ops.pack_texel4(imgs.detach().float().contiguous()), cams)
             if mode != "val":                                                   # surf.py:141-148 (loss-only inputs)

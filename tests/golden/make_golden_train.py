@@ -78,6 +78,18 @@ def main():
     out.update(ref_gray_val=outs["ref_gray_val"].detach(), sampled_gray_val=outs["sampled_gray_val"].detach(),
                smooth_error=outs["smooth_error"].detach(), mid_inside_sphere=outs["mid_inside_sphere"].detach(),
                sdf_depth=outs["sdf_depth"].detach())
+    # ---- train-mode matching field (perturb=True: views 0 and src_idx jittered, matching_field.py:33-35,129-133), stage 1
+    mf = MatchingField(conf["matching_field"]).eval()
+    ipts = dict(scene)
+    ipts["src_idx"] = 2
+    ratios = list(G.MODEL_CONF["range_ratios"]) if "range_ratios" in G.MODEL_CONF else [1.0, 0.4, 0.1, 0.01]
+    pre = list(pipe["s0_depths"])
+    torch.manual_seed(31)
+    with torch.no_grad():
+        d1, _ = mf(ipts, pipe["s1_mvol"][None, None], 1, ratios, pre, perturb=True)
+        torch.manual_seed(31)
+        d0, _ = mf(ipts, pipe["s0_mvol"][None, None], 0, ratios, None, perturb=True)
+    out.update(mf_perturb_s1=torch.stack(d1), mf_perturb_s0=torch.stack(d0), mf_perturb_src_idx=torch.tensor(2))
     # ---- losses on the chain's outputs
     from models.losses.loss import Loss
     from models.losses.ncc import compute_LNCC2

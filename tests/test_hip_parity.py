@@ -549,16 +549,18 @@ def test_finetune_volume_api_round_trip(scene, tmp_path):
             net.out_lin.weight.mul_(4.0)
     model = model.to(d)
     ipts = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in scene.items()}
-    out_a = model("train", ipts, 1.0)
+    out_t = model("train", ipts, 1.0)     # (train mode jitters the matching field: surf.py:139 - not comparable bit for bit)
+    out_a = model("val", ipts, 1.0)
     model.init_volumes(ipts)
     assert model.has_vol and len(model.volumes) == 4 and model.volumes[0].shape[1] == 7
     assert tuple(model.features[-1].shape) == tuple(scene["imgs"].shape[:1]) + (4,) + tuple(scene["imgs"].shape[2:])
     groups = model.get_optim_params({"mlp_lr": 1e-3, "vol_lr": [1e-2, 1e-2, 1e-3, 1e-3]})
     assert len(groups) == 5 and groups[1]["params"] is model.volumes[0]
-    out_b = model("train", dict(ipts, view_ids=[0, 1, 2]), 1.0)
+    out_b = model("val", dict(ipts, view_ids=[0, 1, 2]), 1.0)
     for k in ("color_fine", "render_depth", "sdf_depth", "weights"):
         assert torch.equal(out_a[k], out_b[k]), k
-    assert "depth_stage0" in out_a and "depth_stage0" not in out_b          # a has_vol forward builds nothing
+    assert "depth_stage0" in out_t and "depth_stage0" in out_a and "depth_stage0" not in out_b   # a has_vol forward builds nothing
+    assert float((out_t["depth_stage1"] - out_a["depth_stage1"]).abs().max()) > 0               # the train-mode jitter
     path = tmp_path / "vol.ckpt"
     torch.save({"model": model.get_params_vol()}, path)
     cfg2 = dict(cfg, has_vol=True)
@@ -689,3 +691,25 @@ def test_sparse_unet_train_mode_batch_statistics(golden_pipe):
     out_e, mid_e = net(feats.to(d), coords.to(d).contiguous(), D, s)
     out_eref, mid_eref = O.sparse_unet(sd2, feats, coords.long(), D, s)
     rel_close(mid_e, mid_eref, 1e-3, 1e-4)
+
+
+def test_matching_field_train_jitter_matches_golden(scene, golden_pipe, golden_train):
+    """MatchingField.forward(perturb=True) (train mode, surf.py:139) against the reference's perturbed depth maps."""
+    from surf_amd import conf, ops
+    from surf_amd.matching_field import MatchingField
+    d = dev()
+    gp, gt = golden_pipe, golden_train
+    mf = MatchingField(conf.from_dict({"n_samples_depths": CFG["n_samples_depths"], "n_importance_depths": [0] * 4,
+                                       "up_sample_steps": [0] * 4, "depth_res_levels": CFG["depth_res_levels"]}))
+    intrs, c2ws = scene["intrs"], scene["c2ws"]
+    cams = ops._cams_ext(ops.Cameras(intrs, c2ws), intrs, c2ws)
+    H, W = scene["imgs"].shape[-2:]
+    src_idx = int(gt["mf_perturb_src_idx"])
+    torch.manual_seed(31)
+    d1 = mf(cams, scene["near_fars"], (H, W), gp["s1_mvol"].to(d).contiguous(), 1, CFG["range_ratios"],
+            gp["s0_depths"].to(d).contiguous(), perturb=True, src_idx=src_idx)
+    rel_close(d1, gt["mf_perturb_s1"], 1e-4, 2e-5)
+    torch.manual_seed(31)
+    d0 = mf(cams, scene["near_fars"], (H, W), gp["s0_mvol"].to(d).contiguous(), 0, CFG["range_ratios"], None, perturb=True,
+            src_idx=src_idx)
+    rel_close(d0, gt["mf_perturb_s0"], 1e-4, 2e-5)

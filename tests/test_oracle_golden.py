@@ -194,3 +194,19 @@ def test_f2_lncc(golden_train):
     close(O.lncc(gt["unit_ref"], gt["unit_src"]), gt["unit_ncc"], atol=2e-6, rtol=1e-5)
     close(O.lncc(gt["ref_gray_val"], gt["sampled_gray_val"]), gt["ncc"], atol=2e-6, rtol=1e-5)
     assert float(gt["unit_ncc"].min()) < 0.7 and float(gt["unit_ncc"].max()) > 0.95
+
+
+def test_a7_matching_field_train_jitter(scene, golden_pipe, golden_train):
+    """matching_field.py:33-35,129-133 (perturb=True): the reference's own depth maps with the CPU generator seeded alike."""
+    gp, gt = golden_pipe, golden_train
+    src_idx = int(gt["mf_perturb_src_idx"])
+    args = (scene["imgs"].shape[-2:], scene["intrs"], scene["c2ws"], scene["near_fars"])
+    torch.manual_seed(31)
+    d1 = O.matching_field(*args, gp["s1_mvol"], 1, CFG["range_ratios"], CFG["n_samples_depths"], CFG["depth_res_levels"],
+                          list(gp["s0_depths"]), perturb=True, src_idx=src_idx)
+    close(torch.stack(d1), gt["mf_perturb_s1"], atol=2e-5, rtol=1e-5)
+    torch.manual_seed(31)
+    d0 = O.matching_field(*args, gp["s0_mvol"], 0, CFG["range_ratios"], CFG["n_samples_depths"], CFG["depth_res_levels"],
+                          None, perturb=True, src_idx=src_idx)
+    close(torch.stack(d0), gt["mf_perturb_s0"], atol=2e-5, rtol=1e-5)
+    assert float((gt["mf_perturb_s1"] - gp["s1_depths"]).abs().max()) > 1e-4      # the jitter moved something
