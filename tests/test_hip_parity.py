@@ -550,13 +550,13 @@ def test_finetune_volume_api_round_trip(scene, tmp_path):
     model = model.to(d)
     ipts = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in scene.items()}
     out_t = model("train", ipts, 1.0)     # (train mode jitters the matching field: surf.py:139 - not comparable bit for bit)
-    out_a = model("val", ipts, 1.0)
+    out_a = model("test", ipts, 1.0)      # any mode but "train" / "val": the plain render without jitter and without a mesh
     model.init_volumes(ipts)
     assert model.has_vol and len(model.volumes) == 4 and model.volumes[0].shape[1] == 7
     assert tuple(model.features[-1].shape) == tuple(scene["imgs"].shape[:1]) + (4,) + tuple(scene["imgs"].shape[2:])
     groups = model.get_optim_params({"mlp_lr": 1e-3, "vol_lr": [1e-2, 1e-2, 1e-3, 1e-3]})
     assert len(groups) == 5 and groups[1]["params"] is model.volumes[0]
-    out_b = model("val", dict(ipts, view_ids=[0, 1, 2]), 1.0)
+    out_b = model("test", dict(ipts, view_ids=[0, 1, 2]), 1.0)
     for k in ("color_fine", "render_depth", "sdf_depth", "weights"):
         assert torch.equal(out_a[k], out_b[k]), k
     assert "depth_stage0" in out_t and "depth_stage0" in out_a and "depth_stage0" not in out_b   # a has_vol forward builds nothing
