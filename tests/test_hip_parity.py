@@ -713,3 +713,22 @@ def test_matching_field_train_jitter_matches_golden(scene, golden_pipe, golden_t
     d0 = mf(cams, scene["near_fars"], (H, W), gp["s0_mvol"].to(d).contiguous(), 0, CFG["range_ratios"], None, perturb=True,
             src_idx=src_idx)
     rel_close(d0, gt["mf_perturb_s0"], 1e-4, 2e-5)
+
+
+@pytest.mark.parametrize("D", [10, 12, 6, 16])
+def test_densify_matches_oracle(D):
+    """surf_densify (volume.py:99-132) on small lattices incl. sizes that are not multiples of 4: x2 trilinear upsample of
+    the previous logits + scatter + index table, against the oracle, with and without `prev`."""
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(D)
+    occ = torch.rand(D, D, D, generator=g) < 0.2
+    coords = occ.nonzero().to(torch.int32)
+    rows = torch.randn(coords.shape[0], 8, generator=g)
+    prev = torch.randn(D // 2, D // 2, D // 2, generator=g)
+    for pv in (None, prev):
+        ref, mask = O.sparse2dense(rows[:, 0], coords, D, pv)
+        dense, table = ops.densify(coords.to(d).contiguous(), rows.to(d).contiguous(), D, None if pv is None else pv.to(d).contiguous())
+        rel_close(dense, ref, 1e-6, 1e-6)
+        assert torch.equal(table.cpu() >= 0, mask > 0)
+        assert torch.equal(table.cpu().long(), O.get_index(coords, D))
