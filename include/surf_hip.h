@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 14
+#define SURF_ABI_VERSION 15
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -137,6 +137,18 @@ int surf_sdf_smooth(const float* pts, const int32_t* idx, int64_t n, const float
  */
 int surf_lncc(const float* ref, const float* src, int64_t n_rays, int n_src, int patch_elems, int channels, float* out,
               void* stream);
+
+/*
+ * Per-pixel terms of the photometric loss of one depth map (training).  Replaces compute_ptloss + SSIM
+ * (models/losses/photometric_loss.py:54-125, :6-33): the other nv-1 views are warped into view ref_idx through `depth` (H,W)
+ * (bilinear, zeros, align_corners=True) into `warp` (nv-1,H,W,4: rgb + validity); terms (H,W,8) =
+ * [l1 m, grad_x mx, grad_y my, ssim m | m, mx, my, 0], every loss value being the SUM of its topk smallest source views
+ * and m / mx / my the reference mask and its products with the right / lower neighbour.  The loss is
+ * sum(col0)/(sum(col4)+1e-8) + sum(col1)/(sum(col5)+1e-8) + sum(col2)/(sum(col6)+1e-8) + sum(col3)/(sum(col4)+1e-8).
+ * imgs_t4 (nv,H,W,4) texel4; h_intrs / h_c2w / h_w2c: host (nv,4,4) intrinsics, camera-to-world and their inverses.
+ */
+int surf_ptloss_terms(const float* imgs_t4, int nv, int H, int W, const float* depth, const float* mask, int ref_idx, int topk,
+                      const float* h_intrs, const float* h_c2w, const float* h_w2c, float* warp, float* terms, void* stream);
 
 /*
  * Multi-view feature fetch + blending MLP.

@@ -1,0 +1,181 @@
+// K16  per-stage photometric loss of the matching-field depth maps (training).
+// Replaces compute_ptloss  models/losses/photometric_loss.py:54-125  (+ SSIM :6-33): every other view is warped into view
+// `ref` through its depth map (bilinear, zeros, align_corners=True); per pixel and source view: smooth-L1, smooth-L1 of
+// the horizontal / vertical image gradients, SSIM (3x3 means, reflection padding, masked); each reduced to the SUM of its
+// `topk` smallest source views (torch.topk(largest=False)) and weighted by the reference mask.
+//   ptloss_warp_kernel   one thread per (source, pixel): texel4 (rgb, valid) of the warped image
+//   ptloss_terms_kernel  one thread per pixel: [l1 m, gx mx, gy my, ssim m | m, mx, my, 0]; the caller sums the columns
+// Byte-bound image-space work; sources <= SURF_MAX_VIEWS - 1.
+#include "common.h"
+
+namespace {
+
+struct PtArgs {
+  const float* imgs;    // (nv,H,W,4) texel4 rgb
+  const float* depth;   // (H,W) depth of view `ref`
+  const float* mask;    // (H,W) reference mask
+  int nv, ref, H, W, ns, topk;
+  float Kinv[9];                        // inverse(intrs[ref])[:3,:3]
+  float c2w[12];                        // c2ws[ref][:3,:4]
+  float w2c[SURF_MAX_VIEWS][12];        // inverse(c2ws[s])[:3,:4] per SOURCE slot
+  float K[SURF_MAX_VIEWS][9];           // intrs[s][:3,:3]
+  int view[SURF_MAX_VIEWS];             // source slot -> view index
+  float* warp;          // (ns,H,W,4)
+  float* terms;         // (H,W,8)
+};
+
+__device__ __forceinline__ float smooth_l1(float d) {
+  const float a = fabsf(d);
+  return a < 1.0f ? 0.5f * d * d : a - 0.5f;
+}
+
+__global__ __launch_bounds__(256) void ptloss_warp_kernel(PtArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)a.H * a.W;
+  if (i >= per * a.ns) return;
+  const int s = (int)(i / per), p = (int)(i % per), y = p / a.W, x = p % a.W;
+  const float d = a.depth[p];
+  const float X = (float)x * d, Y = (float)y * d, Z = d;
+  const float cx = a.Kinv[0] * X + a.Kinv[1] * Y + a.Kinv[2] * Z;
+  const float cy = a.Kinv[3] * X + a.Kinv[4] * Y + a.Kinv[5] * Z;
+  const float cz = a.Kinv[6] * X + a.Kinv[7] * Y + a.Kinv[8] * Z;
+  const float wx = a.c2w[0] * cx + a.c2w[1] * cy + a.c2w[2] * cz + a.c2w[3];
+  const float wy = a.c2w[4] * cx + a.c2w[5] * cy + a.c2w[6] * cz + a.c2w[7];
+  const float wz = a.c2w[8] * cx + a.c2w[9] * cy + a.c2w[10] * cz + a.c2w[11];
+  const float* M = a.w2c[s];
+  const float sx = M[0] * wx + M[1] * wy + M[2] * wz + M[3];
+  const float sy = M[4] * wx + M[5] * wy + M[6] * wz + M[7];
+  const float sz = M[8] * wx + M[9] * wy + M[10] * wz + M[11];
+  const float* K = a.K[s];
+  const float px = K[0] * sx + K[1] * sy + K[2] * sz;
+  const float py = K[3] * sx + K[4] * sy + K[5] * sz;
+  const float pz = K[6] * sx + K[7] * sy + K[8] * sz;
+  const float u = px / (pz + 1e-8f), v = py / (pz + 1e-8f);
+  const float nx = u / ((float)(a.W - 1) / 2.0f) - 1.0f, ny = v / ((float)(a.H - 1) / 2.0f) - 1.0f;
+  const bool ok = fabsf(nx) <= 1.0f && fabsf(ny) <= 1.0f && pz > 0.0f;
+  const float gx = ((nx + 1.0f) / 2.0f) * (float)(a.W - 1), gy = ((ny + 1.0f) / 2.0f) * (float)(a.H - 1);   // align_corners=True
+  f32x4 t = bilinear_texel4(a.imgs + (int64_t)a.view[s] * per * 4, a.H, a.W, gx, gy);
+  t[3] = ok ? 1.0f : 0.0f;
+  reinterpret_cast<f32x4*>(a.warp)[i] = t;
+}
+
+__device__ __forceinline__ int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__global__ __launch_bounds__(256) void ptloss_terms_kernel(PtArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)a.H * a.W;
+  if (p >= per) return;
+  const int y = (int)(p / a.W), x = (int)(p % a.W);
+  const f32x4* __restrict__ ref = reinterpret_cast<const f32x4*>(a.imgs) + (int64_t)a.ref * per;
+  const float mref = a.mask[p];
+  const float mx = x + 1 < a.W ? mref * a.mask[p + 1] : 0.f;
+  const float my = y + 1 < a.H ? mref * a.mask[p + a.W] : 0.f;
+  // reference 3x3 statistics (shared by all sources)
+  float r_mu[3] = {0, 0, 0}, r_sq[3] = {0, 0, 0};
+  int yy[3], xx[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { yy[k] = reflect(y + k - 1, a.H); xx[k] = reflect(x + k - 1, a.W); }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const f32x4 r = ref[(int64_t)yy[j] * a.W + xx[k]];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { r_mu[c] += r[c]; r_sq[c] = fmaf(r[c], r[c], r_sq[c]); }
+    }
+  const f32x4 r0 = ref[p];
+  const f32x4 rxn = x + 1 < a.W ? ref[p + 1] : r0, ryn = y + 1 < a.H ? ref[p + a.W] : r0;
+  float best[4][SURF_MAX_VIEWS];      // per term: the values of all sources, kept sorted ascending
+  for (int s = 0; s < a.ns; ++s) {
+    const f32x4* __restrict__ w = reinterpret_cast<const f32x4*>(a.warp) + (int64_t)s * per;
+    const f32x4 w0 = w[p];
+    float l1 = 0.f, gx = 0.f, gy = 0.f;
+    const f32x4 wxn = x + 1 < a.W ? w[p + 1] : w0, wyn = y + 1 < a.H ? w[p + a.W] : w0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      l1 += smooth_l1(w0[c] - r0[c]);
+      gx += smooth_l1((w0[c] - wxn[c]) - (r0[c] - rxn[c]));
+      gy += smooth_l1((w0[c] - wyn[c]) - (r0[c] - ryn[c]));
+    }
+    l1 /= 3.0f; gx /= 3.0f; gy /= 3.0f;
+    float w_mu[3] = {0, 0, 0}, w_sq[3] = {0, 0, 0}, wr[3] = {0, 0, 0}, mpool = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int64_t q = (int64_t)yy[j] * a.W + xx[k];
+        const f32x4 t = w[q], r = ref[q];
+        mpool += (t[3] > 0.5f && a.mask[q] > 0.5f) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { w_mu[c] += t[c]; w_sq[c] = fmaf(t[c], t[c], w_sq[c]); wr[c] = fmaf(t[c], r[c], wr[c]); }
+      }
+    mpool /= 9.0f;
+    float ssim = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float mux = w_mu[c] / 9.0f, muy = r_mu[c] / 9.0f;
+      const float sgx = w_sq[c] / 9.0f - mux * mux, sgy = r_sq[c] / 9.0f - muy * muy, sgxy = wr[c] / 9.0f - mux * muy;
+      const float n = (2.0f * mux * muy + 1e-4f) * (2.0f * sgxy + 9e-4f);
+      const float d = (mux * mux + muy * muy + 1e-4f) * (sgx + sgy + 9e-4f);
+      ssim += mpool * fminf(fmaxf((1.0f - n / d) / 2.0f, 0.0f), 1.0f);
+    }
+    ssim /= 3.0f;
+    const float v4[4] = {l1, gx, gy, ssim};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {       // insertion into the ascending list
+      int j = s;
+      while (j > 0 && best[t][j - 1] > v4[t]) { best[t][j] = best[t][j - 1]; --j; }
+      best[t][j] = v4[t];
+    }
+  }
+  float sum[4] = {0, 0, 0, 0};
+  for (int t = 0; t < 4; ++t)
+    for (int k = 0; k < a.topk; ++k) sum[t] += best[t][k];
+  f32x4* out = reinterpret_cast<f32x4*>(a.terms) + p * 2;
+  out[0] = f32x4{sum[0] * mref, sum[1] * mx, sum[2] * my, sum[3] * mref};
+  out[1] = f32x4{mref, mx, my, 0.f};
+}
+
+}  // namespace
+
+extern "C" int surf_ptloss_terms(const float* imgs_t4, int nv, int H, int W, const float* depth, const float* mask, int ref_idx,
+                                 int topk, const float* h_intrs, const float* h_c2w, const float* h_w2c, float* warp,
+                                 float* terms, void* stream) {
+  if (!imgs_t4 || !depth || !mask || !h_intrs || !h_c2w || !h_w2c || !warp || !terms) return SURF_E_ARG;
+  if (nv < 2 || nv > SURF_MAX_VIEWS || ref_idx < 0 || ref_idx >= nv || H < 2 || W < 2) return SURF_E_ARG;
+  if (topk < 1 || topk > nv - 1) return SURF_E_ARG;
+  PtArgs a;
+  a.imgs = imgs_t4; a.depth = depth; a.mask = mask; a.nv = nv; a.ref = ref_idx; a.H = H; a.W = W; a.ns = nv - 1; a.topk = topk;
+  a.warp = warp; a.terms = terms;
+  // inverse of the reference intrinsics' upper-left 3x3 (host, double)
+  {
+    const float* K = h_intrs + ref_idx * 16;
+    const double m[9] = {K[0], K[1], K[2], K[4], K[5], K[6], K[8], K[9], K[10]};
+    const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (det == 0.0) return SURF_E_ARG;
+    const double inv[9] = {(m[4] * m[8] - m[5] * m[7]) / det, (m[2] * m[7] - m[1] * m[8]) / det, (m[1] * m[5] - m[2] * m[4]) / det,
+                           (m[5] * m[6] - m[3] * m[8]) / det, (m[0] * m[8] - m[2] * m[6]) / det, (m[2] * m[3] - m[0] * m[5]) / det,
+                           (m[3] * m[7] - m[4] * m[6]) / det, (m[1] * m[6] - m[0] * m[7]) / det, (m[0] * m[4] - m[1] * m[3]) / det};
+    for (int k = 0; k < 9; ++k) a.Kinv[k] = (float)inv[k];
+  }
+  for (int k = 0; k < 12; ++k) a.c2w[k] = h_c2w[ref_idx * 16 + k];
+  int slot = 0;
+  for (int v = 0; v < nv; ++v) {
+    if (v == ref_idx) continue;
+    a.view[slot] = v;
+    for (int k = 0; k < 12; ++k) a.w2c[slot][k] = h_w2c[v * 16 + k];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) a.K[slot][r * 3 + c] = h_intrs[v * 16 + r * 4 + c];
+    ++slot;
+  }
+  for (; slot < SURF_MAX_VIEWS; ++slot) {
+    a.view[slot] = 0;
+    for (int k = 0; k < 12; ++k) a.w2c[slot][k] = 0.f;
+    for (int k = 0; k < 9; ++k) a.K[slot][k] = 0.f;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t per = (int64_t)H * W;
+  hipLaunchKernelGGL(ptloss_warp_kernel, dim3((unsigned)((per * a.ns + 255) / 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ptloss_terms_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, a);
+  return surf_check_launch();
+}

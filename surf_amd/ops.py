@@ -470,6 +470,27 @@ def patch_warp(pts, grads, maps_t4, cams, patch_size=11):
     return ref, src
 
 
+def photometric_loss(depth, imgs_t4, mask_ref, cams, ref_idx=0, topk=2, return_warp=False):
+    """compute_ptloss (losses/photometric_loss.py:54-125) of one (H,W) depth map of view ref_idx: scalar tensor.
+    imgs_t4 (nv,H,W,4) texel4; cams: ops.Cameras (host matrices)."""
+    _chk(depth, torch.float32, "depth")
+    _chk(imgs_t4, torch.float32, "imgs_t4")
+    _chk(mask_ref, torch.float32, "mask_ref")
+    nv, H, W, _ = imgs_t4.shape
+    assert tuple(depth.shape) == (H, W) and tuple(mask_ref.shape) == (H, W) and cams.nv == nv
+    dev = depth.device
+    warp = torch.empty(nv - 1, H, W, 4, dtype=torch.float32, device=dev)
+    terms = torch.empty(H, W, 8, dtype=torch.float32, device=dev)
+    intr16 = np.ascontiguousarray(cams.intrs.reshape(nv, -1))
+    assert intr16.shape[1] == 16
+    rc = _lib.lib().surf_ptloss_terms(_p(imgs_t4), nv, H, W, _p(depth), _p(mask_ref), int(ref_idx), int(topk), _np_ptr(intr16),
+                                      _np_ptr(cams.c2w), _np_ptr(cams.w2c), _p(warp), _p(terms), _stream())
+    _lib.check(rc, "surf_ptloss_terms")
+    t = terms.view(-1, 8).sum(dim=0, dtype=torch.float64)
+    loss = (t[0] / (t[4] + 1e-8) + t[1] / (t[5] + 1e-8) + t[2] / (t[6] + 1e-8) + t[3] / (t[4] + 1e-8)).float()
+    return (loss, warp) if return_warp else loss
+
+
 def lncc(ref_gray_val, sampled_gray_val):
     """compute_LNCC2 (losses/ncc.py:7-51): ref (1,R,P,C), src (nsrc,R,P,C) -> (R,1)."""
     _chk(ref_gray_val, torch.float32, "ref_gray_val")

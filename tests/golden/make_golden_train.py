@@ -90,6 +90,17 @@ def main():
         torch.manual_seed(31)
         d0, _ = mf(ipts, pipe["s0_mvol"][None, None], 0, ratios, None, perturb=True)
     out.update(mf_perturb_s1=torch.stack(d1), mf_perturb_s0=torch.stack(d0), mf_perturb_src_idx=torch.tensor(2))
+    # ---- per-stage photometric term (losses/photometric_loss.py:54-125) on the pipeline's finest depth maps
+    from models.losses.photometric_loss import compute_ptloss
+    g = torch.Generator().manual_seed(41)
+    H, W = scene["imgs"].shape[-2:]
+    mask_ref = (torch.rand(H, W, generator=g) > 0.15).float()
+    mask_src = (torch.rand(H, W, generator=g) > 0.15).float()
+    with torch.no_grad():
+        pt_ref = compute_ptloss(pipe["s3_depths"][0], scene["imgs"], mask_ref, intrs, c2ws)
+        pt_src = compute_ptloss(pipe["s3_depths"][2], scene["imgs"], mask_src, intrs, c2ws, ref_idx=2, topk=1)
+        pt_far = compute_ptloss(pipe["s3_depths"][0] * 3.0, scene["imgs"], mask_ref, intrs, c2ws)      # many pixels leave the frusta
+    out.update(pt_mask_ref=mask_ref, pt_mask_src=mask_src, pt_ref=pt_ref.reshape(1), pt_src=pt_src.reshape(1), pt_far=pt_far.reshape(1))
     # ---- losses on the chain's outputs
     from models.losses.loss import Loss
     from models.losses.ncc import compute_LNCC2
