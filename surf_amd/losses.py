@@ -1,10 +1,10 @@
 """Host-side mirror of the reference's training loss (models/losses/loss.py:10-111), forward values only.
 
 Same constructor keys (`confs/surf.conf:49-63`), same `forward(preds, targets, step, mode)` and the same output dictionary.
-The terms are scalar reductions of the hot path's outputs; the one with real work, the local NCC of the surface patches
-(`compute_LNCC2`, losses/ncc.py:7-51), runs in `surf_lncc` (csrc/lncc.hip).  NOT built: the per-stage photometric term
+Most terms are scalar reductions of the hot path's outputs; the two with real work run in HIP: the local NCC of the
+surface patches (`compute_LNCC2`, losses/ncc.py:7-51 -> `surf_lncc`, csrc/lncc.hip) and the per-stage photometric term
 (`compute_ptloss`, losses/photometric_loss.py:54-125: inverse warping of the source images by the matching-field depths,
-SSIM + L1 + gradient), which `mode == "train"` needs when `ptloss_weight != 0`, and every backward pass:
+SSIM + smooth-L1 + gradient -> `surf_ptloss_terms`, csrc/ptloss.hip).  NOT built: every backward pass -
 nothing here is differentiable.
 """
 import torch
@@ -45,10 +45,16 @@ class Loss(nn.Module):
         zero = 0.0
         photo_loss = pseudo_auxi = auxi = auxi0 = src_auxi = src_auxi0 = zero
         if mode == "train":
-            if self.ptloss_weight != 0:
-                raise NotImplementedError("compute_ptloss (per-stage photometric term) is not built: SURVEY 8f-f2")
             n = len(self.stage_weights)
+            imgs_t4 = ops.pack_texel4(targets["imgs"].float().contiguous())
+            cams = ops.Cameras(targets["intrs"], targets["c2ws"])
+            src_idx = int(targets["src_idx"])
+            mask_ref, mask_src = targets["mask_ref"].float().contiguous(), targets["mask_src"].float().contiguous()
             for i in range(n):
+                ref_photo = ops.photometric_loss(preds[f"depth_stage{i}"].float().contiguous(), imgs_t4, mask_ref, cams)
+                src_photo = ops.photometric_loss(preds[f"depth_src_stage{i}"].float().contiguous(), imgs_t4, mask_src, cams,
+                                                 ref_idx=src_idx, topk=1)
+                photo_loss = photo_loss + (ref_photo + src_photo) * self.stage_weights[i]
                 pa = self._masked_l1(preds[f"depth_stage{i}"], targets["pseudo_depth_ref"], targets["pseudo_depth_ref"] > 0)
                 spa = self._masked_l1(preds[f"depth_src_stage{i}"], targets["pseudo_depth_src"], targets["pseudo_depth_src"] > 0)
                 pseudo_auxi = pseudo_auxi + (pa + spa) * self.stage_weights[i]

@@ -121,6 +121,21 @@ def main():
         out["loss_pred_" + k] = preds[k].float() if preds[k].dtype == torch.bool else preds[k]
     for k, v in lo.items():
         out["loss_out_" + k] = torch.as_tensor(v, dtype=torch.float32).reshape(-1)
+    # ... and mode "train": adds the per-stage photometric / auxiliary depth terms (targets from the pipeline's depth maps)
+    targets_t = dict(targets, imgs=scene["imgs"], intrs=intrs, c2ws=c2ws, src_idx=2, mask_ref=mask_ref, mask_src=mask_src,
+                     pseudo_depth_ref=pipe["s3_depths"][0] * (torch.rand(H, W, generator=g) > 0.4).float(),
+                     pseudo_depth_src=pipe["s3_depths"][2] * (torch.rand(H, W, generator=g) > 0.4).float(),
+                     depth_ref=pipe["s3_depths"][0] * 1.02, depth_src=pipe["s3_depths"][2] * 0.98)
+    preds_t = dict(preds)
+    for i in range(4):
+        preds_t[f"depth_stage{i}"] = pipe[f"s{i}_depths"][0]
+        preds_t[f"depth_src_stage{i}"] = pipe[f"s{i}_depths"][2]
+    with torch.no_grad():
+        lt = loss_fn(preds_t, targets_t, step=3, mode="train")
+    for k in ("pseudo_depth_ref", "pseudo_depth_src", "depth_ref", "depth_src"):
+        out["loss_target_t_" + k] = targets_t[k]
+    for k, v in lt.items():
+        out["loss_train_" + k] = torch.as_tensor(v, dtype=torch.float32).reshape(-1)
     G.ONLY.clear()
     G.npz("train_outputs.npz", **out)
 

@@ -3,6 +3,8 @@
 Tolerances (BASELINE.json north_star): 1e-4 abs on SDF values, 1e-3 relative on rendered RGB / depth.
 Index / mask outputs must match exactly.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -656,8 +658,39 @@ def test_lncc_and_loss_match_golden(golden_train):
     for k, v in out.items():
         got = torch.as_tensor(v, dtype=torch.float32).reshape(-1)
         rel_close(got, gt["loss_out_" + k], 1e-5, 1e-6)
-    with pytest.raises(NotImplementedError):
-        Loss(conf.from_dict(LOSS_CONF))(preds, targets, step=1, mode="train")
+    # mode "train": + the per-stage photometric / auxiliary depth terms
+    gp = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden", "pipeline.npz")).items()}
+    sc = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden", "scene.npz")).items()}
+    targets_t = dict(targets, imgs=sc["imgs"].to(d), intrs=sc["intrs"], c2ws=sc["c2ws"], src_idx=2,
+                     mask_ref=gt["pt_mask_ref"].to(d), mask_src=gt["pt_mask_src"].to(d))
+    for k in ("pseudo_depth_ref", "pseudo_depth_src", "depth_ref", "depth_src"):
+        targets_t[k] = gt["loss_target_t_" + k].to(d)
+    preds_t = dict(preds)
+    for i in range(4):
+        preds_t[f"depth_stage{i}"] = gp[f"s{i}_depths"][0].to(d)
+        preds_t[f"depth_src_stage{i}"] = gp[f"s{i}_depths"][2].to(d)
+    out_t = Loss(conf.from_dict(LOSS_CONF))(preds_t, targets_t, step=3, mode="train")
+    for k, v in out_t.items():
+        rel_close(torch.as_tensor(v, dtype=torch.float32).reshape(-1), gt["loss_train_" + k], 2e-5, 2e-6)
+
+
+def test_photometric_loss_matches_golden(scene, golden_pipe, golden_train):
+    """surf_ptloss_terms (losses/photometric_loss.py:54-125): the warped images and validity masks against the oracle, the
+    scalar against the reference's own values (three cases, see the oracle test)."""
+    from surf_amd import ops
+    d = dev()
+    gt, gp = golden_train, golden_pipe
+    imgs_t4 = ops.pack_texel4(scene["imgs"].to(d).contiguous())
+    cams = ops.Cameras(scene["intrs"], scene["c2ws"])
+    for name, depth, mask, ref_idx, topk in (("pt_ref", gp["s3_depths"][0], gt["pt_mask_ref"], 0, 2),
+                                             ("pt_src", gp["s3_depths"][2], gt["pt_mask_src"], 2, 1),
+                                             ("pt_far", gp["s3_depths"][0] * 3.0, gt["pt_mask_ref"], 0, 2)):
+        loss, warp = ops.photometric_loss(depth.to(d).contiguous(), imgs_t4, mask.to(d).contiguous(), cams, ref_idx, topk,
+                                          return_warp=True)
+        _, w_ref, v_ref = O.photometric_loss(depth, scene["imgs"], mask, scene["intrs"], scene["c2ws"], ref_idx, topk)
+        rel_close(warp[..., :3].permute(0, 3, 1, 2), w_ref, 1e-4, 2e-5)
+        assert float((warp[..., 3].cpu() != v_ref.float()).float().mean()) < 2e-3      # validity flags (frustum-edge ties)
+        rel_close(loss.reshape(1), gt[name], 2e-5, 2e-6)
 
 
 def test_sparse_unet_train_mode_batch_statistics(golden_pipe):

@@ -210,3 +210,15 @@ def test_a7_matching_field_train_jitter(scene, golden_pipe, golden_train):
                           None, perturb=True, src_idx=src_idx)
     close(torch.stack(d0), gt["mf_perturb_s0"], atol=2e-5, rtol=1e-5)
     assert float((gt["mf_perturb_s1"] - gp["s1_depths"]).abs().max()) > 1e-4      # the jitter moved something
+
+
+def test_f2_photometric_loss(scene, golden_pipe, golden_train):
+    """losses/photometric_loss.py:54-125 on the pipeline's finest depth maps: reference view (topk 2), a source view as the
+    reference (topk 1), and a depth map that throws most pixels out of the source frusta."""
+    gt, gp = golden_train, golden_pipe
+    args = (scene["imgs"], None, scene["intrs"], scene["c2ws"])
+    for name, depth, mask, ref_idx, topk in (("pt_ref", gp["s3_depths"][0], gt["pt_mask_ref"], 0, 2),
+                                             ("pt_src", gp["s3_depths"][2], gt["pt_mask_src"], 2, 1),
+                                             ("pt_far", gp["s3_depths"][0] * 3.0, gt["pt_mask_ref"], 0, 2)):
+        v, _, _ = O.photometric_loss(depth, scene["imgs"], mask, scene["intrs"], scene["c2ws"], ref_idx, topk)
+        close(v.reshape(1), gt[name], atol=2e-6, rtol=1e-5)
