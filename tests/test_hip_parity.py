@@ -765,3 +765,40 @@ def test_densify_matches_oracle(D):
         rel_close(dense, ref, 1e-6, 1e-6)
         assert torch.equal(table.cpu() >= 0, mask > 0)
         assert torch.equal(table.cpu().long(), O.get_index(coords, D))
+
+
+def test_training_step_forward_end_to_end(scene):
+    """SuRF.forward("train") (FPN in train-mode InstanceNorm = same; U-Net BatchNorm with batch statistics; jittered
+    matching field; render + patch warps + H.1) feeding Loss.forward(mode="train"): every term finite, the forward values of
+    one training step (runner.py:150-162 without the backward)."""
+    from surf_amd import conf
+    from surf_amd.losses import Loss
+    from surf_amd.surf import SuRF
+    from tests.golden.make_golden import MODEL_CONF
+    from tests.golden.make_golden_train import LOSS_CONF
+    d = dev()
+    cfg = {k: v for k, v in MODEL_CONF.items()}
+    cfg["reg_network"] = {"d_in": [8, 16, 16, 16], "d_base": [8] * 4, "d_out": [8] * 4}
+    torch.manual_seed(2)
+    model = SuRF(conf.from_dict(cfg))
+    with torch.no_grad():
+        model.implicit_surface.deviation_network.variance.fill_(0.45)
+        for net in model.reg_network.nets:
+            net.out_lin.weight.mul_(4.0)
+    model = model.to(d).train()
+    ipts = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    ipts["src_idx"] = 1
+    preds = model("train", ipts, 0.5, step=3)
+    R = scene["rays_o"].shape[0]
+    H, W = scene["imgs"].shape[-2:]
+    g = torch.Generator().manual_seed(3)
+    targets = {"color": torch.rand(R, 3, generator=g).to(d), "imgs": ipts["imgs"], "intrs": scene["intrs"], "c2ws": scene["c2ws"],
+               "src_idx": 1, "mask_ref": torch.ones(H, W, device=d), "mask_src": torch.ones(H, W, device=d),
+               "pseudo_depth_ref": torch.zeros(H, W, device=d), "pseudo_depth_src": torch.zeros(H, W, device=d),
+               "depth_ref": preds["depth_stage3"] * 1.01, "depth_src": preds["depth_src_stage3"] * 0.99}
+    out = Loss(conf.from_dict(LOSS_CONF))(preds, targets, step=3, mode="train")
+    for k, v in out.items():
+        assert bool(torch.isfinite(torch.as_tensor(v, dtype=torch.float32)).all()), k
+    assert float(out["photo_loss"]) > 0 and float(out["loss"]) > 0
+    bn = model.reg_network.nets[0].conv0.net[1]
+    assert int(bn.num_batches_tracked) == 1            # train mode updated the running statistics
