@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 15
+#define SURF_ABI_VERSION 16
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -206,6 +206,17 @@ int surf_composite(const float* sdf, const float* grad, const float* color, cons
                    const float* h_rot_ref, float* out_color, float* out_depth, float* out_sdf_depth,
                    float* out_normal, float* out_normal_val, uint8_t* out_valid, uint8_t* out_mid_inside,
                    float* out_weights, float* out_inside, float* out_eik, float* out_z_sdf0, void* stream);
+/*
+ * Backward of surf_composite for the outputs the training loss differentiates (colour_fine, render_depth, the eikonal
+ * sums): the autograd of render_core's tail (implicit_surface.py:126-166) in closed form.  g_color (R,3), g_depth (R, may
+ * be NULL): upstream gradients; eik_scale = dL/d gradient_error / (sum relax + 1e-5).  Outputs: d_sdf (R,S), d_grad (R,S,3),
+ * d_color (R,S,3), d_inv_s (R) per-ray partial sums.  First kernel of the training row's backward side.
+ */
+int surf_composite_backward(const float* sdf, const float* grad, const float* color, const float* mid_z, const float* dists,
+                            const float* pts, const uint8_t* vmask, const float* rays_d, int n_rays, int S, float inv_s,
+                            float cos_anneal_ratio, const float* h_rot_ref, const float* g_color, const float* g_depth,
+                            float eik_scale, float* d_sdf, float* d_grad, float* d_color, float* d_inv_s, void* stream);
+
 
 /* =====================================================================================================
  * Volume build (surf.py:80-131).  Voxel coordinates are int32 triples; voxel_size = 2/(D-1), origin -1.

@@ -421,6 +421,25 @@ def composite(sdf, grad, color, n_valid, setup, rays_d, inv_s, cos_anneal_ratio,
     return out
 
 
+def composite_backward(sdf, grad, color, setup, rays_d, inv_s, cos_anneal_ratio, cams, g_color, g_depth=None, eik_scale=0.0):
+    """Backward of `composite` w.r.t. (sdf, grad, color, inv_s) for upstream gradients of colour_fine (R,3) and
+    render_depth (R) and the eikonal term (eik_scale = dL/d gradient_error / (sum relax + 1e-5)).
+    Returns (d_sdf (R*S,), d_grad (R*S,3), d_color (R*S,3), d_inv_s scalar tensor)."""
+    R, S = setup["mid_z"].shape
+    dev = sdf.device
+    _chk(g_color, torch.float32, "g_color")
+    d_sdf = torch.empty(R * S, dtype=torch.float32, device=dev)
+    d_grad = torch.empty(R * S, 3, dtype=torch.float32, device=dev)
+    d_color = torch.empty(R * S, 3, dtype=torch.float32, device=dev)
+    d_is = torch.empty(R, dtype=torch.float32, device=dev)
+    rc = _lib.lib().surf_composite_backward(_p(sdf), _p(grad), _p(color), _p(setup["mid_z"]), _p(setup["dists"]), _p(setup["pts"]),
+                                            _p(setup["vmask"]), _p(rays_d), R, S, ctypes.c_float(inv_s),
+                                            ctypes.c_float(cos_anneal_ratio), _np_ptr(cams.rot_ref), _p(g_color), _p(g_depth),
+                                            ctypes.c_float(float(eik_scale)), _p(d_sdf), _p(d_grad), _p(d_color), _p(d_is), _stream())
+    _lib.check(rc, "surf_composite_backward")
+    return d_sdf, d_grad, d_color, d_is.sum(dtype=torch.float64).float()
+
+
 def upsample_bilinear_t4(x, H, W):
     """F.interpolate(x, size=(H, W), mode="bilinear", align_corners=False) on a texel4 map (n,h,w,4)."""
     _chk(x, torch.float32, "x")
