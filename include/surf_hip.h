@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 16
+#define SURF_ABI_VERSION 17
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -149,6 +149,19 @@ int surf_lncc(const float* ref, const float* src, int64_t n_rays, int n_src, int
  */
 int surf_ptloss_terms(const float* imgs_t4, int nv, int H, int W, const float* depth, const float* mask, int ref_idx, int topk,
                       const float* h_intrs, const float* h_c2w, const float* h_w2c, float* warp, float* terms, void* stream);
+
+/*
+ * Backward of the SDF network for upstream gradients of the SDF value (ybar, n) and of its spatial gradient (gbar, n x 3):
+ * gbar . grad is the forward-mode tangent of the SDF along gbar, so one reverse sweep over a (value, tangent) forward sweep
+ * replaces the reference's double backward (sdf_network.py:129-141 under loss.backward(), runner.py:163).  The kernel writes
+ * per-sample buffers - in_v / in_d (7, n, 160): every layer's inputs and their tangents; tb / tdb (6, n, 128): the adjoints
+ * of lin0..lin5's pre-activations and of their tangents - from which dW_l = tb_l^T in_v_l + tdb_l^T in_d_l, db_l = sum tb_l
+ * (lin6 row 0: sum ybar in_v_6 + in_d_6), and accumulates the gradient of the sparse feature rows into h_dvols[s] (N_s, 8)
+ * with float atomics (caller zero-fills; NULL = skip).  packed: surf_sdf_smooth_pack_weights' image.
+ */
+int surf_sdf_backward(const float* pts, const float* ybar, const float* gbar, int64_t n, const float* const* h_vols,
+                      const int32_t* const* h_tables, const int* h_dims, int n_vol, float* const* h_dvols, const float* packed,
+                      float* in_v, float* in_d, float* tb, float* tdb, void* stream);
 
 /*
  * Multi-view feature fetch + blending MLP.

@@ -1,0 +1,310 @@
+// K9b  backward of the SDF network for the training loss (second backward kernel of row f2 / K12).
+// The loss sees, per sample, the SDF value y and its spatial gradient g = dy/dx (alpha compositing through the cosine term,
+// the eikonal term, the normals): with upstream gradients ybar (scalar) and gbar (3-vector),
+//     gbar . g  =  d/d eps  y(x + eps gbar)  =  ydot,     the forward-mode TANGENT of y along v = gbar,
+// so d(ybar y + gbar . g)/d(weights, features) is ONE reverse sweep over the forward sweep that carries (value, tangent) -
+// reverse over forward - instead of the reference's double backward (torch.autograd.grad(create_graph=True),
+// sdf_network.py:129-141 under loss.backward(), runner.py:163):
+//   forward   t_l = W_l in_l + b_l, t'_l = W_l in'_l;   h = sp(t), h' = sp'(t) t'
+//   seeds     tbar_6[0] = ybar,  t'bar_6[0] = 1
+//   reverse   inbar = W^T tbar, in'bar = W^T t'bar;   tbar_{l-1} = sp'(t) hbar + sp''(t) t' h'bar,   t'bar_{l-1} = sp'(t) h'bar
+//   weights   dW_l = sum_n tbar_l (x) in_l + t'bar_l (x) in'_l,  db_l = sum_n tbar_l      (left to the caller as GEMMs over
+//             the per-sample buffers this kernel writes: IN / IND (n,160) and TB / TDB (n,128) per layer)
+//   features  dF[row_c] += w_c phibar + (grad w_c . v) phi'bar     (float atomics into the sparse volumes' gradient rows)
+// Plain fp32 FMAs, one wavefront per 4 samples, same lane ownership as sdf_smooth.hip (whose packed weight image it reads).
+#include "common.h"
+
+namespace {
+
+constexpr int S = 4, KP = 160, NH = 128, N_E = 27, N_PHI = 28, N_H2 = 101, N_HID = 6;
+constexpr int OFF_WT = 0;
+constexpr int OFF_W = OFF_WT + N_HID * KP * NH;
+constexpr int OFF_B = OFF_W + N_HID * NH * KP;
+constexpr int OFF_W6 = OFF_B + N_HID * NH;
+
+__host__ __device__ constexpr int layer_k(int l) { return l == 0 ? N_E : 156; }
+__host__ __device__ constexpr int layer_n(int l) { return l == 2 ? N_H2 : NH; }
+
+struct BwdArgs {
+  const float* pts;
+  const float* ybar;   // (n)
+  const float* gbar;   // (n,3)
+  int64_t n;
+  const float* vols[SURF_MAX_STAGES];
+  const int32_t* tables[SURF_MAX_STAGES];
+  int dims[SURF_MAX_STAGES];
+  float* dvols[SURF_MAX_STAGES];   // gradient rows (N_s, 8), accumulated with atomics
+  const float* packed;
+  float* in_v;   // (7, n, KP)  layer inputs
+  float* in_d;   // (7, n, KP)  their tangents along gbar
+  float* tb;     // (6, n, NH)  adjoints of the pre-activations
+  float* tdb;    // (6, n, NH)  adjoints of their tangents
+};
+
+struct Act { float h, s1, s2; };
+__device__ __forceinline__ Act softplus100(float t) {
+  const float bt = t * 100.0f;
+  Act a;
+  if (bt > 20.0f) {
+    a.h = t; a.s1 = 1.0f; a.s2 = 0.0f;
+  } else {
+    const float ex = expf(bt);
+    a.h = log1pf(ex) / 100.0f;
+    a.s1 = ex / (1.0f + ex);
+    a.s2 = 100.0f * a.s1 / (1.0f + ex);
+  }
+  return a;
+}
+
+__global__ __launch_bounds__(64) void sdf_bwd_kernel(BwdArgs a) {
+  __shared__ float in_v[S][KP], in_d[S][KP];
+  __shared__ float dl_v[S][NH], dl_d[S][NH];
+  const int lane = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * S;
+  const float inv_sqrt2 = 0.70710678118654752440f;
+  float e[S], je[S];
+  float px[S], py[S], pz[S], vx[S], vy[S], vz[S], yb[S];
+  bool live[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int64_t i = base + s;
+    live[s] = i < a.n;
+    const int64_t ic = live[s] ? i : a.n - 1;
+    px[s] = a.pts[ic * 3 + 0]; py[s] = a.pts[ic * 3 + 1]; pz[s] = a.pts[ic * 3 + 2];
+    vx[s] = live[s] ? a.gbar[ic * 3 + 0] : 0.f; vy[s] = live[s] ? a.gbar[ic * 3 + 1] : 0.f; vz[s] = live[s] ? a.gbar[ic * 3 + 2] : 0.f;
+    yb[s] = live[s] ? a.ybar[ic] : 0.f;
+    {
+      const int c = lane < N_E ? lane : 0;
+      const int axis = c % 3, blk = c / 3;
+      const float x = axis == 0 ? px[s] : (axis == 1 ? py[s] : pz[s]);
+      if (blk == 0) {
+        e[s] = x; je[s] = 1.0f;
+      } else {
+        const float f = (float)(1 << ((blk - 1) >> 1));
+        float sn, cs;
+        sincosf(x * f, &sn, &cs);
+        if ((blk - 1) & 1) { e[s] = cs; je[s] = -f * sn; }
+        else               { e[s] = sn; je[s] = f * cs; }
+      }
+      const float va = axis == 0 ? vx[s] : (axis == 1 ? vy[s] : vz[s]);
+      je[s] *= va;                                  // tangent of the encoding channel along v
+    }
+    float phi = 0.f, phid = 0.f;
+    if (lane < N_PHI) {
+      const int st = lane / 7, ch = lane % 7;
+      const int D = a.dims[st];
+      if (D > 1) {
+        const int32_t* __restrict__ table = a.tables[st];
+        const float* __restrict__ vol = a.vols[st];
+        const float vs = 2.0f / ((float)D - 1.0f);
+        const float gx = (px[s] + 1.0f) / vs, gy = (py[s] + 1.0f) / vs, gz = (pz[s] + 1.0f) / vs;
+        const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+        const float tx = gx - fx, ty = gy - fy, tz = gz - fz;
+        const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int dx = k >> 2, dy = (k >> 1) & 1, dz = k & 1;
+          const int xi = min(max(x0 + dx, 0), D - 1), yi = min(max(y0 + dy, 0), D - 1), zi = min(max(z0 + dz, 0), D - 1);
+          const int row = table[((int64_t)xi * D + yi) * D + zi];
+          const float f = row >= 0 ? vol[(int64_t)row * 8 + ch] : 0.f;
+          const float wx = dx ? tx : 1.0f - tx, wy = dy ? ty : 1.0f - ty, wz = dz ? tz : 1.0f - tz;
+          const float sx = dx ? 1.0f : -1.0f, sy = dy ? 1.0f : -1.0f, sz = dz ? 1.0f : -1.0f;
+          phi += f * (wx * wy * wz);
+          phid += f * ((sx * wy * wz / vs) * vx[s] + (sy * wx * wz / vs) * vy[s] + (sz * wx * wy / vs) * vz[s]);
+        }
+      }
+      in_v[s][NH + lane] = phi;
+      in_d[s][NH + lane] = phid;
+    } else if (lane < KP - NH) {
+      in_v[s][NH + lane] = 0.f;
+      in_d[s][NH + lane] = 0.f;
+    }
+    in_v[s][lane] = 0.f; in_d[s][lane] = 0.f; in_v[s][lane + 64] = 0.f; in_d[s][lane + 64] = 0.f;   // columns 0..127
+    if (lane < N_E) { in_v[s][lane] = e[s]; in_d[s][lane] = je[s]; }
+  }
+  __syncthreads();
+  auto dump_inputs = [&](int l) {
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+      if (live[s]) {
+        const int64_t o = ((int64_t)l * a.n + base + s) * KP;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int k = lane + 64 * j;
+          if (k < KP) { a.in_v[o + k] = in_v[s][k]; a.in_d[o + k] = in_d[s][k]; }
+        }
+      }
+  };
+
+  // ---- forward sweep with tangents -----------------------------------------------------------------------------------------
+  float s1[N_HID][2][S], s2t[N_HID][2][S];
+#pragma unroll
+  for (int l = 0; l < N_HID; ++l) {
+    dump_inputs(l);
+    const float* __restrict__ wt = a.packed + OFF_WT + l * KP * NH;
+    float acc[2][S], accd[2][S];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < S; ++s) acc[j][s] = accd[j][s] = 0.f;
+    const int K = layer_k(l);
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+      const float w0 = wt[k * NH + lane], w1 = wt[k * NH + 64 + lane];
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const float x = in_v[s][k], xd = in_d[s][k];
+        acc[0][s] = fmaf(w0, x, acc[0][s]);
+        acc[1][s] = fmaf(w1, x, acc[1][s]);
+        accd[0][s] = fmaf(w0, xd, accd[0][s]);
+        accd[1][s] = fmaf(w1, xd, accd[1][s]);
+      }
+    }
+    __syncthreads();
+    const int N = layer_n(l);
+    const float post = l == 2 ? inv_sqrt2 : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int nrn = lane + 64 * j;
+      const float b = a.packed[OFF_B + l * NH + nrn];
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const Act t = softplus100(acc[j][s] + b);
+        const bool real = nrn < N;
+        s1[l][j][s] = real ? t.s1 : 0.f;
+        s2t[l][j][s] = real ? t.s2 * accd[j][s] : 0.f;
+        in_v[s][nrn] = real ? t.h * post : 0.f;
+        in_d[s][nrn] = real ? t.s1 * accd[j][s] * post : 0.f;
+      }
+    }
+    if (l == 2) {
+      __syncthreads();
+      if (lane < N_E) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          in_v[s][N_H2 + lane] = e[s] * inv_sqrt2;
+          in_d[s][N_H2 + lane] = je[s] * inv_sqrt2;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  dump_inputs(N_HID);   // inputs of lin6 (its row 0 alone reaches the loss)
+
+  // ---- reverse sweep: adjoints of (pre-activation, its tangent) -------------------------------------------------------------
+  float pbar[S], pdbar[S];   // adjoints of (phi, phi') for lane f < 28
+#pragma unroll
+  for (int s = 0; s < S; ++s) pbar[s] = pdbar[s] = 0.f;
+#pragma unroll
+  for (int l = N_HID; l >= 1; --l) {
+    float g[3][S], gd[3][S];
+    if (l == N_HID) {   // tbar_6 = ybar e_0, t'bar_6 = e_0
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int k = lane + 64 * j;
+        const float w = k < KP ? a.packed[OFF_W6 + k] : 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) { g[j][s] = w * yb[s]; gd[j][s] = live[s] ? w : 0.f; }
+      }
+    } else {
+      const float* __restrict__ w = a.packed + OFF_W + l * NH * KP;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int s = 0; s < S; ++s) g[j][s] = gd[j][s] = 0.f;
+      const int N = layer_n(l);
+      const bool third = lane < KP - 128;
+#pragma unroll 4
+      for (int nrn = 0; nrn < N; ++nrn) {
+        const float w0 = w[nrn * KP + lane], w1 = w[nrn * KP + 64 + lane];
+        const float w2 = third ? w[nrn * KP + 128 + lane] : 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const float d = dl_v[s][nrn], dd = dl_d[s][nrn];
+          g[0][s] = fmaf(w0, d, g[0][s]);
+          g[1][s] = fmaf(w1, d, g[1][s]);
+          g[2][s] = fmaf(w2, d, g[2][s]);
+          gd[0][s] = fmaf(w0, dd, gd[0][s]);
+          gd[1][s] = fmaf(w1, dd, gd[1][s]);
+          gd[2][s] = fmaf(w2, dd, gd[2][s]);
+        }
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s) { pbar[s] += g[2][s]; pdbar[s] += gd[2][s]; }
+    const float pre = l == 3 ? inv_sqrt2 : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = lane + 64 * j;
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const float hb = g[j][s] * pre, hdb = gd[j][s] * pre;       // adjoints of (h, h') of layer l-1 (zero weight beyond its width)
+        const float tbv = fmaf(s2t[l - 1][j][s], hdb, s1[l - 1][j][s] * hb);
+        const float tdbv = s1[l - 1][j][s] * hdb;
+        dl_v[s][k] = tbv;
+        dl_d[s][k] = tdbv;
+        if (live[s]) {
+          const int64_t o = ((int64_t)(l - 1) * a.n + base + s) * NH + k;
+          a.tb[o] = tbv;
+          a.tdb[o] = tdbv;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- feature gradients: dF[row_c] += w_c phibar + (grad w_c . v) phi'bar ---------------------------------------------------
+  if (lane < N_PHI) {
+    const int st = lane / 7, ch = lane % 7;
+    const int D = a.dims[st];
+    if (D > 1 && a.dvols[st]) {
+      const int32_t* __restrict__ table = a.tables[st];
+      float* __restrict__ dvol = a.dvols[st];
+      const float vs = 2.0f / ((float)D - 1.0f);
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        if (!live[s]) continue;
+        const float gx = (px[s] + 1.0f) / vs, gy = (py[s] + 1.0f) / vs, gz = (pz[s] + 1.0f) / vs;
+        const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+        const float tx = gx - fx, ty = gy - fy, tz = gz - fz;
+        const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int dx = k >> 2, dy = (k >> 1) & 1, dz = k & 1;
+          const int xi = min(max(x0 + dx, 0), D - 1), yi = min(max(y0 + dy, 0), D - 1), zi = min(max(z0 + dz, 0), D - 1);
+          const int row = table[((int64_t)xi * D + yi) * D + zi];
+          if (row < 0) continue;
+          const float wx = dx ? tx : 1.0f - tx, wy = dy ? ty : 1.0f - ty, wz = dz ? tz : 1.0f - tz;
+          const float sx = dx ? 1.0f : -1.0f, sy = dy ? 1.0f : -1.0f, sz = dz ? 1.0f : -1.0f;
+          const float wv = (sx * wy * wz / vs) * vx[s] + (sy * wx * wz / vs) * vy[s] + (sz * wx * wy / vs) * vz[s];
+          atomicAdd(dvol + (int64_t)row * 8 + ch, (wx * wy * wz) * pbar[s] + wv * pdbar[s]);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// per-sample buffers (floats): in_v / in_d: 7 n 160 each; tb / tdb: 6 n 128 each
+extern "C" int surf_sdf_backward(const float* pts, const float* ybar, const float* gbar, int64_t n, const float* const* h_vols,
+                                 const int32_t* const* h_tables, const int* h_dims, int n_vol, float* const* h_dvols,
+                                 const float* packed, float* in_v, float* in_d, float* tb, float* tdb, void* stream) {
+  if (!pts || !ybar || !gbar || !h_vols || !h_tables || !h_dims || !packed || !in_v || !in_d || !tb || !tdb) return SURF_E_ARG;
+  if (n <= 0 || n_vol <= 0) return SURF_E_ARG;
+  if (n_vol > SURF_MAX_STAGES) return SURF_E_LIMIT;
+  BwdArgs a;
+  a.pts = pts; a.ybar = ybar; a.gbar = gbar; a.n = n; a.packed = packed; a.in_v = in_v; a.in_d = in_d; a.tb = tb; a.tdb = tdb;
+  for (int s = 0; s < SURF_MAX_STAGES; ++s) {
+    a.vols[s] = s < n_vol ? h_vols[s] : nullptr;
+    a.tables[s] = s < n_vol ? h_tables[s] : nullptr;
+    a.dims[s] = s < n_vol ? h_dims[s] : 0;
+    a.dvols[s] = (s < n_vol && h_dvols) ? h_dvols[s] : nullptr;
+    if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
+  }
+  const int64_t blocks = (n + S - 1) / S;
+  if (blocks > 0x7fffffff) return SURF_E_LIMIT;
+  hipLaunchKernelGGL(sdf_bwd_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, a);
+  return surf_check_launch();
+}

@@ -341,6 +341,39 @@ def sdf_smooth(pts, volumes, packed, active_idx=None, want_grad=False):
     return smooth, grad
 
 
+def sdf_backward(pts, ybar, gbar, volumes, packed, want_dvols=True):
+    """Gradients of sum_n (ybar_n sdf_n + gbar_n . grad_n) w.r.t. the EFFECTIVE (weight-normed) matrices / biases of
+    lin0..lin6 and the sparse feature rows (surf_sdf_backward; the batch reductions are rocBLAS GEMMs through torch.matmul).
+    packed: sdf_smooth_pack_weights.  Returns {"weight": [7 tensors shaped like W_l], "bias": [7], "volumes": [per level (N_s,8)]}."""
+    _chk(pts, torch.float32, "pts")
+    _chk(ybar, torch.float32, "ybar")
+    _chk(gbar, torch.float32, "gbar")
+    _chk(packed, torch.float32, "packed weights")
+    n, dev = pts.shape[0], pts.device
+    in_v = torch.empty(7, n, 160, dtype=torch.float32, device=dev)
+    in_d = torch.empty(7, n, 160, dtype=torch.float32, device=dev)
+    tb = torch.empty(6, n, 128, dtype=torch.float32, device=dev)
+    tdb = torch.empty(6, n, 128, dtype=torch.float32, device=dev)
+    dvols = [torch.zeros_like(v) for v in volumes.vols] if want_dvols else None
+    rc = _lib.lib().surf_sdf_backward(_p(pts), _p(ybar), _p(gbar), n, volumes._vp, volumes._tp, volumes._dp, volumes.n,
+                                      _ptr_array(dvols) if dvols is not None else None, _p(packed), _p(in_v), _p(in_d), _p(tb),
+                                      _p(tdb), _stream())
+    _lib.check(rc, "surf_sdf_backward")
+    shapes = [(128, 27), (128, 156), (101, 156), (128, 156), (128, 156), (128, 156), (129, 156)]
+    dW, db = [], []
+    for l in range(6):
+        full = tb[l].t() @ in_v[l] + tdb[l].t() @ in_d[l]                       # (128, 160)
+        dW.append(full[:shapes[l][0], :shapes[l][1]].contiguous())
+        db.append(tb[l].sum(dim=0)[:shapes[l][0]].contiguous())
+    w6 = torch.zeros(shapes[6], dtype=torch.float32, device=dev)                # only row 0 of lin6 reaches the loss
+    w6[0] = (ybar[:, None] * in_v[6] + in_d[6]).sum(dim=0)[:156]
+    b6 = torch.zeros(129, dtype=torch.float32, device=dev)
+    b6[0] = ybar.sum()
+    dW.append(w6)
+    db.append(b6)
+    return {"weight": dW, "bias": db, "volumes": dvols}
+
+
 class Cameras:
     """Host copies of the 4x4 camera matrices the kernels take by value."""
 

@@ -849,3 +849,32 @@ def test_composite_backward_matches_autograd(scene, weights, gpu_scene):
     rel_close(d_col.cpu()[m], x_col.grad[m].float(), 1e-4, 1e-6)
     assert abs(float(d_is) - float(x_is.grad)) <= 2e-3 * abs(float(x_is.grad)) + 1e-6
     assert bool((d_sdf.cpu()[~m] == 0).all()) and bool((d_col.cpu()[~m] == 0).all())
+
+
+def test_sdf_backward_matches_autograd(weights, gpu_scene, golden_render):
+    """surf_sdf_backward (row f2): gradients of sum_n (ybar_n sdf_n + gbar_n . grad_n) w.r.t. the effective weights, the biases
+    and the sparse feature rows against torch autograd through the oracle (which differentiates the closed-form gradient,
+    i.e. the reference's double backward), incl. a sample count that leaves a partial wavefront tile."""
+    from surf_amd import ops
+    d = dev()
+    c = gpu_scene["cpu"]
+    pts = golden_render["pts"][:301].clone()
+    g = torch.Generator().manual_seed(13)
+    ybar, gbar = torch.randn(301, generator=g), torch.randn(301, 3, generator=g) * 0.5
+    layers = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in O.sdf_weights(weights)]
+    vols = [v.clone().requires_grad_(True) for v in c["vols"]]
+    phi, jphi = O.lookup_sparse_volume(pts, vols, c["tabs"], with_jac=True)
+    sdf, grad, _ = O.sdf_mlp(layers, pts, phi, jphi)
+    ((sdf * ybar).sum() + (grad * gbar).sum()).backward()
+    out = ops.sdf_backward(pts.to(d).contiguous(), ybar.to(d), gbar.to(d).contiguous(), gpu_scene["sv"],
+                           ops.sdf_smooth_pack_weights(weights, d))
+    torch.cuda.synchronize()
+    for l, (W, b) in enumerate(layers):
+        gw = W.grad if W.grad is not None else torch.zeros_like(W)
+        rel_close(out["weight"][l], gw, 2e-3, 2e-4 * float(gw.abs().max()) + 1e-7)
+        gb = b.grad if b.grad is not None else torch.zeros_like(b)
+        rel_close(out["bias"][l], gb, 2e-3, 2e-4 * float(gb.abs().max()) + 1e-7)
+    for lvl, v in enumerate(vols):
+        gv = v.grad
+        assert float(gv.abs().max()) > 0
+        rel_close(out["volumes"][lvl][:, :gv.shape[1]], gv, 2e-3, 2e-4 * float(gv.abs().max()))
