@@ -294,7 +294,52 @@ class ImplicitSurface(nn.Module):
             occ = scene.occupied_any(pr)
             sdf_r, _ = ops.sdf_mlp(pr, scene.sv, sdf_w, mask=occ.to(torch.uint8), want_grad=False)
             out["sparse_sdf"] = torch.cat([torch.where(occ, sdf_r, torch.zeros_like(sdf_r)), sdf]).view(-1, 1)
+            # what backward_render needs of this forward (row f2: the partial backward of the render)
+            self._ctx = dict(st=st, act=act, sdf=sdf, grad=grad, col=col, rays_d=rays_d, anneal=float(cos_anneal_ratio),
+                             scene=scene, eik_den=float(eik[1]), random_pts=pr, random_occ=occ)
         return out
+
+    @torch.no_grad()
+    def backward_render(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None):
+        """Partial backward of the last training forward (`render_scene(patch_warp=True)`), SURVEY 8f-f2: given the loss's
+        gradients w.r.t. `color_fine` (R,3), `render_depth` (R), `gradient_error` (scalar) and `sparse_sdf` ((1024 + R*S),1),
+        ACCUMULATES `.grad` on sdf_network.lin*.{weight_g, weight_v, bias} and deviation_network.variance and returns the
+        gradients of the scene's sparse feature rows, fine -> coarse, (N_s, 7).  Kernels: surf_composite_backward ->
+        surf_sdf_backward (reverse over forward: the spatial-gradient upstream is a tangent direction).
+        NOT differentiated (so far): the colour network and the FPN features behind it (d colour / d network), the smooth
+        (H.1) and patch-NCC terms, the volume build."""
+        c = self._ctx
+        st, act, scene = c["st"], c["act"], c["scene"]
+        dev = c["sdf"].device
+        inv_s = self.deviation_network.inv_s()
+        d_sdf, d_grad, _, d_is = ops.composite_backward(c["sdf"], c["grad"], c["col"], st, c["rays_d"], inv_s, c["anneal"], scene.cams,
+                                                        g_color.float().contiguous(),
+                                                        None if g_depth is None else g_depth.float().contiguous(),
+                                                        eik_scale=float(g_gradient_error) / (c["eik_den"] + 1e-5))
+        idx = act.long()
+        ybar = d_sdf[idx]
+        pts = st["pts"][idx]
+        gbar = d_grad[idx]
+        if g_sparse_sdf is not None:
+            gs = g_sparse_sdf.reshape(-1).float()
+            ybar = ybar + gs[1024:][idx]                      # the samples' own share of sparse_sdf (masked-out rows are constants)
+            occ = c["random_occ"]
+            pts = torch.cat([pts, c["random_pts"][occ]])
+            ybar = torch.cat([ybar, gs[:1024][occ]])
+            gbar = torch.cat([gbar, torch.zeros(int(occ.sum()), 3, device=dev)])
+        res = ops.sdf_backward(pts.contiguous(), ybar.contiguous(), gbar.contiguous(), scene.sv, self.smooth_weights(dev))
+        with torch.enable_grad():                             # weight norm: W = g v / |v|_row (sdf_network.py:88-89)
+            for l in range(7):
+                lin = getattr(self.sdf_network, f"lin{l}")
+                W = lin.weight_v * (lin.weight_g / torch.linalg.norm(lin.weight_v, dim=1, keepdim=True))
+                W.backward(res["weight"][l])
+                lin.bias.grad = res["bias"][l] if lin.bias.grad is None else lin.bias.grad + res["bias"][l]
+        var = self.deviation_network.variance
+        raw = float(torch.exp(var.detach() * 10.0))
+        dvar = d_is * 10.0 * inv_s if 1e-6 < raw < 1e6 else torch.zeros((), device=dev)
+        dvar = dvar.to(var.device).reshape(var.shape)
+        var.grad = dvar if var.grad is None else var.grad + dvar
+        return [g[:, :7].contiguous() for g in res["volumes"]]
 
     def draw_jitter(self, n_rays, ref_chunk=None):
         """The `torch.rand([batch, 1]) - 0.5` draws of ImplicitSurface.render (:274-277, :304-306) on the CPU generator,

@@ -878,3 +878,52 @@ def test_sdf_backward_matches_autograd(weights, gpu_scene, golden_render):
         gv = v.grad
         assert float(gv.abs().max()) > 0
         rel_close(out["volumes"][lvl][:, :gv.shape[1]], gv, 2e-3, 2e-4 * float(gv.abs().max()))
+
+
+def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
+    """ImplicitSurface.backward_render (row f2, partial): the gradients of a loss on colour_fine, render_depth, gradient_error
+    and sparse_sdf w.r.t. the SDF network's weight-norm parameters, the variance and the sparse feature rows, chained through
+    surf_composite_backward and surf_sdf_backward, against torch autograd through the oracle's whole render."""
+    from bench import model_conf
+    from surf_amd.implicit_surface import ImplicitSurface, SceneVolumes
+    d = dev()
+    model = ImplicitSurface(model_conf(CFG["n_samples"], "f32"))
+    model.load_state_dict({k[len("implicit_surface."):]: v for k, v in weights.items() if k.startswith("implicit_surface.")})
+    model = model.to(d)
+    sc = SceneVolumes.from_device_layouts(gpu_scene["mvol"], gpu_scene["sv"].vols, gpu_scene["sv"].tables, gpu_scene["feats_t4"],
+                                          gpu_scene["imgs_t4"], gpu_scene["cams"])
+    R = scene["rays_o"].shape[0]
+    S = sum(CFG["n_samples"])
+    near, far = scene["near"].repeat(R, 1), scene["far"].repeat(R, 1)
+    torch.manual_seed(33)
+    out = model.render_scene(scene["rays_o"].to(d), scene["rays_d"].to(d), near.to(d), far.to(d), sc, 0.6, patch_warp=True)
+    g = torch.Generator().manual_seed(34)
+    g_color, g_depth = torch.randn(R, 3, generator=g), torch.randn(R, generator=g) * 0.3
+    g_eik = 0.25
+    g_sparse = torch.randn(1024 + R * S, 1, generator=g) * 0.01
+    dvols = model.backward_render(g_color.to(d), g_depth.to(d), g_eik, g_sparse.to(d))
+    # oracle autograd
+    c = gpu_scene["cpu"]
+    sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in weights.items() if k.startswith("implicit_surface.")}
+    vols = [v.clone().requires_grad_(True) for v in c["vols"]]
+    o = O.render(sd, scene["rays_o"], scene["rays_d"], near, far, c["mvol"], vols, c["tabs"], c["masks"], c["feats"], scene["imgs"],
+                 scene["intrs"], scene["c2ws"], CFG["n_samples"], CFG["sample_ranges"], CFG["n_depth"], 0.6)
+    torch.manual_seed(33)
+    pr = torch.rand([1024, 3]) * 2 - 1
+    occ = torch.stack([O.lookup_volume_nearest(pr, mk) for mk in c["masks"]], dim=-1).any(dim=-1)
+    phi = O.lookup_sparse_volume(pr, vols, c["tabs"])
+    sdf_r = O.sdf_mlp(O.sdf_weights(sd), pr, phi)[0] * occ.float()
+    loss = ((o["color_fine"] * g_color).sum() + (o["render_depth"] * g_depth).sum() + o["gradient_error"] * g_eik
+            + (sdf_r * g_sparse[:1024, 0]).sum() + (o["sdf"].reshape(-1) * g_sparse[1024:, 0]).sum())
+    loss.backward()
+    rel_close(out["color_fine"], o["color_fine"].detach(), 1e-3, 1e-5)
+    names = [f"sdf_network.lin{l}.{p}" for l in range(7) for p in ("weight_g", "weight_v", "bias")] + ["deviation_network.variance"]
+    params = dict(model.named_parameters())
+    for n in names:
+        ref = sd["implicit_surface." + n].grad
+        ref = torch.zeros_like(sd["implicit_surface." + n]) if ref is None else ref
+        got = params[n].grad
+        assert got is not None, n
+        rel_close(got, ref, 5e-3, 5e-4 * float(ref.abs().max()) + 1e-7)
+    for lvl, v in enumerate(vols):
+        rel_close(dvols[lvl], v.grad, 5e-3, 5e-4 * float(v.grad.abs().max()))
