@@ -927,3 +927,39 @@ def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
         rel_close(got, ref, 5e-3, 5e-4 * float(ref.abs().max()) + 1e-7)
     for lvl, v in enumerate(vols):
         rel_close(dvols[lvl], v.grad, 5e-3, 5e-4 * float(v.grad.abs().max()))
+
+
+def test_adam_steps_on_sdf_network_reduce_the_loss(scene, weights, gpu_scene):
+    """A few optimiser steps driven by the HIP backward kernels alone (colour network frozen): colour L1 + eikonal + sparse
+    terms of losses/loss.py through torch autograd on the per-ray outputs, then backward_render, then Adam on the SDF
+    network and the variance (runner.py:150-166 restricted to those parameters).  The loss must go down."""
+    from bench import model_conf
+    from surf_amd.implicit_surface import ImplicitSurface, SceneVolumes
+    d = dev()
+    model = ImplicitSurface(model_conf(CFG["n_samples"], "f32"))
+    model.load_state_dict({k[len("implicit_surface."):]: v for k, v in weights.items() if k.startswith("implicit_surface.")})
+    model = model.to(d)
+    sc = SceneVolumes.from_device_layouts(gpu_scene["mvol"], gpu_scene["sv"].vols, gpu_scene["sv"].tables, gpu_scene["feats_t4"],
+                                          gpu_scene["imgs_t4"], gpu_scene["cams"])
+    R = scene["rays_o"].shape[0]
+    near, far = scene["near"].repeat(R, 1).to(d), scene["far"].repeat(R, 1).to(d)
+    rays_o, rays_d = scene["rays_o"].to(d), scene["rays_d"].to(d)
+    g = torch.Generator().manual_seed(50)
+    target = torch.rand(R, 3, generator=g).to(d)
+    params = list(model.sdf_network.parameters()) + [model.deviation_network.variance]
+    opt = torch.optim.Adam(params, lr=5e-4)
+    history = []
+    for step in range(8):
+        torch.manual_seed(60)                                   # the same random sparse points every step
+        out = model.render_scene(rays_o, rays_d, near, far, sc, 1.0, patch_warp=True)
+        leaves = {k: out[k].detach().clone().requires_grad_(True) for k in ("color_fine", "gradient_error", "sparse_sdf")}
+        vm = out["valid_mask"].float()
+        loss = (((leaves["color_fine"] - target).abs() * vm).sum() / (vm.sum() + 1e-5) + 0.1 * leaves["gradient_error"]
+                + 0.02 * torch.exp(-leaves["sparse_sdf"].abs() * 100).mean())
+        loss.backward()
+        history.append(float(loss.detach()))
+        opt.zero_grad()
+        model.backward_render(leaves["color_fine"].grad, None, float(leaves["gradient_error"].grad), leaves["sparse_sdf"].grad)
+        opt.step()
+        model.invalidate_packed()
+    assert history[-1] < history[0] - 1e-3, history
