@@ -374,6 +374,46 @@ def sdf_backward(pts, ybar, gbar, volumes, packed, want_dvols=True):
     return {"weight": dW, "bias": db, "volumes": dvols}
 
 
+_BLEND_LAYERS = [  # (state_dict prefix, in, out, IN column, ADJ column) of surf_blend_backward's rows
+    ("ray_dir_fc.0", 4, 16, 0, 4), ("ray_dir_fc.2", 16, 19, 20, 36), ("base_fc.0", 57, 64, 55, 112), ("base_fc.2", 64, 32, 176, 240),
+    ("vis_fc.0", 32, 32, 272, 304), ("vis_fc.2", 32, 33, 336, 368), ("vis_fc2.0", 32, 32, 401, 433), ("vis_fc2.2", 32, 1, 465, 497),
+    ("rgb_fc.0", 37, 16, 498, 535), ("rgb_fc.2", 16, 8, 551, 567), ("rgb_fc.4", 8, 1, 575, 583)]
+
+
+def blend_backward(pts, active_idx, gcolor, feats_t4, imgs_t4, cams, raw_weights, want_color=False):
+    """Gradients of sum_n gcolor_n . colour_n w.r.t. the blending network's parameters (surf_blend_backward; the batch
+    reductions are small GEMMs through torch.matmul).  raw_weights: device tensor of blend_raw_weights(sd).
+    Returns {state_dict name: gradient} (+ "_color": the recomputed colours of the active samples, if asked)."""
+    _chk(pts, torch.float32, "pts")
+    _chk(gcolor, torch.float32, "gcolor")
+    _chk(raw_weights, torch.float32, "raw weights")
+    assert len(feats_t4) == 4 and gcolor.shape[0] == pts.shape[0]
+    dev = pts.device
+    n = int(active_idx.shape[0]) if active_idx is not None else pts.shape[0]
+    V = cams.nv - 1
+    ROW = _lib.lib().surf_blend_backward_row_floats()
+    rows = torch.empty(max(n, 1), V, ROW, dtype=torch.float32, device=dev)
+    ds = torch.zeros(max(n, 1), dtype=torch.float32, device=dev)
+    color = torch.empty(max(n, 1), 3, dtype=torch.float32, device=dev) if want_color else None
+    out = {}
+    if n > 0:
+        hw = (ctypes.c_int * 8)(*[int(v) for f in feats_t4 for v in f.shape[1:3]])
+        intr16 = np.ascontiguousarray(cams.intrs.reshape(cams.nv, -1))
+        rc = _lib.lib().surf_blend_backward(_p(pts), _p(active_idx), n, _p(gcolor), _ptr_array(list(feats_t4)), hw, _p(imgs_t4),
+                                            cams.nv, _np_ptr(intr16), _np_ptr(cams.w2c), _np_ptr(cams.c2w), _p(raw_weights),
+                                            _p(rows), _p(ds), _p(color), _stream())
+        _lib.check(rc, "surf_blend_backward")
+    flat = rows[:n].reshape(-1, ROW)
+    for name, cin, cout, c_in, c_ad in _BLEND_LAYERS:
+        ad, x = flat[:, c_ad:c_ad + cout], flat[:, c_in:c_in + cin]
+        out[name + ".weight"] = ad.t() @ x
+        out[name + ".bias"] = ad.sum(dim=0)
+    out["s"] = ds[:n].sum().reshape(())
+    if want_color:
+        out["_color"] = color[:n]
+    return out
+
+
 class Cameras:
     """Host copies of the 4x4 camera matrices the kernels take by value."""
 

@@ -963,3 +963,39 @@ def test_adam_steps_on_sdf_network_reduce_the_loss(scene, weights, gpu_scene):
         opt.step()
         model.invalidate_packed()
     assert history[-1] < history[0] - 1e-3, history
+
+
+def test_blend_backward_matches_autograd(weights, gpu_scene, golden_render, scene):
+    """surf_blend_backward (row f2): the recomputed colours against the forward kernel, and the gradients of
+    sum_n gcolor_n . colour_n w.r.t. every parameter of the blending network against torch autograd through the oracle's
+    lookup_feature + blending (points with all, some and no valid source views)."""
+    from surf_amd import ops
+    d = dev()
+    c = gpu_scene["cpu"]
+    pts = golden_render["pts"].clone()
+    n = pts.shape[0]
+    g = torch.Generator().manual_seed(21)
+    gcolor = torch.randn(n, 3, generator=g)
+    idx = torch.arange(0, n, dtype=torch.int32)[torch.rand(n, generator=g) > 0.2].contiguous()
+    raw = torch.from_numpy(ops.blend_raw_weights(weights)).to(d)
+    res = ops.blend_backward(pts.to(d).contiguous(), idx.to(d), gcolor.to(d).contiguous(), gpu_scene["feats_t4"], gpu_scene["imgs_t4"],
+                             gpu_scene["cams"], raw, want_color=True)
+    col_fwd, _ = ops.blend(pts.to(d).contiguous(), gpu_scene["feats_t4"], gpu_scene["imgs_t4"], gpu_scene["cams"], gpu_scene["blend_w"])
+    rel_close(res["_color"], col_fwd.cpu()[idx.long()], 1e-3, 2e-5)
+    prefix = "implicit_surface.color_network."
+    sd = {k: v.clone().requires_grad_(True) for k, v in weights.items() if k.startswith(prefix)}
+    rf, rdiff, mval = O.lookup_feature(pts[idx.long()], scene["imgs"], scene["intrs"], scene["c2ws"], c["feats"])
+    assert 0 < int(mval.sum()) < mval.numel()
+    col = O.blending(sd, rf, rdiff, mval)
+    (col * gcolor[idx.long()]).sum().backward()
+    for k, v in sd.items():
+        name = k[len(prefix):]
+        ref = v.grad if v.grad is not None else torch.zeros_like(v)
+        got = res[name].reshape(ref.shape)
+        if name == "s":
+            # d/ds goes through (ex_v - min_u ex_u) with ex = exp(|s| (cos - 1)) ~ 0.99 for every view: a difference of
+            # nearly equal fp32 numbers (1e-5 apart), ill-conditioned in the reference's own fp32 autograd too
+            # (per-sample values agree to 1e-3 on 90 % of the samples, scripts/dbg_blend_bwd.py)
+            assert abs(float(got) - float(ref)) <= 0.35 * abs(float(ref)) + 1e-5
+            continue
+        rel_close(got, ref, 2e-3, 2e-4 * float(ref.abs().max()) + 1e-7)
