@@ -998,4 +998,4 @@ def test_blend_backward_matches_autograd(weights, gpu_scene, golden_render, scen
             # (per-sample values agree to 1e-3 on 90 % of the samples, scripts/dbg_blend_bwd.py)
             assert abs(float(got) - float(ref)) <= 0.35 * abs(float(ref)) + 1e-5
             continue
-        rel_close(got, ref, 2e-3, 2e-4 * float(ref.abs().max()) + 1e-7)
+        rel_close(got, ref, 2e-3, 2e-4 * max(float(ref.abs().max()), 1e-2))    # (rgb_fc.4.bias: the softmax gradients sum to 0)
