@@ -303,16 +303,17 @@ class ImplicitSurface(nn.Module):
     def backward_render(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None):
         """Partial backward of the last training forward (`render_scene(patch_warp=True)`), SURVEY 8f-f2: given the loss's
         gradients w.r.t. `color_fine` (R,3), `render_depth` (R), `gradient_error` (scalar) and `sparse_sdf` ((1024 + R*S),1),
-        ACCUMULATES `.grad` on sdf_network.lin*.{weight_g, weight_v, bias} and deviation_network.variance and returns the
-        gradients of the scene's sparse feature rows, fine -> coarse, (N_s, 7).  Kernels: surf_composite_backward ->
-        surf_sdf_backward (reverse over forward: the spatial-gradient upstream is a tangent direction).
-        NOT differentiated (so far): the colour network and the FPN features behind it (d colour / d network), the smooth
-        (H.1) and patch-NCC terms, the volume build."""
+        ACCUMULATES `.grad` on every parameter of the implicit surface - sdf_network.lin*.{weight_g, weight_v, bias},
+        color_network.*, deviation_network.variance - and returns the gradients of the scene's sparse feature rows, fine ->
+        coarse, (N_s, 7).  Kernels: surf_composite_backward -> surf_sdf_backward (reverse over forward: the spatial-gradient
+        upstream is a tangent direction) and surf_blend_backward.
+        NOT differentiated (so far): the FPN feature maps behind the colour network, the smooth (H.1) and patch-NCC terms,
+        the volume build - what the reference's finetune mode (has_vol) trains is covered except for those two loss terms."""
         c = self._ctx
         st, act, scene = c["st"], c["act"], c["scene"]
         dev = c["sdf"].device
         inv_s = self.deviation_network.inv_s()
-        d_sdf, d_grad, _, d_is = ops.composite_backward(c["sdf"], c["grad"], c["col"], st, c["rays_d"], inv_s, c["anneal"], scene.cams,
+        d_sdf, d_grad, d_col, d_is = ops.composite_backward(c["sdf"], c["grad"], c["col"], st, c["rays_d"], inv_s, c["anneal"], scene.cams,
                                                         g_color.float().contiguous(),
                                                         None if g_depth is None else g_depth.float().contiguous(),
                                                         eik_scale=float(g_gradient_error) / (c["eik_den"] + 1e-5))
@@ -334,6 +335,12 @@ class ImplicitSurface(nn.Module):
                 W = lin.weight_v * (lin.weight_g / torch.linalg.norm(lin.weight_v, dim=1, keepdim=True))
                 W.backward(res["weight"][l])
                 lin.bias.grad = res["bias"][l] if lin.bias.grad is None else lin.bias.grad + res["bias"][l]
+        sd = self.state_dict()
+        raw_w = torch.from_numpy(ops.blend_raw_weights(sd, prefix="color_network.")).to(dev)
+        gb = ops.blend_backward(st["pts"], act, d_col, scene.feats_t4, scene.imgs_t4, scene.cams, raw_w)
+        for name, p in self.color_network.named_parameters():
+            gp = gb[name].reshape(p.shape).to(p.dtype)
+            p.grad = gp if p.grad is None else p.grad + gp
         var = self.deviation_network.variance
         raw = float(torch.exp(var.detach() * 10.0))
         dvar = d_is * 10.0 * inv_s if 1e-6 < raw < 1e6 else torch.zeros((), device=dev)

@@ -882,8 +882,9 @@ def test_sdf_backward_matches_autograd(weights, gpu_scene, golden_render):
 
 def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
     """ImplicitSurface.backward_render (row f2, partial): the gradients of a loss on colour_fine, render_depth, gradient_error
-    and sparse_sdf w.r.t. the SDF network's weight-norm parameters, the variance and the sparse feature rows, chained through
-    surf_composite_backward and surf_sdf_backward, against torch autograd through the oracle's whole render."""
+    and sparse_sdf w.r.t. the SDF network's weight-norm parameters, the colour network, the variance and the sparse feature
+    rows, chained through surf_composite_backward, surf_sdf_backward and surf_blend_backward, against torch autograd through
+    the oracle's whole render (color_network.s: ill-conditioned in fp32, see test_blend_backward_matches_autograd)."""
     from bench import model_conf
     from surf_amd.implicit_surface import ImplicitSurface, SceneVolumes
     d = dev()
@@ -918,6 +919,7 @@ def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
     loss.backward()
     rel_close(out["color_fine"], o["color_fine"].detach(), 1e-3, 1e-5)
     names = [f"sdf_network.lin{l}.{p}" for l in range(7) for p in ("weight_g", "weight_v", "bias")] + ["deviation_network.variance"]
+    names += [n for n, _ in model.named_parameters() if n.startswith("color_network.") and n != "color_network.s"]
     params = dict(model.named_parameters())
     for n in names:
         ref = sd["implicit_surface." + n].grad
@@ -929,10 +931,10 @@ def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
         rel_close(dvols[lvl], v.grad, 5e-3, 5e-4 * float(v.grad.abs().max()))
 
 
-def test_adam_steps_on_sdf_network_reduce_the_loss(scene, weights, gpu_scene):
-    """A few optimiser steps driven by the HIP backward kernels alone (colour network frozen): colour L1 + eikonal + sparse
-    terms of losses/loss.py through torch autograd on the per-ray outputs, then backward_render, then Adam on the SDF
-    network and the variance (runner.py:150-166 restricted to those parameters).  The loss must go down."""
+def test_adam_steps_on_the_implicit_surface_reduce_the_loss(scene, weights, gpu_scene):
+    """A few optimiser steps driven by the HIP backward kernels alone: colour L1 + eikonal + sparse terms of losses/loss.py
+    through torch autograd on the per-ray outputs, then backward_render, then Adam on every parameter of the implicit surface
+    (runner.py:150-166 for what the reference's finetune mode trains, minus the feature rows).  The loss must go down."""
     from bench import model_conf
     from surf_amd.implicit_surface import ImplicitSurface, SceneVolumes
     d = dev()
@@ -946,7 +948,7 @@ def test_adam_steps_on_sdf_network_reduce_the_loss(scene, weights, gpu_scene):
     rays_o, rays_d = scene["rays_o"].to(d), scene["rays_d"].to(d)
     g = torch.Generator().manual_seed(50)
     target = torch.rand(R, 3, generator=g).to(d)
-    params = list(model.sdf_network.parameters()) + [model.deviation_network.variance]
+    params = list(model.parameters())                       # SDF network, colour network, variance
     opt = torch.optim.Adam(params, lr=5e-4)
     history = []
     for step in range(8):
