@@ -94,6 +94,17 @@ class SuRF(nn.Module):
         self.has_vol = True
         self._vol_scene = None
 
+    def backward(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None):
+        """Partial backward of the last train-mode forward (row f2): `.grad` of every implicit-surface parameter and, in
+        finetune mode (has_vol), of the per-scene feature volumes - what surf.py:36-45 hands the optimiser there.  See
+        ImplicitSurface.backward_render for what is not differentiated yet (FPN / volume build, smooth and patch-NCC terms)."""
+        dvols = self.implicit_surface.backward_render(g_color, g_depth, g_gradient_error, g_sparse_sdf)
+        if self.has_vol:
+            for p, g in zip(self.volumes, dvols[::-1]):          # volumes are kept coarse -> fine
+                g = g.to(p.dtype)
+                p.grad = g if p.grad is None else p.grad + g
+        return dvols
+
     def _frozen_scene(self, ipts):
         """SceneVolumes of the frozen volumes for the views of this call (surf.py:150-156: features[view_ids])."""
         view_ids = [int(v) for v in ipts["view_ids"]] if "view_ids" in ipts else list(range(ipts["imgs"].shape[0]))

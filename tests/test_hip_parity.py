@@ -1001,3 +1001,41 @@ def test_blend_backward_matches_autograd(weights, gpu_scene, golden_render, scen
             assert abs(float(got) - float(ref)) <= 0.35 * abs(float(ref)) + 1e-5
             continue
         rel_close(got, ref, 2e-3, 2e-4 * max(float(ref.abs().max()), 1e-2))    # (rgb_fc.4.bias: the softmax gradients sum to 0)
+
+
+def test_finetune_steps_train_volumes_and_networks(scene):
+    """surf_amd.training.finetune_step on a has_vol model (surf.py:36-45: implicit surface + per-scene feature volumes): six
+    Adam steps with the reference's loss weights on a fixed ray batch lower the differentiated part of the loss and move both
+    parameter groups."""
+    from surf_amd import conf
+    from surf_amd.losses import Loss
+    from surf_amd.surf import SuRF
+    from surf_amd.training import finetune_step
+    from tests.golden.make_golden import MODEL_CONF
+    from tests.golden.make_golden_train import LOSS_CONF
+    d = dev()
+    cfg = {k: v for k, v in MODEL_CONF.items()}
+    cfg["reg_network"] = {"d_in": [8, 16, 16, 16], "d_base": [8] * 4, "d_out": [8] * 4}
+    torch.manual_seed(4)
+    model = SuRF(conf.from_dict(cfg)).eval()
+    with torch.no_grad():
+        model.implicit_surface.deviation_network.variance.fill_(0.3)
+        for net in model.reg_network.nets:
+            net.out_lin.weight.mul_(4.0)
+    model = model.to(d)
+    ipts = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    model.init_volumes(ipts)
+    R = scene["rays_o"].shape[0]
+    g = torch.Generator().manual_seed(5)
+    targets = {"color": torch.rand(R, 3, generator=g).to(d)}
+    opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "vol_lr": [1e-2] * 4}))
+    vol0 = [v.detach().clone() for v in model.volumes]
+    w0 = model.implicit_surface.color_network.base_fc[0].weight.detach().clone()
+    loss_fn = Loss(conf.from_dict(dict(LOSS_CONF, mfc_weight=0.0, smooth_weight=0.0)))
+    hist = []
+    for step in range(6):
+        torch.manual_seed(70)
+        hist.append(finetune_step(model, ipts, targets, loss_fn, opt, 1.0, step + 2)["loss"])
+    assert hist[-1] < hist[0] - 1e-3, hist
+    assert any(float((v.detach() - v0).abs().max()) > 0 for v, v0 in zip(model.volumes, vol0))
+    assert float((model.implicit_surface.color_network.base_fc[0].weight.detach() - w0).abs().max()) > 0
