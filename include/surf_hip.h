@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 18
+#define SURF_ABI_VERSION 19
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -128,6 +128,16 @@ int surf_sdf_smooth_pack_weights(const float* const* h_W, const float* const* h_
 int surf_sdf_smooth(const float* pts, const int32_t* idx, int64_t n, const float* const* h_vols,
                     const int32_t* const* h_tables, const int* h_dims, int n_vol, const float* packed, float* grad,
                     float* smooth, void* stream);
+
+/*
+ * Tall-skinny reduction for the weight / bias gradients of the backward kernels:
+ *   out (M, N + with_sum) = (accumulate ? out : 0) + A[:, :M]^T [ X[:, :N] | 1 ]      A (rows, ldA), X (rows, ldX) row-major
+ * M <= 128, N + with_sum <= 160.  workspace: surf_colgram_workspace_floats(rows, M, N) device floats.  Deterministic
+ * (slab partials + a second pass, no atomics).
+ */
+int64_t surf_colgram_workspace_floats(int64_t rows, int M, int N);
+int surf_colgram(const float* A, int ldA, int M, const float* X, int ldX, int N, int64_t rows, int with_sum, int accumulate,
+                 float* workspace, float* out, void* stream);
 
 /*
  * Backward of the blending network w.r.t. its parameters for an upstream gradient of the per-sample colour (gcolor, indexed

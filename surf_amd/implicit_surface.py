@@ -335,8 +335,8 @@ class ImplicitSurface(nn.Module):
                 W = lin.weight_v * (lin.weight_g / torch.linalg.norm(lin.weight_v, dim=1, keepdim=True))
                 W.backward(res["weight"][l])
                 lin.bias.grad = res["bias"][l] if lin.bias.grad is None else lin.bias.grad + res["bias"][l]
-        sd = self.state_dict()
-        raw_w = torch.from_numpy(ops.blend_raw_weights(sd, prefix="color_network.")).to(dev)
+        cn = dict(self.color_network.named_parameters())     # raw parameter buffer in state_dict order, built on the device
+        raw_w = torch.cat([cn[k].detach().reshape(-1).float() for k in ops.BLEND_KEYS]).contiguous()
         gb = ops.blend_backward(st["pts"], act, d_col, scene.feats_t4, scene.imgs_t4, scene.cams, raw_w)
         for name, p in self.color_network.named_parameters():
             gp = gb[name].reshape(p.shape).to(p.dtype)

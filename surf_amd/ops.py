@@ -362,9 +362,11 @@ def sdf_backward(pts, ybar, gbar, volumes, packed, want_dvols=True):
     shapes = [(128, 27), (128, 156), (101, 156), (128, 156), (128, 156), (128, 156), (129, 156)]
     dW, db = [], []
     for l in range(6):
-        full = tb[l].t() @ in_v[l] + tdb[l].t() @ in_d[l]                       # (128, 160)
-        dW.append(full[:shapes[l][0], :shapes[l][1]].contiguous())
-        db.append(tb[l].sum(dim=0)[:shapes[l][0]].contiguous())
+        nl, kl = shapes[l]
+        full = colgram(tb[l][:, :nl], in_v[l][:, :kl], with_sum=True)            # (N_l, K_l + 1): [tb^T in | sum tb]
+        db.append(full[:, kl].contiguous())
+        full = colgram(tdb[l][:, :nl], in_d[l][:, :kl], with_sum=True, out=full)  # + tdb^T in'   (its sum column is unused)
+        dW.append(full[:, :kl].contiguous())
     w6 = torch.zeros(shapes[6], dtype=torch.float32, device=dev)                # only row 0 of lin6 reaches the loss
     w6[0] = (ybar[:, None] * in_v[6] + in_d[6]).sum(dim=0)[:156]
     b6 = torch.zeros(129, dtype=torch.float32, device=dev)
@@ -372,6 +374,24 @@ def sdf_backward(pts, ybar, gbar, volumes, packed, want_dvols=True):
     dW.append(w6)
     db.append(b6)
     return {"weight": dW, "bias": db, "volumes": dvols}
+
+
+def colgram(A, X, with_sum=False, out=None):
+    """out (M, N [+1]) = A^T [X | 1] for row-major 2-D views A (rows, M), X (rows, N) that share contiguous rows (column
+    slices of a wider buffer are fine: the row stride is taken from the view).  `out` given: accumulated into."""
+    assert A.dim() == 2 and X.dim() == 2 and A.shape[0] == X.shape[0] and A.stride(1) == 1 and X.stride(1) == 1
+    assert A.dtype == torch.float32 and X.dtype == torch.float32 and A.is_cuda and X.is_cuda
+    rows, M, N = int(A.shape[0]), int(A.shape[1]), int(X.shape[1])
+    acc = out is not None
+    if out is None:
+        out = torch.empty(M, N + (1 if with_sum else 0), dtype=torch.float32, device=A.device)
+    if rows == 0:
+        return out if acc else out.zero_()
+    ws = torch.empty(_lib.lib().surf_colgram_workspace_floats(rows, M, N), dtype=torch.float32, device=A.device)
+    rc = _lib.lib().surf_colgram(_p(A), int(A.stride(0)), M, _p(X), int(X.stride(0)), N, rows, int(with_sum), int(acc), _p(ws),
+                                 _p(out), _stream())
+    _lib.check(rc, "surf_colgram")
+    return out
 
 
 _BLEND_LAYERS = [  # (state_dict prefix, in, out, IN column, ADJ column) of surf_blend_backward's rows
@@ -405,9 +425,9 @@ def blend_backward(pts, active_idx, gcolor, feats_t4, imgs_t4, cams, raw_weights
         _lib.check(rc, "surf_blend_backward")
     flat = rows[:n].reshape(-1, ROW)
     for name, cin, cout, c_in, c_ad in _BLEND_LAYERS:
-        ad, x = flat[:, c_ad:c_ad + cout], flat[:, c_in:c_in + cin]
-        out[name + ".weight"] = ad.t() @ x
-        out[name + ".bias"] = ad.sum(dim=0)
+        g = colgram(flat[:, c_ad:c_ad + cout], flat[:, c_in:c_in + cin], with_sum=True)
+        out[name + ".weight"] = g[:, :cin].contiguous()
+        out[name + ".bias"] = g[:, cin].contiguous()
     out["s"] = ds[:n].sum().reshape(())
     if want_color:
         out["_color"] = color[:n]

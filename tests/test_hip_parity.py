@@ -1039,3 +1039,20 @@ def test_finetune_steps_train_volumes_and_networks(scene):
     assert hist[-1] < hist[0] - 1e-3, hist
     assert any(float((v.detach() - v0).abs().max()) > 0 for v, v0 in zip(model.volumes, vol0))
     assert float((model.implicit_surface.color_network.base_fc[0].weight.detach() - w0).abs().max()) > 0
+
+
+@pytest.mark.parametrize("rows,M,N", [(5000, 33, 57), (1, 1, 4), (1025, 64, 63), (3333, 128, 156), (2048, 101, 27)])
+def test_colgram_matches_matmul(rows, M, N):
+    """surf_colgram (the weight / bias reductions of the backward kernels) on column slices of wider buffers, with the
+    ones column and in accumulate mode, against float64 matmul."""
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(rows + M)
+    buf = torch.randn(rows, M + N + 7, generator=g).to(d)
+    A, X = buf[:, 3:3 + M], buf[:, 5 + M:5 + M + N]
+    ref = (A.double().t() @ torch.cat([X.double(), torch.ones(rows, 1, dtype=torch.float64, device=d)], dim=1)).float()
+    out = ops.colgram(A, X, with_sum=True)
+    rel_close(out, ref, 1e-4, 1e-4 * float(ref.abs().max()))
+    out2 = ops.colgram(A, X, with_sum=True, out=out.clone())
+    rel_close(out2, 2 * ref, 1e-4, 2e-4 * float(ref.abs().max()))
+    rel_close(ops.colgram(A, X), ref[:, :N], 1e-4, 1e-4 * float(ref.abs().max()))
