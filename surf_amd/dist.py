@@ -1,7 +1,8 @@
 """Multi-GPU plumbing of the hot path.  Inference shards by scene: scenes are independent, every rank
 renders its own share, there is NO data-path collective.  torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in
-the CPU tests) is only used for the barrier / max-over-ranks timing of bench.py and to gather small per-scene
-result records."""
+the CPU tests) is only used for the barrier / max-over-ranks timing of bench.py, to gather small per-scene result records
+and - training (runner.py:102,163: DDP) - for the gradient all-reduce of `all_reduce_gradients`: the backward kernels do
+not run under autograd, so the averaging DDP does in its hooks is one explicit bucketed all-reduce after `SuRF.backward`."""
 import os
 
 import torch
@@ -49,3 +50,34 @@ def gather_records(record, dst=0):
     out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
     dist.gather_object(record, out, dst=dst)
     return out
+
+
+def all_reduce_gradients(params, bucket_bytes=25 << 20):
+    """Average `.grad` over the ranks (what DistributedDataParallel does under loss.backward(), runner.py:102,163): the
+    gradients are flattened into buckets of at most `bucket_bytes` (DDP's default 25 MB: the ~1.4 M parameters of SuRF, 5.6 MB,
+    make ONE bucket - a single ring all-reduce over xGMI, latency-bound), summed with all_reduce and divided by the world
+    size.  Parameters without a gradient contribute zeros so that every rank issues the same collectives."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    params = [p for p in params if p.requires_grad]
+    world = dist.get_world_size()
+    buckets, cur, size = [], [], 0
+    for p in params:
+        nbytes = p.numel() * 4
+        if cur and size + nbytes > bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+        cur.append(p)
+        size += nbytes
+    if cur:
+        buckets.append(cur)
+    for bucket in buckets:
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= world
+        off = 0
+        for p in bucket:
+            g = flat[off:off + p.numel()].view_as(p).to(p.dtype)
+            off += p.numel()
+            p.grad = g.clone() if p.grad is None else p.grad.copy_(g)
+    return len(buckets)

@@ -98,3 +98,44 @@ def test_bench_under_a_launcher_and_world_size_mismatch():
     bad = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry"], env=dict(_clean_env(), WORLD_SIZE="1", RANK="0"),
                          capture_output=True, text=True, timeout=120)
     assert bad.returncode == 2 and "WORLD_SIZE" in bad.stderr
+
+
+GRAD_WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import torch
+    from surf_amd import dist as D
+    rank, local_rank, world = D.init_from_env(backend="gloo")
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(300, 7)), torch.nn.Parameter(torch.zeros(11)), torch.nn.Parameter(torch.zeros(4, 4))]
+    params[0].grad = torch.full((300, 7), float(rank + 1))
+    params[1].grad = torch.arange(11.0) * (rank + 1)
+    # params[2] has no gradient on rank 1 (e.g. a volume level no ray touched)
+    if rank == 0:
+        params[2].grad = torch.ones(4, 4)
+    n = D.all_reduce_gradients(params, bucket_bytes=4096)
+    if rank == 0:
+        print(json.dumps({"buckets": n, "g0": float(params[0].grad.mean()), "g1": params[1].grad.tolist(), "g2": float(params[2].grad.mean())}))
+    else:
+        assert abs(float(params[2].grad.mean()) - 0.5) < 1e-6
+""") % ROOT
+
+
+def test_gradient_all_reduce_two_ranks(tmp_path):
+    """dist.all_reduce_gradients (the DDP averaging of runner.py:102 done explicitly): bucketing, missing gradients, mean."""
+    script = tmp_path / "grad_worker.py"
+    script.write_text(GRAD_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    import json
+    res = json.loads([l for l in outs[0][0].strip().splitlines() if l.startswith("{")][-1])
+    assert res["buckets"] == 2                       # [8400 B] (alone: it exceeds the 4096-byte bucket), [44 B + 64 B]
+    assert abs(res["g0"] - 1.5) < 1e-6 and abs(res["g2"] - 0.5) < 1e-6
+    assert all(abs(a - 1.5 * k) < 1e-6 for k, a in enumerate(res["g1"]))
