@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 19
+#define SURF_ABI_VERSION 20
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -128,6 +128,23 @@ int surf_sdf_smooth_pack_weights(const float* const* h_W, const float* const* h_
 int surf_sdf_smooth(const float* pts, const int32_t* idx, int64_t n, const float* const* h_vols,
                     const int32_t* const* h_tables, const int* h_dims, int n_vol, const float* packed, float* grad,
                     float* smooth, void* stream);
+
+/*
+ * Backward of the multi-view feature-consistency term (mfc_loss, losses/loss.py:43-45) w.r.t. the SDF: the patches depend
+ * on the network only through the surface point p = o + d z0 (normal and feature maps are detached, implicit_surface.py:
+ * 224-235), so d ncc / d z0 is the forward-mode tangent of (surface_patch_warp2 -> compute_LNCC2) along the ray.
+ *   surf_patch_warp_tangent  surf_patch_warp's outputs plus their derivatives along dirs (R,3) = d pts / d z0
+ *   surf_lncc_jvp            ncc (optional) and d ncc / d z0 (n_rays) from patches and tangents
+ *   surf_crossing_backward   d_sdf (R,S) += g_z0 dz0/d sdf at the two samples bracketing the first sign change
+ *                            (implicit_surface.py:181-220; nothing where there is no crossing or z0 left [0, *zmax])
+ */
+int surf_patch_warp_tangent(const float* pts, const float* dirs, const float* grads, int n_rays, const float* const* h_maps_t4,
+                            int nv, int H, int W, const float* h_intrs, const float* h_kinv_ref, const float* h_c2w,
+                            int patch_size, float* ref_out, float* src_out, float* ref_tan, float* src_tan, void* stream);
+int surf_lncc_jvp(const float* ref, const float* src, const float* ref_tan, const float* src_tan, int64_t n_rays, int n_src,
+                  int patch_elems, int channels, float* ncc, float* dncc, void* stream);
+int surf_crossing_backward(const float* sdf, const uint8_t* vmask, const float* mid_z, int n_rays, int S, const float* zmax,
+                           const float* g_z0, float* d_sdf, void* stream);
 
 /*
  * Tall-skinny reduction for the weight / bias gradients of the backward kernels:

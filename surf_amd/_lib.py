@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
 # must equal SURF_ABI_VERSION of include/surf_hip.h (tests/test_host_modules.py compares the two texts); lib() refuses a
 # library built from another header
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -48,6 +48,9 @@ SIGNATURES = {
     "surf_blend_backward": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_colgram_workspace_floats": (c_i64, [c_i64, c_int, c_int]),
     "surf_colgram": (c_int, [c_ptr, c_int, c_int, c_ptr, c_int, c_int, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    "surf_patch_warp_tangent": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_lncc_jvp": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    "surf_crossing_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_lncc": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),
     "surf_sdf_smooth_packed_floats": (c_i64, []),
     "surf_sdf_smooth_pack_weights": (c_int, [c_ptr, c_ptr, c_ptr]),

@@ -603,6 +603,44 @@ def photometric_loss(depth, imgs_t4, mask_ref, cams, ref_idx=0, topk=2, return_w
     return (loss, warp) if return_warp else loss
 
 
+def patch_warp_tangent(pts, dirs, grads, maps_t4, cams, patch_size=11):
+    """patch_warp + the derivatives of both patch stacks along d pts / d z0 = dirs (R,3) (surf_patch_warp_tangent).
+    Returns (ref, src, ref_tan, src_tan)."""
+    for t, nm in ((pts, "pts"), (dirs, "dirs"), (grads, "grads")):
+        _chk(t, torch.float32, nm)
+    nv, H, W, _ = maps_t4[0].shape
+    R, dev, P = pts.shape[0], pts.device, patch_size * patch_size
+    if not hasattr(cams, "kinv_ref"):
+        cams.kinv_ref = np.ascontiguousarray(torch.inverse(torch.from_numpy(cams.intrs))[0, :3, :3].contiguous().numpy())
+    ref, ref_t = (torch.empty(1, R, P, 12, dtype=torch.float32, device=dev) for _ in range(2))
+    src, src_t = (torch.empty(nv - 1, R, P, 12, dtype=torch.float32, device=dev) for _ in range(2))
+    rc = _lib.lib().surf_patch_warp_tangent(_p(pts), _p(dirs), _p(grads), R, _ptr_array(list(maps_t4)), nv, H, W, _np_ptr(cams.intrs),
+                                            _np_ptr(cams.kinv_ref), _np_ptr(cams.c2w), int(patch_size), _p(ref), _p(src), _p(ref_t),
+                                            _p(src_t), _stream())
+    _lib.check(rc, "surf_patch_warp_tangent")
+    return ref, src, ref_t, src_t
+
+
+def lncc_jvp(ref, src, ref_tan, src_tan):
+    """(ncc (R,1), d ncc / d z0 (R,)) of compute_LNCC2 for patch tangents (surf_lncc_jvp)."""
+    nsrc, R, P, C = src.shape
+    ncc = torch.empty(R, 1, dtype=torch.float32, device=ref.device)
+    d = torch.empty(R, dtype=torch.float32, device=ref.device)
+    rc = _lib.lib().surf_lncc_jvp(_p(ref), _p(src), _p(ref_tan), _p(src_tan), R, int(nsrc), int(P), int(C), _p(ncc), _p(d), _stream())
+    _lib.check(rc, "surf_lncc_jvp")
+    return ncc, d
+
+
+def crossing_backward(sdf, vmask, mid_z, zmax, g_z0, d_sdf):
+    """d_sdf (R*S,) += g_z0 (R,) d z0 / d sdf at the first zero crossing of every ray (surf_crossing_backward); zmax: 0-d tensor."""
+    R, S = mid_z.shape
+    _chk(d_sdf, torch.float32, "d_sdf")
+    rc = _lib.lib().surf_crossing_backward(_p(sdf), _p(vmask), _p(mid_z), R, S, _p(zmax.reshape(1).float().contiguous()),
+                                           _p(g_z0.float().contiguous()), _p(d_sdf), _stream())
+    _lib.check(rc, "surf_crossing_backward")
+    return d_sdf
+
+
 def lncc(ref_gray_val, sampled_gray_val):
     """compute_LNCC2 (losses/ncc.py:7-51): ref (1,R,P,C), src (nsrc,R,P,C) -> (R,1)."""
     _chk(ref_gray_val, torch.float32, "ref_gray_val")
