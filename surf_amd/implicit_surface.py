@@ -296,19 +296,21 @@ class ImplicitSurface(nn.Module):
             out["sparse_sdf"] = torch.cat([torch.where(occ, sdf_r, torch.zeros_like(sdf_r)), sdf]).view(-1, 1)
             # what backward_render needs of this forward (row f2: the partial backward of the render)
             self._ctx = dict(st=st, act=act, sdf=sdf, grad=grad, col=col, rays_d=rays_d, anneal=float(cos_anneal_ratio),
-                             scene=scene, eik_den=float(eik[1]), random_pts=pr, random_occ=occ)
+                             scene=scene, eik_den=float(eik[1]), random_pts=pr, random_occ=occ, pts0=pts0, g0=g0, maps=maps)
         return out
 
     @torch.no_grad()
-    def backward_render(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None):
+    def backward_render(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None):
         """Partial backward of the last training forward (`render_scene(patch_warp=True)`), SURVEY 8f-f2: given the loss's
-        gradients w.r.t. `color_fine` (R,3), `render_depth` (R), `gradient_error` (scalar) and `sparse_sdf` ((1024 + R*S),1),
+        gradients w.r.t. `color_fine` (R,3), `render_depth` (R), `gradient_error` (scalar), `sparse_sdf` ((1024 + R*S),1) and
+        the per-ray patch NCC (R,1) (= compute_LNCC2 of ref_gray_val / sampled_gray_val, the mfc term),
         ACCUMULATES `.grad` on every parameter of the implicit surface - sdf_network.lin*.{weight_g, weight_v, bias},
         color_network.*, deviation_network.variance - and returns the gradients of the scene's sparse feature rows, fine ->
         coarse, (N_s, 7).  Kernels: surf_composite_backward -> surf_sdf_backward (reverse over forward: the spatial-gradient
-        upstream is a tangent direction) and surf_blend_backward.
-        NOT differentiated (so far): the FPN feature maps behind the colour network, the smooth (H.1) and patch-NCC terms,
-        the volume build - what the reference's finetune mode (has_vol) trains is covered except for those two loss terms."""
+        upstream is a tangent direction), surf_blend_backward, and for the NCC term surf_patch_warp_tangent -> surf_lncc_jvp ->
+        surf_crossing_backward (d ncc / d z0 as a forward-mode tangent along the ray, then into the two bracketing samples).
+        NOT differentiated (so far): the FPN feature maps behind the colour network, the smooth (H.1) term, the volume build -
+        what the reference's finetune mode (has_vol) trains is covered except for that one loss term (weight 1e-4)."""
         c = self._ctx
         st, act, scene = c["st"], c["act"], c["scene"]
         dev = c["sdf"].device
@@ -317,6 +319,10 @@ class ImplicitSurface(nn.Module):
                                                         g_color.float().contiguous(),
                                                         None if g_depth is None else g_depth.float().contiguous(),
                                                         eik_scale=float(g_gradient_error) / (c["eik_den"] + 1e-5))
+        if g_ncc is not None:
+            ref, src, ref_t, src_t = ops.patch_warp_tangent(c["pts0"], c["rays_d"], c["g0"], c["maps"], scene.cams)
+            _, dncc = ops.lncc_jvp(ref, src, ref_t, src_t)
+            ops.crossing_backward(c["sdf"], st["vmask"], st["mid_z"], st["z_vals"].max(), g_ncc.reshape(-1).float() * dncc, d_sdf)
         idx = act.long()
         ybar = d_sdf[idx]
         pts = st["pts"][idx]

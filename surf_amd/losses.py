@@ -38,7 +38,8 @@ class Loss(nn.Module):
         anneal = min(1.0, step / 2)                                                                          # loss.py:37
         sparse_loss = torch.exp(-preds["sparse_sdf"].abs() * self.sparse_scale_factor).mean() * anneal
         smooth_loss = preds["smooth_error"].mean()
-        ncc = ops.lncc(preds["ref_gray_val"].contiguous(), preds["sampled_gray_val"].contiguous())          # (R,1)
+        # (R,1); a caller that wants d loss / d ncc (training.finetune_step) passes the values in as a leaf
+        ncc = preds["ncc"] if "ncc" in preds else ops.lncc(preds["ref_gray_val"].contiguous(), preds["sampled_gray_val"].contiguous())
         ncc_mask = vm * preds["mid_inside_sphere"]
         mfc_loss = 0.5 * ((ncc * ncc_mask).sum(dim=0) / (ncc_mask.sum(dim=0) + 1e-8)).squeeze(-1)
 

@@ -94,11 +94,11 @@ class SuRF(nn.Module):
         self.has_vol = True
         self._vol_scene = None
 
-    def backward(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None):
+    def backward(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None):
         """Partial backward of the last train-mode forward (row f2): `.grad` of every implicit-surface parameter and, in
         finetune mode (has_vol), of the per-scene feature volumes - what surf.py:36-45 hands the optimiser there.  See
-        ImplicitSurface.backward_render for what is not differentiated yet (FPN / volume build, smooth and patch-NCC terms)."""
-        dvols = self.implicit_surface.backward_render(g_color, g_depth, g_gradient_error, g_sparse_sdf)
+        ImplicitSurface.backward_render for what is not differentiated yet (FPN / volume build, the smooth term)."""
+        dvols = self.implicit_surface.backward_render(g_color, g_depth, g_gradient_error, g_sparse_sdf, g_ncc)
         if self.has_vol:
             for p, g in zip(self.volumes, dvols[::-1]):          # volumes are kept coarse -> fine
                 g = g.to(p.dtype)

@@ -902,20 +902,23 @@ def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
     g_color, g_depth = torch.randn(R, 3, generator=g), torch.randn(R, generator=g) * 0.3
     g_eik = 0.25
     g_sparse = torch.randn(1024 + R * S, 1, generator=g) * 0.01
-    dvols = model.backward_render(g_color.to(d), g_depth.to(d), g_eik, g_sparse.to(d))
+    g_ncc = torch.randn(R, 1, generator=g) * 0.2 * out["mid_inside_sphere"].cpu()
+    assert float(g_ncc.abs().sum()) > 0
+    dvols = model.backward_render(g_color.to(d), g_depth.to(d), g_eik, g_sparse.to(d), g_ncc.to(d))
     # oracle autograd
     c = gpu_scene["cpu"]
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in weights.items() if k.startswith("implicit_surface.")}
     vols = [v.clone().requires_grad_(True) for v in c["vols"]]
     o = O.render(sd, scene["rays_o"], scene["rays_d"], near, far, c["mvol"], vols, c["tabs"], c["masks"], c["feats"], scene["imgs"],
-                 scene["intrs"], scene["c2ws"], CFG["n_samples"], CFG["sample_ranges"], CFG["n_depth"], 0.6)
+                 scene["intrs"], scene["c2ws"], CFG["n_samples"], CFG["sample_ranges"], CFG["n_depth"], 0.6, patch_warp=True)
     torch.manual_seed(33)
     pr = torch.rand([1024, 3]) * 2 - 1
     occ = torch.stack([O.lookup_volume_nearest(pr, mk) for mk in c["masks"]], dim=-1).any(dim=-1)
     phi = O.lookup_sparse_volume(pr, vols, c["tabs"])
     sdf_r = O.sdf_mlp(O.sdf_weights(sd), pr, phi)[0] * occ.float()
     loss = ((o["color_fine"] * g_color).sum() + (o["render_depth"] * g_depth).sum() + o["gradient_error"] * g_eik
-            + (sdf_r * g_sparse[:1024, 0]).sum() + (o["sdf"].reshape(-1) * g_sparse[1024:, 0]).sum())
+            + (sdf_r * g_sparse[:1024, 0]).sum() + (o["sdf"].reshape(-1) * g_sparse[1024:, 0]).sum()
+            + (O.lncc(o["ref_gray_val"], o["sampled_gray_val"]) * g_ncc).sum())
     loss.backward()
     rel_close(out["color_fine"], o["color_fine"].detach(), 1e-3, 1e-5)
     names = [f"sdf_network.lin{l}.{p}" for l in range(7) for p in ("weight_g", "weight_v", "bias")] + ["deviation_network.variance"]
@@ -1031,7 +1034,7 @@ def test_finetune_steps_train_volumes_and_networks(scene):
     opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "vol_lr": [1e-2] * 4}))
     vol0 = [v.detach().clone() for v in model.volumes]
     w0 = model.implicit_surface.color_network.base_fc[0].weight.detach().clone()
-    loss_fn = Loss(conf.from_dict(dict(LOSS_CONF, mfc_weight=0.0, smooth_weight=0.0)))
+    loss_fn = Loss(conf.from_dict(dict(LOSS_CONF, smooth_weight=0.0)))
     hist = []
     for step in range(6):
         torch.manual_seed(70)
@@ -1056,3 +1059,64 @@ def test_colgram_matches_matmul(rows, M, N):
     out2 = ops.colgram(A, X, with_sum=True, out=out.clone())
     rel_close(out2, 2 * ref, 1e-4, 2e-4 * float(ref.abs().max()))
     rel_close(ops.colgram(A, X), ref[:, :N], 1e-4, 1e-4 * float(ref.abs().max()))
+
+
+def test_mfc_backward_pieces_match_autograd(scene, gpu_scene, golden_train, golden_fpn):
+    """Row f2: the forward-mode tangent of (surface_patch_warp2 -> compute_LNCC2) along the ray (surf_patch_warp_tangent,
+    surf_lncc_jvp) against torch.autograd.functional.jvp through the oracle, and surf_crossing_backward against autograd of
+    the zero-crossing formula."""
+    from torch.autograd.functional import jvp
+    from surf_amd import ops
+    d = dev()
+    gt = golden_train
+    f_t4 = gpu_scene["feats_t4"]
+    H, W = f_t4[0].shape[1:3]
+    maps = [f_t4[0], ops.upsample_bilinear_t4(f_t4[1], H, W), ops.upsample_bilinear_t4(f_t4[2], H, W)]
+    pts, grads = gt["unit_pts"], gt["unit_grads"]
+    g = torch.Generator().manual_seed(77)
+    dirs = torch.nn.functional.normalize(torch.randn(pts.shape[0], 3, generator=g), dim=1)
+    ref, src, ref_t, src_t = ops.patch_warp_tangent(pts.to(d).contiguous(), dirs.to(d).contiguous(), grads.to(d).contiguous(), maps,
+                                                    gpu_scene["cams"])
+    rel_close(ref, gt["unit_ref"], 1e-4, 2e-5)
+    rel_close(src, gt["unit_src"], 1e-3, 2e-4)
+    warp_feats = gt["unit_warp_feats"]
+
+    def patches(t):
+        r, s_ = O.surface_patch_warp(pts + t[:, None] * dirs, grads, warp_feats, scene["intrs"], scene["c2ws"])
+        return torch.cat([r, s_], dim=0)
+    _, tan = jvp(patches, (torch.zeros(pts.shape[0]),), (torch.ones(pts.shape[0]),))
+    got = torch.cat([ref_t, src_t], dim=0).cpu()
+    err = (got - tan).abs()
+    scale = float(tan.abs().max())
+    assert scale > 1e-2
+    # bilinear kinks (a sample exactly on a texel boundary) and the ill-conditioned homography of steep planes: outlier allowance
+    assert float((err < 2e-3 * scale + 1e-3 * tan.abs()).float().mean()) > 0.995, float(err.max())
+    # LNCC tangent
+    ncc, dncc = ops.lncc_jvp(ref, src, ref_t, src_t)
+    rel_close(ncc, gt["unit_ncc"], 1e-5, 2e-6)
+    rc, sc_, rtc, stc = ref.cpu(), src.cpu(), ref_t.cpu(), src_t.cpu()
+    _, dref = jvp(lambda t: O.lncc(rc + t.view(1, -1, 1, 1) * rtc, sc_ + t.view(1, -1, 1, 1) * stc)[:, 0], (torch.zeros(pts.shape[0]),),
+                  (torch.ones(pts.shape[0]),))
+    rel_close(dncc, dref, 2e-3, 2e-4 * float(dref.abs().max()))
+    # zero-crossing backward
+    R, S = 37, 24
+    sdf = torch.randn(R, S, generator=g) * 0.3 + torch.linspace(0.4, -0.4, S)[None]
+    vmask = (torch.rand(R, S, generator=g) > 0.15).to(torch.uint8)
+    mid = torch.sort(torch.rand(R, S, generator=g) * 2 + 0.5, dim=1).values
+    g_z0 = torch.randn(R, generator=g)
+    zmax = mid.max() * 0.97
+    x = sdf.clone().requires_grad_(True)
+    tot = torch.zeros(())
+    for r in range(R):
+        for k in range(S - 1):
+            if vmask[r, k] and vmask[r, k + 1] and float(sdf[r, k] * sdf[r, k + 1]) <= 0:
+                z0 = (x[r, k] * mid[r, k + 1] - x[r, k + 1] * mid[r, k]) / (x[r, k] - x[r, k + 1] + 1e-10)
+                if 0 <= float(z0.detach()) <= float(zmax):
+                    tot = tot + g_z0[r] * z0
+                break
+    tot.backward()
+    d_sdf = torch.zeros(R * S, device=d)
+    ops.crossing_backward(sdf.reshape(-1).to(d).contiguous(), vmask.reshape(-1).to(d).contiguous(), mid.to(d).contiguous(), zmax.to(d),
+                          g_z0.to(d), d_sdf)
+    rel_close(d_sdf.view(R, S), x.grad, 1e-4, 1e-5 * float(x.grad.abs().max()))
+    assert float(x.grad.abs().max()) > 0
