@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 20
+#define SURF_ABI_VERSION 21
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -370,6 +370,14 @@ int surf_bn_train_affine(const float* x, int64_t n, int channels, const float* g
                          void* stream);
 int surf_bn_relu_apply(const float* x, int64_t n, int channels, const float* scale, const float* shift, const float* skip,
                        float* out, void* stream);
+
+/*
+ * Weight gradient of surf_spconv (no BN): dW (27, C_in, C_out) += sum_i x[neighbour_k(i)] (x) dy[i]  (float atomics; the caller
+ * zero-fills).  The INPUT gradient is surf_spconv itself on the swapped lattices: submanifold with mirrored offsets
+ * (slice 26 - k), stride-2 down <-> transposed up, kernel slices transposed (surf_amd.ops.spconv_backward).
+ */
+int surf_spconv_wgrad(const float* x, int cin, const int32_t* in_table, int D_in, const int32_t* out_coords, int64_t n_out,
+                      int mode, const float* dy, int cout, float* dW, void* stream);
 
 /* bbox (device int32[6]) = [min x, min y, min z, max x, max y, max z] of coords (n,3) */
 int surf_coords_bbox(const int32_t* coords, int64_t n, int32_t* bbox, void* stream);

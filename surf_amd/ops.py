@@ -895,6 +895,27 @@ def spconv(x, in_table, out_coords, mode, weight, bn_scale=None, bn_shift=None, 
     return out
 
 
+def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight, dy):
+    """Backward of y = spconv(x, in_table, out_coords, mode, weight) (no BN / ReLU / skip).  Returns (dx (n_in, Cin),
+    dW (27, Cin, Cout)).  dx is a sparse convolution of dy over the OUTPUT lattice (`out_table` indexes out_coords):
+    submanifold with mirrored offsets, down <-> up, kernel slices transposed."""
+    _chk(dy, torch.float32, "dy")
+    cin, cout = int(weight.shape[1]), int(weight.shape[2])
+    wt = weight.transpose(1, 2).contiguous()                        # (27, Cout, Cin)
+    if mode == SUBM:
+        dx = spconv(dy, out_table, in_coords, SUBM, wt.flip(0).contiguous())
+    elif mode == DOWN:
+        dx = spconv(dy, out_table, in_coords, UP, wt)
+    else:
+        dx = spconv(dy, out_table, in_coords, DOWN, wt)
+    dW = torch.zeros_like(weight)
+    if out_coords.shape[0] > 0 and x.shape[0] > 0:
+        rc = _lib.lib().surf_spconv_wgrad(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords), out_coords.shape[0],
+                                          int(mode), _p(dy), cout, _p(dW), _stream())
+        _lib.check(rc, "surf_spconv_wgrad")
+    return dx, dW
+
+
 def bn_train_relu(x, bn, skip=None):
     """spnn.BatchNorm in train mode + ReLU (+ skip) on raw convolution outputs x (n, C): batch statistics, running
     statistics updated in place like torch (reg_network.py:14-15,28-29).  bn: the block's nn.BatchNorm1d."""

@@ -1120,3 +1120,37 @@ def test_mfc_backward_pieces_match_autograd(scene, gpu_scene, golden_train, gold
                           g_z0.to(d), d_sdf)
     rel_close(d_sdf.view(R, S), x.grad, 1e-4, 1e-5 * float(x.grad.abs().max()))
     assert float(x.grad.abs().max()) > 0
+
+
+@pytest.mark.parametrize("cin,cout", [(8, 16), (16, 8), (32, 64), (64, 64)])
+def test_spconv_backward_matches_autograd(cin, cout):
+    """Row f2 (volume-build side): the input gradient of a sparse convolution as a sparse convolution on the swapped lattices
+    and surf_spconv_wgrad, for the three modes, against torch autograd through the oracle's convolutions."""
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(cin + 3 * cout)
+    D = 14
+    occ = torch.rand(D, D, D, generator=g) < 0.3
+    coords = occ.nonzero().to(torch.int32).contiguous()
+    cd_ref, D2 = O.down_coords(coords.long(), D)
+    cd = cd_ref.to(torch.int32).contiguous()
+    tf, tc = ops.table_from_coords(coords.to(d), D), ops.table_from_coords(cd.to(d), D2)
+    w = (torch.randn(27, cin, cout, generator=g) / (27 * cin) ** 0.5)
+    for mode, n_in, n_out in ((ops.SUBM, coords.shape[0], coords.shape[0]), (ops.DOWN, coords.shape[0], cd.shape[0]),
+                              (ops.UP, cd.shape[0], coords.shape[0])):
+        x = torch.randn(n_in, cin, generator=g)
+        dy = torch.randn(n_out, cout, generator=g)
+        xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        if mode == ops.SUBM:
+            y = O.spconv_subm(xr, coords.long(), D, wr)
+            args = (tf, coords.to(d), tf, coords.to(d))
+        elif mode == ops.DOWN:
+            y = O.spconv_down(xr, coords.long(), D, wr)[0]
+            args = (tf, coords.to(d), tc, cd.to(d))
+        else:
+            y = O.spconv_up(xr, cd.long(), coords.long(), D, wr)
+            args = (tc, cd.to(d), tf, coords.to(d))
+        (y * dy).sum().backward()
+        dx, dW = ops.spconv_backward(x.to(d), args[0], args[1], args[2], args[3], mode, w.to(d), dy.to(d))
+        rel_close(dx, xr.grad, 1e-4, 1e-5 * float(xr.grad.abs().max()))
+        rel_close(dW, wr.grad, 1e-4, 2e-5 * float(wr.grad.abs().max()))
