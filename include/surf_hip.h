@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 21
+#define SURF_ABI_VERSION 22
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -362,14 +362,21 @@ int surf_spconv_mfma(const float* in, int cin, const int32_t* in_table, int D_in
  * BatchNorm with BATCH statistics over the voxel rows x (n, C) (train mode of spnn.BatchNorm, reg_network.py:14-15,28-29;
  * C in {8, 16, 32, 64}): scale = gamma / sqrt(var + eps), shift = beta - mean scale (device, C floats each), fp64 reduction;
  * running_mean / running_var (may both be NULL) are updated in place as torch.nn.BatchNorm1d does (momentum, unbiased
- * variance).  surf_bn_relu_apply: out = relu(x scale + shift) (+ skip).  workspace: surf_bn_workspace_bytes(C) device bytes.
+ * variance); batch_stats (may be NULL): mean | 1/sqrt(var + eps) (2C floats), what the backward needs.  surf_bn_relu_apply: out = relu(x scale + shift) (+ skip).  workspace: surf_bn_workspace_bytes(C) device bytes.
  */
 int64_t surf_bn_workspace_bytes(int channels);
 int surf_bn_train_affine(const float* x, int64_t n, int channels, const float* gamma, const float* beta, float eps,
-                         float momentum, float* running_mean, float* running_var, float* scale, float* shift, void* workspace,
-                         void* stream);
+                         float momentum, float* running_mean, float* running_var, float* scale, float* shift, float* batch_stats,
+                         void* workspace, void* stream);
 int surf_bn_relu_apply(const float* x, int64_t n, int channels, const float* scale, const float* shift, const float* skip,
                        float* out, void* stream);
+/* Backward of y = relu(x scale + shift) (+ skip; the skip's gradient is dy itself) with scale = gamma invstd, shift = beta -
+ * mean scale: x the raw convolution output, scale / shift the forward's affine, mean / invstd (C each) the statistics behind it.
+ * train != 0: batch statistics (dx = scale (zbar - mean(zbar) - xhat mean(zbar xhat))); 0: running statistics (dx = scale zbar).
+ * Outputs dgamma, dbeta (C), dx (n, C).  workspace: surf_bn_workspace_bytes(C). */
+int surf_bn_relu_backward(const float* x, const float* dy, int64_t n, int channels, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, int train, void* workspace, float* dgamma, float* dbeta,
+                          float* dx, void* stream);
 
 /*
  * Weight gradient of surf_spconv (no BN): dW (27, C_in, C_out) += sum_i x[neighbour_k(i)] (x) dy[i]  (float atomics; the caller

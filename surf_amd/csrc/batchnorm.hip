@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
 
 __global__ void bn_finalize_kernel(const double* __restrict__ part, int blocks, int C, int64_t n, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift) {
+                                   float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ batch_stats) {
   const int c = threadIdx.x;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
@@ -46,6 +47,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ part, int blocks, 
   const float sc = gamma[c] / sqrtf((float)var + eps);
   scale[c] = sc;
   shift[c] = beta[c] - (float)mean * sc;
+  if (batch_stats) {
+    batch_stats[c] = (float)mean;
+    batch_stats[C + c] = 1.0f / sqrtf((float)var + eps);
+  }
   if (running_mean) {
     const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
     running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
@@ -68,13 +73,90 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   reinterpret_cast<f32x4*>(out)[i] = y;
 }
 
+// ---- backward of y = relu(xhat gamma + beta) (+ skip), xhat = (x - mean) invstd -------------------------------------------
+//   zbar = dy [relu_out > 0];  dbeta = sum zbar;  dgamma = sum zbar xhat
+//   train (batch statistics):  dx = gamma invstd (zbar - mean(zbar) - xhat mean(zbar xhat));   eval: dx = gamma invstd zbar
+template <int C>
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t n,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             double* __restrict__ part) {
+  constexpr int G = 256 / C;
+  __shared__ double sh[2][256];
+  const int c = threadIdx.x % C, g = threadIdx.x / C;
+  const float mu = mean[c], is = invstd[c], sc = scale[c], sh0 = shift[c];
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * G + g; r < n; r += (int64_t)gridDim.x * G) {
+    const float xv = x[r * C + c];
+    const float zb = xv * sc + sh0 > 0.f ? dy[r * C + c] : 0.f;      // the forward's own pre-activation (bn_apply_kernel)
+    s1 += (double)zb;
+    s2 += (double)zb * (double)((xv - mu) * is);
+  }
+  sh[0][threadIdx.x] = s1;
+  sh[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < G; ++k) { a += sh[0][k * C + threadIdx.x]; b += sh[1][k * C + threadIdx.x]; }
+    part[((int64_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = a;
+    part[((int64_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = b;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int blocks, int C, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < blocks; ++b) { s1 += part[((int64_t)b * 2 + 0) * C + c]; s2 += part[((int64_t)b * 2 + 1) * C + c]; }
+  dbeta[c] = (float)s1;
+  dgamma[c] = (float)s2;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t n, int C,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ dgamma, const float* __restrict__ dbeta, int train,
+                                                           float* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * C) return;
+  const int c = (int)(i % C);
+  const float xv = x[i];
+  const float zb = xv * scale[c] + shift[c] > 0.f ? dy[i] : 0.f;
+  const float xh = (xv - mean[c]) * invstd[c];
+  float v = zb;
+  if (train) v = zb - dbeta[c] / (float)n - xh * (dgamma[c] / (float)n);
+  dx[i] = scale[c] * v;                                               // gamma invstd = the forward's scale
+}
+
 }  // namespace
+
+extern "C" int surf_bn_relu_backward(const float* x, const float* dy, int64_t n, int channels, const float* scale,
+                                     const float* shift, const float* mean, const float* invstd, int train, void* workspace,
+                                     float* dgamma, float* dbeta, float* dx, void* stream) {
+  if (!x || !dy || !scale || !shift || !mean || !invstd || !workspace || !dgamma || !dbeta || !dx || n <= 0) return SURF_E_ARG;
+  const int64_t want = (n * channels + 255) / 256;
+  const int blocks = (int)(want < BN_BLOCKS ? want : BN_BLOCKS);
+  double* part = (double*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  switch (channels) {
+    case 8: hipLaunchKernelGGL(bn_bwd_partial_kernel<8>, dim3(blocks), dim3(256), 0, s, x, dy, n, scale, shift, mean, invstd, part); break;
+    case 16: hipLaunchKernelGGL(bn_bwd_partial_kernel<16>, dim3(blocks), dim3(256), 0, s, x, dy, n, scale, shift, mean, invstd, part); break;
+    case 32: hipLaunchKernelGGL(bn_bwd_partial_kernel<32>, dim3(blocks), dim3(256), 0, s, x, dy, n, scale, shift, mean, invstd, part); break;
+    case 64: hipLaunchKernelGGL(bn_bwd_partial_kernel<64>, dim3(blocks), dim3(256), 0, s, x, dy, n, scale, shift, mean, invstd, part); break;
+    default: return SURF_E_LIMIT;
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, s, part, blocks, channels, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n * channels + 255) / 256)), dim3(256), 0, s, x, dy, n, channels,
+                     scale, shift, mean, invstd, dgamma, dbeta, train, dx);
+  return surf_check_launch();
+}
 
 extern "C" int64_t surf_bn_workspace_bytes(int channels) { return (int64_t)BN_BLOCKS * 2 * channels * sizeof(double); }
 
 extern "C" int surf_bn_train_affine(const float* x, int64_t n, int channels, const float* gamma, const float* beta, float eps,
                                     float momentum, float* running_mean, float* running_var, float* scale, float* shift,
-                                    void* workspace, void* stream) {
+                                    float* batch_stats, void* workspace, void* stream) {
   if (!x || !gamma || !beta || !scale || !shift || !workspace || n <= 0) return SURF_E_ARG;
   if ((running_mean == nullptr) != (running_var == nullptr)) return SURF_E_ARG;
   const int64_t want = (n * channels + 255) / 256;
@@ -89,7 +171,7 @@ extern "C" int surf_bn_train_affine(const float* x, int64_t n, int channels, con
     default: return SURF_E_LIMIT;
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, part, blocks, channels, n, gamma, beta, eps, momentum,
-                     running_mean, running_var, scale, shift);
+                     running_mean, running_var, scale, shift, batch_stats);
   return surf_check_launch();
 }
 

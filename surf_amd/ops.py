@@ -916,9 +916,10 @@ def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight,
     return dx, dW
 
 
-def bn_train_relu(x, bn, skip=None):
+def bn_train_relu(x, bn, skip=None, saved=None):
     """spnn.BatchNorm in train mode + ReLU (+ skip) on raw convolution outputs x (n, C): batch statistics, running
-    statistics updated in place like torch (reg_network.py:14-15,28-29).  bn: the block's nn.BatchNorm1d."""
+    statistics updated in place like torch (reg_network.py:14-15,28-29).  bn: the block's nn.BatchNorm1d.
+    saved: a dict that receives what bn_relu_backward needs (scale, shift, stats = mean | invstd)."""
     _chk(x, torch.float32, "x")
     n, C = x.shape
     dev = x.device
@@ -927,17 +928,41 @@ def bn_train_relu(x, bn, skip=None):
         return out
     scale = torch.empty(C, dtype=torch.float32, device=dev)
     shift = torch.empty(C, dtype=torch.float32, device=dev)
+    stats = torch.empty(2 * C, dtype=torch.float32, device=dev) if saved is not None else None
     ws = torch.empty(_lib.lib().surf_bn_workspace_bytes(C), dtype=torch.uint8, device=dev)
     momentum = 0.1 if bn.momentum is None else float(bn.momentum)
     track = bn.track_running_stats and bn.running_mean is not None
     rc = _lib.lib().surf_bn_train_affine(_p(x), n, C, _p(bn.weight.detach()), _p(bn.bias.detach()), float(bn.eps), momentum,
                                          _p(bn.running_mean if track else None), _p(bn.running_var if track else None),
-                                         _p(scale), _p(shift), _p(ws), _stream())
+                                         _p(scale), _p(shift), _p(stats), _p(ws), _stream())
     _lib.check(rc, "surf_bn_train_affine")
     if track:
         bn.num_batches_tracked += 1
+    if saved is not None:
+        saved.update(scale=scale, shift=shift, stats=stats)
     _lib.check(_lib.lib().surf_bn_relu_apply(_p(x), n, C, _p(scale), _p(shift), _p(skip), _p(out), _stream()), "surf_bn_relu_apply")
     return out
+
+
+def bn_relu_backward(x, dy, scale, shift, stats, train=True):
+    """Backward of bn_train_relu (train) / of the folded eval-mode BN + ReLU (train=False): x the raw convolution output
+    (n, C), dy the gradient of the block output (which is also the skip's gradient), scale / shift the forward's affine,
+    stats = mean | invstd (2C).  Returns (dx (n, C), dgamma (C), dbeta (C))."""
+    _chk(x, torch.float32, "x")
+    _chk(dy, torch.float32, "dy")
+    n, C = x.shape
+    dev = x.device
+    dx = torch.empty_like(x)
+    dgamma = torch.zeros(C, dtype=torch.float32, device=dev)
+    dbeta = torch.zeros(C, dtype=torch.float32, device=dev)
+    if n == 0:
+        return dx, dgamma, dbeta
+    ws = torch.empty(_lib.lib().surf_bn_workspace_bytes(C), dtype=torch.uint8, device=dev)
+    mean, invstd = stats[:C], stats[C:]
+    rc = _lib.lib().surf_bn_relu_backward(_p(x), _p(dy), n, C, _p(scale), _p(shift), _p(mean), _p(invstd), int(bool(train)),
+                                          _p(ws), _p(dgamma), _p(dbeta), _p(dx), _stream())
+    _lib.check(rc, "surf_bn_relu_backward")
+    return dx, dgamma, dbeta
 
 
 def row_linear8(x, weight):

@@ -6,7 +6,8 @@ running_mean,running_var,num_batches_tracked}``, ``nets.{s}.out_lin.weight``.  T
 ``surf_spconv`` (csrc/spconv.hip).  torchsparse itself is absent here (third party): the convolution
 semantics are those documented in ``oracle.surf_oracle.sparse_unet`` -- PARITY UNPINNED.
 Eval-mode BatchNorm (running statistics) is folded into the convolution epilogues; train mode uses batch statistics
-(`surf_bn_train_affine`, forward only) and updates the running ones like torch.
+(`surf_bn_train_affine`) and updates the running ones like torch; a train-mode forward can record a tape for
+`SparseCostRegNet.backward` (HIP kernels throughout: no autograd graph).
 """
 import math
 
@@ -79,32 +80,86 @@ class SparseCostRegNet(nn.Module):
         self.conv11 = _Block(2 * b, b, stride=2, transposed=True)
         self.out_lin = nn.Linear(b, d_out, bias=False)
 
-    def _conv(self, blk, x, table, out_coords, mode, skip=None):
+    def _conv(self, blk, x, in_site, out_site, mode, skip=None, tape=None):
+        """One block on x (rows of `in_site` = (table, coords)) -> rows of `out_site`.  tape: a list that receives what
+        `backward` needs (train mode only: eval mode folds the BN into the convolution epilogue and keeps no raw output)."""
         w, scale, shift, packed = blk.prepared(self.use_mfma)
-        if self.training:   # batch statistics (forward only: nothing here is differentiable), running statistics updated
-            raw = ops.spconv(x, table, out_coords, mode, w, None, None, None, packed=packed)
+        if self.training:   # batch statistics, running statistics updated
+            raw = ops.spconv(x, in_site[0], out_site[1], mode, w, None, None, None, packed=packed)
             blk._bn_dirty = True
-            return ops.bn_train_relu(raw, blk.net[1], skip)
-        return ops.spconv(x, table, out_coords, mode, w, scale, shift, skip, packed=packed)
+            saved = {} if tape is not None else None
+            y = ops.bn_train_relu(raw, blk.net[1], skip, saved)
+            if tape is not None:
+                tape.append(dict(blk=blk, x=x, raw=raw, y=y, skip=skip, in_site=in_site, out_site=out_site, mode=mode, w=w, **saved))
+            return y
+        if tape is not None:
+            raise RuntimeError("SparseCostRegNet: the backward tape is recorded in train mode only")
+        return ops.spconv(x, in_site[0], out_site[1], mode, w, scale, shift, skip, packed=packed)
 
-    def forward(self, feats, coords, D, table=None):
+    def forward(self, feats, coords, D, table=None, tape=None):
         """feats (N, d_in) fp32, coords (N,3) int32 on the D lattice -> (out (N,8), mid (N,8))  (reg_network.py:69-88)"""
         t0 = table if table is not None else ops.table_from_coords(coords, D)
-        c0 = self._conv(self.conv0, feats, t0, coords, ops.SUBM)
+        s0 = (t0, coords)
+        c0 = self._conv(self.conv0, feats, s0, s0, ops.SUBM, tape=tape)
         cd1, t1, D1 = ops.down_sites(coords, D, self.down_rule)
-        x = self._conv(self.conv1, c0, t0, cd1, ops.DOWN)
-        c2 = self._conv(self.conv2, x, t1, cd1, ops.SUBM)
+        s1 = (t1, cd1)
+        x = self._conv(self.conv1, c0, s0, s1, ops.DOWN, tape=tape)
+        c2 = self._conv(self.conv2, x, s1, s1, ops.SUBM, tape=tape)
         cd2, t2, D2 = ops.down_sites(cd1, D1, self.down_rule)
-        x = self._conv(self.conv3, c2, t1, cd2, ops.DOWN)
-        c4 = self._conv(self.conv4, x, t2, cd2, ops.SUBM)
+        s2 = (t2, cd2)
+        x = self._conv(self.conv3, c2, s1, s2, ops.DOWN, tape=tape)
+        c4 = self._conv(self.conv4, x, s2, s2, ops.SUBM, tape=tape)
         cd3, t3, D3 = ops.down_sites(cd2, D2, self.down_rule)
-        x = self._conv(self.conv5, c4, t2, cd3, ops.DOWN)
-        x = self._conv(self.conv6, x, t3, cd3, ops.SUBM)
-        x = self._conv(self.conv7, x, t3, cd2, ops.UP, skip=c4)
-        x = self._conv(self.conv9, x, t2, cd1, ops.UP, skip=c2)
-        x = self._conv(self.conv11, x, t1, coords, ops.UP, skip=c0)
+        s3 = (t3, cd3)
+        x = self._conv(self.conv5, c4, s2, s3, ops.DOWN, tape=tape)
+        x = self._conv(self.conv6, x, s3, s3, ops.SUBM, tape=tape)
+        x = self._conv(self.conv7, x, s3, s2, ops.UP, skip=c4, tape=tape)
+        x = self._conv(self.conv9, x, s2, s1, ops.UP, skip=c2, tape=tape)
+        x = self._conv(self.conv11, x, s1, s0, ops.UP, skip=c0, tape=tape)
         out = ops.row_linear8(x, self.out_lin.weight.detach().float().contiguous())
+        if tape is not None:
+            tape.append(dict(lin=True, x=x, feats=feats))
         return out, x
+
+    def backward(self, tape, d_out, d_mid=None):
+        """Reverse sweep over a tape recorded by a train-mode forward: gradients of sum(out d_out) + sum(mid d_mid) are
+        ACCUMULATED into the `.grad` of every convolution kernel, BatchNorm weight / bias and out_lin.weight; returns the
+        gradient of `feats` (N, d_in).  Each block: BatchNorm(batch statistics) + ReLU + skip backward (surf_bn_relu_backward),
+        then the convolution's input gradient as a sparse convolution on the swapped lattices and its kernel gradient
+        (ops.spconv_backward)."""
+        def acc(p, g):
+            p.grad = g.to(p.dtype) if p.grad is None else p.grad + g.to(p.dtype)
+
+        last = tape[-1]
+        assert last.get("lin"), "tape: recorded by SparseCostRegNet.forward(..., tape=[])"
+        x11, feats = last["x"], last["feats"]
+        W = self.out_lin.weight.detach().float().contiguous()
+        grads = {}
+
+        def add(t, g):
+            k = id(t)
+            grads[k] = g if k not in grads else grads[k] + g
+
+        d_out = d_out.float().contiguous()
+        add(x11, ops.row_linear8(d_out, W.t().contiguous()))            # d_out @ W
+        if d_mid is not None:
+            add(x11, d_mid.float().contiguous())
+        acc(self.out_lin.weight, ops.colgram(d_out, x11))                # d_out^T x11
+        for e in reversed(tape[:-1]):
+            g = grads.pop(id(e["y"]), None)
+            if g is None:
+                continue
+            if e["skip"] is not None:
+                add(e["skip"], g)
+            draw, dgamma, dbeta = ops.bn_relu_backward(e["raw"], g.contiguous(), e["scale"], e["shift"], e["stats"], train=True)
+            bn = e["blk"].net[1]
+            acc(bn.weight, dgamma)
+            acc(bn.bias, dbeta)
+            dx, dW = ops.spconv_backward(e["x"], e["in_site"][0], e["in_site"][1], e["out_site"][0], e["out_site"][1], e["mode"],
+                                         e["w"], draw)
+            acc(e["blk"].net[0].kernel, dW)
+            add(e["x"], dx)
+        return grads.pop(id(feats))
 
 
 class SparseCostRegNetList(nn.Module):
@@ -116,5 +171,5 @@ class SparseCostRegNetList(nn.Module):
         rule = confs.get_string("down_rule", "dilate")
         self.nets = nn.ModuleList([SparseCostRegNet(d_in[i], d_out[i], d_base[i], rule) for i in range(self.num_stages)])
 
-    def forward(self, feats, coords, D, stage_idx, table=None):
-        return self.nets[stage_idx](feats, coords, D, table)
+    def forward(self, feats, coords, D, stage_idx, table=None, tape=None):
+        return self.nets[stage_idx](feats, coords, D, table, tape)

@@ -726,6 +726,48 @@ def test_sparse_unet_train_mode_batch_statistics(golden_pipe):
     rel_close(mid_e, mid_eref, 1e-3, 1e-4)
 
 
+def test_sparse_unet_backward_matches_autograd(golden_pipe):
+    """SparseCostRegNet.backward (train-mode BatchNorm backward + sparse-convolution backward kernels) against torch
+    autograd through the oracle's sparse_unet(training=True): every kernel, BatchNorm weight / bias, out_lin and the
+    input features, for upstream gradients on both outputs (out, mid)."""
+    from surf_amd import conf
+    from surf_amd.reg_network import SparseCostRegNetList
+    d = dev()
+    torch.manual_seed(9)
+    net = SparseCostRegNetList(conf.from_dict({"d_in": [8, 16, 16, 16], "d_out": [8] * 4, "d_base": [8] * 4}))
+    s, D = 1, 16
+    with torch.no_grad():      # non-trivial BatchNorm affine so that dgamma / dbeta are exercised away from (1, 0)
+        for name, p_ in net.named_parameters():
+            if name.endswith("net.1.weight"):
+                p_.uniform_(0.5, 1.5)
+            elif name.endswith("net.1.bias"):
+                p_.uniform_(-0.3, 0.3)
+    sd = {"reg_network." + k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()}
+    coords = golden_pipe[f"s{s}_coords"].to(torch.int32)
+    feats = golden_pipe[f"s{s}_reg_in"].contiguous()
+    g = torch.Generator().manual_seed(4)
+    d_out = torch.randn(feats.shape[0], 8, generator=g)
+    d_mid = torch.randn(feats.shape[0], 8, generator=g)
+    f_ref = feats.clone().requires_grad_(True)
+    out_ref, mid_ref = O.sparse_unet(sd, f_ref, coords.long(), D, s, training=True)
+    ((out_ref * d_out).sum() + (mid_ref * d_mid).sum()).backward()
+
+    net = net.to(d).train()
+    tape = []
+    out, mid = net(feats.to(d), coords.to(d).contiguous(), D, s, tape=tape)
+    rel_close(out, out_ref.detach(), 1e-3, 1e-4)
+    d_feats = net.nets[s].backward(tape, d_out.to(d), d_mid.to(d))
+    scale = float(f_ref.grad.abs().max())
+    rel_close(d_feats, f_ref.grad, 2e-3, 2e-4 * scale)
+    checked = 0
+    for name, p_ in net.nets[s].named_parameters():
+        ref = sd[f"reg_network.nets.{s}.{name}"].grad
+        assert ref is not None and p_.grad is not None, name
+        rel_close(p_.grad, ref, 2e-3, 2e-4 * max(float(ref.abs().max()), 1e-3))
+        checked += 1
+    assert checked == 10 * 3 + 1
+
+
 def test_matching_field_train_jitter_matches_golden(scene, golden_pipe, golden_train):
     """MatchingField.forward(perturb=True) (train mode, surf.py:139) against the reference's perturbed depth maps."""
     from surf_amd import conf, ops
