@@ -378,6 +378,29 @@ int surf_bn_relu_backward(const float* x, const float* dy, int64_t n, int channe
                           const float* mean, const float* invstd, int train, void* workspace, float* dgamma, float* dbeta,
                           float* dx, void* stream);
 
+/* ---- backward of the volume build (train mode; the autograd of surf.py:80-131 under loss.backward(), runner.py:163) ----
+ * surf_matching_depth_backward: same geometry arguments as surf_matching_depth; g_full (nv,H,W) = d loss / d depth maps
+ * (zero for the views rendered under no_grad, matching_field.py:132); g_lr (nv,h,w) scratch; dmvol (D,D,D) ACCUMULATED.
+ * The bands are constants (pre_depths are detached, matching_field.py:104).
+ * surf_densify_backward: g_rows[i * row_stride] += g_dense[coords[i]]; g_prev (D/2)^3 (may be NULL) accumulates the
+ * background's share through the transposed x2 trilinear upsample (sites of the index table pass nothing).
+ * surf_scatter_rows_add: backward of surf_gather_rows (float rows, atomics).
+ * surf_costvol_backward: for the kept voxels `coords` (n,3) of a stage and g (n,8) = [d mean | d var], accumulates the
+ * gradients of the summed feature levels into h_gfeats[l] (texel4 maps like h_feats[l], l >= stage) and of agg_mlp
+ * (w1 | b1 | w2 | b2, 49 floats, device) into g_agg. */
+int surf_matching_depth_backward(const float* mvol, int D, int nv, const float* h_kinv, const float* h_c2w, const float* h_rinv,
+                                 const float* h_near_fars, int H, int W, int h, int w, const float* lin_x, const float* lin_y,
+                                 const float* lin_n, int n, const float* pre_depths, float ratio_cur, float ratio_prev,
+                                 const float* jitter, const float* g_full, float* g_lr, float* dmvol, void* stream);
+int surf_densify_backward(const int32_t* coords, int64_t n, int D, const int32_t* table, const float* g_dense, int row_stride,
+                          float* g_rows, float* g_prev, void* stream);
+int surf_scatter_rows_add(const float* g_dst, const int32_t* idx, int64_t n, int row_words, int idx_shift, int dst_stride_words,
+                          int dst_offset_words, float* g_src, void* stream);
+int surf_costvol_backward(const int32_t* coords, const float* g, int64_t n, int D, const float* const* h_feats,
+                          float* const* h_gfeats, const int* h_hw, int stage, int nv, const float* h_intrs, const float* h_w2c,
+                          const float* h_agg, float* g_agg, void* stream);
+
+
 /*
  * Weight gradient of surf_spconv (no BN): dW (27, C_in, C_out) += sum_i x[neighbour_k(i)] (x) dy[i]  (float atomics; the caller
  * zero-fills).  The INPUT gradient is surf_spconv itself on the swapped lattices: submanifold with mirrored offsets

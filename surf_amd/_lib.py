@@ -85,6 +85,11 @@ SIGNATURES = {
     "surf_spconv": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_bn_workspace_bytes": (c_i64, [c_int]),
     "surf_bn_train_affine": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, ctypes.c_float, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_matching_depth_backward": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr,
+                                              c_int, c_ptr, ctypes.c_float, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_densify_backward": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
+    "surf_scatter_rows_add": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "surf_costvol_backward": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_bn_relu_backward": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_bn_relu_apply": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_spconv_wgrad": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr]),

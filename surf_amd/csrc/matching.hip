@@ -109,7 +109,127 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
   dst[i] = hy * (hx * s[y0 * w + x0] + lx * s[y0 * w + x1]) + ly * (hx * s[y1 * w + x0] + lx * s[y1 * w + x1]);
 }
 
+// ---- backward (train mode): d loss / d matching volume given d loss / d full-resolution depth maps --------------------
+// Transpose of upsample_bilinear_kernel: one thread per full-resolution pixel, four atomics into the low-resolution map.
+__global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float* __restrict__ g_full, int nv, int h, int w, int H,
+                                                                    int W, float* __restrict__ g_lr) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)H * W;
+  if (i >= per * nv) return;
+  const float g = g_full[i];
+  if (g == 0.f) return;
+  const int v = (int)(i / per);
+  const int y = (int)((i % per) / W), x = (int)(i % W);
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  float fy = sy * ((float)y + 0.5f) - 0.5f, fx = sx * ((float)x + 0.5f) - 0.5f;
+  if (fy < 0.f) fy = 0.f;
+  if (fx < 0.f) fx = 0.f;
+  const int y0 = (int)fy, x0 = (int)fx;
+  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.0f - ly, hx = 1.0f - lx;
+  float* d = g_lr + (int64_t)v * h * w;
+  atomicAdd(d + y0 * w + x0, g * hy * hx);
+  atomicAdd(d + y0 * w + x1, g * hy * lx);
+  atomicAdd(d + y1 * w + x0, g * ly * hx);
+  atomicAdd(d + y1 * w + x1, g * ly * lx);
+}
+
+__device__ __forceinline__ void trilinear_scatter(float* __restrict__ vol, int D, float gx, float gy, float gz, float g) {
+  const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+  const float tx = gx - fx, ty = gy - fy, tz = gz - fz;
+  const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+#pragma unroll
+  for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dz = 0; dz < 2; ++dz) {
+        const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
+        const float wgt = (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) * (dz ? tz : 1.0f - tz);
+        if ((xi >= 0) & (xi < D) & (yi >= 0) & (yi < D) & (zi >= 0) & (zi < D) && wgt != 0.f)
+          atomicAdd(vol + ((int64_t)xi * D + yi) * D + zi, g * wgt);
+      }
+}
+
+// depth = cosz sum_k z_k softmax(rho)_k with the z_k constants (the bands come from detached depths, matching_field.py:104):
+//   d rho_k = g cosz w_k (z_k - E),  E = depth / cosz;  each d rho_k is scattered through the trilinear taps of its sample.
+// Pass 1 recomputes the softmax statistics (m, den), pass 2 the weights: nothing was stored per sample in the forward.
+__global__ __launch_bounds__(256) void matching_depth_bwd_kernel(MatchArgs a, const float* __restrict__ g_lr, float* __restrict__ dmvol) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per_view = (int64_t)a.h * a.w;
+  if (i >= per_view * a.nv) return;
+  const float g = g_lr[i];
+  if (g == 0.f) return;
+  const int v = (int)(i / per_view);
+  const int p = (int)(i % per_view);
+  const float px = a.lin_x[p % a.w], py = a.lin_y[p / a.w];
+  const float* Ki = a.Kinv[v];
+  float cx = Ki[0] * px + Ki[1] * py + Ki[2];
+  float cy = Ki[3] * px + Ki[4] * py + Ki[5];
+  float cz_ = Ki[6] * px + Ki[7] * py + Ki[8];
+  const float nrm = sqrtf(cx * cx + cy * cy + cz_ * cz_);
+  cx /= nrm; cy /= nrm; cz_ /= nrm;
+  const float* R = a.R[v];
+  const float dx = R[0] * cx + R[1] * cy + R[2] * cz_;
+  const float dy = R[3] * cx + R[4] * cy + R[5] * cz_;
+  const float dz = R[6] * cx + R[7] * cy + R[8] * cz_;
+  const float* Ri = a.Rinv[v];
+  const float cosz = Ri[6] * dx + Ri[7] * dy + Ri[8] * dz;
+  const float ox = a.t[v][0], oy = a.t[v][1], oz = a.t[v][2];
+  const float n0 = a.nearv[v], f0 = a.farv[v];
+  float lo[2], hi[2];
+  int nb = 1;
+  lo[0] = n0; hi[0] = f0; lo[1] = n0; hi[1] = f0;
+  if (a.pre) {
+    const float pre = a.pre[((int64_t)v * a.H + (int)py) * a.W + (int)px];
+    const float zc = pre / cosz;
+    band(zc, ((f0 - n0) * a.ratio_cur) / 2.0f, n0, f0, lo[0], hi[0]);
+    band(zc, ((f0 - n0) * a.ratio_prev) / 2.0f, n0, f0, lo[1], hi[1]);
+    nb = 2;
+  }
+  float m = -INFINITY, den = 0.f, num = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    const float E = pass ? num / den : 0.f;
+    for (int b = 0; b < nb; ++b) {
+      const float rng = hi[b] - lo[b];
+      const float shift = a.jitter ? a.jitter[i * 2 + b] * rng / (float)a.n : 0.f;
+      for (int k = 0; k < a.n; ++k) {
+        float z = lo[b] + rng * a.lin_n[k];
+        if (a.jitter) z = z + shift;
+        const float qx = unnorm_acf(ox + dx * z, a.D), qy = unnorm_acf(oy + dy * z, a.D), qz = unnorm_acf(oz + dz * z, a.D);
+        const float rho = trilinear_zeros(a.mvol, a.D, qx, qy, qz);
+        if (pass == 0) {
+          const float mn = fmaxf(m, rho);
+          const float sc = expf(m - mn), e = expf(rho - mn);
+          den = den * sc + e;
+          num = num * sc + e * z;
+          m = mn;
+        } else {
+          const float wk = expf(rho - m) / den;
+          trilinear_scatter(dmvol, a.D, qx, qy, qz, g * cosz * wk * (z - E));
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
+
+static void fill_match_args(MatchArgs& a, int nv, const float* h_kinv, const float* h_c2w, const float* h_rinv, const float* h_near_fars) {
+  for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
+    const int s = v < nv ? v : 0;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) {
+        a.Kinv[v][r * 3 + c] = h_kinv[s * 9 + r * 3 + c];
+        a.R[v][r * 3 + c] = h_c2w[s * 16 + r * 4 + c];
+        a.Rinv[v][r * 3 + c] = h_rinv[s * 9 + r * 3 + c];
+      }
+    for (int r = 0; r < 3; ++r) a.t[v][r] = h_c2w[s * 16 + r * 4 + 3];
+    a.nearv[v] = h_near_fars[s * 2 + 0];
+    a.farv[v] = h_near_fars[s * 2 + 1];
+  }
+}
 
 extern "C" int surf_matching_depth(const float* mvol, int D, int nv, const float* h_kinv, const float* h_c2w,
                                    const float* h_rinv, const float* h_near_fars, int H, int W, int h, int w,
@@ -123,22 +243,34 @@ extern "C" int surf_matching_depth(const float* mvol, int D, int nv, const float
   MatchArgs a;
   a.mvol = mvol; a.D = D; a.nv = nv; a.H = H; a.W = W; a.h = h; a.w = w; a.lin_x = lin_x; a.lin_y = lin_y; a.lin_n = lin_n;
   a.n = n; a.pre = pre_depths; a.ratio_cur = ratio_cur; a.ratio_prev = ratio_prev; a.jitter = jitter; a.out = depth_lr;
-  for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
-    const int s = v < nv ? v : 0;
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) {
-        a.Kinv[v][r * 3 + c] = h_kinv[s * 9 + r * 3 + c];
-        a.R[v][r * 3 + c] = h_c2w[s * 16 + r * 4 + c];
-        a.Rinv[v][r * 3 + c] = h_rinv[s * 9 + r * 3 + c];
-      }
-    for (int r = 0; r < 3; ++r) a.t[v][r] = h_c2w[s * 16 + r * 4 + 3];
-    a.nearv[v] = h_near_fars[s * 2 + 0];
-    a.farv[v] = h_near_fars[s * 2 + 1];
-  }
+  fill_match_args(a, nv, h_kinv, h_c2w, h_rinv, h_near_fars);
   hipStream_t st = (hipStream_t)stream;
   const int64_t n_lr = (int64_t)nv * h * w, n_full = (int64_t)nv * H * W;
   hipLaunchKernelGGL(matching_depth_kernel, dim3((unsigned)((n_lr + 255) / 256)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(upsample_bilinear_kernel, dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, st, depth_lr, nv, h, w,
                      H, W, depth_full);
+  return surf_check_launch();
+}
+
+extern "C" int surf_matching_depth_backward(const float* mvol, int D, int nv, const float* h_kinv, const float* h_c2w,
+                                            const float* h_rinv, const float* h_near_fars, int H, int W, int h, int w,
+                                            const float* lin_x, const float* lin_y, const float* lin_n, int n,
+                                            const float* pre_depths, float ratio_cur, float ratio_prev, const float* jitter,
+                                            const float* g_full, float* g_lr, float* dmvol, void* stream) {
+  if (!mvol || !h_kinv || !h_c2w || !h_rinv || !h_near_fars || !lin_x || !lin_y || !lin_n || !g_full || !g_lr || !dmvol)
+    return SURF_E_ARG;
+  if (D < 2 || H < 1 || W < 1 || h < 1 || w < 1 || n < 1) return SURF_E_ARG;
+  if (nv < 1 || nv > SURF_MAX_VIEWS) return SURF_E_LIMIT;
+  MatchArgs a;
+  a.mvol = mvol; a.D = D; a.nv = nv; a.H = H; a.W = W; a.h = h; a.w = w; a.lin_x = lin_x; a.lin_y = lin_y; a.lin_n = lin_n;
+  a.n = n; a.pre = pre_depths; a.ratio_cur = ratio_cur; a.ratio_prev = ratio_prev; a.jitter = jitter; a.out = nullptr;
+  fill_match_args(a, nv, h_kinv, h_c2w, h_rinv, h_near_fars);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n_lr = (int64_t)nv * h * w, n_full = (int64_t)nv * H * W;
+  const hipError_t e = hipMemsetAsync(g_lr, 0, n_lr * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, st, g_full, nv, h, w, H,
+                     W, g_lr);
+  hipLaunchKernelGGL(matching_depth_bwd_kernel, dim3((unsigned)((n_lr + 255) / 256)), dim3(256), 0, st, a, g_lr, dmvol);
   return surf_check_launch();
 }

@@ -333,6 +333,199 @@ __global__ __launch_bounds__(256) void dense_scatter_kernel(const int32_t* __res
   table[o] = (int32_t)i;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward kernels of the volume build (train mode; surf.py:80-131 under loss.backward(), runner.py:163).
+// ---------------------------------------------------------------------------------------------------------
+// K6 backward: the scattered sites take their gradient from the dense one, the background passes the rest to the previous
+// stage's matching volume through the transposed x2 trilinear upsample (sites overwritten by the scatter pass nothing).
+__global__ __launch_bounds__(256) void dense_rows_bwd_kernel(const int32_t* __restrict__ coords, const float* __restrict__ g_dense,
+                                                             int64_t n, int D, int row_stride, float* __restrict__ g_rows) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t o = ((int64_t)coords[i * 3 + 0] * D + coords[i * 3 + 1]) * D + coords[i * 3 + 2];
+  g_rows[i * row_stride] += g_dense[o];
+}
+
+__global__ __launch_bounds__(256) void dense_init_bwd_kernel(const float* __restrict__ g_dense, const int32_t* __restrict__ table,
+                                                             int D, float* __restrict__ g_prev) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)D * D * D;
+  if (i >= total) return;
+  if (table[i] >= 0) return;
+  const float g = g_dense[i];
+  if (g == 0.f) return;
+  const int Dp = D / 2;
+  const int z = (int)(i % D), y = (int)((i / D) % D), x = (int)(i / ((int64_t)D * D));
+  int x0, x1, y0, y1, z0, z1;
+  float lx, ly, lz;
+  up2_src(x, Dp, x0, x1, lx);
+  up2_src(y, Dp, y0, y1, ly);
+  up2_src(z, Dp, z0, z1, lz);
+  const float hx = 1.0f - lx, hy = 1.0f - ly, hz = 1.0f - lz;
+  auto A = [&](int xi, int yi, int zi, float wgt) {
+    if (wgt != 0.f) atomicAdd(g_prev + ((int64_t)xi * Dp + yi) * Dp + zi, g * wgt);
+  };
+  A(x0, y0, z0, hx * hy * hz); A(x0, y0, z1, hx * hy * lz); A(x0, y1, z0, hx * ly * hz); A(x0, y1, z1, hx * ly * lz);
+  A(x1, y0, z0, lx * hy * hz); A(x1, y0, z1, lx * hy * lz); A(x1, y1, z0, lx * ly * hz); A(x1, y1, z1, lx * ly * lz);
+}
+
+// backward of gather_rows: g_src[idx[i] >> shift, 0:w] += g_dst[i, off : off + w]
+__global__ __launch_bounds__(256) void scatter_rows_add_kernel(const float* __restrict__ g_dst, const int32_t* __restrict__ idx,
+                                                               int64_t n, int w, int shift, int dst_stride, int dst_off,
+                                                               float* __restrict__ g_src) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * w) return;
+  const int64_t i = t / w;
+  const int c = (int)(t % w);
+  atomicAdd(g_src + (int64_t)(idx[i] >> shift) * w + c, g_dst[i * dst_stride + dst_off + c]);
+}
+
+__device__ __forceinline__ void bilinear_texel4_scatter(float* __restrict__ map, int H, int W, float x, float y, const float g[4]) {
+  const float fx = floorf(x), fy = floorf(y);
+  const float tx = x - fx, ty = y - fy;
+  const int x0 = (int)fx, y0 = (int)fy;
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int xi = x0 + dx, yi = y0 + dy;
+      const float wgt = (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty);
+      if ((xi >= 0) & (xi < W) & (yi >= 0) & (yi < H) && wgt != 0.f) {
+        float* d = map + ((int64_t)yi * W + xi) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) atomicAdd(d + c, g[c] * wgt);
+      }
+    }
+}
+
+// K2 backward for the kept voxels (coords of the stage's rows): recomputes the warp and the view softmax, then
+//   d wf_v = g_mean + 2 g_var (wf_v - mean);  d f_v = d wf_v w_v + W1^T d h_v;  d w_v = d wf_v . f_v;
+//   d logit_v = w_v (d w_v - sum_u w_u d w_u)  (views outside the frustum have a constant logit);
+//   agg_mlp gradients are reduced over the wavefront and added atomically (49 floats: w1 | b1 | w2 | b2);
+//   d f_v goes to the bilinear taps of every summed level's gradient map (texel4, atomics).
+struct CostVolBwdArgs {
+  const int32_t* coords;
+  const float* g;         // (n, 8) = [d mean | d var]
+  int64_t n;
+  float voxel_size;
+  const float* feats[4];
+  float* gfeats[4];
+  int hw[8];
+  int stage;
+  ViewSet vs;
+  float w1[32], b1[8], w2[8], b2;
+  float* gagg;            // 49 floats
+};
+
+__global__ __launch_bounds__(256) void costvol_bwd_kernel(CostVolBwdArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < a.n;
+  float gacc[49];
+#pragma unroll
+  for (int k = 0; k < 49; ++k) gacc[k] = 0.f;
+  if (live) {
+    const float wx = (float)a.coords[i * 3 + 0] * a.voxel_size + (-1.0f), wy = (float)a.coords[i * 3 + 1] * a.voxel_size + (-1.0f),
+                wz = (float)a.coords[i * 3 + 2] * a.voxel_size + (-1.0f);
+    const int Hf = a.hw[6], Wf = a.hw[7];
+    const float half_w = (float)(Wf - 1) / 2.0f, half_h = (float)(Hf - 1) / 2.0f;
+    float f[SURF_MAX_VIEWS][4], logit[SURF_MAX_VIEWS], nxv[SURF_MAX_VIEWS], nyv[SURF_MAX_VIEWS];
+    bool inside[SURF_MAX_VIEWS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
+      f[v][0] = f[v][1] = f[v][2] = f[v][3] = 0.f;
+      logit[v] = -INFINITY;
+      inside[v] = false;
+      nxv[v] = nyv[v] = 0.f;
+      if (v < a.vs.nv) {
+        float qz;
+        inside[v] = project_voxel(a.vs, v, wx, wy, wz, half_w, half_h, nxv[v], nyv[v], qz);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int l = a.stage; l < 4; ++l) {
+          const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
+          acc += bilinear_texel4(a.feats[l] + (int64_t)v * H * W * 4, H, W, unnorm_act(nxv[v], W), unnorm_act(nyv[v], H));
+        }
+        f[v][0] = acc[0]; f[v][1] = acc[1]; f[v][2] = acc[2]; f[v][3] = acc[3];
+        float s = a.b2;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          float h = a.b1[o];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) h += a.w1[o * 4 + c] * f[v][c];
+          h = h > 0.f ? h : expm1f(h);
+          s += a.w2[o] * h;
+        }
+        logit[v] = inside[v] ? s : -1e9f;
+        mx = fmaxf(mx, logit[v]);
+      }
+    }
+    float den = 0.f, wv[SURF_MAX_VIEWS];
+#pragma unroll
+    for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
+      wv[v] = (v < a.vs.nv) ? expf(logit[v] - mx) : 0.f;
+      den += wv[v];
+    }
+    float mean[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
+      wv[v] /= den;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) mean[c] += f[v][c] * wv[v];
+    }
+    float gm[4], gv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { gm[c] = a.g[i * 8 + c]; gv[c] = a.g[i * 8 + 4 + c]; }
+    float dw[SURF_MAX_VIEWS], dwf[SURF_MAX_VIEWS][4], dot = 0.f;
+#pragma unroll
+    for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
+      dw[v] = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        dwf[v][c] = gm[c] + 2.0f * gv[c] * (f[v][c] * wv[v] - mean[c]);
+        dw[v] += dwf[v][c] * f[v][c];
+      }
+      dot += wv[v] * dw[v];
+    }
+#pragma unroll
+    for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
+      if (v < a.vs.nv) {
+        float df[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) df[c] = dwf[v][c] * wv[v];
+        const float ds = inside[v] ? wv[v] * (dw[v] - dot) : 0.f;
+        if (ds != 0.f) {
+          gacc[48] += ds;
+#pragma unroll
+          for (int o = 0; o < 8; ++o) {
+            float h = a.b1[o];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) h += a.w1[o * 4 + c] * f[v][c];
+            const float act = h > 0.f ? h : expm1f(h);
+            const float dh = ds * a.w2[o] * (h > 0.f ? 1.0f : expf(h));
+            gacc[40 + o] += ds * act;
+            gacc[32 + o] += dh;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              gacc[o * 4 + c] += dh * f[v][c];
+              df[c] += dh * a.w1[o * 4 + c];
+            }
+          }
+        }
+        for (int l = a.stage; l < 4; ++l) {
+          const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
+          bilinear_texel4_scatter(a.gfeats[l] + (int64_t)v * H * W * 4, H, W, unnorm_act(nxv[v], W), unnorm_act(nyv[v], H), df);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 49; ++k) {
+    const float t = wave_sum(gacc[k]);
+    if ((threadIdx.x & 63) == 0 && t != 0.f) atomicAdd(a.gagg + k, t);
+  }
+}
+
 void fill_views(ViewSet& vs, int nv, const float* h_intrs, const float* h_w2c) {
   vs.nv = nv;
   for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
@@ -421,5 +614,46 @@ extern "C" int surf_densify(const int32_t* coords, const float* rows, int row_st
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(dense_init_kernel, grid1d((int64_t)D * D * D, 256), dim3(256), 0, st, prev, D, dense, table);
   hipLaunchKernelGGL(dense_scatter_kernel, grid1d(n, 256), dim3(256), 0, st, coords, rows, row_stride, n, D, dense, table);
+  return surf_check_launch();
+}
+
+extern "C" int surf_densify_backward(const int32_t* coords, int64_t n, int D, const int32_t* table, const float* g_dense,
+                                     int row_stride, float* g_rows, float* g_prev, void* stream) {
+  if (!coords || !table || !g_dense || !g_rows || n <= 0 || D < 2 || row_stride < 1) return SURF_E_ARG;
+  if (g_prev && (D & 1)) return SURF_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(dense_rows_bwd_kernel, grid1d(n, 256), dim3(256), 0, st, coords, g_dense, n, D, row_stride, g_rows);
+  if (g_prev)
+    hipLaunchKernelGGL(dense_init_bwd_kernel, grid1d((int64_t)D * D * D, 256), dim3(256), 0, st, g_dense, table, D, g_prev);
+  return surf_check_launch();
+}
+
+extern "C" int surf_scatter_rows_add(const float* g_dst, const int32_t* idx, int64_t n, int row_words, int idx_shift,
+                                     int dst_stride_words, int dst_offset_words, float* g_src, void* stream) {
+  if (!g_dst || !idx || !g_src || n <= 0 || row_words <= 0 || idx_shift < 0 || dst_stride_words < row_words) return SURF_E_ARG;
+  hipLaunchKernelGGL(scatter_rows_add_kernel, grid1d(n * row_words, 256), dim3(256), 0, (hipStream_t)stream, g_dst, idx, n,
+                     row_words, idx_shift, dst_stride_words, dst_offset_words, g_src);
+  return surf_check_launch();
+}
+
+extern "C" int surf_costvol_backward(const int32_t* coords, const float* g, int64_t n, int D, const float* const* h_feats,
+                                     float* const* h_gfeats, const int* h_hw, int stage, int nv, const float* h_intrs,
+                                     const float* h_w2c, const float* h_agg, float* g_agg, void* stream) {
+  if (!coords || !g || !h_feats || !h_gfeats || !h_hw || !h_intrs || !h_w2c || !h_agg || !g_agg || n <= 0 || D < 2) return SURF_E_ARG;
+  if (nv < 1 || nv > SURF_MAX_VIEWS || stage < 0 || stage > 3) return SURF_E_LIMIT;
+  CostVolBwdArgs a;
+  a.coords = coords; a.g = g; a.n = n; a.voxel_size = (float)(2.0 / (double)(D - 1)); a.stage = stage; a.gagg = g_agg;
+  for (int l = 0; l < 4; ++l) {
+    if (!h_feats[l] || (l >= stage && !h_gfeats[l])) return SURF_E_ARG;
+    a.feats[l] = h_feats[l];
+    a.gfeats[l] = h_gfeats[l];
+    a.hw[2 * l] = h_hw[2 * l];
+    a.hw[2 * l + 1] = h_hw[2 * l + 1];
+  }
+  fill_views(a.vs, nv, h_intrs, h_w2c);
+  for (int k = 0; k < 32; ++k) a.w1[k] = h_agg[k];
+  for (int k = 0; k < 8; ++k) { a.b1[k] = h_agg[32 + k]; a.w2[k] = h_agg[40 + k]; }
+  a.b2 = h_agg[48];
+  hipLaunchKernelGGL(costvol_bwd_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, a);
   return surf_check_launch();
 }

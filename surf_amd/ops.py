@@ -772,6 +772,68 @@ def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, r
     return (full, lr) if return_lr else full
 
 
+def matching_depth_backward(mvol, cams, near_fars, H, W, res_level, n, g_full, pre_depths=None, ratio_cur=1.0, ratio_prev=1.0,
+                            jitter=None, dmvol=None):
+    """Backward of matching_depth w.r.t. the matching volume: g_full (nv,H,W) = d loss / d depth maps (zero for the views the
+    reference renders under no_grad).  Returns dmvol (D,D,D), accumulated into `dmvol` if given."""
+    _chk(mvol, torch.float32, "matching volume")
+    _chk(g_full, torch.float32, "g_full")
+    dev = mvol.device
+    h, w = H // res_level, W // res_level
+    assert tuple(g_full.shape) == (cams.nv, H, W)
+    lin_x = torch.linspace(0, W - 1, w).to(dev)
+    lin_y = torch.linspace(0, H - 1, h).to(dev)
+    lin_n = torch.linspace(0.0, 1.0, n).to(dev)
+    nf = np.ascontiguousarray(near_fars.detach().to("cpu", torch.float32).numpy())
+    g_lr = torch.empty(cams.nv, h, w, dtype=torch.float32, device=dev)
+    if dmvol is None:
+        dmvol = torch.zeros_like(mvol)
+    rc = _lib.lib().surf_matching_depth_backward(_p(mvol), int(mvol.shape[0]), cams.nv, _np_ptr(cams.kinv), _np_ptr(cams.c2w),
+                                                 _np_ptr(cams.rinv), _np_ptr(nf), H, W, h, w, _p(lin_x), _p(lin_y), _p(lin_n),
+                                                 int(n), _p(pre_depths), ctypes.c_float(float(ratio_cur)),
+                                                 ctypes.c_float(float(ratio_prev)), _p(jitter), _p(g_full), _p(g_lr), _p(dmvol),
+                                                 _stream())
+    _lib.check(rc, "surf_matching_depth_backward")
+    return dmvol
+
+
+def densify_backward(coords, table, g_dense, g_rows, g_prev=None):
+    """Backward of densify: g_rows[:, 0] += g_dense[coords]; g_prev (D/2)^3 (if given) accumulates the background's share."""
+    _chk(coords, torch.int32, "coords")
+    _chk(g_dense, torch.float32, "g_dense")
+    _chk(g_rows, torch.float32, "g_rows")
+    D = int(g_dense.shape[0])
+    rc = _lib.lib().surf_densify_backward(_p(coords), coords.shape[0], D, _p(table), _p(g_dense), g_rows.shape[1], _p(g_rows),
+                                          _p(g_prev), _stream())
+    _lib.check(rc, "surf_densify_backward")
+    return g_rows, g_prev
+
+
+def scatter_rows_add(g_dst, idx, g_src, shift=0, dst_off=0):
+    """Backward of gather_rows: g_src[idx[i] >> shift] += g_dst[i, off : off + w], w = g_src.shape[1]."""
+    _chk(g_dst, torch.float32, "g_dst")
+    _chk(g_src, torch.float32, "g_src")
+    _chk(idx, torch.int32, "idx")
+    rc = _lib.lib().surf_scatter_rows_add(_p(g_dst), _p(idx), idx.shape[0], g_src.shape[1], int(shift), g_dst.shape[1],
+                                          int(dst_off), _p(g_src), _stream())
+    _lib.check(rc, "surf_scatter_rows_add")
+    return g_src
+
+
+def costvol_backward(feats_t4_c2f, gfeats_t4_c2f, stage, D, cams, agg, coords, g, g_agg):
+    """Backward of costvol for the kept voxels: accumulates into gfeats_t4_c2f[l] (l >= stage) and g_agg (49,)."""
+    _chk(coords, torch.int32, "coords")
+    _chk(g, torch.float32, "g")
+    _chk(g_agg, torch.float32, "g_agg")
+    assert g.shape[1] == 8 and g_agg.numel() == 49
+    hw = (ctypes.c_int * 8)(*[int(v) for f in feats_t4_c2f for v in f.shape[1:3]])
+    agg = np.ascontiguousarray(agg, dtype=np.float32)
+    rc = _lib.lib().surf_costvol_backward(_p(coords), _p(g), coords.shape[0], int(D), _ptr_array(feats_t4_c2f),
+                                          _ptr_array(gfeats_t4_c2f), hw, int(stage), cams.nv, _np_ptr(cams.intrs),
+                                          _np_ptr(cams.w2c), _np_ptr(agg), _p(g_agg), _stream())
+    _lib.check(rc, "surf_costvol_backward")
+
+
 def raster_first_hit(vertices, faces, intr, c2w, hw, upscale=1):
     """Face id of the first triangle hit by the ray through every sample of the (h*upscale, w*upscale) lattice
     torch.linspace(0, w-1, w*upscale) x torch.linspace(0, h-1, h*upscale) of one view; -1 where nothing is hit."""

@@ -1,0 +1,138 @@
+"""GPU parity of the volume-build backward kernels (row f2): each HIP backward against torch autograd through the CPU
+oracle's restatement of the same reference function, on the golden scene.  Gradients are sums of many float atomics:
+tolerances are relative to the largest reference entry of each tensor."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import surf_oracle as O
+from tests.golden_cfg import CFG
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def grad_close(a, b, rtol=2e-3, floor=1e-6):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(float(b.abs().max()), floor)
+    err = (a - b).abs()
+    bad = err > rtol * b.abs() + 2e-4 * scale
+    assert not bool(bad.any()), f"{int(bad.sum())}/{bad.numel()} off, max err {err.max().item():.3e} (scale {scale:.3e})"
+
+
+def _cams(scene):
+    from surf_amd import ops
+    return ops._cams_ext(ops.Cameras(scene["intrs"], scene["c2ws"]), scene["intrs"], scene["c2ws"])
+
+
+@pytest.mark.parametrize("stage,perturb", [(0, False), (1, True), (2, False)])
+def test_matching_depth_backward(scene, golden_pipe, golden_train, stage, perturb):
+    """d depth maps / d matching volume (matching_field.py:18-71 under autograd): views 0 and src_idx only, bands from the
+    detached previous depths, with and without the train-mode jitter."""
+    from surf_amd import conf, ops
+    from surf_amd.matching_field import MatchingField
+    d = dev()
+    gp = golden_pipe
+    H, W = scene["imgs"].shape[-2:]
+    nv = scene["intrs"].shape[0]
+    src_idx = int(golden_train["mf_perturb_src_idx"])
+    mvol = gp[f"s{stage}_mvol"].clone().requires_grad_(True)
+    pre = None if stage == 0 else gp[f"s{stage - 1}_depths"]
+    g = torch.Generator().manual_seed(3 + stage)
+    G = torch.randn(nv, H, W, generator=g)
+    for v in range(nv):
+        if v != 0 and v != src_idx:
+            G[v] = 0
+    torch.manual_seed(31)
+    ref = O.matching_field((H, W), scene["intrs"], scene["c2ws"], scene["near_fars"], mvol, stage, CFG["range_ratios"],
+                           CFG["n_samples_depths"], CFG["depth_res_levels"], None if pre is None else list(pre),
+                           perturb=perturb, src_idx=src_idx)
+    (torch.stack(ref) * G).sum().backward()
+
+    mf = MatchingField(conf.from_dict({"n_samples_depths": CFG["n_samples_depths"], "n_importance_depths": [0] * 4,
+                                       "up_sample_steps": [0] * 4, "depth_res_levels": CFG["depth_res_levels"]}))
+    lvl = CFG["depth_res_levels"][stage]
+    jitter = None
+    if perturb:
+        torch.manual_seed(31)
+        jitter = mf.draw_jitter(nv, (H // lvl) * (W // lvl), 1 if pre is None else 2, src_idx).to(d).contiguous()
+    dm = ops.matching_depth_backward(gp[f"s{stage}_mvol"].to(d).contiguous(), _cams(scene), scene["near_fars"], H, W, lvl,
+                                     CFG["n_samples_depths"][stage], G.to(d).contiguous(),
+                                     None if pre is None else pre.to(d).contiguous(), CFG["range_ratios"][stage],
+                                     CFG["range_ratios"][stage - 1] if stage > 0 else 1.0, jitter=jitter)
+    assert float(mvol.grad.abs().max()) > 0
+    grad_close(dm, mvol.grad)
+
+
+@pytest.mark.parametrize("D", [8, 12, 32])
+def test_densify_backward(D):
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(D)
+    occ = torch.rand(D, D, D, generator=g) < 0.3
+    coords = occ.nonzero().to(torch.int32)
+    n = coords.shape[0]
+    logit = torch.randn(n, generator=g).requires_grad_(True)
+    prev = torch.randn(D // 2, D // 2, D // 2, generator=g).requires_grad_(True)
+    Gd = torch.randn(D, D, D, generator=g)
+    dense, _ = O.sparse2dense(logit, coords, D, prev)
+    (dense * Gd).sum().backward()
+    rows = torch.randn(n, 8, generator=g)
+    _, table = ops.densify(coords.to(d).contiguous(), rows.to(d).contiguous(), D, prev.detach().to(d).contiguous())
+    g_rows = torch.zeros(n, 8, device=d)
+    g_prev = torch.zeros(D // 2, D // 2, D // 2, device=d)
+    ops.densify_backward(coords.to(d).contiguous(), table, Gd.to(d).contiguous(), g_rows, g_prev)
+    grad_close(g_rows[:, 0], logit.grad)
+    assert float(g_rows[:, 1:].abs().max()) == 0.0
+    grad_close(g_prev, prev.grad)
+    # stage 0: no background
+    g_rows2 = torch.zeros(n, 8, device=d)
+    ops.densify_backward(coords.to(d).contiguous(), table, Gd.to(d).contiguous(), g_rows2, None)
+    assert torch.equal(g_rows2, g_rows)
+
+
+def test_scatter_rows_add():
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(1)
+    n_src, n = 300, 1500
+    idx = torch.randint(0, n_src * 8, (n,), generator=g).to(torch.int32)
+    g_dst = torch.randn(n, 16, generator=g)
+    ref = torch.zeros(n_src, 8).index_add_(0, (idx >> 3).long(), g_dst[:, 8:])
+    out = ops.scatter_rows_add(g_dst.to(d).contiguous(), idx.to(d), torch.zeros(n_src, 8, device=d), shift=3, dst_off=8)
+    grad_close(out, ref, 1e-5)
+
+
+@pytest.mark.parametrize("stage", [0, 2, 3])
+def test_costvol_backward(scene, weights, golden_fpn, golden_pipe, stage):
+    """d [mean | var] rows -> the summed FPN levels' maps and agg_mlp (volume.py:54-97 under autograd)."""
+    from surf_amd import ops
+    d = dev()
+    gp = golden_pipe
+    D = CFG["base_volume_dim"] * 2 ** stage
+    coords = gp[f"s{stage}_coords"].to(torch.int32)
+    sd = {k: v.clone().requires_grad_(True) for k, v in weights.items() if k.startswith("volume.agg_mlp")}
+    feats = [golden_fpn[f"out{i}"].clone().requires_grad_(True) for i in range(4)]
+    cv, _ = O.back_proj_multiscale(sd, feats, coords.float(), D, scene["intrs"], scene["c2ws"], stage)
+    g = torch.Generator().manual_seed(stage)
+    G = torch.randn(cv.shape, generator=g)
+    (cv * G).sum().backward()
+
+    feats_t4 = [ops.pack_texel4(golden_fpn[f"out{i}"].to(d).contiguous()) for i in range(4)]
+    gfeats = [torch.zeros_like(f) for f in feats_t4]
+    g_agg = torch.zeros(49, device=d)
+    ops.costvol_backward(feats_t4, gfeats, stage, D, _cams(scene), ops.agg_mlp_host(weights), coords.to(d).contiguous(),
+                         G.to(d).contiguous(), g_agg)
+    for l in range(4):
+        if l < stage:
+            assert feats[l].grad is None and float(gfeats[l].abs().max()) == 0.0
+        else:
+            grad_close(gfeats[l].permute(0, 3, 1, 2), feats[l].grad)
+    ref_agg = torch.cat([sd["volume.agg_mlp.0.weight"].grad.reshape(-1), sd["volume.agg_mlp.0.bias"].grad.reshape(-1),
+                         sd["volume.agg_mlp.2.weight"].grad.reshape(-1), sd["volume.agg_mlp.2.bias"].grad.reshape(-1)])
+    grad_close(g_agg, ref_agg)
