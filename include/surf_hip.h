@@ -400,6 +400,17 @@ int surf_costvol_backward(const int32_t* coords, const float* g, int64_t n, int 
                           float* const* h_gfeats, const int* h_hw, int stage, int nv, const float* h_intrs, const float* h_w2c,
                           const float* h_agg, float* g_agg, void* stream);
 
+/* Weight gradient of the FPN's 3x3 convolutions (train mode; the autograd of feature_network.py:6-25,57-75):
+ * out[ky][kx][cb][cs] = sum_(n,ys,xs) big[n][ys S + ky - 1][xs S + kx - 1][cb] small[n][ys][xs][cs], zero padding, NHWC maps,
+ * big (N, Hs S, Ws S, cb), small (N, Hs, Ws, cs).  Conv2d: big = layer input, small = d output -> [ky][kx][ci][co];
+ * ConvTranspose2d (S = 2): big = d output, small = layer input -> [ky][kx][co][ci].  Input gradients run on the forward
+ * kernels: stride 1 -> surf_conv3x3 with the flipped, transposed kernel; stride 2 -> surf_deconv3x3_s2; deconv -> stride-2
+ * surf_conv3x3.  InstanceNorm + ReLU backward = surf_bn_relu_backward per view (scale = rstd, shift = -mean rstd). */
+int64_t surf_conv3x3_wgrad_workspace_floats(int N, int Hs, int Ws, int cb, int cs);
+int surf_conv3x3_wgrad(const float* big, const float* small, int N, int Hs, int Ws, int cb, int cs, int stride,
+                       float* workspace, float* out, void* stream);
+
+
 
 /*
  * Weight gradient of surf_spconv (no BN): dW (27, C_in, C_out) += sum_i x[neighbour_k(i)] (x) dy[i]  (float atomics; the caller

@@ -166,6 +166,94 @@ __global__ __launch_bounds__(256) void inorm_relu_kernel(float* __restrict__ x, 
   reinterpret_cast<f32x4*>(x)[t] = v;
 }
 
+
+// ---- weight gradient of the 3x3 convolutions (train mode) --------------------------------------------------------
+// out[tap][cb][cs] = sum over (n, ys, xs) of big[n][ys S + ky - 1][xs S + kx - 1][cb] * small[n][ys][xs][cs] (zero padding).
+//   Conv2d (stride S):      big = the layer input, small = d output  -> d W[ky][kx][ci][co]
+//   ConvTranspose2d (S = 2): big = d output,       small = the layer input -> d W[ky][kx][co][ci] (the caller transposes)
+// One workgroup = one tap x one chunk of small-map pixels: 64 pixels at a time are staged in LDS (the shifted big rows and
+// the small rows), every thread owns CB CS / 256 outputs (or, for fewer than 256 outputs, one output on a 1/G share of the
+// pixels); per-chunk partials, summed by wgrad_finalize_kernel (deterministic, no atomics).
+constexpr int WG_PIX = 64, WG_CHUNK = 2048;
+
+template <int STRIDE>
+__global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ big, const float* __restrict__ small, int N, int Hb,
+                                                    int Wb, int Hs, int Ws, int CB, int CS, float* __restrict__ part) {
+  __shared__ float sb[WG_PIX * 64];
+  __shared__ float ss[WG_PIX * 64];
+  __shared__ float red[256];
+  const int tap = blockIdx.y, ky = tap / 3, kx = tap % 3;
+  const int64_t total = (int64_t)N * Hs * Ws;
+  const int64_t p_begin = (int64_t)blockIdx.x * WG_CHUNK;
+  const int64_t p_end = p_begin + WG_CHUNK < total ? p_begin + WG_CHUNK : total;
+  const int O = CB * CS;
+  const int G = O >= 256 ? 1 : 256 / O;          // pixel groups sharing one output
+  const int per = O >= 256 ? O / 256 : 1;        // outputs per thread
+  const int g = O >= 256 ? 0 : threadIdx.x / O;
+  const int o0 = O >= 256 ? threadIdx.x : threadIdx.x % O;
+  const bool active = O >= 256 || threadIdx.x < G * O;
+  float acc[16];
+  int ob[16], os[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    acc[k] = 0.f;
+    const int o = (o0 + k * 256) % O;
+    ob[k] = o / CS;
+    os[k] = o % CS;
+  }
+  for (int64_t p0 = p_begin; p0 < p_end; p0 += WG_PIX) {
+    const int np = (int)(p_end - p0 < WG_PIX ? p_end - p0 : WG_PIX);
+    __syncthreads();
+    for (int e = threadIdx.x; e < WG_PIX * CB; e += 256) {
+      const int pl = e / CB, c = e % CB;
+      float v = 0.f;
+      if (pl < np) {
+        const int64_t p = p0 + pl;
+        const int xs = (int)(p % Ws), ys = (int)((p / Ws) % Hs), n = (int)(p / ((int64_t)Ws * Hs));
+        const int yb = ys * STRIDE + ky - 1, xb = xs * STRIDE + kx - 1;
+        if (yb >= 0 && yb < Hb && xb >= 0 && xb < Wb) v = big[(((int64_t)n * Hb + yb) * Wb + xb) * CB + c];
+      }
+      sb[pl * CB + c] = v;
+    }
+    for (int e = threadIdx.x; e < WG_PIX * CS; e += 256) {
+      const int pl = e / CS, c = e % CS;
+      ss[pl * CS + c] = pl < np ? small[(p0 + pl) * CS + c] : 0.f;
+    }
+    __syncthreads();
+    if (active) {
+      for (int pl = g; pl < WG_PIX; pl += G) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          if (k < per) acc[k] = fmaf(sb[pl * CB + ob[k]], ss[pl * CS + os[k]], acc[k]);
+        }
+      }
+    }
+  }
+  float* dst = part + ((int64_t)blockIdx.x * 9 + tap) * O;
+  if (O >= 256) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (k < per) dst[o0 + k * 256] = acc[k];
+  } else {
+    __syncthreads();
+    red[threadIdx.x] = active ? acc[0] : 0.f;
+    __syncthreads();
+    if (threadIdx.x < O) {
+      float t = 0.f;
+      for (int q = 0; q < G; ++q) t += red[q * O + threadIdx.x];
+      dst[threadIdx.x] = t;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ part, int nchunk, int total, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  double t = 0.0;
+  for (int b = 0; b < nchunk; ++b) t += (double)part[(int64_t)b * total + i];
+  out[i] = (float)t;
+}
+
 inline dim3 grid1d(int64_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
 
 }  // namespace
@@ -191,6 +279,7 @@ extern "C" int surf_conv3x3(const float* in, const float* weight, int N, int H, 
   const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
   CONV_CASE(4, 8, 1) CONV_CASE(8, 8, 1) CONV_CASE(8, 16, 2) CONV_CASE(16, 16, 1) CONV_CASE(16, 32, 2) CONV_CASE(32, 32, 1)
   CONV_CASE(32, 64, 2) CONV_CASE(64, 64, 1) CONV_CASE(8, 4, 1) CONV_CASE(16, 4, 1) CONV_CASE(32, 4, 1) CONV_CASE(64, 4, 1)
+  CONV_CASE(4, 16, 1) CONV_CASE(4, 32, 1) CONV_CASE(4, 64, 1) /* the heads' input gradients (train mode) */
   return SURF_E_LIMIT;
 }
 
@@ -216,5 +305,27 @@ extern "C" int surf_inorm_relu(float* x, int N, int H, int W, int C, const float
   hipLaunchKernelGGL(inorm_partial_kernel, dim3(nblk, N), dim3(256), 4 * C * 2 * sizeof(double), st, x, HW, C, nblk, workspace);
   hipLaunchKernelGGL(inorm_finalize_kernel, grid1d(N * C, 64), dim3(64), 0, st, workspace, N, nblk, C, HW, stats);
   hipLaunchKernelGGL(inorm_relu_kernel, grid1d((int64_t)N * HW * (C / 4), 256), dim3(256), 0, st, x, stats, skip, N, HW, C);
+  return surf_check_launch();
+}
+
+extern "C" int64_t surf_conv3x3_wgrad_workspace_floats(int N, int Hs, int Ws, int cb, int cs) {
+  const int64_t nchunk = ((int64_t)N * Hs * Ws + WG_CHUNK - 1) / WG_CHUNK;
+  return nchunk * 9 * cb * cs;
+}
+
+extern "C" int surf_conv3x3_wgrad(const float* big, const float* small, int N, int Hs, int Ws, int cb, int cs, int stride,
+                                  float* workspace, float* out, void* stream) {
+  if (!big || !small || !workspace || !out || N <= 0 || Hs <= 0 || Ws <= 0) return SURF_E_ARG;
+  if (cb < 4 || cb > 64 || cs < 4 || cs > 64 || (stride != 1 && stride != 2)) return SURF_E_LIMIT;
+  const int O = cb * cs;
+  if (O >= 256 ? (O % 256 != 0 || O / 256 > 16) : (256 % O != 0)) return SURF_E_LIMIT;
+  hipStream_t st = (hipStream_t)stream;
+  const int nchunk = (int)(((int64_t)N * Hs * Ws + WG_CHUNK - 1) / WG_CHUNK);
+  const int Hb = Hs * stride, Wb = Ws * stride;
+  if (stride == 1)
+    hipLaunchKernelGGL(wgrad_kernel<1>, dim3(nchunk, 9), dim3(256), 0, st, big, small, N, Hb, Wb, Hs, Ws, cb, cs, workspace);
+  else
+    hipLaunchKernelGGL(wgrad_kernel<2>, dim3(nchunk, 9), dim3(256), 0, st, big, small, N, Hb, Wb, Hs, Ws, cb, cs, workspace);
+  hipLaunchKernelGGL(wgrad_finalize_kernel, grid1d(9 * O, 256), dim3(256), 0, st, workspace, nchunk, 9 * O, out);
   return surf_check_launch();
 }

@@ -58,24 +58,92 @@ class FeatureNetwork(nn.Module):
             if i < self.num_stage - 1:
                 self.decoder_layers.append(_Deconv(d_base * 2 ** (i + 1), m))
 
-    def forward(self, imgs):
-        """imgs (nv,3,H,W) in [0,1) -> list of 4 texel4 maps (nv,h,w,4), coarse -> fine."""
+    def forward(self, imgs, tape=None):
+        """imgs (nv,3,H,W) in [0,1) -> list of 4 texel4 maps (nv,h,w,4), coarse -> fine.  tape: a list that receives what
+        `backward` needs (layer inputs, raw convolution outputs, InstanceNorm statistics)."""
         if imgs.shape[-2] % 8 or imgs.shape[-1] % 8:
             raise ValueError("image height and width must be divisible by 8")
         x = ops.pack_texel4(imgs.detach().float().contiguous())
-        enc = []
+        rec = tape is not None
+
+        def norm(y, skip=None):
+            if not rec:
+                return ops.inorm_relu_(y, skip=skip), None, None
+            raw = y.clone()
+            y, stats = ops.inorm_relu_(y, skip=skip, want_stats=True)
+            return y, raw, stats
+
+        enc, enc_rec = [], []
         for i in range(self.num_stage):
             for blk in self.encoder_layers[i]:
+                x_in = x
                 x = ops.conv3x3(x, _pack_conv(blk.conv.weight), blk.conv.out_channels, blk.stride)
-                ops.inorm_relu_(x)
+                x, raw, stats = norm(x)
+                enc_rec.append(dict(blk=blk, x_in=x_in, raw=raw, stats=stats))
             enc.append(x)
         d = enc[-1]
         dec = [None] * self.num_stage
         dec[-1] = d
+        dec_rec = [None] * self.num_stage
         for i in range(self.num_stage - 2, -1, -1):
             blk = self.decoder_layers[i]
+            d_in = d
             d = ops.deconv3x3_s2(d, _pack_deconv(blk.conv.weight), blk.conv.out_channels)
-            ops.inorm_relu_(d, skip=enc[i])
+            d, raw, stats = norm(d, skip=enc[i])
+            dec_rec[i] = dict(blk=blk, x_in=d_in, raw=raw, stats=stats)
             dec[i] = d
         outs = [ops.conv3x3(dec[i], _pack_conv(self.out_layers[i].weight), 4, 1) for i in range(self.num_stage)]
+        if rec:
+            tape.append(dict(enc=enc_rec, dec=dec_rec, dec_out=dec))
         return outs[::-1]
+
+    def backward(self, tape, g_outs_c2f):
+        """Reverse sweep: g_outs_c2f = gradients of the four texel4 outputs (coarse -> fine, like forward's return value).
+        ACCUMULATES into the `.grad` of every convolution weight.  Input gradients reuse the forward kernels (stride 1: the
+        flipped, transposed kernel; stride 2 <-> transposed convolution), weight gradients `surf_conv3x3_wgrad`, the
+        InstanceNorm + ReLU (+ skip) backward `surf_bn_relu_backward` per view."""
+        def acc(p, g):
+            p.grad = g.to(p.dtype) if p.grad is None else p.grad + g.to(p.dtype)
+
+        def flipT(w):
+            """Conv2d weight (Cout, Cin, 3, 3) -> the packed kernel [ky][kx][Cout][Cin] of its input gradient (stride 1)."""
+            return w.detach().float().flip(2, 3).permute(2, 3, 0, 1).contiguous()
+
+        t = tape[-1]
+        n = self.num_stage
+        g_outs = g_outs_c2f[::-1]                                               # index i = level i (0 = finest)
+        d_dec = []
+        for i in range(n):
+            w = self.out_layers[i].weight
+            g = g_outs[i].contiguous()
+            d_dec.append(ops.conv3x3(g, flipT(w), w.shape[1], 1))
+            dw = ops.conv3x3_wgrad(t["dec_out"][i], g, 1)                       # [ky][kx][ci][co]
+            acc(w, dw.permute(3, 2, 0, 1))
+        d_enc = [None] * n
+        for i in range(n - 1):                                                  # dec[i] = IN(deconv(dec[i+1])) + enc[i]
+            r = t["dec"][i]
+            w = r["blk"].conv.weight                                            # (Cin, Cout, 3, 3)
+            g = d_dec[i]
+            d_enc[i] = g
+            d_raw = ops.inorm_relu_backward(r["raw"], g, r["stats"])
+            # input gradient of the transposed convolution = stride-2 convolution with [ky][kx][co][ci]
+            d_dec[i + 1] = d_dec[i + 1] + ops.conv3x3(d_raw, w.detach().float().permute(2, 3, 1, 0).contiguous(), w.shape[0], 2)
+            dw = ops.conv3x3_wgrad(d_raw, r["x_in"], 2)                         # [ky][kx][co][ci]
+            acc(w, dw.permute(3, 2, 0, 1))
+        d_enc[n - 1] = d_dec[n - 1]
+        g = d_enc[n - 1]
+        for k in range(2 * n - 1, -1, -1):                                      # encoder blocks, last to first
+            i, j = k // 2, k % 2
+            r = t["enc"][k]
+            w = r["blk"].conv.weight                                            # (Cout, Cin, 3, 3)
+            d_raw = ops.inorm_relu_backward(r["raw"], g.contiguous(), r["stats"])
+            dw = ops.conv3x3_wgrad(r["x_in"], d_raw, r["blk"].stride)           # [ky][kx][ci (padded)][co]
+            acc(w, dw[:, :, :w.shape[1]].permute(3, 2, 0, 1))
+            if k == 0:
+                break
+            if r["blk"].stride == 1:
+                g = ops.conv3x3(d_raw, flipT(w), w.shape[1], 1)
+            else:                                                               # stride-2 conv <- transposed conv, [ky][kx][co][ci]
+                g = ops.deconv3x3_s2(d_raw, w.detach().float().permute(2, 3, 0, 1).contiguous(), w.shape[1])
+            if j == 0:                                                          # entering stage i - 1's output: add its skip gradient
+                g = g + d_enc[i - 1]

@@ -1062,11 +1062,40 @@ def deconv3x3_s2(x, w_packed, cout):
     return out
 
 
-def inorm_relu_(x, skip=None):
+def conv3x3_wgrad(big, small, stride=1):
+    """out[ky][kx][cb][cs] = sum big[n][ys S + ky - 1][xs S + kx - 1][cb] small[n][ys][xs][cs]: the weight gradient of a 3x3
+    convolution (big = input, small = d output) or of the stride-2 transposed one (big = d output, small = input)."""
+    _chk(big, torch.float32, "big")
+    _chk(small, torch.float32, "small")
+    N, Hs, Ws, cs = small.shape
+    cb = big.shape[3]
+    assert tuple(big.shape[:3]) == (N, Hs * stride, Ws * stride)
+    ws = torch.empty(_lib.lib().surf_conv3x3_wgrad_workspace_floats(N, Hs, Ws, cb, cs), dtype=torch.float32, device=big.device)
+    out = torch.empty(3, 3, cb, cs, dtype=torch.float32, device=big.device)
+    rc = _lib.lib().surf_conv3x3_wgrad(_p(big), _p(small), N, Hs, Ws, cb, cs, int(stride), _p(ws), _p(out), _stream())
+    _lib.check(rc, f"surf_conv3x3_wgrad({cb}x{cs}, stride {stride})")
+    return out
+
+
+def inorm_relu_backward(raw, dy, stats):
+    """Backward of inorm_relu_ (the skip's gradient is dy itself): raw (N,H,W,C) the convolution output before the in-place
+    normalisation, stats (N,C,2) = mean | rstd.  InstanceNorm = BatchNorm over one view's pixels: surf_bn_relu_backward per
+    view with scale = rstd, shift = -mean rstd."""
+    N, H, W, C = raw.shape
+    dx = torch.empty_like(raw)
+    for n in range(N):
+        mean, rstd = stats[n, :, 0].contiguous(), stats[n, :, 1].contiguous()
+        st = torch.cat([mean, rstd])
+        d, _, _ = bn_relu_backward(raw[n].reshape(H * W, C), dy[n].reshape(H * W, C), rstd, (-mean * rstd).contiguous(), st, train=True)
+        dx[n] = d.reshape(H, W, C)
+    return dx
+
+
+def inorm_relu_(x, skip=None, want_stats=False):
     """In place x = relu(instance_norm(x)) (+ skip); x (N,H,W,C) NHWC."""
     _chk(x, torch.float32, "x")
     N, H, W, C = x.shape
     ws = torch.empty(_lib.lib().surf_inorm_workspace_doubles(N, H, W, C), dtype=torch.float64, device=x.device)
     stats = torch.empty(N, C, 2, dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().surf_inorm_relu(_p(x), N, H, W, C, _p(skip), _p(ws), _p(stats), _stream()), "surf_inorm_relu")
-    return x
+    return (x, stats) if want_stats else x

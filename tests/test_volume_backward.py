@@ -136,3 +136,32 @@ def test_costvol_backward(scene, weights, golden_fpn, golden_pipe, stage):
     ref_agg = torch.cat([sd["volume.agg_mlp.0.weight"].grad.reshape(-1), sd["volume.agg_mlp.0.bias"].grad.reshape(-1),
                          sd["volume.agg_mlp.2.weight"].grad.reshape(-1), sd["volume.agg_mlp.2.bias"].grad.reshape(-1)])
     grad_close(g_agg, ref_agg)
+
+
+def test_fpn_backward_matches_autograd(scene):
+    """FeatureNetwork.backward (input gradients on the forward kernels, surf_conv3x3_wgrad, InstanceNorm backward) against
+    torch autograd through the oracle's fpn_forward: every convolution weight, for upstream gradients on all four maps."""
+    from surf_amd import conf, ops
+    from surf_amd.feature_network import FeatureNetwork
+    d = dev()
+    torch.manual_seed(2)
+    net = FeatureNetwork(conf.from_dict({"d_in": 3, "d_base": 8, "d_out": [4, 4, 4, 4]}))
+    sd = {"feature_network." + k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    imgs = scene["imgs"][:3, :, :64, :96].contiguous()
+    outs_ref = O.fpn_forward(sd, imgs)
+    g = torch.Generator().manual_seed(6)
+    G = [torch.randn(o.shape, generator=g) for o in outs_ref]
+    sum((o * gg).sum() for o, gg in zip(outs_ref, G)).backward()
+    net = net.to(d)
+    tape = []
+    outs = net(imgs.to(d), tape=tape)
+    for o, r in zip(outs, outs_ref):
+        grad_close(o.permute(0, 3, 1, 2), r.detach(), 1e-3)
+    net.backward(tape, [gg.permute(0, 2, 3, 1).contiguous().to(d) for gg in G])
+    n = 0
+    for name, p_ in net.named_parameters():
+        ref = sd["feature_network." + name].grad
+        assert ref is not None and p_.grad is not None, name
+        grad_close(p_.grad, ref, 5e-3)
+        n += 1
+    assert n == 8 + 3 + 4
