@@ -410,6 +410,15 @@ int64_t surf_conv3x3_wgrad_workspace_floats(int N, int Hs, int Ws, int cb, int c
 int surf_conv3x3_wgrad(const float* big, const float* small, int N, int Hs, int Ws, int cb, int cs, int stride,
                        float* workspace, float* out, void* stream);
 
+/* Backward of surf_ptloss_terms w.r.t. the depth map (train mode; the autograd of losses/photometric_loss.py:54-125):
+ * warp = the forward's warped images; coef (device, 4 floats) = upstream / (M_t + 1e-8) for the l1, gx, gy and ssim terms;
+ * g_warp (ns,H,W,4) scratch (zeroed here); g_depth (H,W) written.  Only the topk sources selected by the forward receive
+ * gradient (torch.topk's backward); validity masks and the SSIM mask pool are constants. */
+int surf_ptloss_backward(const float* imgs_t4, int nv, int H, int W, const float* depth, const float* mask, int ref_idx, int topk,
+                         const float* h_intrs, const float* h_c2w, const float* h_w2c, const float* warp, const float* coef,
+                         float* g_warp, float* g_depth, void* stream);
+
+
 
 
 /*

@@ -136,7 +136,208 @@ __global__ __launch_bounds__(256) void ptloss_terms_kernel(PtArgs a) {
   out[1] = f32x4{mref, mx, my, 0.f};
 }
 
+// ---- backward w.r.t. the depth map (train mode) --------------------------------------------------------------------
+// loss = sum_t T_t / (M_t + 1e-8); coef[t] = upstream / (M_t + 1e-8) (device, 4 floats: l1, gx, gy, ssim).
+//   ptloss_bwd_terms_kernel  one thread per pixel: recomputes the four per-source values, selects the topk sources of each
+//                            term like the forward, and scatters d loss / d warped rgb into g_warp (ns,H,W,4) (atomics: the
+//                            gradient and SSIM windows overlap);
+//   ptloss_bwd_depth_kernel  one thread per pixel: d warped / d depth = bilinear derivative x d(u,v)/d depth (the pixel's
+//                            projection is affine in its depth: p(d) = d a + b), summed over the sources.
+__device__ __forceinline__ float smooth_l1_grad(float d) { return fabsf(d) < 1.0f ? d : (d > 0.f ? 1.0f : -1.0f); }
+
+struct PtBwd {
+  const float* coef;
+  float* g_warp;
+  float* g_depth;
+};
+
+template <bool BWD>
+__device__ __forceinline__ void pt_source(const PtArgs& a, const PtBwd& b, int s, int64_t p, int x, int y, const int yy[3],
+                                          const int xx[3], const float r_mu[3], const float r_sq[3], float mref, float mx,
+                                          float my, const unsigned sel /* bit t: this source is selected for term t */,
+                                          float v4[4]) {
+  const int64_t per = (int64_t)a.H * a.W;
+  const f32x4* __restrict__ ref = reinterpret_cast<const f32x4*>(a.imgs) + (int64_t)a.ref * per;
+  const f32x4* __restrict__ w = reinterpret_cast<const f32x4*>(a.warp) + (int64_t)s * per;
+  float* gw = BWD ? b.g_warp + (int64_t)s * per * 4 : nullptr;
+  const f32x4 r0 = ref[p], w0 = w[p];
+  const bool hx = x + 1 < a.W, hy = y + 1 < a.H;
+  const f32x4 rxn = hx ? ref[p + 1] : r0, ryn = hy ? ref[p + a.W] : r0;
+  const f32x4 wxn = hx ? w[p + 1] : w0, wyn = hy ? w[p + a.W] : w0;
+  float l1 = 0.f, gx = 0.f, gy = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float d0 = w0[c] - r0[c], d1 = (w0[c] - wxn[c]) - (r0[c] - rxn[c]), d2 = (w0[c] - wyn[c]) - (r0[c] - ryn[c]);
+    l1 += smooth_l1(d0);
+    gx += smooth_l1(d1);
+    gy += smooth_l1(d2);
+    if (BWD) {
+      float g0 = 0.f;
+      if (sel & 1u) g0 += b.coef[0] * mref * smooth_l1_grad(d0) / 3.0f;
+      if ((sel & 2u) && hx) {
+        const float g = b.coef[1] * mx * smooth_l1_grad(d1) / 3.0f;
+        g0 += g;
+        if (g != 0.f) atomicAdd(gw + (p + 1) * 4 + c, -g);
+      }
+      if ((sel & 4u) && hy) {
+        const float g = b.coef[2] * my * smooth_l1_grad(d2) / 3.0f;
+        g0 += g;
+        if (g != 0.f) atomicAdd(gw + (p + a.W) * 4 + c, -g);
+      }
+      if (g0 != 0.f) atomicAdd(gw + p * 4 + c, g0);
+    }
+  }
+  float w_mu[3] = {0, 0, 0}, w_sq[3] = {0, 0, 0}, wr[3] = {0, 0, 0}, mpool = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int64_t q = (int64_t)yy[j] * a.W + xx[k];
+      const f32x4 t = w[q], r = ref[q];
+      mpool += (t[3] > 0.5f && a.mask[q] > 0.5f) ? 1.0f : 0.0f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { w_mu[c] += t[c]; w_sq[c] = fmaf(t[c], t[c], w_sq[c]); wr[c] = fmaf(t[c], r[c], wr[c]); }
+    }
+  mpool /= 9.0f;
+  float ssim = 0.f;
+  float dmu[3], dsq[3], dwr[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float mux = w_mu[c] / 9.0f, muy = r_mu[c] / 9.0f;
+    const float sgx = w_sq[c] / 9.0f - mux * mux, sgy = r_sq[c] / 9.0f - muy * muy, sgxy = wr[c] / 9.0f - mux * muy;
+    const float A = 2.0f * mux * muy + 1e-4f, B = 2.0f * sgxy + 9e-4f;
+    const float Cc = mux * mux + muy * muy + 1e-4f, Dd = sgx + sgy + 9e-4f;
+    const float n = A * B, d = Cc * Dd;
+    const float f = (1.0f - n / d) / 2.0f;
+    ssim += mpool * fminf(fmaxf(f, 0.0f), 1.0f);
+    dmu[c] = dsq[c] = dwr[c] = 0.f;
+    if (BWD && (sel & 8u) && f > 0.0f && f < 1.0f) {
+      const float up = b.coef[3] * mref * mpool / 3.0f;                 // d loss / d f
+      const float fn = -0.5f / d, fd = 0.5f * n / (d * d);              // d f / d n, d f / d d
+      // in the window sums' variables: mux = w_mu / 9, q = w_sq / 9, z = wr / 9
+      dmu[c] = up * (fn * (2.0f * muy * B - 2.0f * muy * A) + fd * (2.0f * mux * Dd - 2.0f * mux * Cc));
+      dsq[c] = up * fd * Cc;
+      dwr[c] = up * fn * 2.0f * A;
+    }
+  }
+  if (BWD && (sel & 8u)) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int64_t q = (int64_t)yy[j] * a.W + xx[k];
+        const f32x4 t = w[q], r = ref[q];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float g = (dmu[c] + 2.0f * t[c] * dsq[c] + r[c] * dwr[c]) / 9.0f;
+          if (g != 0.f) atomicAdd(gw + q * 4 + c, g);
+        }
+      }
+  }
+  v4[0] = l1 / 3.0f; v4[1] = gx / 3.0f; v4[2] = gy / 3.0f; v4[3] = ssim / 3.0f;
+}
+
+__global__ __launch_bounds__(256) void ptloss_bwd_terms_kernel(PtArgs a, PtBwd b) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)a.H * a.W;
+  if (p >= per) return;
+  const int y = (int)(p / a.W), x = (int)(p % a.W);
+  const f32x4* __restrict__ ref = reinterpret_cast<const f32x4*>(a.imgs) + (int64_t)a.ref * per;
+  const float mref = a.mask[p];
+  const float mx = x + 1 < a.W ? mref * a.mask[p + 1] : 0.f;
+  const float my = y + 1 < a.H ? mref * a.mask[p + a.W] : 0.f;
+  if (mref == 0.f) return;                       // every term of this pixel carries a factor mref
+  float r_mu[3] = {0, 0, 0}, r_sq[3] = {0, 0, 0};
+  int yy[3], xx[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { yy[k] = reflect(y + k - 1, a.H); xx[k] = reflect(x + k - 1, a.W); }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const f32x4 r = ref[(int64_t)yy[j] * a.W + xx[k]];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { r_mu[c] += r[c]; r_sq[c] = fmaf(r[c], r[c], r_sq[c]); }
+    }
+  float best[4][SURF_MAX_VIEWS];
+  int bidx[4][SURF_MAX_VIEWS];
+  for (int s = 0; s < a.ns; ++s) {
+    float v4[4];
+    pt_source<false>(a, b, s, p, x, y, yy, xx, r_mu, r_sq, mref, mx, my, 0u, v4);
+    for (int t = 0; t < 4; ++t) {
+      int j = s;
+      while (j > 0 && best[t][j - 1] > v4[t]) { best[t][j] = best[t][j - 1]; bidx[t][j] = bidx[t][j - 1]; --j; }
+      best[t][j] = v4[t];
+      bidx[t][j] = s;
+    }
+  }
+  for (int s = 0; s < a.ns; ++s) {
+    unsigned sel = 0;
+    for (int t = 0; t < 4; ++t)
+      for (int k = 0; k < a.topk; ++k)
+        if (bidx[t][k] == s) sel |= 1u << t;
+    if (!sel) continue;
+    float v4[4];
+    pt_source<true>(a, b, s, p, x, y, yy, xx, r_mu, r_sq, mref, mx, my, sel, v4);
+  }
+}
+
+__global__ __launch_bounds__(256) void ptloss_bwd_depth_kernel(PtArgs a, PtBwd b) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)a.H * a.W;
+  if (p >= per) return;
+  const int y = (int)(p / a.W), x = (int)(p % a.W);
+  const float d = a.depth[p];
+  // direction of the pixel's ray in the reference camera and the world (the depth-linear part)
+  const float rx = a.Kinv[0] * (float)x + a.Kinv[1] * (float)y + a.Kinv[2];
+  const float ry = a.Kinv[3] * (float)x + a.Kinv[4] * (float)y + a.Kinv[5];
+  const float rz = a.Kinv[6] * (float)x + a.Kinv[7] * (float)y + a.Kinv[8];
+  const float ax = a.c2w[0] * rx + a.c2w[1] * ry + a.c2w[2] * rz;
+  const float ay = a.c2w[4] * rx + a.c2w[5] * ry + a.c2w[6] * rz;
+  const float az = a.c2w[8] * rx + a.c2w[9] * ry + a.c2w[10] * rz;
+  const float wx = ax * d + a.c2w[3], wy = ay * d + a.c2w[7], wz = az * d + a.c2w[11];
+  float acc = 0.f;
+  for (int s = 0; s < a.ns; ++s) {
+    const f32x4 g = reinterpret_cast<const f32x4*>(b.g_warp)[(int64_t)s * per + p];
+    if (g[0] == 0.f && g[1] == 0.f && g[2] == 0.f) continue;
+    const float* M = a.w2c[s];
+    const float* K = a.K[s];
+    const float sx = M[0] * wx + M[1] * wy + M[2] * wz + M[3], sy = M[4] * wx + M[5] * wy + M[6] * wz + M[7],
+                sz = M[8] * wx + M[9] * wy + M[10] * wz + M[11];
+    const float tx = M[0] * ax + M[1] * ay + M[2] * az, ty = M[4] * ax + M[5] * ay + M[6] * az, tz = M[8] * ax + M[9] * ay + M[10] * az;
+    const float px = K[0] * sx + K[1] * sy + K[2] * sz, py = K[3] * sx + K[4] * sy + K[5] * sz, pz = K[6] * sx + K[7] * sy + K[8] * sz;
+    const float qx = K[0] * tx + K[1] * ty + K[2] * tz, qy = K[3] * tx + K[4] * ty + K[5] * tz, qz = K[6] * tx + K[7] * ty + K[8] * tz;
+    const float den = pz + 1e-8f;
+    const float u = px / den, v = py / den;
+    const float du = (qx * den - px * qz) / (den * den), dv = (qy * den - py * qz) / (den * den);
+    // the forward's sampling position: gx = ((u / ((W-1)/2) - 1 + 1) / 2) (W-1) = u up to rounding; same for v
+    const float nx = u / ((float)(a.W - 1) / 2.0f) - 1.0f, ny = v / ((float)(a.H - 1) / 2.0f) - 1.0f;
+    const float gxp = ((nx + 1.0f) / 2.0f) * (float)(a.W - 1), gyp = ((ny + 1.0f) / 2.0f) * (float)(a.H - 1);
+    const float fx = floorf(gxp), fy = floorf(gyp);
+    const float lx = gxp - fx, ly = gyp - fy;
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float* img = a.imgs + (int64_t)a.view[s] * per * 4;
+    float dgx = 0.f, dgy = 0.f;
+#pragma unroll
+    for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+      for (int dxx = 0; dxx < 2; ++dxx) {
+        const int xi = x0 + dxx, yi = y0 + dyy;
+        if ((xi >= 0) & (xi < a.W) & (yi >= 0) & (yi < a.H)) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(img + ((int64_t)yi * a.W + xi) * 4);
+          const float gt = g[0] * t[0] + g[1] * t[1] + g[2] * t[2];
+          dgx += gt * (dxx ? 1.0f : -1.0f) * (dyy ? ly : 1.0f - ly);
+          dgy += gt * (dyy ? 1.0f : -1.0f) * (dxx ? lx : 1.0f - lx);
+        }
+      }
+    acc += dgx * du + dgy * dv;
+  }
+  b.g_depth[p] = acc;
+}
+
 }  // namespace
+
+static int fill_pt_args(PtArgs& a, int nv, int ref_idx, const float* h_intrs, const float* h_c2w, const float* h_w2c);
 
 extern "C" int surf_ptloss_terms(const float* imgs_t4, int nv, int H, int W, const float* depth, const float* mask, int ref_idx,
                                  int topk, const float* h_intrs, const float* h_c2w, const float* h_w2c, float* warp,
@@ -147,6 +348,15 @@ extern "C" int surf_ptloss_terms(const float* imgs_t4, int nv, int H, int W, con
   PtArgs a;
   a.imgs = imgs_t4; a.depth = depth; a.mask = mask; a.nv = nv; a.ref = ref_idx; a.H = H; a.W = W; a.ns = nv - 1; a.topk = topk;
   a.warp = warp; a.terms = terms;
+  if (const int rc = fill_pt_args(a, nv, ref_idx, h_intrs, h_c2w, h_w2c)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t per = (int64_t)H * W;
+  hipLaunchKernelGGL(ptloss_warp_kernel, dim3((unsigned)((per * a.ns + 255) / 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(ptloss_terms_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, a);
+  return surf_check_launch();
+}
+
+static int fill_pt_args(PtArgs& a, int nv, int ref_idx, const float* h_intrs, const float* h_c2w, const float* h_w2c) {
   // inverse of the reference intrinsics' upper-left 3x3 (host, double)
   {
     const float* K = h_intrs + ref_idx * 16;
@@ -173,9 +383,26 @@ extern "C" int surf_ptloss_terms(const float* imgs_t4, int nv, int H, int W, con
     for (int k = 0; k < 12; ++k) a.w2c[slot][k] = 0.f;
     for (int k = 0; k < 9; ++k) a.K[slot][k] = 0.f;
   }
+  return 0;
+}
+
+extern "C" int surf_ptloss_backward(const float* imgs_t4, int nv, int H, int W, const float* depth, const float* mask, int ref_idx,
+                                    int topk, const float* h_intrs, const float* h_c2w, const float* h_w2c, const float* warp,
+                                    const float* coef, float* g_warp, float* g_depth, void* stream) {
+  if (!imgs_t4 || !depth || !mask || !h_intrs || !h_c2w || !h_w2c || !warp || !coef || !g_warp || !g_depth) return SURF_E_ARG;
+  if (nv < 2 || nv > SURF_MAX_VIEWS || ref_idx < 0 || ref_idx >= nv || H < 2 || W < 2) return SURF_E_ARG;
+  if (topk < 1 || topk > nv - 1) return SURF_E_ARG;
+  PtArgs a;
+  a.imgs = imgs_t4; a.depth = depth; a.mask = mask; a.nv = nv; a.ref = ref_idx; a.H = H; a.W = W; a.ns = nv - 1; a.topk = topk;
+  a.warp = const_cast<float*>(warp); a.terms = nullptr;
+  if (const int rc = fill_pt_args(a, nv, ref_idx, h_intrs, h_c2w, h_w2c)) return rc;
+  PtBwd b;
+  b.coef = coef; b.g_warp = g_warp; b.g_depth = g_depth;
   hipStream_t st = (hipStream_t)stream;
   const int64_t per = (int64_t)H * W;
-  hipLaunchKernelGGL(ptloss_warp_kernel, dim3((unsigned)((per * a.ns + 255) / 256)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(ptloss_terms_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, a);
+  const hipError_t e = hipMemsetAsync(g_warp, 0, per * a.ns * 4 * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(ptloss_bwd_terms_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, a, b);
+  hipLaunchKernelGGL(ptloss_bwd_depth_kernel, dim3((unsigned)((per + 255) / 256)), dim3(256), 0, st, a, b);
   return surf_check_launch();
 }

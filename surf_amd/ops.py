@@ -603,6 +603,28 @@ def photometric_loss(depth, imgs_t4, mask_ref, cams, ref_idx=0, topk=2, return_w
     return (loss, warp) if return_warp else loss
 
 
+def photometric_loss_backward(depth, imgs_t4, mask_ref, cams, ref_idx=0, topk=2, upstream=1.0):
+    """d (upstream * photometric_loss(depth, ...)) / d depth (H,W) (surf_ptloss_backward; the forward kernels are re-run for
+    the warped images and the mask sums).  upstream: float or 0-d device tensor."""
+    _chk(depth, torch.float32, "depth")
+    nv, H, W, _ = imgs_t4.shape
+    dev = depth.device
+    warp = torch.empty(nv - 1, H, W, 4, dtype=torch.float32, device=dev)
+    terms = torch.empty(H, W, 8, dtype=torch.float32, device=dev)
+    intr16 = np.ascontiguousarray(cams.intrs.reshape(nv, -1))
+    rc = _lib.lib().surf_ptloss_terms(_p(imgs_t4), nv, H, W, _p(depth), _p(mask_ref), int(ref_idx), int(topk), _np_ptr(intr16),
+                                      _np_ptr(cams.c2w), _np_ptr(cams.w2c), _p(warp), _p(terms), _stream())
+    _lib.check(rc, "surf_ptloss_terms")
+    t = terms.view(-1, 8).sum(dim=0, dtype=torch.float64)
+    coef = (upstream / (torch.stack([t[4], t[5], t[6], t[4]]) + 1e-8)).float().contiguous()
+    g_warp = torch.empty_like(warp)
+    g_depth = torch.empty(H, W, dtype=torch.float32, device=dev)
+    rc = _lib.lib().surf_ptloss_backward(_p(imgs_t4), nv, H, W, _p(depth), _p(mask_ref), int(ref_idx), int(topk), _np_ptr(intr16),
+                                         _np_ptr(cams.c2w), _np_ptr(cams.w2c), _p(warp), _p(coef), _p(g_warp), _p(g_depth), _stream())
+    _lib.check(rc, "surf_ptloss_backward")
+    return g_depth
+
+
 def patch_warp_tangent(pts, dirs, grads, maps_t4, cams, patch_size=11):
     """patch_warp + the derivatives of both patch stacks along d pts / d z0 = dirs (R,3) (surf_patch_warp_tangent).
     Returns (ref, src, ref_tan, src_tan)."""

@@ -165,3 +165,27 @@ def test_fpn_backward_matches_autograd(scene):
         grad_close(p_.grad, ref, 5e-3)
         n += 1
     assert n == 8 + 3 + 4
+
+
+def test_photometric_loss_backward(scene, golden_pipe, golden_train):
+    """d compute_ptloss / d depth (losses/photometric_loss.py:54-125 under autograd): smooth-L1, image-gradient and SSIM
+    terms through the top-k source selection.  The loss is piecewise smooth (top-k switches, SSIM clamp, bilinear cell
+    borders): a small share of pixels may sit on a different piece in fp32, so the check is on the bulk + the total."""
+    from surf_amd import ops
+    d = dev()
+    gt, gp = golden_train, golden_pipe
+    imgs_t4 = ops.pack_texel4(scene["imgs"].to(d).contiguous())
+    cams = ops.Cameras(scene["intrs"], scene["c2ws"])
+    for depth, mask, ref_idx, topk in ((gp["s3_depths"][0], gt["pt_mask_ref"], 0, 2), (gp["s3_depths"][2], gt["pt_mask_src"], 2, 1)):
+        dep = depth.clone().requires_grad_(True)
+        loss, _, _ = O.photometric_loss(dep, scene["imgs"], mask, scene["intrs"], scene["c2ws"], ref_idx, topk)
+        (loss * 3.0).backward()
+        g = ops.photometric_loss_backward(depth.to(d).contiguous(), imgs_t4, mask.to(d).contiguous(), cams, ref_idx, topk,
+                                          upstream=3.0).cpu()
+        ref = dep.grad
+        scale = float(ref.abs().max())
+        assert scale > 0
+        err = (g - ref).abs()
+        bad = err > 5e-3 * ref.abs() + 1e-3 * scale
+        assert float(bad.float().mean()) < 5e-3, f"{int(bad.sum())}/{bad.numel()} off, max err {err.max().item():.3e} (scale {scale:.3e})"
+        assert abs(float(g.sum() - ref.sum())) < 2e-2 * float(ref.abs().sum())
