@@ -24,7 +24,7 @@ class MatchingField(nn.Module):
         return jit
 
     def forward(self, cams, near_fars, hw, matching_volume, stage_idx, range_ratios, pre_depths=None, return_lr=False,
-                perturb=False, src_idx=0):
+                perturb=False, src_idx=0, saved=None):
         """matching_field.py:73-141 -> depth maps (nv,H,W).  perturb (train mode, surf.py:139): the per-ray z jitter of the
         reference and source views; `occ_reg` (unused by the loss) is not produced."""
         H, W = hw
@@ -33,6 +33,17 @@ class MatchingField(nn.Module):
             lvl = self.depth_res_levels[stage_idx]
             jitter = self.draw_jitter(cams.nv, (H // lvl) * (W // lvl), 1 if pre_depths is None else 2, src_idx)
             jitter = jitter.to(matching_volume.device).contiguous()
+        if saved is not None:
+            saved["jitter"] = jitter
         return ops.matching_depth(matching_volume, cams, near_fars, H, W, self.depth_res_levels[stage_idx],
                                   self.n_samples_depths[stage_idx], pre_depths, range_ratios[stage_idx],
                                   range_ratios[stage_idx - 1] if stage_idx > 0 else 1.0, return_lr=return_lr, jitter=jitter)
+
+    def backward(self, cams, near_fars, hw, matching_volume, stage_idx, range_ratios, g_full, pre_depths=None, jitter=None,
+                 dmvol=None):
+        """d loss / d matching volume from g_full (nv,H,W) = d loss / d this stage's depth maps (zero for the views rendered
+        under no_grad, matching_field.py:132); accumulates into `dmvol` if given."""
+        H, W = hw
+        return ops.matching_depth_backward(matching_volume, cams, near_fars, H, W, self.depth_res_levels[stage_idx],
+                                           self.n_samples_depths[stage_idx], g_full, pre_depths, range_ratios[stage_idx],
+                                           range_ratios[stage_idx - 1] if stage_idx > 0 else 1.0, jitter=jitter, dmvol=dmvol)

@@ -151,6 +151,8 @@ class SparseCostRegNet(nn.Module):
                 continue
             if e["skip"] is not None:
                 add(e["skip"], g)
+            if e["raw"].shape[0] == 0:        # an empty level (tiny lattices): nothing flows through this block
+                continue
             draw, dgamma, dbeta = ops.bn_relu_backward(e["raw"], g.contiguous(), e["scale"], e["shift"], e["stats"], train=True)
             bn = e["blk"].net[1]
             acc(bn.weight, dgamma)

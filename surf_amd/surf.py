@@ -105,6 +105,55 @@ class SuRF(nn.Module):
                 p.grad = g if p.grad is None else p.grad + g
         return dvols
 
+    def backward_volumes(self, row_grads_f2c, g_depths=None):
+        """Backward of the volume build + FPN of the last `forward("train", ..., record=True)` (surf.py:80-131 under
+        loss.backward()): row_grads_f2c = d loss / d the stages' feature rows (N_s, 7), fine -> coarse (what
+        ImplicitSurface.backward_render returns); g_depths = {stage: (d loss / d depth_stage{s} (H,W) or None,
+        d loss / d depth_src_stage{s} or None)}.  Accumulates `.grad` of every parameter of reg_network, volume.agg_mlp and
+        feature_network.  Per stage, fine -> coarse: matching-field backward -> densify backward (-> the coarser matching
+        volume) -> sparse U-Net backward -> cost-volume backward (-> FPN maps, agg_mlp) and the parent-feature scatter
+        (-> the coarser stage's `mid` rows); then the FPN backward.  Not propagated: the colour path's gradient into the
+        FPN maps the blending network samples (rendering_network inputs), the voxel selections, the detached depths."""
+        t = self._train_tape
+        if t is None:
+            raise RuntimeError("backward_volumes needs forward('train', ..., record=True) of a volume-building model first")
+        if not self.reg_network.training:
+            raise RuntimeError("backward_volumes: the sparse U-Net's tape is recorded in train mode (model.train())")
+        feats, cams = t["feats"], t["cams"]
+        dev = feats[0].device
+        nv = feats[0].shape[0]
+        H, W = t["hw"]
+        gfeats = [torch.zeros_like(f) for f in feats]
+        g_agg = torch.zeros(49, dtype=torch.float32, device=dev)
+        n = self.num_stage
+        d_mvol, d_mid = None, None
+        for s in range(n - 1, -1, -1):
+            r = t["vol"][s]
+            g_out = torch.zeros(r["coords"].shape[0], 8, dtype=torch.float32, device=dev)
+            g_out[:, 1:] = row_grads_f2c[n - 1 - s]
+            gd = (g_depths or {}).get(s, (None, None))
+            if gd[0] is not None or gd[1] is not None:
+                g_full = torch.zeros(nv, H, W, dtype=torch.float32, device=dev)
+                if gd[0] is not None:
+                    g_full[0] += gd[0]
+                if gd[1] is not None:
+                    g_full[t["src_idx"]] += gd[1]
+                d_mvol = self.matching_field.backward(cams, t["near_fars"], (H, W), r["mvol"], s, self.range_ratios, g_full,
+                                                      r["pre_depths"], r.get("jitter"), dmvol=d_mvol)
+            d_prev = None
+            if d_mvol is not None:
+                if s > 0:
+                    Dp = r["D"] // 2
+                    d_prev = torch.zeros(Dp, Dp, Dp, dtype=torch.float32, device=dev)
+                ops.densify_backward(r["coords"], r["table"], d_mvol, g_out, d_prev)
+            d_reg_in = self.reg_network.nets[s].backward(r["reg_tape"], g_out, d_mid)
+            d_mid = self.volume.stage_backward(s, r["D"], feats, gfeats, cams, r["coords"], d_reg_in, g_agg, r.get("pidx"),
+                                               r["n_parents"])
+            d_mvol = d_prev
+        self.volume.assign_agg_grad(g_agg)
+        self.feature_network.backward(t["fpn"], gfeats)
+        return gfeats
+
     def _frozen_scene(self, ipts):
         """SceneVolumes of the frozen volumes for the views of this call (surf.py:150-156: features[view_ids])."""
         view_ids = [int(v) for v in ipts["view_ids"]] if "view_ids" in ipts else list(range(ipts["imgs"].shape[0]))
@@ -118,12 +167,14 @@ class SuRF(nn.Module):
         return self._vol_scene[1]
 
     @torch.no_grad()
-    def build_volumes(self, ipts, features_c2f, cams=None, logit_override=None, timings=None, trace=None, perturb=False):
+    def build_volumes(self, ipts, features_c2f, cams=None, logit_override=None, timings=None, trace=None, perturb=False,
+                      tape=None):
         """surf.py:80-131 (perturb = the train-mode z jitter of the matching field, surf.py:139).  features_c2f: texel4 maps coarse -> fine.
         Returns (outputs, volumes, tables, matching_volume) with per-stage lists coarse -> fine.
         `logit_override(coords, D) -> (N,)` (bench / tests only) replaces the U-Net's matching logit so that an
         untrained network still produces a realistic, surface-concentrated pyramid; `timings` (dict) receives
-        per-stage HIP-event pairs; `trace` (dict, tests only) receives every stage's intermediate tensors."""
+        per-stage HIP-event pairs; `trace` (dict, tests only) receives every stage's intermediate tensors; `tape` (list,
+        train mode) receives per stage what `backward_volumes` needs."""
         intrs, c2ws = ipts["intrs"], ipts["c2ws"]
         if cams is None:
             cams = ops._cams_ext(ops.Cameras(intrs, c2ws), intrs, c2ws)
@@ -139,11 +190,13 @@ class SuRF(nn.Module):
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timings is not None else None
             if ev: ev[0].record()
             parents, pre_depths = coords, depths
+            rec = {} if tape is not None else None
             coords, reg_in = self.volume.stage_inputs(s, D, features_c2f, cams, coords, mid, depths,
-                                                      base_range * self.range_ratios[s])
+                                                      base_range * self.range_ratios[s], saved=rec)
             if ev: ev[1].record()
             table = ops.table_from_coords(coords, D)
-            out, mid = self.reg_network(reg_in, coords, D, s, table=table)
+            reg_tape = [] if tape is not None else None
+            out, mid = self.reg_network(reg_in, coords, D, s, table=table, tape=reg_tape)
             if logit_override is not None:
                 out[:, 0] = logit_override(coords, D)
             if ev: ev[2].record()
@@ -151,7 +204,11 @@ class SuRF(nn.Module):
             if ev: ev[3].record()
             depths = self.matching_field(cams, ipts["near_fars"], (H, W), mvol, s, self.range_ratios, depths,
                                          return_lr=trace is not None, perturb=perturb,
-                                         src_idx=int(ipts["src_idx"]) if "src_idx" in ipts else 0)
+                                         src_idx=int(ipts["src_idx"]) if "src_idx" in ipts else 0, saved=rec)
+            if tape is not None:
+                rec.update(D=D, coords=coords, reg_tape=reg_tape, table=table, mvol=mvol, pre_depths=pre_depths,
+                           n_parents=0 if parents is None else int(parents.shape[0]))
+                tape.append(rec)
             if trace is not None:
                 depths, lr = depths
                 trace[s] = {"D": D, "parents": parents, "pre_depths": pre_depths, "coords": coords, "reg_in": reg_in,
@@ -167,15 +224,22 @@ class SuRF(nn.Module):
         return outputs, volumes, tables, mvol
 
     @torch.no_grad()
-    def forward(self, mode, ipts, cos_anneal_ratio=1.0, step=None):
+    def forward(self, mode, ipts, cos_anneal_ratio=1.0, step=None, record=False):
+        """record (train mode of a volume-building model): keep the tapes `backward_volumes` needs in `self._train_tape`."""
         imgs = ipts["imgs"]
+        self._train_tape = None
         intrs, c2ws = ipts["intrs"], ipts["c2ws"]
         if self.has_vol:                                                        # surf.py:149-156
             outputs, scene = {}, self._frozen_scene(ipts)
         else:
             cams = ops._cams_ext(ops.Cameras(intrs, c2ws), intrs, c2ws)
-            features = self.feature_network(imgs)                               # texel4, coarse -> fine
-            outputs, volumes, tables, mvol = self.build_volumes(ipts, features, cams, perturb=(mode == "train"))   # surf.py:139
+            fpn_tape, vol_tape = ([], []) if record else (None, None)
+            features = self.feature_network(imgs, tape=fpn_tape)                # texel4, coarse -> fine
+            outputs, volumes, tables, mvol = self.build_volumes(ipts, features, cams, perturb=(mode == "train"),
+                                                                tape=vol_tape)                                      # surf.py:139
+            if record:
+                self._train_tape = dict(fpn=fpn_tape, vol=vol_tape, feats=features, cams=cams, near_fars=ipts["near_fars"],
+                                        hw=tuple(imgs.shape[-2:]), src_idx=int(ipts["src_idx"]) if "src_idx" in ipts else 0)
             scene = SceneVolumes.from_device_layouts(mvol, [v[:, 1:] for v in volumes[::-1]], tables[::-1], features[::-1],
                                                      ops.pack_texel4(imgs.detach().float().contiguous()), cams)
             if mode != "val":                                                   # surf.py:141-148 (loss-only inputs)

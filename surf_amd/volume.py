@@ -23,9 +23,10 @@ class Volume(nn.Module):
         return np.concatenate([p.detach().to("cpu", torch.float32).numpy().reshape(-1) for p in
                                (self.agg_mlp[0].weight, self.agg_mlp[0].bias, self.agg_mlp[2].weight, self.agg_mlp[2].bias)])
 
-    def stage_inputs(self, stage, D, feats_c2f, cams, parents=None, parent_feats=None, depths=None, depth_range=None):
+    def stage_inputs(self, stage, D, feats_c2f, cams, parents=None, parent_feats=None, depths=None, depth_range=None, saved=None):
         """up_sample + depth_filtering + back_proj_multiscale + the row selections of surf.py:97-109.
-        Returns coords (N,3) int32 and the U-Net input rows (N, 8 or 16)."""
+        Returns coords (N,3) int32 and the U-Net input rows (N, 8 or 16).  saved (dict, train mode): receives `pidx`, the
+        child-candidate index of every row (row i copies the features of parent row pidx[i] >> 3), for `stage_backward`."""
         agg = self.agg_host()
         if stage == 0:
             c_all, cv, keep = ops.costvol(feats_c2f, 0, D, cams, agg)
@@ -43,5 +44,27 @@ class Volume(nn.Module):
         reg_in = torch.empty(idx2.shape[0], 8 if stage == 0 else 16, dtype=torch.float32, device=coords.device)
         ops.gather_rows(cv, idx2, dst=reg_in, dst_off=0)
         if stage > 0:
-            ops.gather_rows(parent_feats, ops.compose_index(idx1, idx2), shift=3, dst=reg_in, dst_off=8)
+            pidx = ops.compose_index(idx1, idx2)
+            ops.gather_rows(parent_feats, pidx, shift=3, dst=reg_in, dst_off=8)
+            if saved is not None:
+                saved["pidx"] = pidx
         return coords, reg_in
+
+    def stage_backward(self, stage, D, feats_c2f, gfeats_c2f, cams, coords, d_reg_in, g_agg, pidx=None, n_parents=0):
+        """Backward of stage_inputs for the kept rows: d_reg_in (N, 8 or 16) -> the FPN maps' gradients (accumulated into
+        gfeats_c2f), agg_mlp's (accumulated into g_agg, 49 floats) and, for stage > 0, the gradient of the previous stage's
+        `mid` rows (returned, (n_parents, 8)).  The voxel selection (depth filter, visibility) is not differentiable."""
+        g_cv = d_reg_in[:, :8].contiguous()
+        ops.costvol_backward(feats_c2f, gfeats_c2f, stage, D, cams, self.agg_host(), coords, g_cv, g_agg)
+        if stage == 0:
+            return None
+        d_mid = torch.zeros(n_parents, 8, dtype=torch.float32, device=d_reg_in.device)
+        return ops.scatter_rows_add(d_reg_in, pidx, d_mid, shift=3, dst_off=8)
+
+    def assign_agg_grad(self, g_agg):
+        """Split the 49 floats of costvol_backward (w1 | b1 | w2 | b2) into agg_mlp's `.grad` (accumulating)."""
+        parts = ((self.agg_mlp[0].weight, 0, 32), (self.agg_mlp[0].bias, 32, 40), (self.agg_mlp[2].weight, 40, 48),
+                 (self.agg_mlp[2].bias, 48, 49))
+        for p_, a, b in parts:
+            g = g_agg[a:b].reshape(p_.shape).to(p_.dtype)
+            p_.grad = g if p_.grad is None else p_.grad + g
