@@ -267,3 +267,54 @@ def test_volume_build_backward_end_to_end(scene):
     worst.sort(reverse=True)
     assert worst[0][0] < 2e-2, worst[:5]
     assert sum(1 for w_, _ in worst if w_ > 5e-3) <= len(worst) // 10, worst[:8]
+
+
+def test_train_steps_move_every_parameter_group(scene):
+    """surf_amd.training.train_step on a volume-building model in train mode (runner.py:150-166): a few Adam steps with the
+    reference's loss weights lower the loss on a fixed batch, and every parameter group of surf.py:36-45 (implicit surface,
+    FPN, sparse U-Net, agg_mlp) receives a finite gradient and moves."""
+    from surf_amd import conf
+    from surf_amd.losses import Loss
+    from surf_amd.surf import SuRF
+    from surf_amd.training import train_step
+    from tests.golden.make_golden import MODEL_CONF
+    from tests.golden.make_golden_train import LOSS_CONF
+    d = dev()
+    cfg = {k: v for k, v in MODEL_CONF.items()}
+    cfg["reg_network"] = {"d_in": [8, 16, 16, 16], "d_base": [8] * 4, "d_out": [8] * 4}
+    torch.manual_seed(4)
+    model = SuRF(conf.from_dict(cfg))
+    with torch.no_grad():
+        model.implicit_surface.deviation_network.variance.fill_(0.3)
+        for net in model.reg_network.nets:
+            net.out_lin.weight.mul_(4.0)
+    model = model.to(d).train()
+    ipts = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    ipts["src_idx"] = 1
+    R = scene["rays_o"].shape[0]
+    H, W = scene["imgs"].shape[-2:]
+    g = torch.Generator().manual_seed(5)
+    targets = {"color": torch.rand(R, 3, generator=g).to(d), "imgs": ipts["imgs"], "intrs": scene["intrs"], "c2ws": scene["c2ws"],
+               "src_idx": 1, "mask_ref": torch.ones(H, W, device=d), "mask_src": torch.ones(H, W, device=d),
+               "pseudo_depth_ref": torch.full((H, W), 1.0, device=d), "pseudo_depth_src": torch.full((H, W), 1.0, device=d),
+               "depth_ref": torch.full((H, W), 1.0, device=d), "depth_src": torch.full((H, W), 1.0, device=d)}
+    opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}))
+    before = {k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad}
+    loss_fn = Loss(conf.from_dict(dict(LOSS_CONF, smooth_weight=0.0)))
+    hist = []
+    for step in range(5):
+        torch.manual_seed(70)
+        out = train_step(model, ipts, targets, loss_fn, opt, 1.0, step + 2)
+        hist.append(out["loss"])
+        if step == 0:
+            for k, v in model.named_parameters():
+                if v.grad is not None:
+                    assert bool(torch.isfinite(v.grad).all()), k
+    assert all(np.isfinite(hist)), hist
+    assert hist[-1] < hist[0], hist
+    moved = {grp: 0 for grp in ("feature_network", "reg_network", "volume", "implicit_surface")}
+    for k, v in model.named_parameters():
+        if v.requires_grad and float((v.detach() - before[k]).abs().max()) > 0:
+            moved[k.split(".")[0]] += 1
+    assert all(c > 0 for c in moved.values()), moved
+    assert moved["feature_network"] == 15 and moved["volume"] >= 3
