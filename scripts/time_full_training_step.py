@@ -1,0 +1,84 @@
+"""Time one full training step (runner.py:150-166, generalisation training: FPN -> 4-stage volume build -> render -> loss ->
+HIP backward of everything -> Adam) of a volume-building SuRF on the bench scene (5 views, 576x800, 88^3 base lattice) for a
+batch of 512 rays x 128 samples.  Weights are random-init: the analytic sphere logit replaces the U-Net's matching logit in
+the forward (as in bench.py's volume-build timing) so that the voxel pyramid is the surface-concentrated one a trained
+network produces; the backward still runs through every kernel."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from surf_amd import synthetic, ops, conf, training
+from surf_amd.losses import Loss
+from surf_amd.surf import SuRF
+from bench import surf_conf
+
+dev = torch.device("cuda:0")
+nv, H, W, R = 5, 576, 800, int(sys.argv[1]) if len(sys.argv) > 1 else 512
+torch.manual_seed(0)
+model = SuRF(conf.from_dict(surf_conf(88))).to(dev).train()
+model.logit_override = synthetic.sphere_logit
+model.matching_field.device_jitter = os.environ.get("SURF_CPU_JITTER", "0") != "1"   # reference draws on the CPU generator
+intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
+imgs = synthetic.procedural_images(nv, H, W, 0, dev)
+rays_o, rays_d = synthetic.pixel_rays(intrs[0], c2ws[0], H, W, 1, dev)
+sel = torch.randperm(rays_o.shape[0], device=dev)[:R]
+ipts = {"imgs": imgs, "intrs": intrs.to(dev), "c2ws": c2ws.to(dev), "near_fars": near_fars.to(dev),
+        "near": near_fars[0, 0].reshape(1, 1).to(dev), "far": near_fars[0, 1].reshape(1, 1).to(dev),
+        "rays_o": rays_o[sel].contiguous(), "rays_d": rays_d[sel].contiguous(), "src_idx": 1}
+ones = torch.ones(H, W, device=dev)
+targets = {"color": torch.rand(R, 3, device=dev), "imgs": imgs, "intrs": intrs, "c2ws": c2ws, "src_idx": 1, "mask_ref": ones,
+           "mask_src": ones, "pseudo_depth_ref": ones * 2.0, "pseudo_depth_src": ones * 2.0, "depth_ref": ones * 2.0,
+           "depth_src": ones * 2.0}
+loss_fn = Loss(conf.from_dict({"color_weight": 1.0, "sparse_scale_factor": 100, "sparse_weight": 0.02, "igr_weight": 0.1,
+                               "mfc_weight": 0.5, "smooth_weight": 0.0, "depth_weight": 0.0, "ptloss_weight": 1.0,
+                               "pseudo_auxi_depth_weight": 1.0, "pseudo_sdf_weight": 0.0, "pseudo_depth_weight": 0.0,
+                               "stage_weights": [0.25, 0.5, 0.75, 1.0]}))
+opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}))
+
+# instrument the phases with HIP events by wrapping the model's entry points
+marks = []
+
+
+def wrap(obj, name, label):
+    fn = getattr(obj, name)
+
+    def timed(*a, **k):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        marks.append((label, e0, e1))
+        return r
+    setattr(obj, name, timed)
+
+
+wrap(model.feature_network, "forward", "fwd  FPN")
+wrap(model, "build_volumes", "fwd  volume build (4 stages)")
+wrap(model.implicit_surface, "render_scene", "fwd  render (+ patch warp, H.1, sparse sdf)")
+wrap(ops, "photometric_loss", "loss photometric terms (8 maps)")
+wrap(ops, "photometric_loss_backward", "bwd  photometric terms")
+wrap(model.implicit_surface, "backward_render", "bwd  render (composite, sdf, blend)")
+wrap(model.feature_network, "backward", "bwd  FPN")
+for s, net in enumerate(model.reg_network.nets):
+    wrap(net, "backward", "bwd  sparse U-Net")
+wrap(model.volume, "stage_backward", "bwd  cost volume + parent rows")
+wrap(model.matching_field, "backward", "bwd  matching field")
+wrap(ops, "densify_backward", "bwd  densify")
+wrap(opt, "step", "Adam")
+
+for _ in range(2):
+    marks.clear()
+    training.train_step(model, ipts, targets, loss_fn, opt, 1.0, 3)
+N = 5
+acc = {}
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(N):
+    marks.clear()
+    out = training.train_step(model, ipts, targets, loss_fn, opt, 1.0, 3)
+    torch.cuda.synchronize()
+    for label, e0, e1 in marks:
+        acc[label] = acc.get(label, 0.0) + e0.elapsed_time(e1)
+wall = (time.perf_counter() - t0) / N * 1e3
+nvox = [int(r["coords"].shape[0]) for r in model._train_tape["vol"]]
+print(f"{R} rays x 128 samples, {nv} views {H}x{W}, voxels per stage {nvox}: wall {wall:.1f} ms per training step, loss {out['loss']:.4f}")
+for k, v in acc.items():
+    print(f"  {k}: {v / N:.2f} ms")

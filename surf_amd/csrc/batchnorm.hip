@@ -33,14 +33,30 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
+// Sum the per-block partials (blocks, 2, C) with one 256-thread workgroup: thread (g, c) takes the blocks b = g (mod 256 / C),
+// the slices meet in LDS in a fixed order (deterministic).  Returns true for the C threads that hold the totals.
+__device__ __forceinline__ bool reduce_partials(const double* __restrict__ part, int blocks, int C, double& s1, double& s2) {
+  __shared__ double red[2][256];
+  const int G = 256 / C, c = threadIdx.x % C, g = threadIdx.x / C;
+  double a = 0.0, b2 = 0.0;
+  if (g < G)
+    for (int b = g; b < blocks; b += G) { a += part[((int64_t)b * 2 + 0) * C + c]; b2 += part[((int64_t)b * 2 + 1) * C + c]; }
+  red[0][threadIdx.x] = a;
+  red[1][threadIdx.x] = b2;
+  __syncthreads();
+  s1 = s2 = 0.0;
+  if (threadIdx.x >= C) return false;
+  for (int k = 0; k < G; ++k) { s1 += red[0][k * C + threadIdx.x]; s2 += red[1][k * C + threadIdx.x]; }
+  return true;
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ part, int blocks, int C, int64_t n, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ batch_stats) {
+  double s1, s2;
+  if (!reduce_partials(part, blocks, C, s1, s2)) return;
   const int c = threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < blocks; ++b) { s1 += part[((int64_t)b * 2 + 0) * C + c]; s2 += part[((int64_t)b * 2 + 1) * C + c]; }
   const double mean = s1 / (double)n;
   double var = s2 / (double)n - mean * mean;      // biased (what the normalisation uses)
   if (var < 0.0) var = 0.0;
@@ -105,10 +121,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int blocks, int C, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta) {
+  double s1, s2;
+  if (!reduce_partials(part, blocks, C, s1, s2)) return;
   const int c = threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < blocks; ++b) { s1 += part[((int64_t)b * 2 + 0) * C + c]; s2 += part[((int64_t)b * 2 + 1) * C + c]; }
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
 }
@@ -146,7 +161,7 @@ extern "C" int surf_bn_relu_backward(const float* x, const float* dy, int64_t n,
     case 64: hipLaunchKernelGGL(bn_bwd_partial_kernel<64>, dim3(blocks), dim3(256), 0, s, x, dy, n, scale, shift, mean, invstd, part); break;
     default: return SURF_E_LIMIT;
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(64), 0, s, part, blocks, channels, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, part, blocks, channels, dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n * channels + 255) / 256)), dim3(256), 0, s, x, dy, n, channels,
                      scale, shift, mean, invstd, dgamma, dbeta, train, dx);
   return surf_check_launch();
@@ -170,7 +185,7 @@ extern "C" int surf_bn_train_affine(const float* x, int64_t n, int channels, con
     case 64: hipLaunchKernelGGL(bn_partial_kernel<64>, dim3(blocks), dim3(256), 0, s, x, n, part); break;
     default: return SURF_E_LIMIT;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(64), 0, s, part, blocks, channels, n, gamma, beta, eps, momentum,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, part, blocks, channels, n, gamma, beta, eps, momentum,
                      running_mean, running_var, scale, shift, batch_stats);
   return surf_check_launch();
 }

@@ -2,9 +2,10 @@
 //     dW[k][ci][co] = sum over output sites i whose offset-k neighbour j exists of  x[j][ci] * dy[i][co]
 // (the input gradient of a sparse convolution is itself a sparse convolution - submanifold with mirrored offsets, stride-2
 // down <-> transposed up - with the transposed kernel slices, so it runs on spconv.hip's kernels: ops.spconv_backward).
-// One workgroup sweeps tiles of 64 output sites; per kernel offset the 64 gathered input rows and the 64 dy rows sit in LDS and
-// every thread owns C_in C_out / 256 entries of that offset's slice, accumulated in registers over the workgroup's tiles and
-// added to dW with one float atomic per entry and workgroup.
+// One workgroup sweeps tiles of 64 (wide layers) or 256 (thin layers) output sites; per kernel offset the gathered input rows and
+// the dy rows sit in LDS and every thread owns C_in C_out / 256 entries of that offset's slice (thin layers: one entry on a
+// 1/G share of the tile's sites), accumulated in registers over the workgroup's tiles and added to dW with one float atomic per
+// entry and workgroup.
 #include "common.h"
 
 namespace {
@@ -24,12 +25,18 @@ struct WgArgs {
 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgArgs a) {
-  constexpr int TS = 64;                         // output sites per tile
-  constexpr int PER = (CIN * COUT + 255) / 256;  // dW entries per thread
+  constexpr int O = CIN * COUT;
+  constexpr int TS = (CIN + COUT <= 48) ? 256 : 64;   // output sites per tile (LDS: TS (CIN + COUT + 2) floats)
+  constexpr int PER = O >= 256 ? O / 256 : 1;         // dW entries per thread
+  constexpr int G = O >= 256 ? 1 : 256 / O;           // site groups sharing one entry (thin layers: every thread has work)
+  static_assert(O >= 256 ? O % 256 == 0 : 256 % O == 0, "CIN * COUT must divide or be a multiple of 256");
   __shared__ float xs[TS][CIN + 1], ds[TS][COUT + 1];
   __shared__ int rows[TS];
+  __shared__ float red[256];
   const int D = a.Din;
   const int64_t n_tiles = (a.n_out + TS - 1) / TS;
+  const int g = O >= 256 ? 0 : threadIdx.x / O;
+  const int e0 = O >= 256 ? threadIdx.x : threadIdx.x % O;
   for (int k = 0; k < 27; ++k) {
     const int ox = k % 3 - 1, oy = (k / 3) % 3 - 1, oz = k / 9 - 1;
     float acc[PER];
@@ -37,8 +44,8 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgArgs a) {
     for (int e = 0; e < PER; ++e) acc[e] = 0.f;
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
       __syncthreads();
-      if (threadIdx.x < TS) {
-        const int64_t i = tile * TS + threadIdx.x;
+      for (int t = threadIdx.x; t < TS; t += 256) {
+        const int64_t i = tile * TS + t;
         int row = -1;
         if (i < a.n_out) {
           const int cx = a.out_coords[i * 3 + 0], cy = a.out_coords[i * 3 + 1], cz = a.out_coords[i * 3 + 2];
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgArgs a) {
           ok = ok && x >= 0 && x < D && y >= 0 && y < D && z >= 0 && z < D;
           if (ok) row = a.in_table[((int64_t)x * D + y) * D + z];
         }
-        rows[threadIdx.x] = row;
+        rows[t] = row;
       }
       __syncthreads();
       for (int e = threadIdx.x; e < TS * CIN; e += 256) {
@@ -69,20 +76,27 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgArgs a) {
       __syncthreads();
 #pragma unroll
       for (int e = 0; e < PER; ++e) {
-        const int idx = threadIdx.x + 256 * e;
-        if (idx < CIN * COUT) {
-          const int ci = idx / COUT, co = idx % COUT;
-          float s = acc[e];
+        const int idx = e0 + 256 * e;
+        const int ci = idx / COUT, co = idx % COUT;
+        float s = acc[e];
 #pragma unroll 8
-          for (int t = 0; t < TS; ++t) s = fmaf(xs[t][ci], ds[t][co], s);
-          acc[e] = s;
-        }
+        for (int t = g; t < TS; t += G) s = fmaf(xs[t][ci], ds[t][co], s);
+        acc[e] = s;
       }
     }
+    if (O >= 256) {
 #pragma unroll
-    for (int e = 0; e < PER; ++e) {
-      const int idx = threadIdx.x + 256 * e;
-      if (idx < CIN * COUT && acc[e] != 0.f) atomicAdd(a.dW + (int64_t)k * CIN * COUT + idx, acc[e]);
+      for (int e = 0; e < PER; ++e)
+        if (acc[e] != 0.f) atomicAdd(a.dW + (int64_t)k * O + e0 + 256 * e, acc[e]);
+    } else {
+      __syncthreads();
+      red[threadIdx.x] = acc[0];
+      __syncthreads();
+      if (threadIdx.x < O) {
+        float t = 0.f;
+        for (int q = 0; q < G; ++q) t += red[q * O + threadIdx.x];
+        if (t != 0.f) atomicAdd(a.dW + (int64_t)k * O + threadIdx.x, t);
+      }
     }
   }
 }
@@ -96,8 +110,9 @@ extern "C" int surf_spconv_wgrad(const float* x, int cin, const int32_t* in_tabl
   if (!x || !in_table || !out_coords || !dy || !dW || n_out <= 0 || D_in < 1 || mode < 0 || mode > 2) return SURF_E_ARG;
   WgArgs a;
   a.x = x; a.in_table = in_table; a.Din = D_in; a.out_coords = out_coords; a.n_out = n_out; a.mode = mode; a.dy = dy; a.dW = dW;
-  const int64_t tiles = (n_out + 63) / 64;
-  const unsigned grid = (unsigned)(tiles < 512 ? tiles : 512);
+  const int ts = (cin + cout <= 48) ? 256 : 64;
+  const int64_t tiles = (n_out + ts - 1) / ts;
+  const unsigned grid = (unsigned)(tiles < 1024 ? tiles : 1024);
 #define X(CI, CO)                                                                                              \
   if (cin == CI && cout == CO) {                                                                               \
     hipLaunchKernelGGL((spconv_wgrad_kernel<CI, CO>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);        \

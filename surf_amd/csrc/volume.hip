@@ -419,6 +419,8 @@ struct CostVolBwdArgs {
 };
 
 __global__ __launch_bounds__(256) void costvol_bwd_kernel(CostVolBwdArgs a) {
+  // voxels in lattice order: neighbouring threads hit neighbouring texels (a strided order that spreads the atomics over the
+  // maps measured 30 % slower - the kernel is bound by the locality of its gathers and atomics, not by same-line contention)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i < a.n;
   float gacc[49];
@@ -512,6 +514,7 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(CostVolBwdArgs a) {
             }
           }
         }
+        if (df[0] == 0.f && df[1] == 0.f && df[2] == 0.f && df[3] == 0.f) continue;   // views outside the frustum
         for (int l = a.stage; l < 4; ++l) {
           const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
           bilinear_texel4_scatter(a.gfeats[l] + (int64_t)v * H * W * 4, H, W, unnorm_act(nxv[v], W), unnorm_act(nyv[v], H), df);

@@ -235,8 +235,8 @@ class SuRF(nn.Module):
             cams = ops._cams_ext(ops.Cameras(intrs, c2ws), intrs, c2ws)
             fpn_tape, vol_tape = ([], []) if record else (None, None)
             features = self.feature_network(imgs, tape=fpn_tape)                # texel4, coarse -> fine
-            outputs, volumes, tables, mvol = self.build_volumes(ipts, features, cams, perturb=(mode == "train"),
-                                                                tape=vol_tape)                                      # surf.py:139
+            outputs, volumes, tables, mvol = self.build_volumes(ipts, features, cams, perturb=(mode == "train"), tape=vol_tape,
+                                                                logit_override=getattr(self, "logit_override", None))  # surf.py:139
             if record:
                 self._train_tape = dict(fpn=fpn_tape, vol=vol_tape, feats=features, cams=cams, near_fars=ipts["near_fars"],
                                         hw=tuple(imgs.shape[-2:]), src_idx=int(ipts["src_idx"]) if "src_idx" in ipts else 0)
