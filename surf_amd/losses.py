@@ -1,11 +1,13 @@
-"""Host-side mirror of the reference's training loss (models/losses/loss.py:10-111), forward values only.
+"""Host-side mirror of the reference's training loss (models/losses/loss.py:10-111).
 
 Same constructor keys (`confs/surf.conf:49-63`), same `forward(preds, targets, step, mode)` and the same output dictionary.
 Most terms are scalar reductions of the hot path's outputs; the two with real work run in HIP: the local NCC of the
 surface patches (`compute_LNCC2`, losses/ncc.py:7-51 -> `surf_lncc`, csrc/lncc.hip) and the per-stage photometric term
 (`compute_ptloss`, losses/photometric_loss.py:54-125: inverse warping of the source images by the matching-field depths,
-SSIM + smooth-L1 + gradient -> `surf_ptloss_terms`, csrc/ptloss.hip).  NOT built: every backward pass -
-nothing here is differentiable.
+SSIM + smooth-L1 + gradient -> `surf_ptloss_terms`, csrc/ptloss.hip).  The scalar terms are plain torch ops on the hot
+path's outputs: `surf_amd.training` differentiates them with torch autograd on leaf copies of those outputs and feeds the
+results to the HIP backward kernels; the two HIP terms have their own backward entries (`surf_lncc_jvp`,
+`surf_ptloss_backward`).
 """
 import torch
 import torch.nn as nn
