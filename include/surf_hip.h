@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 22
+#define SURF_ABI_VERSION 23
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -162,12 +162,14 @@ int surf_colgram(const float* A, int ldA, int M, const float* X, int ldX, int N,
  * rows (n, nv-1, surf_blend_backward_row_floats()): per (sample, view) the INPUT vector and the pre-activation ADJOINT of
  * each of the 11 linear layers (column layout in blend_bwd.hip); dW = adj^T in, db = sum adj.  ds (n): per-sample d/d s.
  * color (n,3), optional: the recomputed forward colour.  raw_weights: DEVICE copy of the raw parameter buffer
- * (surf_blend_raw_floats(), state_dict order).  Gradients into the feature maps are not produced.
+ * (surf_blend_raw_floats(), state_dict order).  h_gfeats_t4 (may be NULL): four texel4 maps like h_feats_t4 that ACCUMULATE
+ * the gradient of the sampled feature channels (generalisation training: the FPN's share of the colour loss).
  */
 int surf_blend_backward_row_floats(void);
 int surf_blend_backward(const float* pts, const int32_t* idx, int64_t n, const float* gcolor, const float* const* h_feats_t4,
                         const int* h_feat_hw, const float* imgs_t4, int nv, const float* h_intrs, const float* h_w2c,
-                        const float* h_c2w, const float* raw_weights, float* rows, float* ds, float* color, void* stream);
+                        const float* h_c2w, const float* raw_weights, float* rows, float* ds, float* color,
+                        float* const* h_gfeats_t4, void* stream);
 
 /*
  * Local normalised cross-correlation of the surface patches: out (n_rays) = mean of the two smallest per-view values of

@@ -5,8 +5,10 @@
 // cross-view couplings (softmax over views, weighted mean / variance, the normalised anti-aliasing weights and their min)
 // in between.  For every linear layer the kernel writes, per (sample, view), the layer's INPUT vector and the ADJOINT of its
 // pre-activation into one row of `rows`; the caller forms dW = adj^T in, db = sum adj as small GEMMs (rocBLAS through
-// torch.matmul) and gets d|s| from `ds` (per-sample partials).  Gradients w.r.t. the fetched features / colours (i.e. into
-// the FPN) and w.r.t. the sample position are NOT produced: the feature maps are frozen in the reference's finetune mode.
+// torch.matmul) and gets d|s| from `ds` (per-sample partials).  The adjoint of the fetched feature channels (f = rgb_feat +
+// dfeat: channels 3..18 of the adjoint of f) is scattered through the bilinear taps into `gfeats` when given (generalisation
+// training: the FPN receives gradient from the colour path, surf.py:139-146); the source images' and the sample position's
+// gradients are not produced (nothing trainable lies behind them).
 #include "blend_raw.h"
 #include "common.h"
 
@@ -45,6 +47,7 @@ struct BbArgs {
   float* rows;             // (n, nv-1, ROW)
   float* ds;               // (n) per-sample d loss / d s
   float* color;            // (n, 3) recomputed forward colour (check against surf_blend), may be null
+  float* gfeats[4];        // gradients of the feature maps (texel4, like feats; accumulated by float atomics) or null
 };
 
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expf(x) - 1.0f; }
@@ -346,6 +349,39 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(BbArgs a) {
     sb = wave_sum(sb);
     if (lane == 0) a.ds[s] = sb * (w[R_S] < 0.f ? -1.0f : 1.0f);
   }
+  // ---- the fetched features' share of the adjoint of f -> the FPN maps (lane = view-in-chunk x level x tap, 4 channels each) ----
+  __syncthreads();
+  if (a.gfeats[0]) {
+    for (int v0 = 0; v0 < V; v0 += 4) {
+      const int v = v0 + (lane >> 4), lv = (lane >> 2) & 3, tap = lane & 3;
+      if (v < V) {
+        const int cam = v + 1;
+        const float* M = a.w2c[cam];
+        const float X = M[0] * px + M[1] * py + M[2] * pz + M[3];
+        const float Y = M[4] * px + M[5] * py + M[6] * pz + M[7];
+        const float Z = M[8] * px + M[9] * py + M[10] * pz + M[11];
+        const float* K = a.K[cam];
+        const float qx = K[0] * X + K[1] * Y + K[2] * Z, qy = K[3] * X + K[4] * Y + K[5] * Z, qz = K[6] * X + K[7] * Y + K[8] * Z;
+        float sc = 1.0f;
+        for (int q = 0; q < lv; ++q) sc *= 0.5f;
+        const int H = a.hw[2 * lv], W = a.hw[2 * lv + 1];
+        const float u = (qx / qz) * sc, vv = (qy / qz) * sc;
+        const float nx = u / ((float)(W - 1) / 2.0f) - 1.0f, ny = vv / ((float)(H - 1) / 2.0f) - 1.0f;
+        const float gx = ((nx + 1.0f) * (float)W - 1.0f) / 2.0f, gy = ((ny + 1.0f) * (float)H - 1.0f) / 2.0f;
+        const float fx = floorf(gx), fy = floorf(gy);
+        const int xi = (int)fx + (tap & 1), yi = (int)fy + (tap >> 1);
+        const float wgt = ((tap & 1) ? gx - fx : 1.0f - (gx - fx)) * ((tap >> 1) ? gy - fy : 1.0f - (gy - fy));
+        if ((xi >= 0) & (xi < W) & (yi >= 0) & (yi < H) && wgt != 0.f) {
+          float* dst = a.gfeats[lv] + (((int64_t)cam * H + yi) * W + xi) * 4;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float g = L[v][F_FB + 3 + 4 * lv + c] * wgt;
+            if (g != 0.f) atomicAdd(dst + c, g);
+          }
+        }
+      }
+    }
+  }
   // ---- reverse A: f = f0 + elu(dfpre) --------------------------------------------------------------------------------------------
   __syncthreads();
   for (int v = 0; v < V; ++v) {
@@ -369,7 +405,7 @@ extern "C" int surf_blend_backward_row_floats(void) { return ROW; }
 extern "C" int surf_blend_backward(const float* pts, const int32_t* idx, int64_t n, const float* gcolor,
                                    const float* const* h_feats_t4, const int* h_feat_hw, const float* imgs_t4, int nv,
                                    const float* h_intrs, const float* h_w2c, const float* h_c2w, const float* raw_weights,
-                                   float* rows, float* ds, float* color, void* stream) {
+                                   float* rows, float* ds, float* color, float* const* h_gfeats_t4, void* stream) {
   if (!pts || !gcolor || !h_feats_t4 || !h_feat_hw || !imgs_t4 || !h_intrs || !h_w2c || !h_c2w || !raw_weights || !rows || !ds)
     return SURF_E_ARG;
   if (n <= 0 || nv < 2) return SURF_E_ARG;
@@ -382,6 +418,8 @@ extern "C" int surf_blend_backward(const float* pts, const int32_t* idx, int64_t
     a.feats[l] = h_feats_t4[l];
     a.hw[2 * l] = h_feat_hw[2 * l];
     a.hw[2 * l + 1] = h_feat_hw[2 * l + 1];
+    a.gfeats[l] = h_gfeats_t4 ? h_gfeats_t4[l] : nullptr;
+    if (h_gfeats_t4 && !h_gfeats_t4[l]) return SURF_E_ARG;
   }
   for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
     const int sidx = v < nv ? v : 0;

@@ -300,7 +300,7 @@ class ImplicitSurface(nn.Module):
         return out
 
     @torch.no_grad()
-    def backward_render(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None):
+    def backward_render(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None, gfeats_t4=None):
         """Partial backward of the last training forward (`render_scene(patch_warp=True)`), SURVEY 8f-f2: given the loss's
         gradients w.r.t. `color_fine` (R,3), `render_depth` (R), `gradient_error` (scalar), `sparse_sdf` ((1024 + R*S),1) and
         the per-ray patch NCC (R,1) (= compute_LNCC2 of ref_gray_val / sampled_gray_val, the mfc term),
@@ -309,8 +309,9 @@ class ImplicitSurface(nn.Module):
         coarse, (N_s, 7).  Kernels: surf_composite_backward -> surf_sdf_backward (reverse over forward: the spatial-gradient
         upstream is a tangent direction), surf_blend_backward, and for the NCC term surf_patch_warp_tangent -> surf_lncc_jvp ->
         surf_crossing_backward (d ncc / d z0 as a forward-mode tangent along the ray, then into the two bracketing samples).
-        NOT differentiated (so far): the FPN feature maps behind the colour network, the smooth (H.1) term, the volume build -
-        what the reference's finetune mode (has_vol) trains is covered except for that one loss term (weight 1e-4)."""
+        gfeats_t4 (fine -> coarse, like the scene's feature maps): accumulates the colour path's gradient into the FPN maps
+        (generalisation training).  NOT differentiated: the smooth (H.1) term (weight 1e-4); the volume build's backward is
+        SuRF.backward_volumes."""
         c = self._ctx
         st, act, scene = c["st"], c["act"], c["scene"]
         dev = c["sdf"].device
@@ -343,7 +344,7 @@ class ImplicitSurface(nn.Module):
                 lin.bias.grad = res["bias"][l] if lin.bias.grad is None else lin.bias.grad + res["bias"][l]
         cn = dict(self.color_network.named_parameters())     # raw parameter buffer in state_dict order, built on the device
         raw_w = torch.cat([cn[k].detach().reshape(-1).float() for k in ops.BLEND_KEYS]).contiguous()
-        gb = ops.blend_backward(st["pts"], act, d_col, scene.feats_t4, scene.imgs_t4, scene.cams, raw_w)
+        gb = ops.blend_backward(st["pts"], act, d_col, scene.feats_t4, scene.imgs_t4, scene.cams, raw_w, gfeats_t4=gfeats_t4)
         for name, p in self.color_network.named_parameters():
             gp = gb[name].reshape(p.shape).to(p.dtype)
             p.grad = gp if p.grad is None else p.grad + gp

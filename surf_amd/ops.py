@@ -400,9 +400,10 @@ _BLEND_LAYERS = [  # (state_dict prefix, in, out, IN column, ADJ column) of surf
     ("rgb_fc.0", 37, 16, 498, 535), ("rgb_fc.2", 16, 8, 551, 567), ("rgb_fc.4", 8, 1, 575, 583)]
 
 
-def blend_backward(pts, active_idx, gcolor, feats_t4, imgs_t4, cams, raw_weights, want_color=False):
+def blend_backward(pts, active_idx, gcolor, feats_t4, imgs_t4, cams, raw_weights, want_color=False, gfeats_t4=None):
     """Gradients of sum_n gcolor_n . colour_n w.r.t. the blending network's parameters (surf_blend_backward; the batch
     reductions are small GEMMs through torch.matmul).  raw_weights: device tensor of blend_raw_weights(sd).
+    gfeats_t4: four texel4 maps shaped like feats_t4 that accumulate the gradient of the sampled feature channels.
     Returns {state_dict name: gradient} (+ "_color": the recomputed colours of the active samples, if asked)."""
     _chk(pts, torch.float32, "pts")
     _chk(gcolor, torch.float32, "gcolor")
@@ -421,7 +422,8 @@ def blend_backward(pts, active_idx, gcolor, feats_t4, imgs_t4, cams, raw_weights
         intr16 = np.ascontiguousarray(cams.intrs.reshape(cams.nv, -1))
         rc = _lib.lib().surf_blend_backward(_p(pts), _p(active_idx), n, _p(gcolor), _ptr_array(list(feats_t4)), hw, _p(imgs_t4),
                                             cams.nv, _np_ptr(intr16), _np_ptr(cams.w2c), _np_ptr(cams.c2w), _p(raw_weights),
-                                            _p(rows), _p(ds), _p(color), _stream())
+                                            _p(rows), _p(ds), _p(color),
+                                            None if gfeats_t4 is None else _ptr_array(list(gfeats_t4)), _stream())
         _lib.check(rc, "surf_blend_backward")
     flat = rows[:n].reshape(-1, ROW)
     for name, cin, cout, c_in, c_ad in _BLEND_LAYERS:

@@ -98,7 +98,11 @@ class SuRF(nn.Module):
         """Partial backward of the last train-mode forward (row f2): `.grad` of every implicit-surface parameter and, in
         finetune mode (has_vol), of the per-scene feature volumes - what surf.py:36-45 hands the optimiser there.  See
         ImplicitSurface.backward_render for what is not differentiated yet (FPN / volume build, the smooth term)."""
-        dvols = self.implicit_surface.backward_render(g_color, g_depth, g_gradient_error, g_sparse_sdf, g_ncc)
+        gfeats = None
+        if getattr(self, "_train_tape", None) is not None:       # volume-building model: the colour path's share of d FPN maps
+            self._train_tape["gfeats"] = [torch.zeros_like(f) for f in self._train_tape["feats"]]      # coarse -> fine
+            gfeats = self._train_tape["gfeats"][::-1]
+        dvols = self.implicit_surface.backward_render(g_color, g_depth, g_gradient_error, g_sparse_sdf, g_ncc, gfeats_t4=gfeats)
         if self.has_vol:
             for p, g in zip(self.volumes, dvols[::-1]):          # volumes are kept coarse -> fine
                 g = g.to(p.dtype)
@@ -112,8 +116,8 @@ class SuRF(nn.Module):
         d loss / d depth_src_stage{s} or None)}.  Accumulates `.grad` of every parameter of reg_network, volume.agg_mlp and
         feature_network.  Per stage, fine -> coarse: matching-field backward -> densify backward (-> the coarser matching
         volume) -> sparse U-Net backward -> cost-volume backward (-> FPN maps, agg_mlp) and the parent-feature scatter
-        (-> the coarser stage's `mid` rows); then the FPN backward.  Not propagated: the colour path's gradient into the
-        FPN maps the blending network samples (rendering_network inputs), the voxel selections, the detached depths."""
+        (-> the coarser stage's `mid` rows); then the FPN backward on the maps' total gradient (cost volumes + the colour
+        path's share that `SuRF.backward` accumulated).  Not differentiable: the voxel selections, the detached depths."""
         t = self._train_tape
         if t is None:
             raise RuntimeError("backward_volumes needs forward('train', ..., record=True) of a volume-building model first")
@@ -123,7 +127,7 @@ class SuRF(nn.Module):
         dev = feats[0].device
         nv = feats[0].shape[0]
         H, W = t["hw"]
-        gfeats = [torch.zeros_like(f) for f in feats]
+        gfeats = t.pop("gfeats", None) or [torch.zeros_like(f) for f in feats]     # SuRF.backward leaves the colour path's share
         g_agg = torch.zeros(49, dtype=torch.float32, device=dev)
         n = self.num_stage
         d_mvol, d_mid = None, None

@@ -9,8 +9,7 @@ terms through torch autograd on the depth maps, the photometric term through `su
 surf.py:36-45 receives its gradient.
 
 Differentiated terms: colour, eikonal, sparse-SDF, rendered-depth, the patch-NCC term (`mfc_loss`), the per-stage
-photometric and pseudo-depth terms.  NOT differentiated: the smooth term (H.1, weight 1e-4) and the colour path's gradient
-into the FPN maps the blending network samples.
+photometric and pseudo-depth terms.  NOT differentiated: the smooth term (H.1, weight 1e-4).
 """
 import torch
 

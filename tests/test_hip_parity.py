@@ -946,12 +946,14 @@ def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
     g_sparse = torch.randn(1024 + R * S, 1, generator=g) * 0.01
     g_ncc = torch.randn(R, 1, generator=g) * 0.2 * out["mid_inside_sphere"].cpu()
     assert float(g_ncc.abs().sum()) > 0
-    dvols = model.backward_render(g_color.to(d), g_depth.to(d), g_eik, g_sparse.to(d), g_ncc.to(d))
+    gfeats = [torch.zeros_like(f) for f in gpu_scene["feats_t4"]]          # fine -> coarse: the colour path's share of d FPN maps
+    dvols = model.backward_render(g_color.to(d), g_depth.to(d), g_eik, g_sparse.to(d), g_ncc.to(d), gfeats_t4=gfeats)
     # oracle autograd
     c = gpu_scene["cpu"]
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in weights.items() if k.startswith("implicit_surface.")}
     vols = [v.clone().requires_grad_(True) for v in c["vols"]]
-    o = O.render(sd, scene["rays_o"], scene["rays_d"], near, far, c["mvol"], vols, c["tabs"], c["masks"], c["feats"], scene["imgs"],
+    feats_g = [f.clone().requires_grad_(True) for f in c["feats"]]
+    o = O.render(sd, scene["rays_o"], scene["rays_d"], near, far, c["mvol"], vols, c["tabs"], c["masks"], feats_g, scene["imgs"],
                  scene["intrs"], scene["c2ws"], CFG["n_samples"], CFG["sample_ranges"], CFG["n_depth"], 0.6, patch_warp=True)
     torch.manual_seed(33)
     pr = torch.rand([1024, 3]) * 2 - 1
@@ -974,6 +976,9 @@ def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
         rel_close(got, ref, 5e-3, 5e-4 * float(ref.abs().max()) + 1e-7)
     for lvl, v in enumerate(vols):
         rel_close(dvols[lvl], v.grad, 5e-3, 5e-4 * float(v.grad.abs().max()))
+    for lvl, f in enumerate(feats_g):                                       # view 0 is the reference view: never sampled
+        assert float(f.grad.abs().max()) > 0 and float(f.grad[0].abs().max()) == 0.0
+        rel_close(gfeats[lvl].permute(0, 3, 1, 2), f.grad, 5e-3, 5e-4 * float(f.grad.abs().max()))
 
 
 def test_adam_steps_on_the_implicit_surface_reduce_the_loss(scene, weights, gpu_scene):
