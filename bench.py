@@ -216,6 +216,55 @@ def volume_build_timing(args, dev):
     return res
 
 
+def training_step_setup(dev, H=576, W=800, nv=5, base_dim=88, rays=512, device_jitter=True):
+    """A volume-building SuRF in train mode on the synthetic scene + the inputs / loss targets of one training step
+    (runner.py:150-166).  Weights are random-init, so the analytic sphere logit replaces the U-Net's matching logit in the
+    forward (as in volume_build_timing); the backward still runs through every kernel."""
+    from surf_amd import conf, synthetic
+    from surf_amd.losses import Loss
+    from surf_amd.surf import SuRF
+    torch.manual_seed(0)
+    model = SuRF(conf.from_dict(surf_conf(base_dim))).to(dev).train()
+    model.logit_override = synthetic.sphere_logit
+    model.matching_field.device_jitter = device_jitter      # False: the reference's CPU-generator draw (host-bound)
+    intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
+    imgs = synthetic.procedural_images(nv, H, W, 0, dev)
+    rays_o, rays_d = synthetic.pixel_rays(intrs[0], c2ws[0], H, W, 1, dev)
+    sel = torch.randperm(rays_o.shape[0], device=dev)[:rays]
+    ipts = {"imgs": imgs, "intrs": intrs.to(dev), "c2ws": c2ws.to(dev), "near_fars": near_fars.to(dev),
+            "near": near_fars[0, 0].reshape(1, 1).to(dev), "far": near_fars[0, 1].reshape(1, 1).to(dev),
+            "rays_o": rays_o[sel].contiguous(), "rays_d": rays_d[sel].contiguous(), "src_idx": 1}
+    ones = torch.ones(H, W, device=dev)
+    targets = {"color": torch.rand(rays, 3, device=dev), "imgs": imgs, "intrs": intrs, "c2ws": c2ws, "src_idx": 1,
+               "mask_ref": ones, "mask_src": ones, "pseudo_depth_ref": ones * 2.0, "pseudo_depth_src": ones * 2.0,
+               "depth_ref": ones * 2.0, "depth_src": ones * 2.0}
+    loss_fn = Loss(conf.from_dict({"color_weight": 1.0, "sparse_scale_factor": 100, "sparse_weight": 0.02, "igr_weight": 0.1,
+                                   "mfc_weight": 0.5, "smooth_weight": 0.0, "depth_weight": 0.0, "ptloss_weight": 1.0,
+                                   "pseudo_auxi_depth_weight": 1.0, "pseudo_sdf_weight": 0.0, "pseudo_depth_weight": 0.0,
+                                   "stage_weights": [0.25, 0.5, 0.75, 1.0]}))
+    opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}))
+    return model, ipts, targets, loss_fn, opt
+
+
+def training_step_timing(args, dev, steps=3):
+    """Wall time of one full training step (forward with tapes -> loss -> HIP backward of the render, the 4-stage volume
+    build and the FPN -> Adam) on the bench scene, reported beside the render metric."""
+    from surf_amd import training
+    model, ipts, targets, loss_fn, opt = training_step_setup(dev, args.height, args.width, args.views, args.base_dim)
+    for _ in range(2):
+        out = training.train_step(model, ipts, targets, loss_fn, opt, 1.0, 3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = training.train_step(model, ipts, targets, loss_fn, opt, 1.0, 3)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": ms, "rays": int(ipts["rays_o"].shape[0]), "samples_per_ray": 128,
+            "voxels_per_stage": [int(r["coords"].shape[0]) for r in model._train_tape["vol"]],
+            "loss": out["loss"], "what": "forward (FPN, volume build, render) + loss + HIP backward of all of it + Adam; "
+                                         "smooth term excluded; matching-field jitter on the device generator"}
+
+
 def mesh_grid_timing(model, scene, dev, resolution):
     """The lattice of extract_geometry (implicit_surface.py:337-351, row a16): resolution^3 forward-only SDF
     evaluations, timed end to end and per kernel launch (HIP events)."""
@@ -289,6 +338,7 @@ def parse_args(argv):
     ap.add_argument("--n-samples", type=str, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline (0 = skip)")
     ap.add_argument("--build", type=int, default=1, help="also time one full volume build (FPN + 4 stages), N=1 only")
+    ap.add_argument("--train-step", type=int, default=1, help="also time one full training step (N=1, dtu workload)")
     ap.add_argument("--mesh-grid", type=int, default=512, help="also time the resolution^3 SDF lattice of "
                                                                "extract_geometry (0 = skip), N=1 only")
     ap.add_argument("--sdf-precision", default="bf16x3", choices=sorted(SDF_KERNELS),
@@ -587,6 +637,8 @@ def run_rank(args):
         if world == 1 and args.build and args.workload == "dtu":
             sc0["cpu"] = None
             result["volume_build"] = volume_build_timing(args, dev)
+        if world == 1 and args.train_step and args.workload == "dtu":
+            result["training_step"] = training_step_timing(args, dev)
         print(json.dumps(result))
     if world > 1:
         torch.distributed.destroy_process_group()

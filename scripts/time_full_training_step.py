@@ -5,33 +5,13 @@ the forward (as in bench.py's volume-build timing) so that the voxel pyramid is 
 network produces; the backward still runs through every kernel."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from surf_amd import synthetic, ops, conf, training
-from surf_amd.losses import Loss
-from surf_amd.surf import SuRF
-from bench import surf_conf
+from surf_amd import ops, training
+
+from bench import training_step_setup
 
 dev = torch.device("cuda:0")
 nv, H, W, R = 5, 576, 800, int(sys.argv[1]) if len(sys.argv) > 1 else 512
-torch.manual_seed(0)
-model = SuRF(conf.from_dict(surf_conf(88))).to(dev).train()
-model.logit_override = synthetic.sphere_logit
-model.matching_field.device_jitter = os.environ.get("SURF_CPU_JITTER", "0") != "1"   # reference draws on the CPU generator
-intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
-imgs = synthetic.procedural_images(nv, H, W, 0, dev)
-rays_o, rays_d = synthetic.pixel_rays(intrs[0], c2ws[0], H, W, 1, dev)
-sel = torch.randperm(rays_o.shape[0], device=dev)[:R]
-ipts = {"imgs": imgs, "intrs": intrs.to(dev), "c2ws": c2ws.to(dev), "near_fars": near_fars.to(dev),
-        "near": near_fars[0, 0].reshape(1, 1).to(dev), "far": near_fars[0, 1].reshape(1, 1).to(dev),
-        "rays_o": rays_o[sel].contiguous(), "rays_d": rays_d[sel].contiguous(), "src_idx": 1}
-ones = torch.ones(H, W, device=dev)
-targets = {"color": torch.rand(R, 3, device=dev), "imgs": imgs, "intrs": intrs, "c2ws": c2ws, "src_idx": 1, "mask_ref": ones,
-           "mask_src": ones, "pseudo_depth_ref": ones * 2.0, "pseudo_depth_src": ones * 2.0, "depth_ref": ones * 2.0,
-           "depth_src": ones * 2.0}
-loss_fn = Loss(conf.from_dict({"color_weight": 1.0, "sparse_scale_factor": 100, "sparse_weight": 0.02, "igr_weight": 0.1,
-                               "mfc_weight": 0.5, "smooth_weight": 0.0, "depth_weight": 0.0, "ptloss_weight": 1.0,
-                               "pseudo_auxi_depth_weight": 1.0, "pseudo_sdf_weight": 0.0, "pseudo_depth_weight": 0.0,
-                               "stage_weights": [0.25, 0.5, 0.75, 1.0]}))
-opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}))
+model, ipts, targets, loss_fn, opt = training_step_setup(dev, H, W, nv, 88, R, device_jitter=os.environ.get("SURF_CPU_JITTER", "0") != "1")
 
 # instrument the phases with HIP events by wrapping the model's entry points
 marks = []

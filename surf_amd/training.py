@@ -13,7 +13,14 @@ photometric and pseudo-depth terms.  NOT differentiated: the smooth term (H.1, w
 """
 import torch
 
-from . import ops
+from . import dist, ops
+
+
+def _sync_gradients(optimizer):
+    """Data-parallel step (one process per GPU, runner.py's DDP): average the gradients over the ranks with bucketed
+    all-reduces (RCCL on GPUs, gloo in the CPU tests) before the optimiser step.  No-op for a single process."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        dist.all_reduce_gradients([p for g in optimizer.param_groups for p in g["params"]])
 
 LEAVES = ("color_fine", "render_depth", "gradient_error", "sparse_sdf", "ncc")
 
@@ -29,6 +36,7 @@ def finetune_step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio=1.0
     g = {k: v.grad for k, v in leaves.items()}
     model.backward(g["color_fine"], g["render_depth"], 0.0 if g["gradient_error"] is None else float(g["gradient_error"]),
                    g["sparse_sdf"], g["ncc"])
+    _sync_gradients(optimizer)
     optimizer.step()
     return {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in out.items()}
 
@@ -69,5 +77,6 @@ def train_step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio=1.0, s
     rows = model.backward(g["color_fine"], g["render_depth"], 0.0 if g["gradient_error"] is None else float(g["gradient_error"]),
                           g["sparse_sdf"], g["ncc"])
     model.backward_volumes(rows, g_depths)
+    _sync_gradients(optimizer)
     optimizer.step()
     return {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in out.items()}
