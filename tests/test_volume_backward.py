@@ -318,3 +318,77 @@ def test_train_steps_move_every_parameter_group(scene):
             moved[k.split(".")[0]] += 1
     assert all(c > 0 for c in moved.values()), moved
     assert moved["feature_network"] == 15 and moved["volume"] >= 3
+
+
+def test_seven_view_backward_kernels(weights):
+    """The Tanks&Temples view count (7 views = 6 sources, SURF_MAX_VIEWS - 1): the view loops of surf_costvol_backward,
+    surf_blend_backward (parameters + the feature maps' gradient, two chunks of four source views), surf_ptloss_backward and
+    surf_matching_depth_backward against autograd through the oracle on a synthetic ring of cameras."""
+    from surf_amd import ops, synthetic
+    d = dev()
+    nv, H, W = 7, 48, 64
+    intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
+    g = torch.Generator().manual_seed(8)
+    imgs = torch.rand(nv, 3, H, W, generator=g)
+    feats_c2f = [torch.randn(nv, 4, H >> (3 - l), W >> (3 - l), generator=g) * 0.5 for l in range(4)]
+    cams = ops._cams_ext(ops.Cameras(intrs, c2ws), intrs, c2ws)
+    feats_t4 = [ops.pack_texel4(f.to(d).contiguous()) for f in feats_c2f]
+    imgs_t4 = ops.pack_texel4(imgs.to(d).contiguous())
+
+    # cost volume, stage 1 (levels 1..3), a random sparse set of voxels
+    D, stage = 16, 1
+    coords = (torch.rand(D, D, D, generator=g) < 0.2).nonzero().to(torch.int32)
+    sd = {k: v.clone().requires_grad_(True) for k, v in weights.items() if k.startswith("volume.agg_mlp")}
+    fr = [f.clone().requires_grad_(True) for f in feats_c2f]
+    cv, _ = O.back_proj_multiscale(sd, fr, coords.float(), D, intrs, c2ws, stage)
+    G = torch.randn(cv.shape, generator=g)
+    (cv * G).sum().backward()
+    gfeats = [torch.zeros_like(f) for f in feats_t4]
+    g_agg = torch.zeros(49, device=d)
+    ops.costvol_backward(feats_t4, gfeats, stage, D, cams, ops.agg_mlp_host(weights), coords.to(d).contiguous(), G.to(d).contiguous(), g_agg)
+    for l in range(1, 4):
+        grad_close(gfeats[l].permute(0, 3, 1, 2), fr[l].grad)
+    grad_close(g_agg[:48], torch.cat([sd[f"volume.agg_mlp.{k}"].grad.reshape(-1) for k in ("0.weight", "0.bias", "2.weight")]))
+
+    # blending network: parameters and the sampled feature maps (fine -> coarse)
+    pts = (torch.rand(600, 3, generator=g) * 2 - 1) * 0.6
+    gcolor = torch.randn(600, 3, generator=g)
+    prefix = "implicit_surface.color_network."
+    sdc = {k: v.clone().requires_grad_(True) for k, v in weights.items() if k.startswith(prefix)}
+    f2c = [f.clone().requires_grad_(True) for f in feats_c2f[::-1]]
+    rf, rdiff, mval = O.lookup_feature(pts, imgs, intrs, c2ws, f2c)
+    assert int(mval.sum()) > 0
+    (O.blending(sdc, rf, rdiff, mval) * gcolor).sum().backward()
+    raw = torch.from_numpy(ops.blend_raw_weights(weights)).to(d)
+    gf = [torch.zeros_like(f) for f in feats_t4[::-1]]
+    res = ops.blend_backward(pts.to(d).contiguous(), None, gcolor.to(d).contiguous(), feats_t4[::-1], imgs_t4, cams, raw, gfeats_t4=gf)
+    for l in range(4):
+        grad_close(gf[l].permute(0, 3, 1, 2), f2c[l].grad, 5e-3)
+    for k, v in sdc.items():
+        name = k[len(prefix):]
+        if name == "s":
+            continue                                    # ill-conditioned in fp32 (test_blend_backward_matches_autograd)
+        ref = v.grad if v.grad is not None else torch.zeros_like(v)
+        grad_close(res[name].reshape(ref.shape), ref, 5e-3, 1e-2)
+
+    # photometric term with six sources
+    depth = torch.full((H, W), 2.4) + torch.rand(H, W, generator=g) * 0.2
+    mask = (torch.rand(H, W, generator=g) > 0.1).float()
+    dep = depth.clone().requires_grad_(True)
+    loss, _, _ = O.photometric_loss(dep, imgs, mask, intrs, c2ws, 3, 2)
+    loss.backward()
+    gd = ops.photometric_loss_backward(depth.to(d).contiguous(), imgs_t4, mask.to(d).contiguous(), ops.Cameras(intrs, c2ws), 3, 2, 1.0).cpu()
+    scale = float(dep.grad.abs().max())
+    bad = (gd - dep.grad).abs() > 5e-3 * dep.grad.abs() + 1e-3 * scale
+    assert float(bad.float().mean()) < 1e-2, int(bad.sum())
+
+    # matching field, stage 0, views 0 and 5
+    mvol = torch.randn(16, 16, 16, generator=g)
+    mv = mvol.clone().requires_grad_(True)
+    ratios, nsd, lv = [1.0, 0.4, 0.1, 0.01], [32, 16, 8, 8], [4, 2, 2, 1]
+    ref = O.matching_field((H, W), intrs, c2ws, near_fars, mv, 0, ratios, nsd, lv, None)
+    Gd = torch.zeros(nv, H, W)
+    Gd[0], Gd[5] = torch.randn(H, W, generator=g), torch.randn(H, W, generator=g)
+    (torch.stack(ref) * Gd).sum().backward()
+    dm = ops.matching_depth_backward(mvol.to(d).contiguous(), cams, near_fars, H, W, lv[0], nsd[0], Gd.to(d).contiguous())
+    grad_close(dm, mv.grad)
