@@ -399,11 +399,44 @@ __device__ __forceinline__ void bilinear_texel4_scatter(float* __restrict__ map,
     }
 }
 
+// Octet-cooperative form of bilinear_texel4_scatter, called by ALL 64 lanes of a wavefront: in round r the eight lanes of an
+// octet serve lane 8 o + r's request, lane j adding channel j & 3 of the tap column j >> 2 - the two x-taps of a row are
+// adjacent texels, so one instruction writes 32 contiguous bytes per request instead of eight separate float atomics (the L2
+// atomic rate is per memory transaction, not per float: this is what bounds the kernel).
+__device__ __forceinline__ void bilinear_texel4_scatter_coop(float* __restrict__ map, int H, int W, float x, float y, const float g[4],
+                                                             bool act) {
+  const int lane = threadIdx.x & 63, j = lane & 7, c = j & 3, dx = j >> 2;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int src = (lane & ~7) | r;
+    const float sx = __shfl(x, src), sy = __shfl(y, src);
+    const bool on = __shfl(act ? 1 : 0, src) != 0;
+    const float g0 = __shfl(g[0], src), g1 = __shfl(g[1], src), g2 = __shfl(g[2], src), g3 = __shfl(g[3], src);
+    const float gc = c == 0 ? g0 : (c == 1 ? g1 : (c == 2 ? g2 : g3));
+    if (on && gc != 0.f) {
+      const float fx = floorf(sx), fy = floorf(sy);
+      const float tx = sx - fx, ty = sy - fy;
+      const int xi = (int)fx + dx, y0 = (int)fy;
+      const float wxg = (dx ? tx : 1.0f - tx) * gc;
+      if ((xi >= 0) & (xi < W)) {
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          const int yi = y0 + dy;
+          const float v = wxg * (dy ? ty : 1.0f - ty);
+          if ((yi >= 0) & (yi < H) && v != 0.f) atomicAdd(map + ((int64_t)yi * W + xi) * 4 + c, v);
+        }
+      }
+    }
+  }
+}
+
 // K2 backward for the kept voxels (coords of the stage's rows): recomputes the warp and the view softmax, then
 //   d wf_v = g_mean + 2 g_var (wf_v - mean);  d f_v = d wf_v w_v + W1^T d h_v;  d w_v = d wf_v . f_v;
 //   d logit_v = w_v (d w_v - sum_u w_u d w_u)  (views outside the frustum have a constant logit);
 //   agg_mlp gradients are reduced over the wavefront and added atomically (49 floats: w1 | b1 | w2 | b2);
 //   d f_v goes to the bilinear taps of every summed level's gradient map (texel4, atomics).
+constexpr int CV_REPLICAS = 64;
+
 struct CostVolBwdArgs {
   const int32_t* coords;
   const float* g;         // (n, 8) = [d mean | d var]
@@ -415,18 +448,19 @@ struct CostVolBwdArgs {
   int stage;
   ViewSet vs;
   float w1[32], b1[8], w2[8], b2;
-  float* gagg;            // 49 floats
+  float* gagg;            // CV_REPLICAS x 64 floats (49 used per replica)
 };
 
 __global__ __launch_bounds__(256) void costvol_bwd_kernel(CostVolBwdArgs a) {
   // voxels in lattice order: neighbouring threads hit neighbouring texels (a strided order that spreads the atomics over the
   // maps measured 30 % slower - the kernel is bound by the locality of its gathers and atomics, not by same-line contention)
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = i < a.n;
+  const int64_t i_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i_ < a.n;
+  const int64_t i = live ? i_ : a.n - 1;        // every lane runs the whole body (the scatter below is quad-cooperative)
   float gacc[49];
 #pragma unroll
   for (int k = 0; k < 49; ++k) gacc[k] = 0.f;
-  if (live) {
+  {
     const float wx = (float)a.coords[i * 3 + 0] * a.voxel_size + (-1.0f), wy = (float)a.coords[i * 3 + 1] * a.voxel_size + (-1.0f),
                 wz = (float)a.coords[i * 3 + 2] * a.voxel_size + (-1.0f);
     const int Hf = a.hw[6], Wf = a.hw[7];
@@ -495,7 +529,7 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(CostVolBwdArgs a) {
         float df[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) df[c] = dwf[v][c] * wv[v];
-        const float ds = inside[v] ? wv[v] * (dw[v] - dot) : 0.f;
+        const float ds = (inside[v] && live) ? wv[v] * (dw[v] - dot) : 0.f;
         if (ds != 0.f) {
           gacc[48] += ds;
 #pragma unroll
@@ -514,19 +548,35 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(CostVolBwdArgs a) {
             }
           }
         }
-        if (df[0] == 0.f && df[1] == 0.f && df[2] == 0.f && df[3] == 0.f) continue;   // views outside the frustum
+        const bool act = live && !(df[0] == 0.f && df[1] == 0.f && df[2] == 0.f && df[3] == 0.f);   // views outside the frustum: 0
         for (int l = a.stage; l < 4; ++l) {
           const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
-          bilinear_texel4_scatter(a.gfeats[l] + (int64_t)v * H * W * 4, H, W, unnorm_act(nxv[v], W), unnorm_act(nyv[v], H), df);
+          bilinear_texel4_scatter_coop(a.gfeats[l] + (int64_t)v * H * W * 4, H, W, unnorm_act(nxv[v], W), unnorm_act(nyv[v], H), df, act);
         }
       }
     }
   }
+  // agg_mlp gradients: wavefront sums -> LDS -> one set of 49 atomics per workgroup into one of CV_REPLICAS replicas (every
+  // workgroup adding to the same 49 floats serialises at the memory side: ~12 ns per add and line, 10+ ms at 5 M voxels)
+  __shared__ float red[4][49];
 #pragma unroll
   for (int k = 0; k < 49; ++k) {
     const float t = wave_sum(gacc[k]);
-    if ((threadIdx.x & 63) == 0 && t != 0.f) atomicAdd(a.gagg + k, t);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = t;
   }
+  __syncthreads();
+  if (threadIdx.x < 49) {
+    const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (t != 0.f) atomicAdd(a.gagg + (blockIdx.x % CV_REPLICAS) * 64 + threadIdx.x, t);
+  }
+}
+
+__global__ void costvol_bwd_finalize_kernel(const float* __restrict__ replicas, float* __restrict__ g_agg) {
+  const int k = threadIdx.x;
+  if (k >= 49) return;
+  float t = 0.f;
+  for (int r = 0; r < CV_REPLICAS; ++r) t += replicas[r * 64 + k];
+  g_agg[k] += t;
 }
 
 void fill_views(ViewSet& vs, int nv, const float* h_intrs, const float* h_w2c) {
@@ -641,11 +691,12 @@ extern "C" int surf_scatter_rows_add(const float* g_dst, const int32_t* idx, int
 
 extern "C" int surf_costvol_backward(const int32_t* coords, const float* g, int64_t n, int D, const float* const* h_feats,
                                      float* const* h_gfeats, const int* h_hw, int stage, int nv, const float* h_intrs,
-                                     const float* h_w2c, const float* h_agg, float* g_agg, void* stream) {
-  if (!coords || !g || !h_feats || !h_gfeats || !h_hw || !h_intrs || !h_w2c || !h_agg || !g_agg || n <= 0 || D < 2) return SURF_E_ARG;
+                                     const float* h_w2c, const float* h_agg, float* workspace, float* g_agg, void* stream) {
+  if (!coords || !g || !h_feats || !h_gfeats || !h_hw || !h_intrs || !h_w2c || !h_agg || !workspace || !g_agg || n <= 0 || D < 2)
+    return SURF_E_ARG;
   if (nv < 1 || nv > SURF_MAX_VIEWS || stage < 0 || stage > 3) return SURF_E_LIMIT;
   CostVolBwdArgs a;
-  a.coords = coords; a.g = g; a.n = n; a.voxel_size = (float)(2.0 / (double)(D - 1)); a.stage = stage; a.gagg = g_agg;
+  a.coords = coords; a.g = g; a.n = n; a.voxel_size = (float)(2.0 / (double)(D - 1)); a.stage = stage; a.gagg = workspace;
   for (int l = 0; l < 4; ++l) {
     if (!h_feats[l] || (l >= stage && !h_gfeats[l])) return SURF_E_ARG;
     a.feats[l] = h_feats[l];
@@ -657,6 +708,11 @@ extern "C" int surf_costvol_backward(const int32_t* coords, const float* g, int6
   for (int k = 0; k < 32; ++k) a.w1[k] = h_agg[k];
   for (int k = 0; k < 8; ++k) { a.b1[k] = h_agg[32 + k]; a.w2[k] = h_agg[40 + k]; }
   a.b2 = h_agg[48];
+  const hipError_t e = hipMemsetAsync(workspace, 0, CV_REPLICAS * 64 * sizeof(float), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(costvol_bwd_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(costvol_bwd_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, g_agg);
   return surf_check_launch();
 }
+
+extern "C" int64_t surf_costvol_backward_workspace_floats(void) { return CV_REPLICAS * 64; }

@@ -852,9 +852,10 @@ def costvol_backward(feats_t4_c2f, gfeats_t4_c2f, stage, D, cams, agg, coords, g
     assert g.shape[1] == 8 and g_agg.numel() == 49
     hw = (ctypes.c_int * 8)(*[int(v) for f in feats_t4_c2f for v in f.shape[1:3]])
     agg = np.ascontiguousarray(agg, dtype=np.float32)
+    ws = torch.empty(_lib.lib().surf_costvol_backward_workspace_floats(), dtype=torch.float32, device=g.device)
     rc = _lib.lib().surf_costvol_backward(_p(coords), _p(g), coords.shape[0], int(D), _ptr_array(feats_t4_c2f),
                                           _ptr_array(gfeats_t4_c2f), hw, int(stage), cams.nv, _np_ptr(cams.intrs),
-                                          _np_ptr(cams.w2c), _np_ptr(agg), _p(g_agg), _stream())
+                                          _np_ptr(cams.w2c), _np_ptr(agg), _p(ws), _p(g_agg), _stream())
     _lib.check(rc, "surf_costvol_backward")
 
 
