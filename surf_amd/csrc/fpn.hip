@@ -171,77 +171,95 @@ __global__ __launch_bounds__(256) void inorm_relu_kernel(float* __restrict__ x, 
 // out[tap][cb][cs] = sum over (n, ys, xs) of big[n][ys S + ky - 1][xs S + kx - 1][cb] * small[n][ys][xs][cs] (zero padding).
 //   Conv2d (stride S):      big = the layer input, small = d output  -> d W[ky][kx][ci][co]
 //   ConvTranspose2d (S = 2): big = d output,       small = the layer input -> d W[ky][kx][co][ci] (the caller transposes)
-// One workgroup = one tap x one chunk of small-map pixels: 64 pixels at a time are staged in LDS (the shifted big rows and
-// the small rows), every thread owns CB CS / 256 outputs (or, for fewer than 256 outputs, one output on a 1/G share of the
-// pixels); per-chunk partials, summed by wgrad_finalize_kernel (deterministic, no atomics).
-constexpr int WG_PIX = 64, WG_CHUNK = 2048;
+// One workgroup = one tap x one chunk of small-map pixels: 64 or 256 pixels at a time are staged in LDS (the shifted big rows
+// and the small rows), every thread owns 4 x 2 register blocks of the tap's slice (thin layers: one block on a 1/G share of
+// the pixels); per-chunk partials, summed by wgrad_finalize_kernel (deterministic, no atomics).
+constexpr int WG_CHUNK = 2048;
 
-template <int STRIDE>
+template <int CB, int CS, int STRIDE>
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ big, const float* __restrict__ small, int N, int Hb,
-                                                    int Wb, int Hs, int Ws, int CB, int CS, float* __restrict__ part) {
-  __shared__ float sb[WG_PIX * 64];
-  __shared__ float ss[WG_PIX * 64];
-  __shared__ float red[256];
+                                                    int Wb, int Hs, int Ws, float* __restrict__ part) {
+  constexpr int PIX = (CB + CS <= 48) ? 256 : 64;     // pixels staged per round (LDS: PIX (CB + CS + 6) floats)
+  constexpr int NB = (CB / 4) * (CS / 2);             // 4 x 2 register blocks of the tap's (CB, CS) slice
+  constexpr int PERB = NB >= 256 ? NB / 256 : 1;
+  constexpr int G = NB >= 256 ? 1 : 256 / NB;         // pixel groups sharing one block (thin layers: every thread has work)
+  constexpr int XS = CB + 4, DS = CS + 2, O = CB * CS;
+  static_assert(NB >= 256 ? NB % 256 == 0 : 256 % NB == 0, "(CB / 4) (CS / 2) must divide or be a multiple of 256");
+  __shared__ __attribute__((aligned(16))) float sb[PIX * XS];
+  __shared__ __attribute__((aligned(16))) float ss[PIX * DS];
+  __shared__ float red[NB >= 256 ? 1 : 256 * 8];
   const int tap = blockIdx.y, ky = tap / 3, kx = tap % 3;
   const int64_t total = (int64_t)N * Hs * Ws;
   const int64_t p_begin = (int64_t)blockIdx.x * WG_CHUNK;
   const int64_t p_end = p_begin + WG_CHUNK < total ? p_begin + WG_CHUNK : total;
-  const int O = CB * CS;
-  const int G = O >= 256 ? 1 : 256 / O;          // pixel groups sharing one output
-  const int per = O >= 256 ? O / 256 : 1;        // outputs per thread
-  const int g = O >= 256 ? 0 : threadIdx.x / O;
-  const int o0 = O >= 256 ? threadIdx.x : threadIdx.x % O;
-  const bool active = O >= 256 || threadIdx.x < G * O;
-  float acc[16];
-  int ob[16], os[16];
+  const int g = NB >= 256 ? 0 : threadIdx.x / NB;
+  const int b0 = NB >= 256 ? threadIdx.x : threadIdx.x % NB;
+  float acc[PERB][4][2];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    acc[k] = 0.f;
-    const int o = (o0 + k * 256) % O;
-    ob[k] = o / CS;
-    os[k] = o % CS;
-  }
-  for (int64_t p0 = p_begin; p0 < p_end; p0 += WG_PIX) {
-    const int np = (int)(p_end - p0 < WG_PIX ? p_end - p0 : WG_PIX);
+  for (int e = 0; e < PERB; ++e)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[e][q][0] = acc[e][q][1] = 0.f;
+  for (int64_t p0 = p_begin; p0 < p_end; p0 += PIX) {
+    const int np = (int)(p_end - p0 < PIX ? p_end - p0 : PIX);
     __syncthreads();
-    for (int e = threadIdx.x; e < WG_PIX * CB; e += 256) {
-      const int pl = e / CB, c = e % CB;
-      float v = 0.f;
+    for (int e = threadIdx.x; e < PIX * (CB / 4); e += 256) {
+      const int pl = e / (CB / 4), c4 = e % (CB / 4);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (pl < np) {
         const int64_t p = p0 + pl;
         const int xs = (int)(p % Ws), ys = (int)((p / Ws) % Hs), n = (int)(p / ((int64_t)Ws * Hs));
         const int yb = ys * STRIDE + ky - 1, xb = xs * STRIDE + kx - 1;
-        if (yb >= 0 && yb < Hb && xb >= 0 && xb < Wb) v = big[(((int64_t)n * Hb + yb) * Wb + xb) * CB + c];
+        if (yb >= 0 && yb < Hb && xb >= 0 && xb < Wb)
+          v = *reinterpret_cast<const f32x4*>(big + (((int64_t)n * Hb + yb) * Wb + xb) * CB + c4 * 4);
       }
-      sb[pl * CB + c] = v;
+      *reinterpret_cast<f32x4*>(sb + pl * XS + c4 * 4) = v;
     }
-    for (int e = threadIdx.x; e < WG_PIX * CS; e += 256) {
+    for (int e = threadIdx.x; e < PIX * CS; e += 256) {
       const int pl = e / CS, c = e % CS;
-      ss[pl * CS + c] = pl < np ? small[(p0 + pl) * CS + c] : 0.f;
+      ss[pl * DS + c] = pl < np ? small[(p0 + pl) * CS + c] : 0.f;
     }
     __syncthreads();
-    if (active) {
-      for (int pl = g; pl < WG_PIX; pl += G) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          if (k < per) acc[k] = fmaf(sb[pl * CB + ob[k]], ss[pl * CS + os[k]], acc[k]);
+    for (int e = 0; e < PERB; ++e) {
+      const int blk = b0 + 256 * e;
+      const int cb0 = (blk / (CS / 2)) * 4, cs0 = (blk % (CS / 2)) * 2;
+#pragma unroll 4
+      for (int pl = g; pl < PIX; pl += G) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(sb + pl * XS + cb0);
+        const float d0 = ss[pl * DS + cs0], d1 = ss[pl * DS + cs0 + 1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          acc[e][q][0] = fmaf(xv[q], d0, acc[e][q][0]);
+          acc[e][q][1] = fmaf(xv[q], d1, acc[e][q][1]);
         }
       }
     }
   }
   float* dst = part + ((int64_t)blockIdx.x * 9 + tap) * O;
-  if (O >= 256) {
+  if (NB >= 256) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (k < per) dst[o0 + k * 256] = acc[k];
+    for (int e = 0; e < PERB; ++e) {
+      const int blk = b0 + 256 * e;
+      const int cb0 = (blk / (CS / 2)) * 4, cs0 = (blk % (CS / 2)) * 2;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        dst[(cb0 + q) * CS + cs0] = acc[e][q][0];
+        dst[(cb0 + q) * CS + cs0 + 1] = acc[e][q][1];
+      }
+    }
   } else {
     __syncthreads();
-    red[threadIdx.x] = active ? acc[0] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      red[(q * 2 + 0) * 256 + threadIdx.x] = acc[0][q][0];
+      red[(q * 2 + 1) * 256 + threadIdx.x] = acc[0][q][1];
+    }
     __syncthreads();
-    if (threadIdx.x < O) {
+    for (int o = threadIdx.x; o < NB * 8; o += 256) {
+      const int ent = o / NB, blk = o % NB;
       float t = 0.f;
-      for (int q = 0; q < G; ++q) t += red[q * O + threadIdx.x];
-      dst[threadIdx.x] = t;
+      for (int q = 0; q < G; ++q) t += red[ent * 256 + q * NB + blk];
+      dst[((blk / (CS / 2)) * 4 + ent / 2) * CS + (blk % (CS / 2)) * 2 + (ent & 1)] = t;
     }
   }
 }
@@ -316,16 +334,22 @@ extern "C" int64_t surf_conv3x3_wgrad_workspace_floats(int N, int Hs, int Ws, in
 extern "C" int surf_conv3x3_wgrad(const float* big, const float* small, int N, int Hs, int Ws, int cb, int cs, int stride,
                                   float* workspace, float* out, void* stream) {
   if (!big || !small || !workspace || !out || N <= 0 || Hs <= 0 || Ws <= 0) return SURF_E_ARG;
-  if (cb < 4 || cb > 64 || cs < 4 || cs > 64 || (stride != 1 && stride != 2)) return SURF_E_LIMIT;
   const int O = cb * cs;
-  if (O >= 256 ? (O % 256 != 0 || O / 256 > 16) : (256 % O != 0)) return SURF_E_LIMIT;
   hipStream_t st = (hipStream_t)stream;
   const int nchunk = (int)(((int64_t)N * Hs * Ws + WG_CHUNK - 1) / WG_CHUNK);
   const int Hb = Hs * stride, Wb = Ws * stride;
-  if (stride == 1)
-    hipLaunchKernelGGL(wgrad_kernel<1>, dim3(nchunk, 9), dim3(256), 0, st, big, small, N, Hb, Wb, Hs, Ws, cb, cs, workspace);
-  else
-    hipLaunchKernelGGL(wgrad_kernel<2>, dim3(nchunk, 9), dim3(256), 0, st, big, small, N, Hb, Wb, Hs, Ws, cb, cs, workspace);
+  bool done = false;
+#define WGRAD_CASE(B, S, ST)                                                                                                 \
+  if (!done && cb == B && cs == S && stride == ST) {                                                                        \
+    hipLaunchKernelGGL((wgrad_kernel<B, S, ST>), dim3(nchunk, 9), dim3(256), 0, st, big, small, N, Hb, Wb, Hs, Ws, workspace); \
+    done = true;                                                                                                            \
+  }
+  // Conv2d stride 1: (Cin, Cout) of the encoder and the heads; stride 2: the down convolutions, and the transposed ones as (Cout, Cin)
+  WGRAD_CASE(4, 8, 1) WGRAD_CASE(8, 8, 1) WGRAD_CASE(16, 16, 1) WGRAD_CASE(32, 32, 1) WGRAD_CASE(64, 64, 1)
+  WGRAD_CASE(8, 4, 1) WGRAD_CASE(16, 4, 1) WGRAD_CASE(32, 4, 1) WGRAD_CASE(64, 4, 1)
+  WGRAD_CASE(8, 16, 2) WGRAD_CASE(16, 32, 2) WGRAD_CASE(32, 64, 2)
+#undef WGRAD_CASE
+  if (!done) return SURF_E_LIMIT;
   hipLaunchKernelGGL(wgrad_finalize_kernel, grid1d(9 * O, 256), dim3(256), 0, st, workspace, nchunk, 9 * O, out);
   return surf_check_launch();
 }
