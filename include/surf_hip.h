@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 24
+#define SURF_ABI_VERSION 25
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -382,7 +382,8 @@ int surf_bn_relu_backward(const float* x, const float* dy, int64_t n, int channe
 
 /* ---- backward of the volume build (train mode; the autograd of surf.py:80-131 under loss.backward(), runner.py:163) ----
  * surf_matching_depth_backward: same geometry arguments as surf_matching_depth; g_full (nv,H,W) = d loss / d depth maps
- * (zero for the views rendered under no_grad, matching_field.py:132); g_lr (nv,h,w) scratch; dmvol (D,D,D) ACCUMULATED.
+ * of the two views that carry gradient, view0 and view1 (the reference view and src_idx, matching_field.py:129-133; view1 < 0
+ * or == view0: one view); the other views' maps are ignored; g_lr (nv,h,w) scratch; dmvol (D,D,D) ACCUMULATED.
  * The bands are constants (pre_depths are detached, matching_field.py:104).
  * surf_densify_backward: g_rows[i * row_stride] += g_dense[coords[i]]; g_prev (D/2)^3 (may be NULL) accumulates the
  * background's share through the transposed x2 trilinear upsample (sites of the index table pass nothing).
@@ -393,7 +394,8 @@ int surf_bn_relu_backward(const float* x, const float* dy, int64_t n, int channe
 int surf_matching_depth_backward(const float* mvol, int D, int nv, const float* h_kinv, const float* h_c2w, const float* h_rinv,
                                  const float* h_near_fars, int H, int W, int h, int w, const float* lin_x, const float* lin_y,
                                  const float* lin_n, int n, const float* pre_depths, float ratio_cur, float ratio_prev,
-                                 const float* jitter, const float* g_full, float* g_lr, float* dmvol, void* stream);
+                                 const float* jitter, const float* g_full, int view0, int view1, float* g_lr, float* dmvol,
+                                 void* stream);
 int surf_densify_backward(const int32_t* coords, int64_t n, int D, const int32_t* table, const float* g_dense, int row_stride,
                           float* g_rows, float* g_prev, void* stream);
 int surf_scatter_rows_add(const float* g_dst, const int32_t* idx, int64_t n, int row_words, int idx_shift, int dst_stride_words,

@@ -154,15 +154,24 @@ __device__ __forceinline__ void trilinear_scatter(float* __restrict__ vol, int D
 
 // depth = cosz sum_k z_k softmax(rho)_k with the z_k constants (the bands come from detached depths, matching_field.py:104):
 //   d rho_k = g cosz w_k (z_k - E),  E = depth / cosz;  each d rho_k is scattered through the trilinear taps of its sample.
-// Pass 1 recomputes the softmax statistics (m, den), pass 2 the weights: nothing was stored per sample in the forward.
-__global__ __launch_bounds__(256) void matching_depth_bwd_kernel(MatchArgs a, const float* __restrict__ g_lr, float* __restrict__ dmvol) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Eight lanes per ray, lane j = corner (dx, dy, dz) = (j >> 2, (j >> 1) & 1, j & 1) of every sample: the corner values meet by
+// three xor-shuffles (rho), and in the scatter the two z-corners of a row are adjacent lanes AND adjacent floats, so one request
+// carries 8 contiguous bytes (float atomics run at the memory side at a per-request rate; one lane per ray = 64 scattered
+// requests per instruction was 1.8x slower).  Pass 1 recomputes the softmax statistics (m, den), pass 2 the weights: nothing was
+// stored per sample in the forward.  `views`: the views that carry gradient (0 and src_idx), one grid slice each.
+__global__ __launch_bounds__(256) void matching_depth_bwd_kernel(MatchArgs a, const float* __restrict__ g_lr, float* __restrict__ dmvol,
+                                                                 int view0, int view1) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t per_view = (int64_t)a.h * a.w;
-  if (i >= per_view * a.nv) return;
+  const int j = (int)(t & 7);
+  const int64_t r = t >> 3;                          // ray slot; an octet never straddles the bound below
+  if (r >= per_view * 2) return;
+  const int v = r < per_view ? view0 : view1;
+  if (v < 0) return;
+  const int p = (int)(r % per_view);
+  const int64_t i = (int64_t)v * per_view + p;
   const float g = g_lr[i];
-  if (g == 0.f) return;
-  const int v = (int)(i / per_view);
-  const int p = (int)(i % per_view);
+  if (g == 0.f) return;                              // octet-uniform
   const float px = a.lin_x[p % a.w], py = a.lin_y[p / a.w];
   const float* Ki = a.Kinv[v];
   float cx = Ki[0] * px + Ki[1] * py + Ki[2];
@@ -188,6 +197,8 @@ __global__ __launch_bounds__(256) void matching_depth_bwd_kernel(MatchArgs a, co
     band(zc, ((f0 - n0) * a.ratio_prev) / 2.0f, n0, f0, lo[1], hi[1]);
     nb = 2;
   }
+  const int cdx = j >> 2, cdy = (j >> 1) & 1, cdz = j & 1;
+  const int D = a.D;
   float m = -INFINITY, den = 0.f, num = 0.f;
   for (int pass = 0; pass < 2; ++pass) {
     const float E = pass ? num / den : 0.f;
@@ -197,8 +208,17 @@ __global__ __launch_bounds__(256) void matching_depth_bwd_kernel(MatchArgs a, co
       for (int k = 0; k < a.n; ++k) {
         float z = lo[b] + rng * a.lin_n[k];
         if (a.jitter) z = z + shift;
-        const float qx = unnorm_acf(ox + dx * z, a.D), qy = unnorm_acf(oy + dy * z, a.D), qz = unnorm_acf(oz + dz * z, a.D);
-        const float rho = trilinear_zeros(a.mvol, a.D, qx, qy, qz);
+        const float qx = unnorm_acf(ox + dx * z, D), qy = unnorm_acf(oy + dy * z, D), qz = unnorm_acf(oz + dz * z, D);
+        const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
+        const float tx = qx - fx, ty = qy - fy, tz = qz - fz;
+        const int xi = (int)fx + cdx, yi = (int)fy + cdy, zi = (int)fz + cdz;
+        const float wgt = (cdx ? tx : 1.0f - tx) * (cdy ? ty : 1.0f - ty) * (cdz ? tz : 1.0f - tz);
+        const bool ok = (xi >= 0) & (xi < D) & (yi >= 0) & (yi < D) & (zi >= 0) & (zi < D);
+        const int64_t off = ((int64_t)xi * D + yi) * D + zi;
+        float rho = ok ? a.mvol[off] * wgt : 0.f;
+        rho += __shfl_xor(rho, 1);
+        rho += __shfl_xor(rho, 2);
+        rho += __shfl_xor(rho, 4);
         if (pass == 0) {
           const float mn = fmaxf(m, rho);
           const float sc = expf(m - mn), e = expf(rho - mn);
@@ -207,7 +227,8 @@ __global__ __launch_bounds__(256) void matching_depth_bwd_kernel(MatchArgs a, co
           m = mn;
         } else {
           const float wk = expf(rho - m) / den;
-          trilinear_scatter(dmvol, a.D, qx, qy, qz, g * cosz * wk * (z - E));
+          const float gv = g * cosz * wk * (z - E) * wgt;
+          if (ok && gv != 0.f) atomicAdd(dmvol + off, gv);
         }
       }
     }
@@ -256,7 +277,7 @@ extern "C" int surf_matching_depth_backward(const float* mvol, int D, int nv, co
                                             const float* h_rinv, const float* h_near_fars, int H, int W, int h, int w,
                                             const float* lin_x, const float* lin_y, const float* lin_n, int n,
                                             const float* pre_depths, float ratio_cur, float ratio_prev, const float* jitter,
-                                            const float* g_full, float* g_lr, float* dmvol, void* stream) {
+                                            const float* g_full, int view0, int view1, float* g_lr, float* dmvol, void* stream) {
   if (!mvol || !h_kinv || !h_c2w || !h_rinv || !h_near_fars || !lin_x || !lin_y || !lin_n || !g_full || !g_lr || !dmvol)
     return SURF_E_ARG;
   if (D < 2 || H < 1 || W < 1 || h < 1 || w < 1 || n < 1) return SURF_E_ARG;
@@ -271,6 +292,9 @@ extern "C" int surf_matching_depth_backward(const float* mvol, int D, int nv, co
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, st, g_full, nv, h, w, H,
                      W, g_lr);
-  hipLaunchKernelGGL(matching_depth_bwd_kernel, dim3((unsigned)((n_lr + 255) / 256)), dim3(256), 0, st, a, g_lr, dmvol);
+  if (view0 < 0 || view0 >= nv || view1 >= nv) return SURF_E_ARG;
+  const int64_t n_thr = (int64_t)h * w * 2 * 8;     // two view slices x eight lanes per ray
+  hipLaunchKernelGGL(matching_depth_bwd_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, st, a, g_lr, dmvol, view0,
+                     view1 == view0 ? -1 : view1);
   return surf_check_launch();
 }

@@ -49,10 +49,11 @@ class MatchingField(nn.Module):
                                   range_ratios[stage_idx - 1] if stage_idx > 0 else 1.0, return_lr=return_lr, jitter=jitter)
 
     def backward(self, cams, near_fars, hw, matching_volume, stage_idx, range_ratios, g_full, pre_depths=None, jitter=None,
-                 dmvol=None):
+                 dmvol=None, src_idx=0):
         """d loss / d matching volume from g_full (nv,H,W) = d loss / d this stage's depth maps (zero for the views rendered
         under no_grad, matching_field.py:132); accumulates into `dmvol` if given."""
         H, W = hw
         return ops.matching_depth_backward(matching_volume, cams, near_fars, H, W, self.depth_res_levels[stage_idx],
                                            self.n_samples_depths[stage_idx], g_full, pre_depths, range_ratios[stage_idx],
-                                           range_ratios[stage_idx - 1] if stage_idx > 0 else 1.0, jitter=jitter, dmvol=dmvol)
+                                           range_ratios[stage_idx - 1] if stage_idx > 0 else 1.0, jitter=jitter, dmvol=dmvol,
+                                           views=(0, src_idx))

@@ -797,9 +797,10 @@ def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, r
 
 
 def matching_depth_backward(mvol, cams, near_fars, H, W, res_level, n, g_full, pre_depths=None, ratio_cur=1.0, ratio_prev=1.0,
-                            jitter=None, dmvol=None):
-    """Backward of matching_depth w.r.t. the matching volume: g_full (nv,H,W) = d loss / d depth maps (zero for the views the
-    reference renders under no_grad).  Returns dmvol (D,D,D), accumulated into `dmvol` if given."""
+                            jitter=None, dmvol=None, views=(0, 0)):
+    """Backward of matching_depth w.r.t. the matching volume: g_full (nv,H,W) = d loss / d depth maps; only the maps of
+    `views` = (reference view, src_idx) are read (the reference renders the others under no_grad).  Returns dmvol (D,D,D),
+    accumulated into `dmvol` if given."""
     _chk(mvol, torch.float32, "matching volume")
     _chk(g_full, torch.float32, "g_full")
     dev = mvol.device
@@ -815,8 +816,8 @@ def matching_depth_backward(mvol, cams, near_fars, H, W, res_level, n, g_full, p
     rc = _lib.lib().surf_matching_depth_backward(_p(mvol), int(mvol.shape[0]), cams.nv, _np_ptr(cams.kinv), _np_ptr(cams.c2w),
                                                  _np_ptr(cams.rinv), _np_ptr(nf), H, W, h, w, _p(lin_x), _p(lin_y), _p(lin_n),
                                                  int(n), _p(pre_depths), ctypes.c_float(float(ratio_cur)),
-                                                 ctypes.c_float(float(ratio_prev)), _p(jitter), _p(g_full), _p(g_lr), _p(dmvol),
-                                                 _stream())
+                                                 ctypes.c_float(float(ratio_prev)), _p(jitter), _p(g_full), int(views[0]), int(views[1]),
+                                                 _p(g_lr), _p(dmvol), _stream())
     _lib.check(rc, "surf_matching_depth_backward")
     return dmvol
 

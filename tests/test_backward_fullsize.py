@@ -106,7 +106,7 @@ def test_matching_field_backward_shift_invariance_full_size(full_train, stage):
     g_full[0] = torch.randn(H, W, device="cuda", generator=g)
     g_full[t["src_idx"]] = torch.randn(H, W, device="cuda", generator=g)
     dm = model.matching_field.backward(t["cams"], t["near_fars"], (H, W), r["mvol"], stage, model.range_ratios, g_full,
-                                       r["pre_depths"], r.get("jitter"))
+                                       r["pre_depths"], r.get("jitter"), src_idx=t["src_idx"])
     assert float(dm.abs().max()) > 0
     # softmax over a ray's samples: shifting every logit by a constant leaves the depth unchanged -> the taps' gradients sum to
     # zero ray by ray, hence in total (up to the rays whose samples leave the [-1,1]^3 lattice: zero padding)

@@ -64,7 +64,7 @@ def test_matching_depth_backward(scene, golden_pipe, golden_train, stage, pertur
     dm = ops.matching_depth_backward(gp[f"s{stage}_mvol"].to(d).contiguous(), _cams(scene), scene["near_fars"], H, W, lvl,
                                      CFG["n_samples_depths"][stage], G.to(d).contiguous(),
                                      None if pre is None else pre.to(d).contiguous(), CFG["range_ratios"][stage],
-                                     CFG["range_ratios"][stage - 1] if stage > 0 else 1.0, jitter=jitter)
+                                     CFG["range_ratios"][stage - 1] if stage > 0 else 1.0, jitter=jitter, views=(0, src_idx))
     assert float(mvol.grad.abs().max()) > 0
     grad_close(dm, mvol.grad)
 
@@ -390,5 +390,5 @@ def test_seven_view_backward_kernels(weights):
     Gd = torch.zeros(nv, H, W)
     Gd[0], Gd[5] = torch.randn(H, W, generator=g), torch.randn(H, W, generator=g)
     (torch.stack(ref) * Gd).sum().backward()
-    dm = ops.matching_depth_backward(mvol.to(d).contiguous(), cams, near_fars, H, W, lv[0], nsd[0], Gd.to(d).contiguous())
+    dm = ops.matching_depth_backward(mvol.to(d).contiguous(), cams, near_fars, H, W, lv[0], nsd[0], Gd.to(d).contiguous(), views=(0, 5))
     grad_close(dm, mv.grad)
