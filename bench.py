@@ -239,7 +239,7 @@ def training_step_setup(dev, H=576, W=800, nv=5, base_dim=88, rays=512, device_j
                "mask_ref": ones, "mask_src": ones, "pseudo_depth_ref": ones * 2.0, "pseudo_depth_src": ones * 2.0,
                "depth_ref": ones * 2.0, "depth_src": ones * 2.0}
     loss_fn = Loss(conf.from_dict({"color_weight": 1.0, "sparse_scale_factor": 100, "sparse_weight": 0.02, "igr_weight": 0.1,
-                                   "mfc_weight": 0.5, "smooth_weight": 0.0, "depth_weight": 0.0, "ptloss_weight": 1.0,
+                                   "mfc_weight": 0.5, "smooth_weight": 0.0001, "depth_weight": 0.0, "ptloss_weight": 1.0,
                                    "pseudo_auxi_depth_weight": 1.0, "pseudo_sdf_weight": 0.0, "pseudo_depth_weight": 0.0,
                                    "stage_weights": [0.25, 0.5, 0.75, 1.0]}))
     opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}))
@@ -262,7 +262,7 @@ def training_step_timing(args, dev, steps=3):
     return {"ms_per_step": ms, "rays": int(ipts["rays_o"].shape[0]), "samples_per_ray": 128,
             "voxels_per_stage": [int(r["coords"].shape[0]) for r in model._train_tape["vol"]],
             "loss": out["loss"], "what": "forward (FPN, volume build, render) + loss + HIP backward of all of it + Adam; "
-                                         "smooth term excluded; matching-field jitter on the device generator"}
+                                         "every term of losses/loss.py; matching-field jitter on the device generator"}
 
 
 def mesh_grid_timing(model, scene, dev, resolution):

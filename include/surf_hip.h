@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 25
+#define SURF_ABI_VERSION 26
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -204,6 +204,16 @@ int surf_ptloss_terms(const float* imgs_t4, int nv, int H, int W, const float* d
 int surf_sdf_backward(const float* pts, const float* ybar, const float* gbar, int64_t n, const float* const* h_vols,
                       const int32_t* const* h_tables, const int* h_dims, int n_vol, float* const* h_dvols, const float* packed,
                       float* in_v, float* in_d, float* tb, float* tdb, void* stream);
+
+/* Backward of the smooth (H.1) loss term through the SDF network (the autograd of sdf_network.py:143-150 under loss.backward(),
+ * losses/loss.py:40): for sbar (n,3) = d loss / d smooth, the gradients of sum_n sbar_n . (H_n 1) = the mixed second directional
+ * derivative of the SDF along (1,1,1) and sbar_n - one reverse sweep over a forward sweep with four streams (value, tangent
+ * along 1, tangent along sbar, mixed).  Per-sample buffers like surf_sdf_backward's with the four streams stacked per layer:
+ * in (7, 4, n, 160), ab (6, 4, n, 128); dW_l = ab[l]^T in[l] over the 4 n rows, db_l = column sums of ab[l][0]; lin6: dW row 0 =
+ * column sums of in[6][3].  h_dvols: the sparse feature rows' gradients (N_s, 8), accumulated (may be NULL). */
+int surf_sdf_smooth_backward(const float* pts, const float* sbar, int64_t n, const float* const* h_vols,
+                             const int32_t* const* h_tables, const int* h_dims, int n_vol, float* const* h_dvols,
+                             const float* packed, float* in, float* ab, void* stream);
 
 /*
  * Multi-view feature fetch + blending MLP.

@@ -6,8 +6,9 @@ arithmetic runs in the HIP kernels behind ``surf_amd.ops`` (no PyTorch fallback)
 
 Scope of this mirror: inference (`val`) semantics, including the ``render.perturb`` jitter, and the
 forward side of a training step: ``render_scene(patch_warp=True)`` adds the loss-only outputs of ``render_core``
-(``ref_gray_val`` / ``sampled_gray_val`` patch warps, ``smooth_error``, ``sparse_sdf``).  Nothing here is differentiable
-(backward kernels are not built).
+(``ref_gray_val`` / ``sampled_gray_val`` patch warps, ``smooth_error``, ``sparse_sdf``).  There is no autograd graph: the
+backward of a training forward is ``backward_render``, which chains the HIP backward kernels for given
+gradients of the outputs.
 """
 import math
 
@@ -296,11 +297,13 @@ class ImplicitSurface(nn.Module):
             out["sparse_sdf"] = torch.cat([torch.where(occ, sdf_r, torch.zeros_like(sdf_r)), sdf]).view(-1, 1)
             # what backward_render needs of this forward (row f2: the partial backward of the render)
             self._ctx = dict(st=st, act=act, sdf=sdf, grad=grad, col=col, rays_d=rays_d, anneal=float(cos_anneal_ratio),
-                             scene=scene, eik_den=float(eik[1]), random_pts=pr, random_occ=occ, pts0=pts0, g0=g0, maps=maps)
+                             scene=scene, eik_den=float(eik[1]), random_pts=pr, random_occ=occ, pts0=pts0, g0=g0, maps=maps,
+                             smooth=smooth, inside=inside)
         return out
 
     @torch.no_grad()
-    def backward_render(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None, gfeats_t4=None):
+    def backward_render(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None, gfeats_t4=None,
+                        g_smooth_error=0.0):
         """Partial backward of the last training forward (`render_scene(patch_warp=True)`), SURVEY 8f-f2: given the loss's
         gradients w.r.t. `color_fine` (R,3), `render_depth` (R), `gradient_error` (scalar), `sparse_sdf` ((1024 + R*S),1) and
         the per-ray patch NCC (R,1) (= compute_LNCC2 of ref_gray_val / sampled_gray_val, the mfc term),
@@ -310,7 +313,8 @@ class ImplicitSurface(nn.Module):
         upstream is a tangent direction), surf_blend_backward, and for the NCC term surf_patch_warp_tangent -> surf_lncc_jvp ->
         surf_crossing_backward (d ncc / d z0 as a forward-mode tangent along the ray, then into the two bracketing samples).
         gfeats_t4 (fine -> coarse, like the scene's feature maps): accumulates the colour path's gradient into the FPN maps
-        (generalisation training).  NOT differentiated: the smooth (H.1) term (weight 1e-4); the volume build's backward is
+        (generalisation training).  g_smooth_error (scalar): the smooth (H.1) term, through surf_sdf_smooth_backward (reverse
+        over a forward with value, two tangents and their mixed tangent).  The volume build's backward is
         SuRF.backward_volumes."""
         c = self._ctx
         st, act, scene = c["st"], c["act"], c["scene"]
@@ -336,6 +340,16 @@ class ImplicitSurface(nn.Module):
             ybar = torch.cat([ybar, gs[:1024][occ]])
             gbar = torch.cat([gbar, torch.zeros(int(occ.sum()), 3, device=dev)])
         res = ops.sdf_backward(pts.contiguous(), ybar.contiguous(), gbar.contiguous(), scene.sv, self.smooth_weights(dev))
+        if g_smooth_error:
+            # smooth_error = sum_n inside_n |smooth_n| / (sum inside + 1e-5)  ->  sbar_n = g inside_n smooth_n / (|smooth_n| den)
+            sm, ins = c["smooth"][idx], c["inside"][idx]
+            nrm = torch.linalg.norm(sm, ord=2, dim=-1, keepdim=True)
+            sbar = float(g_smooth_error) / (float(c["inside"].sum()) + 1e-5) * ins[:, None] * sm / nrm.clamp_min(1e-30)
+            rs = ops.sdf_smooth_backward(st["pts"][idx].contiguous(), sbar.contiguous(), scene.sv, self.smooth_weights(dev))
+            for l in range(7):
+                res["weight"][l] = res["weight"][l] + rs["weight"][l]
+                res["bias"][l] = res["bias"][l] + rs["bias"][l]
+            res["volumes"] = [a_ + b_ for a_, b_ in zip(res["volumes"], rs["volumes"])]
         with torch.enable_grad():                             # weight norm: W = g v / |v|_row (sdf_network.py:88-89)
             for l in range(7):
                 lin = getattr(self.sdf_network, f"lin{l}")

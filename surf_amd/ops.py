@@ -376,6 +376,33 @@ def sdf_backward(pts, ybar, gbar, volumes, packed, want_dvols=True):
     return {"weight": dW, "bias": db, "volumes": dvols}
 
 
+def sdf_smooth_backward(pts, sbar, volumes, packed, want_dvols=True):
+    """Gradients of sum_n sbar_n . smooth_n (smooth = H.1 of the SDF, sdf_network.py:143-150) w.r.t. the EFFECTIVE matrices /
+    biases of lin0..lin6 and the sparse feature rows (surf_sdf_smooth_backward; the batch reductions are surf_colgram).
+    Returns the same dictionary as sdf_backward."""
+    _chk(pts, torch.float32, "pts")
+    _chk(sbar, torch.float32, "sbar")
+    _chk(packed, torch.float32, "packed weights")
+    n, dev = pts.shape[0], pts.device
+    xin = torch.empty(7, 4, n, 160, dtype=torch.float32, device=dev)
+    ab = torch.empty(6, 4, n, 128, dtype=torch.float32, device=dev)
+    dvols = [torch.zeros_like(v) for v in volumes.vols] if want_dvols else None
+    rc = _lib.lib().surf_sdf_smooth_backward(_p(pts), _p(sbar), n, volumes._vp, volumes._tp, volumes._dp, volumes.n,
+                                             _ptr_array(dvols) if dvols is not None else None, _p(packed), _p(xin), _p(ab), _stream())
+    _lib.check(rc, "surf_sdf_smooth_backward")
+    shapes = [(128, 27), (128, 156), (101, 156), (128, 156), (128, 156), (128, 156), (129, 156)]
+    dW, db = [], []
+    for l in range(6):
+        nl, kl = shapes[l]
+        dW.append(colgram(ab[l].reshape(4 * n, 128)[:, :nl], xin[l].reshape(4 * n, 160)[:, :kl]))   # the four streams in one GEMM
+        db.append(ab[l][0].sum(dim=0)[:nl].contiguous())
+    w6 = torch.zeros(shapes[6], dtype=torch.float32, device=dev)                     # S = lin6 row 0 . (mixed input of lin6)
+    w6[0] = xin[6][3].sum(dim=0)[:156]
+    dW.append(w6)
+    db.append(torch.zeros(129, dtype=torch.float32, device=dev))
+    return {"weight": dW, "bias": db, "volumes": dvols}
+
+
 def colgram(A, X, with_sum=False, out=None):
     """out (M, N [+1]) = A^T [X | 1] for row-major 2-D views A (rows, M), X (rows, N) that share contiguous rows (column
     slices of a wider buffer are fine: the row stride is taken from the view).  `out` given: accumulated into."""

@@ -94,15 +94,16 @@ class SuRF(nn.Module):
         self.has_vol = True
         self._vol_scene = None
 
-    def backward(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None):
+    def backward(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None, g_smooth_error=0.0):
         """Partial backward of the last train-mode forward (row f2): `.grad` of every implicit-surface parameter and, in
         finetune mode (has_vol), of the per-scene feature volumes - what surf.py:36-45 hands the optimiser there.  See
-        ImplicitSurface.backward_render for what is not differentiated yet (FPN / volume build, the smooth term)."""
+        ImplicitSurface.backward_render for the chain; the volume build / FPN backward is `backward_volumes`."""
         gfeats = None
         if getattr(self, "_train_tape", None) is not None:       # volume-building model: the colour path's share of d FPN maps
             self._train_tape["gfeats"] = [torch.zeros_like(f) for f in self._train_tape["feats"]]      # coarse -> fine
             gfeats = self._train_tape["gfeats"][::-1]
-        dvols = self.implicit_surface.backward_render(g_color, g_depth, g_gradient_error, g_sparse_sdf, g_ncc, gfeats_t4=gfeats)
+        dvols = self.implicit_surface.backward_render(g_color, g_depth, g_gradient_error, g_sparse_sdf, g_ncc, gfeats_t4=gfeats,
+                                                      g_smooth_error=g_smooth_error)
         if self.has_vol:
             for p, g in zip(self.volumes, dvols[::-1]):          # volumes are kept coarse -> fine
                 g = g.to(p.dtype)

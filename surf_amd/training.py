@@ -8,8 +8,8 @@ terms through torch autograd on the depth maps, the photometric term through `su
 `SuRF.backward_volumes` (matching field -> densify -> sparse U-Net -> cost volume -> FPN), so that every parameter group of
 surf.py:36-45 receives its gradient.
 
-Differentiated terms: colour, eikonal, sparse-SDF, rendered-depth, the patch-NCC term (`mfc_loss`), the per-stage
-photometric and pseudo-depth terms.  NOT differentiated: the smooth term (H.1, weight 1e-4).
+Differentiated terms: every term of losses/loss.py - colour, eikonal, sparse-SDF, smooth (H.1), rendered-depth, the patch-NCC
+term (`mfc_loss`), the per-stage photometric and pseudo-depth terms.
 """
 import torch
 
@@ -22,7 +22,7 @@ def _sync_gradients(optimizer):
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         dist.all_reduce_gradients([p for g in optimizer.param_groups for p in g["params"]])
 
-LEAVES = ("color_fine", "render_depth", "gradient_error", "sparse_sdf", "ncc")
+LEAVES = ("color_fine", "render_depth", "gradient_error", "sparse_sdf", "ncc", "smooth_error")
 
 
 def finetune_step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio=1.0, step=0):
@@ -35,7 +35,7 @@ def finetune_step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio=1.0
     optimizer.zero_grad(set_to_none=True)
     g = {k: v.grad for k, v in leaves.items()}
     model.backward(g["color_fine"], g["render_depth"], 0.0 if g["gradient_error"] is None else float(g["gradient_error"]),
-                   g["sparse_sdf"], g["ncc"])
+                   g["sparse_sdf"], g["ncc"], 0.0 if g["smooth_error"] is None else float(g["smooth_error"]))
     _sync_gradients(optimizer)
     optimizer.step()
     return {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in out.items()}
@@ -75,7 +75,7 @@ def train_step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio=1.0, s
             g_src = p_src if g_src is None else g_src + p_src
         g_depths[i] = (g_ref, g_src)
     rows = model.backward(g["color_fine"], g["render_depth"], 0.0 if g["gradient_error"] is None else float(g["gradient_error"]),
-                          g["sparse_sdf"], g["ncc"])
+                          g["sparse_sdf"], g["ncc"], 0.0 if g["smooth_error"] is None else float(g["smooth_error"]))
     model.backward_volumes(rows, g_depths)
     _sync_gradients(optimizer)
     optimizer.step()

@@ -922,6 +922,36 @@ def test_sdf_backward_matches_autograd(weights, gpu_scene, golden_render):
         rel_close(out["volumes"][lvl][:, :gv.shape[1]], gv, 2e-3, 2e-4 * float(gv.abs().max()))
 
 
+def test_sdf_smooth_backward_matches_autograd(weights, gpu_scene, golden_render):
+    """surf_sdf_smooth_backward (row f2, the smooth term): gradients of sum_n sbar_n . (H_n 1) w.r.t. the effective weights, the
+    biases and the sparse feature rows against torch autograd through the oracle's closed form of H.1 (i.e. the reference's
+    triple backward), incl. a sample count that leaves a partial wavefront tile.  Values reach ~1e2 (second derivatives of a
+    softplus with beta = 100)."""
+    from surf_amd import ops
+    d = dev()
+    c = gpu_scene["cpu"]
+    pts = golden_render["pts"][:301].clone()
+    g = torch.Generator().manual_seed(14)
+    sbar = torch.randn(301, 3, generator=g) * 0.1
+    layers = [(W.clone().requires_grad_(True), b.clone().requires_grad_(True)) for W, b in O.sdf_weights(weights)]
+    vols = [v.clone().requires_grad_(True) for v in c["vols"]]
+    phi, jphi, mphi = O.lookup_sparse_volume(pts, vols, c["tabs"], with_mixed=True)
+    _, smooth = O.sdf_mlp_smooth(layers, pts, phi, jphi, mphi)
+    (smooth * sbar).sum().backward()
+    out = ops.sdf_smooth_backward(pts.to(d).contiguous(), sbar.to(d).contiguous(), gpu_scene["sv"], ops.sdf_smooth_pack_weights(weights, d))
+    torch.cuda.synchronize()
+    for l, (W, b) in enumerate(layers):
+        gw = W.grad if W.grad is not None else torch.zeros_like(W)
+        assert l == 6 or float(gw.abs().max()) > 0
+        rel_close(out["weight"][l], gw, 3e-3, 3e-4 * float(gw.abs().max()) + 1e-7)
+        gb = b.grad if b.grad is not None else torch.zeros_like(b)
+        rel_close(out["bias"][l], gb, 3e-3, 3e-4 * float(gb.abs().max()) + 1e-7)
+    for lvl, v in enumerate(vols):
+        gv = v.grad
+        assert float(gv.abs().max()) > 0
+        rel_close(out["volumes"][lvl][:, :gv.shape[1]], gv, 3e-3, 3e-4 * float(gv.abs().max()))
+
+
 def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
     """ImplicitSurface.backward_render (row f2, partial): the gradients of a loss on colour_fine, render_depth, gradient_error
     and sparse_sdf w.r.t. the SDF network's weight-norm parameters, the colour network, the variance and the sparse feature
@@ -947,7 +977,9 @@ def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
     g_ncc = torch.randn(R, 1, generator=g) * 0.2 * out["mid_inside_sphere"].cpu()
     assert float(g_ncc.abs().sum()) > 0
     gfeats = [torch.zeros_like(f) for f in gpu_scene["feats_t4"]]          # fine -> coarse: the colour path's share of d FPN maps
-    dvols = model.backward_render(g_color.to(d), g_depth.to(d), g_eik, g_sparse.to(d), g_ncc.to(d), gfeats_t4=gfeats)
+    g_smooth = 0.02                                                         # |H.1| ~ 1e1..1e2 with beta = 100
+    dvols = model.backward_render(g_color.to(d), g_depth.to(d), g_eik, g_sparse.to(d), g_ncc.to(d), gfeats_t4=gfeats,
+                                  g_smooth_error=g_smooth)
     # oracle autograd
     c = gpu_scene["cpu"]
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in weights.items() if k.startswith("implicit_surface.")}
@@ -962,9 +994,10 @@ def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
     sdf_r = O.sdf_mlp(O.sdf_weights(sd), pr, phi)[0] * occ.float()
     loss = ((o["color_fine"] * g_color).sum() + (o["render_depth"] * g_depth).sum() + o["gradient_error"] * g_eik
             + (sdf_r * g_sparse[:1024, 0]).sum() + (o["sdf"].reshape(-1) * g_sparse[1024:, 0]).sum()
-            + (O.lncc(o["ref_gray_val"], o["sampled_gray_val"]) * g_ncc).sum())
+            + (O.lncc(o["ref_gray_val"], o["sampled_gray_val"]) * g_ncc).sum() + o["smooth_error"] * g_smooth)
     loss.backward()
     rel_close(out["color_fine"], o["color_fine"].detach(), 1e-3, 1e-5)
+    rel_close(out["smooth_error"].reshape(1), o["smooth_error"].detach().reshape(1), 2e-3, 1e-4)
     names = [f"sdf_network.lin{l}.{p}" for l in range(7) for p in ("weight_g", "weight_v", "bias")] + ["deviation_network.variance"]
     names += [n for n, _ in model.named_parameters() if n.startswith("color_network.") and n != "color_network.s"]
     params = dict(model.named_parameters())
@@ -1081,7 +1114,7 @@ def test_finetune_steps_train_volumes_and_networks(scene):
     opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "vol_lr": [1e-2] * 4}))
     vol0 = [v.detach().clone() for v in model.volumes]
     w0 = model.implicit_surface.color_network.base_fc[0].weight.detach().clone()
-    loss_fn = Loss(conf.from_dict(dict(LOSS_CONF, smooth_weight=0.0)))
+    loss_fn = Loss(conf.from_dict(LOSS_CONF))
     hist = []
     for step in range(6):
         torch.manual_seed(70)

@@ -300,7 +300,7 @@ def test_train_steps_move_every_parameter_group(scene):
                "depth_ref": torch.full((H, W), 1.0, device=d), "depth_src": torch.full((H, W), 1.0, device=d)}
     opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}))
     before = {k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad}
-    loss_fn = Loss(conf.from_dict(dict(LOSS_CONF, smooth_weight=0.0)))
+    loss_fn = Loss(conf.from_dict(LOSS_CONF))
     hist = []
     for step in range(5):
         torch.manual_seed(70)
