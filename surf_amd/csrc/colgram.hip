@@ -63,13 +63,31 @@ __global__ __launch_bounds__(256) void colgram_kernel(const float* __restrict__ 
     }
 }
 
+// Sum of the slabs' partials: 64 output elements per workgroup, the slabs split over its four wavefronts with four independent
+// accumulators each (the first version walked ~1000 slabs serially per element: 217 us per call, 7 ms of a training step).
+// Fixed summation order: deterministic.
 __global__ __launch_bounds__(256) void colgram_reduce_kernel(const float* __restrict__ partial, int blocks, int64_t count,
                                                              float* __restrict__ out, int accumulate) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
-  float s = accumulate ? out[i] : 0.f;
-  for (int b = 0; b < blocks; ++b) s += partial[(int64_t)b * count + i];
-  out[i] = s;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < count) {
+    int b = w;
+    for (; b + 12 < blocks; b += 16) {
+      s0 += partial[(int64_t)b * count + e];
+      s1 += partial[(int64_t)(b + 4) * count + e];
+      s2 += partial[(int64_t)(b + 8) * count + e];
+      s3 += partial[(int64_t)(b + 12) * count + e];
+    }
+    for (; b < blocks; b += 4) s0 += partial[(int64_t)b * count + e];
+  }
+  red[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && e < count) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    out[e] = accumulate ? out[e] + t : t;
+  }
 }
 
 // slab height: ~1024 workgroups per call (a training batch has 6e4..1e6 rows: 1024-row slabs left most CUs idle)
@@ -102,6 +120,6 @@ extern "C" int surf_colgram(const float* A, int ldA, int M, const float* X, int 
   else
     return SURF_E_LIMIT;
   const int64_t count = (int64_t)M * NX;
-  hipLaunchKernelGGL(colgram_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, workspace, (int)blocks, count, out, accumulate);
+  hipLaunchKernelGGL(colgram_reduce_kernel, dim3((unsigned)((count + 63) / 64)), dim3(256), 0, st, workspace, (int)blocks, count, out, accumulate);
   return surf_check_launch();
 }

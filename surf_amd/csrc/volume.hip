@@ -347,27 +347,43 @@ __global__ __launch_bounds__(256) void dense_rows_bwd_kernel(const int32_t* __re
   g_rows[i * row_stride] += g_dense[o];
 }
 
+// VEC voxels along z per thread (VEC = 4: 16-byte loads of the mostly-zero dense gradient first, the table only where something
+// is non-zero - the 704^3 sweep is otherwise 2.8 GB of traffic and 1.4 M workgroups).
+template <int VEC>
 __global__ __launch_bounds__(256) void dense_init_bwd_kernel(const float* __restrict__ g_dense, const int32_t* __restrict__ table,
                                                              int D, float* __restrict__ g_prev) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)D * D * D;
-  if (i >= total) return;
-  if (table[i] >= 0) return;
-  const float g = g_dense[i];
-  if (g == 0.f) return;
+  const int64_t i0 = t * VEC;
+  if (i0 >= total) return;
+  float gv[VEC];
+  if (VEC == 4) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g_dense + i0);
+    gv[0] = v[0]; gv[1 % VEC] = v[1]; gv[2 % VEC] = v[2]; gv[3 % VEC] = v[3];
+    if (v[0] == 0.f && v[1] == 0.f && v[2] == 0.f && v[3] == 0.f) return;
+  } else {
+    gv[0] = g_dense[i0];
+    if (gv[0] == 0.f) return;
+  }
   const int Dp = D / 2;
-  const int z = (int)(i % D), y = (int)((i / D) % D), x = (int)(i / ((int64_t)D * D));
-  int x0, x1, y0, y1, z0, z1;
-  float lx, ly, lz;
-  up2_src(x, Dp, x0, x1, lx);
-  up2_src(y, Dp, y0, y1, ly);
-  up2_src(z, Dp, z0, z1, lz);
-  const float hx = 1.0f - lx, hy = 1.0f - ly, hz = 1.0f - lz;
-  auto A = [&](int xi, int yi, int zi, float wgt) {
-    if (wgt != 0.f) atomicAdd(g_prev + ((int64_t)xi * Dp + yi) * Dp + zi, g * wgt);
-  };
-  A(x0, y0, z0, hx * hy * hz); A(x0, y0, z1, hx * hy * lz); A(x0, y1, z0, hx * ly * hz); A(x0, y1, z1, hx * ly * lz);
-  A(x1, y0, z0, lx * hy * hz); A(x1, y0, z1, lx * hy * lz); A(x1, y1, z0, lx * ly * hz); A(x1, y1, z1, lx * ly * lz);
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) {
+    const int64_t i = i0 + q;
+    const float g = gv[q];
+    if (g == 0.f || table[i] >= 0) continue;
+    const int z = (int)(i % D), y = (int)((i / D) % D), x = (int)(i / ((int64_t)D * D));
+    int x0, x1, y0, y1, z0, z1;
+    float lx, ly, lz;
+    up2_src(x, Dp, x0, x1, lx);
+    up2_src(y, Dp, y0, y1, ly);
+    up2_src(z, Dp, z0, z1, lz);
+    const float hx = 1.0f - lx, hy = 1.0f - ly, hz = 1.0f - lz;
+    auto A = [&](int xi, int yi, int zi, float wgt) {
+      if (wgt != 0.f) atomicAdd(g_prev + ((int64_t)xi * Dp + yi) * Dp + zi, g * wgt);
+    };
+    A(x0, y0, z0, hx * hy * hz); A(x0, y0, z1, hx * hy * lz); A(x0, y1, z0, hx * ly * hz); A(x0, y1, z1, hx * ly * lz);
+    A(x1, y0, z0, lx * hy * hz); A(x1, y0, z1, lx * hy * lz); A(x1, y1, z0, lx * ly * hz); A(x1, y1, z1, lx * ly * lz);
+  }
 }
 
 // backward of gather_rows: g_src[idx[i] >> shift, 0:w] += g_dst[i, off : off + w]
@@ -677,7 +693,13 @@ extern "C" int surf_densify_backward(const int32_t* coords, int64_t n, int D, co
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(dense_rows_bwd_kernel, grid1d(n, 256), dim3(256), 0, st, coords, g_dense, n, D, row_stride, g_rows);
   if (g_prev)
-    hipLaunchKernelGGL(dense_init_bwd_kernel, grid1d((int64_t)D * D * D, 256), dim3(256), 0, st, g_dense, table, D, g_prev);
+  {
+    const int64_t total = (int64_t)D * D * D;
+    if (D % 4 == 0)
+      hipLaunchKernelGGL(dense_init_bwd_kernel<4>, grid1d(total / 4, 256), dim3(256), 0, st, g_dense, table, D, g_prev);
+    else
+      hipLaunchKernelGGL(dense_init_bwd_kernel<1>, grid1d(total, 256), dim3(256), 0, st, g_dense, table, D, g_prev);
+  }
   return surf_check_launch();
 }
 

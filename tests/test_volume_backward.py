@@ -69,7 +69,7 @@ def test_matching_depth_backward(scene, golden_pipe, golden_train, stage, pertur
     grad_close(dm, mvol.grad)
 
 
-@pytest.mark.parametrize("D", [8, 12, 32])
+@pytest.mark.parametrize("D", [8, 10, 12, 32])
 def test_densify_backward(D):
     from surf_amd import ops
     d = dev()
