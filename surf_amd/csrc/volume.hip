@@ -299,28 +299,44 @@ __device__ __forceinline__ void up2_src(int i, int Dp, int& i0, int& i1, float& 
   l1 = src - (float)i0;
 }
 
+// VEC voxels along z per thread (VEC = 4 when D % 4 == 0: 16-byte stores; 704^3 is 1.4 GB of logits + 1.4 GB of table)
+template <int VEC>
 __global__ __launch_bounds__(256) void dense_init_kernel(const float* __restrict__ prev, int D, float* __restrict__ dense,
                                                          int32_t* __restrict__ table) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)D * D * D;
-  if (i >= total) return;
-  table[i] = -1;
-  float v = 0.f;
-  if (prev) {
-    const int Dp = D / 2;
-    const int z = (int)(i % D), y = (int)((i / D) % D), x = (int)(i / ((int64_t)D * D));
-    int x0, x1, y0, y1, z0, z1;
-    float lx, ly, lz;
-    up2_src(x, Dp, x0, x1, lx);
-    up2_src(y, Dp, y0, y1, ly);
-    up2_src(z, Dp, z0, z1, lz);
-    const float hx = 1.0f - lx, hy = 1.0f - ly, hz = 1.0f - lz;
-    auto P = [&](int xi, int yi, int zi) { return prev[((int64_t)xi * Dp + yi) * Dp + zi]; };
-    // ATen upsample_trilinear3d: w_d (w_h (w_w a + w_w b) + ...) with d = our x, h = y, w = z
-    v = hx * (hy * (hz * P(x0, y0, z0) + lz * P(x0, y0, z1)) + ly * (hz * P(x0, y1, z0) + lz * P(x0, y1, z1))) +
-        lx * (hy * (hz * P(x1, y0, z0) + lz * P(x1, y0, z1)) + ly * (hz * P(x1, y1, z0) + lz * P(x1, y1, z1)));
+  const int64_t i0 = t * VEC;
+  if (i0 >= total) return;
+  // one 32-bit decomposition per thread (64-bit div / mod per voxel cost more than the whole upsample)
+  const unsigned zc = (unsigned)D / VEC, tu = (unsigned)t;
+  const int zb = (int)(tu % zc) * VEC, y = (int)((tu / zc) % (unsigned)D), x = (int)(tu / (zc * (unsigned)D));
+  float out[VEC];
+#pragma unroll
+  for (int q = 0; q < VEC; ++q) {
+    float v = 0.f;
+    if (prev) {
+      const int Dp = D / 2;
+      const int z = zb + q;
+      int x0, x1, y0, y1, z0, z1;
+      float lx, ly, lz;
+      up2_src(x, Dp, x0, x1, lx);
+      up2_src(y, Dp, y0, y1, ly);
+      up2_src(z, Dp, z0, z1, lz);
+      const float hx = 1.0f - lx, hy = 1.0f - ly, hz = 1.0f - lz;
+      auto P = [&](int xi, int yi, int zi) { return prev[((int64_t)xi * Dp + yi) * Dp + zi]; };
+      // ATen upsample_trilinear3d: w_d (w_h (w_w a + w_w b) + ...) with d = our x, h = y, w = z
+      v = hx * (hy * (hz * P(x0, y0, z0) + lz * P(x0, y0, z1)) + ly * (hz * P(x0, y1, z0) + lz * P(x0, y1, z1))) +
+          lx * (hy * (hz * P(x1, y0, z0) + lz * P(x1, y0, z1)) + ly * (hz * P(x1, y1, z0) + lz * P(x1, y1, z1)));
+    }
+    out[q] = v;
   }
-  dense[i] = v;
+  if (VEC == 4) {
+    *reinterpret_cast<f32x4*>(dense + i0) = f32x4{out[0], out[1 % VEC], out[2 % VEC], out[3 % VEC]};
+    *reinterpret_cast<int4*>(table + i0) = int4{-1, -1, -1, -1};
+  } else {
+    dense[i0] = out[0];
+    table[i0] = -1;
+  }
 }
 
 __global__ __launch_bounds__(256) void dense_scatter_kernel(const int32_t* __restrict__ coords, const float* __restrict__ rows,
@@ -366,12 +382,14 @@ __global__ __launch_bounds__(256) void dense_init_bwd_kernel(const float* __rest
     if (gv[0] == 0.f) return;
   }
   const int Dp = D / 2;
+  const unsigned zc = (unsigned)D / VEC, tu = (unsigned)t;
+  const int zb = (int)(tu % zc) * VEC, y = (int)((tu / zc) % (unsigned)D), x = (int)(tu / (zc * (unsigned)D));
 #pragma unroll
   for (int q = 0; q < VEC; ++q) {
     const int64_t i = i0 + q;
     const float g = gv[q];
     if (g == 0.f || table[i] >= 0) continue;
-    const int z = (int)(i % D), y = (int)((i / D) % D), x = (int)(i / ((int64_t)D * D));
+    const int z = zb + q;
     int x0, x1, y0, y1, z0, z1;
     float lx, ly, lz;
     up2_src(x, Dp, x0, x1, lx);
@@ -681,7 +699,10 @@ extern "C" int surf_densify(const int32_t* coords, const float* rows, int row_st
   if (!coords || !rows || !dense || !table || n <= 0 || D < 2 || row_stride < 1) return SURF_E_ARG;
   if (prev && (D & 1)) return SURF_E_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(dense_init_kernel, grid1d((int64_t)D * D * D, 256), dim3(256), 0, st, prev, D, dense, table);
+  if (D % 4 == 0)
+    hipLaunchKernelGGL(dense_init_kernel<4>, grid1d((int64_t)D * D * D / 4, 256), dim3(256), 0, st, prev, D, dense, table);
+  else
+    hipLaunchKernelGGL(dense_init_kernel<1>, grid1d((int64_t)D * D * D, 256), dim3(256), 0, st, prev, D, dense, table);
   hipLaunchKernelGGL(dense_scatter_kernel, grid1d(n, 256), dim3(256), 0, st, coords, rows, row_stride, n, D, dense, table);
   return surf_check_launch();
 }
