@@ -260,7 +260,7 @@ def training_step_timing(args, dev, steps=3):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     return {"ms_per_step": ms, "rays": int(ipts["rays_o"].shape[0]), "samples_per_ray": 128,
-            "voxels_per_stage": [int(r["coords"].shape[0]) for r in model._train_tape["vol"]],
+            "voxels_per_stage": model.last_voxels_per_stage,
             "loss": out["loss"], "what": "forward (FPN, volume build, render) + loss + HIP backward of all of it + Adam; "
                                          "every term of losses/loss.py; matching-field jitter on the device generator"}
 

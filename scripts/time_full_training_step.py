@@ -58,7 +58,7 @@ for _ in range(N):
     for label, e0, e1 in marks:
         acc[label] = acc.get(label, 0.0) + e0.elapsed_time(e1)
 wall = (time.perf_counter() - t0) / N * 1e3
-nvox = [int(r["coords"].shape[0]) for r in model._train_tape["vol"]]
+nvox = model.last_voxels_per_stage
 print(f"{R} rays x 128 samples, {nv} views {H}x{W}, voxels per stage {nvox}: wall {wall:.1f} ms per training step, loss {out['loss']:.4f}")
 for k, v in acc.items():
     print(f"  {k}: {v / N:.2f} ms")

@@ -415,25 +415,7 @@ __global__ __launch_bounds__(256) void scatter_rows_add_kernel(const float* __re
   atomicAdd(g_src + (int64_t)(idx[i] >> shift) * w + c, g_dst[i * dst_stride + dst_off + c]);
 }
 
-__device__ __forceinline__ void bilinear_texel4_scatter(float* __restrict__ map, int H, int W, float x, float y, const float g[4]) {
-  const float fx = floorf(x), fy = floorf(y);
-  const float tx = x - fx, ty = y - fy;
-  const int x0 = (int)fx, y0 = (int)fy;
-#pragma unroll
-  for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int xi = x0 + dx, yi = y0 + dy;
-      const float wgt = (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty);
-      if ((xi >= 0) & (xi < W) & (yi >= 0) & (yi < H) && wgt != 0.f) {
-        float* d = map + ((int64_t)yi * W + xi) * 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) atomicAdd(d + c, g[c] * wgt);
-      }
-    }
-}
-
-// Octet-cooperative form of bilinear_texel4_scatter, called by ALL 64 lanes of a wavefront: in round r the eight lanes of an
+// Octet-cooperative scatter of a texel4 gradient through the bilinear taps, called by ALL 64 lanes of a wavefront: in round r the eight lanes of an
 // octet serve lane 8 o + r's request, lane j adding channel j & 3 of the tap column j >> 2 - the two x-taps of a row are
 // adjacent texels, so one instruction writes 32 contiguous bytes per request instead of eight separate float atomics (the L2
 // atomic rate is per memory transaction, not per float: this is what bounds the kernel).

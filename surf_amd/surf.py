@@ -157,6 +157,8 @@ class SuRF(nn.Module):
             d_mvol = d_prev
         self.volume.assign_agg_grad(g_agg)
         self.feature_network.backward(t["fpn"], gfeats)
+        self.last_voxels_per_stage = [int(r["coords"].shape[0]) for r in t["vol"]]
+        self._train_tape = None                     # the tapes hold every stage's activations (GBs at full size): one backward each
         return gfeats
 
     def _frozen_scene(self, ipts):
