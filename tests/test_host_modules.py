@@ -108,3 +108,65 @@ def test_perturb_draw_order_matches_reference():
     torch.manual_seed(4321)
     t = torch.cat([torch.rand([R, 1]) - 0.5 for _ in range(n_stage)], dim=1)      # the expression in render_scene
     assert torch.equal(t, t_ref)
+
+
+def test_matching_field_jitter_draw_order_matches_the_reference():
+    """MatchingField.draw_jitter consumes the CPU generator like the reference's depth_render calls (matching_field.py:33-35,
+    129-133): views in order, only view 0 and src_idx draw, one `torch.rand([n_rays, 1]) - 0.5` per band."""
+    import torch
+    from surf_amd import conf
+    from surf_amd.matching_field import MatchingField
+    mf = MatchingField(conf.from_dict({"n_samples_depths": [8, 4, 4, 2], "n_importance_depths": [0] * 4, "up_sample_steps": [0] * 4,
+                                       "depth_res_levels": [4, 2, 2, 1]}))
+    nv, n_rays, src_idx = 5, 37, 3
+    for n_bands in (1, 2):
+        torch.manual_seed(123)
+        jit = mf.draw_jitter(nv, n_rays, n_bands, src_idx)
+        torch.manual_seed(123)
+        ref = torch.zeros(nv, n_rays, 2)
+        for i in range(nv):                      # the reference's loop: depth_render(perturb) for i == 0 or i == src_idx only
+            if i == 0 or i == src_idx:
+                for b in range(n_bands):
+                    ref[i, :, b] = (torch.rand([n_rays, 1]) - 0.5)[:, 0]
+        assert torch.equal(jit, ref)
+        assert float(jit[1].abs().max()) == 0.0 and float(jit[0].abs().max()) > 0
+    torch.manual_seed(5)
+    same = mf.draw_jitter(nv, n_rays, 2, 0)      # src_idx == 0: a single drawing view
+    assert float(same[1:].abs().max()) == 0.0
+
+
+def test_agg_mlp_gradient_split_and_step_helpers():
+    """Volume.assign_agg_grad splits costvol_backward's 49 floats (w1 | b1 | w2 | b2) onto agg_mlp's parameters and accumulates;
+    training._sync_gradients is a no-op without a process group."""
+    import torch
+    from surf_amd import conf, training
+    from surf_amd.volume import Volume
+    vol = Volume(conf.from_dict({"base_volume_dim": [8, 8, 8]}))
+    g = torch.arange(49, dtype=torch.float32)
+    vol.assign_agg_grad(g)
+    assert torch.equal(vol.agg_mlp[0].weight.grad, g[:32].reshape(8, 4))
+    assert torch.equal(vol.agg_mlp[0].bias.grad, g[32:40])
+    assert torch.equal(vol.agg_mlp[2].weight.grad, g[40:48].reshape(1, 8))
+    assert torch.equal(vol.agg_mlp[2].bias.grad, g[48:49])
+    vol.assign_agg_grad(g)
+    assert torch.equal(vol.agg_mlp[2].bias.grad, 2 * g[48:49])
+    host = vol.agg_host()
+    assert host.shape == (49,)
+    opt = torch.optim.SGD(vol.parameters(), lr=0.1)
+    before = vol.agg_mlp[0].bias.grad.clone()
+    training._sync_gradients(opt)
+    assert torch.equal(vol.agg_mlp[0].bias.grad, before)
+
+
+def test_backward_entry_points_fail_loudly_without_a_recorded_forward():
+    import pytest as _pytest
+    import torch
+    from surf_amd import conf
+    from surf_amd.surf import SuRF
+    from tests.golden.make_golden import MODEL_CONF
+    cfg = dict(MODEL_CONF)
+    cfg["reg_network"] = {"d_in": [8, 16, 16, 16], "d_base": [8] * 4, "d_out": [8] * 4}
+    model = SuRF(conf.from_dict(cfg))
+    model._train_tape = None
+    with _pytest.raises(RuntimeError, match="record=True"):
+        model.backward_volumes([torch.zeros(1, 7)] * 4)
