@@ -51,26 +51,47 @@ __global__ __launch_bounds__(256) void ray_setup_kernel(RaySetupArgs a) {
   const float range = far - near;
 
   // ---- coarse surface estimate: softmax-expected z over n_depth taps (implicit_surface.py:281-291)
-  float rho[4], zc[4];
+  // two lanes per tap: lane parity = dz, so the two z-corners of a trilinear row are adjacent lanes and adjacent floats (one
+  // 8-byte request instead of two scattered 4-byte ones); the halves meet by one xor-shuffle.  Both lanes of a pair then hold the
+  // same rho: den and num are both counted twice and their ratio is unchanged.
+  float rho[8], zc[8];
   float m = -INFINITY;
+  const int half = lane >> 1, cdz = lane & 1;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int k = lane + 64 * i;
+  for (int i = 0; i < 8; ++i) {
+    const int k = half + 32 * i;
     rho[i] = -INFINITY;
     zc[i] = 0.f;
-    if (k < a.n_depth) {
-      float z = near + range * a.lin_depth[k];
-      float px = ox + dx * z, py = oy + dy * z, pz = oz + dz * z;
-      rho[i] = trilinear_zeros(a.mvol, a.Dm, unnorm_acf(px, a.Dm), unnorm_acf(py, a.Dm), unnorm_acf(pz, a.Dm));
+    float part = 0.f;
+    const bool on = k < a.n_depth;
+    if (on) {
+      const float z = near + range * a.lin_depth[k];
+      const float gx = unnorm_acf(ox + dx * z, a.Dm), gy = unnorm_acf(oy + dy * z, a.Dm), gz = unnorm_acf(oz + dz * z, a.Dm);
+      const float fx = floorf(gx), fy = floorf(gy), fz = floorf(gz);
+      const float tx = gx - fx, ty = gy - fy, tz = gz - fz;
+      const int x0 = (int)fx, y0 = (int)fy, zi = (int)fz + cdz;
+      const float wz = cdz ? tz : 1.0f - tz;
+      if ((zi >= 0) & (zi < a.Dm)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int xi = x0 + (c >> 1), yi = y0 + (c & 1);
+          const float wgt = ((c >> 1) ? tx : 1.0f - tx) * ((c & 1) ? ty : 1.0f - ty) * wz;
+          if ((xi >= 0) & (xi < a.Dm) & (yi >= 0) & (yi < a.Dm)) part += a.mvol[((int64_t)xi * a.Dm + yi) * a.Dm + zi] * wgt;
+        }
+      }
       zc[i] = z;
-      m = fmaxf(m, rho[i]);
+    }
+    part += __shfl_xor(part, 1);
+    if (on) {
+      rho[i] = part;
+      m = fmaxf(m, part);
     }
   }
   m = wave_max(m);
   float den = 0.f, num = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    float e = (lane + 64 * i < a.n_depth) ? expf(rho[i] - m) : 0.f;
+  for (int i = 0; i < 8; ++i) {
+    float e = (half + 32 * i < a.n_depth) ? expf(rho[i] - m) : 0.f;
     den += e;
     num += e * zc[i];
   }
