@@ -10,7 +10,8 @@ from surf_amd import ops, training
 from bench import training_step_setup
 
 dev = torch.device("cuda:0")
-nv, H, W, R = 5, 576, 800, int(sys.argv[1]) if len(sys.argv) > 1 else 512
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+nv, H, W = 5, int(sys.argv[2]) if len(sys.argv) > 2 else 576, int(sys.argv[3]) if len(sys.argv) > 3 else 800      # surf.conf trains at 480 640
 model, ipts, targets, loss_fn, opt = training_step_setup(dev, H, W, nv, 88, R, device_jitter=os.environ.get("SURF_CPU_JITTER", "0") != "1")
 
 # instrument the phases with HIP events by wrapping the model's entry points
