@@ -392,3 +392,41 @@ def test_seven_view_backward_kernels(weights):
     (torch.stack(ref) * Gd).sum().backward()
     dm = ops.matching_depth_backward(mvol.to(d).contiguous(), cams, near_fars, H, W, lv[0], nsd[0], Gd.to(d).contiguous(), views=(0, 5))
     grad_close(dm, mv.grad)
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("C,n", [(8, 1000), (64, 777), (16, 1)])
+def test_bn_relu_backward_both_modes(train, C, n):
+    """surf_bn_relu_backward against torch autograd of BatchNorm1d + ReLU (+ skip): batch statistics (train) and running
+    statistics (eval), every channel count of the U-Net, ragged and single-row inputs."""
+    from surf_amd import ops
+    d = dev()
+    if train and n == 1:
+        pytest.skip("batch statistics of one row: the variance is zero and torch refuses it")
+    g = torch.Generator().manual_seed(C + n)
+    x = torch.randn(n, C, generator=g).requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g)
+        bn.bias.uniform_(-0.3, 0.3, generator=g)
+        bn.running_mean.uniform_(-0.2, 0.2, generator=g)
+        bn.running_var.uniform_(0.5, 2.0, generator=g)
+    bn.train(train)
+    if train:
+        mean, var = x.detach().mean(0), x.detach().var(0, unbiased=False)
+    else:
+        mean, var = bn.running_mean.clone(), bn.running_var.clone()
+    skip = torch.randn(n, C, generator=g).requires_grad_(True)
+    dy = torch.randn(n, C, generator=g)
+    y = torch.relu(bn(x)) + skip
+    (y * dy).sum().backward()
+    invstd = 1.0 / torch.sqrt(var + bn.eps)
+    scale = (bn.weight.detach() * invstd).contiguous()
+    shift = (bn.bias.detach() - mean * scale).contiguous()
+    stats = torch.cat([mean, invstd]).contiguous()
+    dx, dgamma, dbeta = ops.bn_relu_backward(x.detach().to(d).contiguous(), dy.to(d).contiguous(), scale.to(d), shift.to(d), stats.to(d),
+                                            train=train)
+    grad_close(dx, x.grad, 2e-3)
+    grad_close(dgamma, bn.weight.grad, 2e-3)
+    grad_close(dbeta, bn.bias.grad, 2e-3)
+    assert torch.equal(skip.grad, dy)                      # the skip's gradient is dy itself (the caller adds it)
