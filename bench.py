@@ -234,13 +234,15 @@ def training_step_setup(dev, H=576, W=800, nv=5, base_dim=88, rays=512, device_j
     ipts = {"imgs": imgs, "intrs": intrs.to(dev), "c2ws": c2ws.to(dev), "near_fars": near_fars.to(dev),
             "near": near_fars[0, 0].reshape(1, 1).to(dev), "far": near_fars[0, 1].reshape(1, 1).to(dev),
             "rays_o": rays_o[sel].contiguous(), "rays_d": rays_d[sel].contiguous(), "src_idx": 1}
+    pp = torch.randn(4096, 3, device=dev)
+    ipts["pseudo_pts"] = 0.5 * pp / pp.norm(dim=1, keepdim=True)        # the dataset's pseudo surface points (pseudo_sdf term)
     ones = torch.ones(H, W, device=dev)
     targets = {"color": torch.rand(rays, 3, device=dev), "imgs": imgs, "intrs": intrs, "c2ws": c2ws, "src_idx": 1,
                "mask_ref": ones, "mask_src": ones, "pseudo_depth_ref": ones * 2.0, "pseudo_depth_src": ones * 2.0,
                "depth_ref": ones * 2.0, "depth_src": ones * 2.0}
     loss_fn = Loss(conf.from_dict({"color_weight": 1.0, "sparse_scale_factor": 100, "sparse_weight": 0.02, "igr_weight": 0.1,
                                    "mfc_weight": 0.5, "smooth_weight": 0.0001, "depth_weight": 0.0, "ptloss_weight": 1.0,
-                                   "pseudo_auxi_depth_weight": 1.0, "pseudo_sdf_weight": 0.0, "pseudo_depth_weight": 0.0,
+                                   "pseudo_auxi_depth_weight": 1.0, "pseudo_sdf_weight": 1.0, "pseudo_depth_weight": 0.0,
                                    "stage_weights": [0.25, 0.5, 0.75, 1.0]}))
     opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}))
     return model, ipts, targets, loss_fn, opt

@@ -303,7 +303,7 @@ class ImplicitSurface(nn.Module):
 
     @torch.no_grad()
     def backward_render(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None, gfeats_t4=None,
-                        g_smooth_error=0.0):
+                        g_smooth_error=0.0, g_pseudo_sdf=None):
         """Partial backward of the last training forward (`render_scene(patch_warp=True)`), SURVEY 8f-f2: given the loss's
         gradients w.r.t. `color_fine` (R,3), `render_depth` (R), `gradient_error` (scalar), `sparse_sdf` ((1024 + R*S),1) and
         the per-ray patch NCC (R,1) (= compute_LNCC2 of ref_gray_val / sampled_gray_val, the mfc term),
@@ -314,8 +314,8 @@ class ImplicitSurface(nn.Module):
         surf_crossing_backward (d ncc / d z0 as a forward-mode tangent along the ray, then into the two bracketing samples).
         gfeats_t4 (fine -> coarse, like the scene's feature maps): accumulates the colour path's gradient into the FPN maps
         (generalisation training).  g_smooth_error (scalar): the smooth (H.1) term, through surf_sdf_smooth_backward (reverse
-        over a forward with value, two tangents and their mixed tangent).  The volume build's backward is
-        SuRF.backward_volumes."""
+        over a forward with value, two tangents and their mixed tangent).  g_pseudo_sdf (n_pseudo, 1): the pseudo_sdf output
+        (`ImplicitSurface.pseudo_sdf` after the training forward).  The volume build's backward is SuRF.backward_volumes."""
         c = self._ctx
         st, act, scene = c["st"], c["act"], c["scene"]
         dev = c["sdf"].device
@@ -339,6 +339,11 @@ class ImplicitSurface(nn.Module):
             pts = torch.cat([pts, c["random_pts"][occ]])
             ybar = torch.cat([ybar, gs[:1024][occ]])
             gbar = torch.cat([gbar, torch.zeros(int(occ.sum()), 3, device=dev)])
+        if g_pseudo_sdf is not None and "pseudo_pts" in c:        # pseudo_sdf (:425-434): the occupied pseudo points' SDF values
+            occ_p = c["pseudo_occ"]
+            pts = torch.cat([pts, c["pseudo_pts"][occ_p]])
+            ybar = torch.cat([ybar, g_pseudo_sdf.reshape(-1).float()[occ_p]])
+            gbar = torch.cat([gbar, torch.zeros(int(occ_p.sum()), 3, device=dev)])
         res = ops.sdf_backward(pts.contiguous(), ybar.contiguous(), gbar.contiguous(), scene.sv, self.smooth_weights(dev))
         if g_smooth_error:
             # smooth_error = sum_n inside_n |smooth_n| / (sum inside + 1e-5)  ->  sbar_n = g inside_n smooth_n / (|smooth_n| den)
@@ -456,6 +461,17 @@ class ImplicitSurface(nn.Module):
         outputs["render_depth"] = torch.cat(rdeps).cpu().numpy().reshape([height, width])
         return outputs
 
+    def pseudo_sdf(self, pseudo_pts, scene):
+        """implicit_surface.py:425-434: the SDF at the dataset's pseudo surface points (zero where no level is occupied), the
+        input of `pseudo_sdf_loss` (losses/loss.py:67).  Recorded for `backward_render` when a training forward was."""
+        pp = pseudo_pts.float().contiguous()
+        occ = scene.occupied_any(pp)
+        sdf_w, _ = self.packed_weights(pp.device)
+        sdf, _ = ops.sdf_mlp(pp, scene.sv, sdf_w, mask=occ.to(torch.uint8), want_grad=False)
+        if getattr(self, "_ctx", None) is not None:
+            self._ctx["pseudo_pts"], self._ctx["pseudo_occ"] = pp, occ
+        return torch.where(occ, sdf, torch.zeros_like(sdf))[:, None]
+
     def forward(self, mode, ipts, matching_volume, volumes, sparse_idxes, mask_volumes, features, match_features,
                 cos_anneal_ratio=1.0, step=None):
         rays_o, rays_d = ipts["rays_o"], ipts["rays_d"]
@@ -471,15 +487,5 @@ class ImplicitSurface(nn.Module):
         else:
             outputs = self.render_scene(rays_o, rays_d, near, far, scene, cos_anneal_ratio)
         if "pseudo_pts" in ipts:  # implicit_surface.py:425-434
-            pp = ipts["pseudo_pts"].float().contiguous()
-            occ = torch.zeros(pp.shape[0], dtype=torch.bool, device=pp.device)
-            for t in scene.sv.tables:
-                D = t.shape[0]
-                g = torch.round(((pp + 1.0) * D - 1.0) / 2.0).long()
-                ok = ((g >= 0) & (g < D)).all(dim=1)
-                gc = g.clamp(0, D - 1)
-                occ |= ok & (t[gc[:, 0], gc[:, 1], gc[:, 2]] >= 0)
-            sdf_w, _ = self.packed_weights(pp.device)
-            sdf, _ = ops.sdf_mlp(pp, scene.sv, sdf_w, mask=occ.to(torch.uint8), want_grad=False)
-            outputs["pseudo_sdf"] = torch.where(occ, sdf, torch.zeros_like(sdf))[:, None]
+            outputs["pseudo_sdf"] = self.pseudo_sdf(ipts["pseudo_pts"], scene)
         return outputs

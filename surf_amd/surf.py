@@ -94,7 +94,8 @@ class SuRF(nn.Module):
         self.has_vol = True
         self._vol_scene = None
 
-    def backward(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None, g_smooth_error=0.0):
+    def backward(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None, g_smooth_error=0.0,
+                 g_pseudo_sdf=None):
         """Partial backward of the last train-mode forward (row f2): `.grad` of every implicit-surface parameter and, in
         finetune mode (has_vol), of the per-scene feature volumes - what surf.py:36-45 hands the optimiser there.  See
         ImplicitSurface.backward_render for the chain; the volume build / FPN backward is `backward_volumes`."""
@@ -103,7 +104,7 @@ class SuRF(nn.Module):
             self._train_tape["gfeats"] = [torch.zeros_like(f) for f in self._train_tape["feats"]]      # coarse -> fine
             gfeats = self._train_tape["gfeats"][::-1]
         dvols = self.implicit_surface.backward_render(g_color, g_depth, g_gradient_error, g_sparse_sdf, g_ncc, gfeats_t4=gfeats,
-                                                      g_smooth_error=g_smooth_error)
+                                                      g_smooth_error=g_smooth_error, g_pseudo_sdf=g_pseudo_sdf)
         if self.has_vol:
             for p, g in zip(self.volumes, dvols[::-1]):          # volumes are kept coarse -> fine
                 g = g.to(p.dtype)
@@ -266,5 +267,7 @@ class SuRF(nn.Module):
                                      cos_anneal_ratio, step, mesh_resolution=int(ipts.get("mesh_resolution", 512)))
         else:
             surface = isurf.render_scene(rays_o, rays_d, near, far, scene, cos_anneal_ratio, patch_warp=True, step=step)
+            if "pseudo_pts" in ipts:                                            # implicit_surface.py:425-434
+                surface["pseudo_sdf"] = isurf.pseudo_sdf(ipts["pseudo_pts"], scene)
         outputs.update(surface)
         return outputs

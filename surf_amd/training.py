@@ -8,7 +8,7 @@ terms through torch autograd on the depth maps, the photometric term through `su
 `SuRF.backward_volumes` (matching field -> densify -> sparse U-Net -> cost volume -> FPN), so that every parameter group of
 surf.py:36-45 receives its gradient.
 
-Differentiated terms: every term of losses/loss.py - colour, eikonal, sparse-SDF, smooth (H.1), rendered-depth, the patch-NCC
+Differentiated terms: every term of losses/loss.py - colour, eikonal, sparse-SDF, smooth (H.1), rendered-depth, pseudo-SDF (the dataset's `pseudo_pts`), the patch-NCC
 term (`mfc_loss`), the per-stage photometric and pseudo-depth terms.
 """
 import torch
@@ -25,17 +25,21 @@ def _sync_gradients(optimizer):
 LEAVES = ("color_fine", "render_depth", "gradient_error", "sparse_sdf", "ncc", "smooth_error")
 
 
+def _leaf_names(preds):
+    return LEAVES + (("pseudo_sdf",) if "pseudo_sdf" in preds else ())
+
+
 def finetune_step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio=1.0, step=0):
     preds = model("train", ipts, cos_anneal_ratio, step)
     preds["ncc"] = ops.lncc(preds["ref_gray_val"].contiguous(), preds["sampled_gray_val"].contiguous())
-    leaves = {k: preds[k].detach().clone().requires_grad_(True) for k in LEAVES}
+    leaves = {k: preds[k].detach().clone().requires_grad_(True) for k in _leaf_names(preds)}
     with torch.enable_grad():
         out = loss_fn({**preds, **leaves}, targets, step=step, mode="finetune")      # any mode but "train": no per-stage terms
         out["loss"].backward()
     optimizer.zero_grad(set_to_none=True)
     g = {k: v.grad for k, v in leaves.items()}
     model.backward(g["color_fine"], g["render_depth"], 0.0 if g["gradient_error"] is None else float(g["gradient_error"]),
-                   g["sparse_sdf"], g["ncc"], 0.0 if g["smooth_error"] is None else float(g["smooth_error"]))
+                   g["sparse_sdf"], g["ncc"], 0.0 if g["smooth_error"] is None else float(g["smooth_error"]), g.get("pseudo_sdf"))
     _sync_gradients(optimizer)
     optimizer.step()
     return {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in out.items()}
@@ -51,7 +55,7 @@ def train_step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio=1.0, s
     preds["ncc"] = ops.lncc(preds["ref_gray_val"].contiguous(), preds["sampled_gray_val"].contiguous())
     n = model.num_stage
     depth_keys = [f"depth_stage{i}" for i in range(n)] + [f"depth_src_stage{i}" for i in range(n)]
-    leaves = {k: preds[k].detach().clone().requires_grad_(True) for k in LEAVES + tuple(depth_keys)}
+    leaves = {k: preds[k].detach().clone().requires_grad_(True) for k in _leaf_names(preds) + tuple(depth_keys)}
     with torch.enable_grad():
         out = loss_fn({**preds, **leaves}, targets, step=step, mode="train")
         out["loss"].backward()
@@ -75,7 +79,8 @@ def train_step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio=1.0, s
             g_src = p_src if g_src is None else g_src + p_src
         g_depths[i] = (g_ref, g_src)
     rows = model.backward(g["color_fine"], g["render_depth"], 0.0 if g["gradient_error"] is None else float(g["gradient_error"]),
-                          g["sparse_sdf"], g["ncc"], 0.0 if g["smooth_error"] is None else float(g["smooth_error"]))
+                          g["sparse_sdf"], g["ncc"], 0.0 if g["smooth_error"] is None else float(g["smooth_error"]),
+                          g.get("pseudo_sdf"))
     model.backward_volumes(rows, g_depths)
     _sync_gradients(optimizer)
     optimizer.step()

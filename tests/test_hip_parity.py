@@ -978,8 +978,11 @@ def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
     assert float(g_ncc.abs().sum()) > 0
     gfeats = [torch.zeros_like(f) for f in gpu_scene["feats_t4"]]          # fine -> coarse: the colour path's share of d FPN maps
     g_smooth = 0.02                                                         # |H.1| ~ 1e1..1e2 with beta = 100
+    pseudo = (torch.rand(200, 3, generator=g) * 2 - 1) * 0.8               # the dataset's pseudo surface points (:425-434)
+    g_pseudo = torch.randn(200, 1, generator=g) * 0.05
+    pseudo_sdf = model.pseudo_sdf(pseudo.to(d), sc)
     dvols = model.backward_render(g_color.to(d), g_depth.to(d), g_eik, g_sparse.to(d), g_ncc.to(d), gfeats_t4=gfeats,
-                                  g_smooth_error=g_smooth)
+                                  g_smooth_error=g_smooth, g_pseudo_sdf=g_pseudo.to(d))
     # oracle autograd
     c = gpu_scene["cpu"]
     sd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in weights.items() if k.startswith("implicit_surface.")}
@@ -995,6 +998,11 @@ def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
     loss = ((o["color_fine"] * g_color).sum() + (o["render_depth"] * g_depth).sum() + o["gradient_error"] * g_eik
             + (sdf_r * g_sparse[:1024, 0]).sum() + (o["sdf"].reshape(-1) * g_sparse[1024:, 0]).sum()
             + (O.lncc(o["ref_gray_val"], o["sampled_gray_val"]) * g_ncc).sum() + o["smooth_error"] * g_smooth)
+    occ_p = torch.stack([O.lookup_volume_nearest(pseudo, mk) for mk in c["masks"]], dim=-1).any(dim=-1)
+    sdf_p = O.sdf_mlp(O.sdf_weights(sd), pseudo, O.lookup_sparse_volume(pseudo, vols, c["tabs"]))[0] * occ_p.float()
+    assert 0 < int(occ_p.sum()) < 200
+    rel_close(pseudo_sdf[:, 0], sdf_p.detach(), 0, 1e-4)
+    loss = loss + (sdf_p * g_pseudo[:, 0]).sum()
     loss.backward()
     rel_close(out["color_fine"], o["color_fine"].detach(), 1e-3, 1e-5)
     rel_close(out["smooth_error"].reshape(1), o["smooth_error"].detach().reshape(1), 2e-3, 1e-4)

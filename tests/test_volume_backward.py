@@ -294,6 +294,7 @@ def test_train_steps_move_every_parameter_group(scene):
     R = scene["rays_o"].shape[0]
     H, W = scene["imgs"].shape[-2:]
     g = torch.Generator().manual_seed(5)
+    ipts["pseudo_pts"] = ((torch.rand(300, 3, generator=g) * 2 - 1) * 0.7).to(d)      # -> preds["pseudo_sdf"], pseudo_sdf_loss
     targets = {"color": torch.rand(R, 3, generator=g).to(d), "imgs": ipts["imgs"], "intrs": scene["intrs"], "c2ws": scene["c2ws"],
                "src_idx": 1, "mask_ref": torch.ones(H, W, device=d), "mask_src": torch.ones(H, W, device=d),
                "pseudo_depth_ref": torch.full((H, W), 1.0, device=d), "pseudo_depth_src": torch.full((H, W), 1.0, device=d),
@@ -306,6 +307,7 @@ def test_train_steps_move_every_parameter_group(scene):
         torch.manual_seed(70)
         out = train_step(model, ipts, targets, loss_fn, opt, 1.0, step + 2)
         hist.append(out["loss"])
+        assert out["pseudo_sdf_loss"] > 0
         if step == 0:
             for k, v in model.named_parameters():
                 if v.grad is not None:
