@@ -432,3 +432,22 @@ def test_bn_relu_backward_both_modes(train, C, n):
     grad_close(dgamma, bn.weight.grad, 2e-3)
     grad_close(dbeta, bn.bias.grad, 2e-3)
     assert torch.equal(skip.grad, dy)                      # the skip's gradient is dy itself (the caller adds it)
+
+
+def test_train_step_seven_views():
+    """The whole training step at the Tanks&Temples view count (7 views) on a small synthetic scene: every stage's tapes,
+    the jitter shapes, the view loops of every backward kernel; finite loss and gradients, parameters move."""
+    from bench import training_step_setup
+    from surf_amd import training
+    d = dev()
+    model, ipts, targets, loss_fn, opt = training_step_setup(d, H=96, W=128, nv=7, base_dim=16, rays=128)
+    before = {k: v.detach().clone() for k, v in model.named_parameters() if v.requires_grad}
+    for step in range(2):
+        out = training.train_step(model, ipts, targets, loss_fn, opt, 1.0, step + 3)
+        assert np.isfinite(out["loss"]), out
+        for k, v in model.named_parameters():
+            if v.grad is not None:
+                assert bool(torch.isfinite(v.grad).all()), k
+    assert len(model.last_voxels_per_stage) == 4 and min(model.last_voxels_per_stage) > 0
+    moved = sum(1 for k, v in model.named_parameters() if v.requires_grad and float((v.detach() - before[k]).abs().max()) > 0)
+    assert moved > 100
