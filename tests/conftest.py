@@ -63,3 +63,9 @@ def golden_grid():
 @pytest.fixture(scope="session")
 def golden_train():
     return load_npz("train_outputs.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_grads():
+    """The reference's own loss.backward() through its own render (tests/golden/make_golden_grad.py)."""
+    return load_npz("train_grads.npz")

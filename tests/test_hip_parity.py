@@ -1022,6 +1022,59 @@ def test_backward_render_matches_oracle_autograd(scene, weights, gpu_scene):
         rel_close(gfeats[lvl].permute(0, 3, 1, 2), f.grad, 5e-3, 5e-4 * float(f.grad.abs().max()))
 
 
+def test_training_backward_equals_the_reference_loss_backward(scene, weights, gpu_scene, golden_grads):
+    """Row f2 against the REFERENCE itself: the reference's own ImplicitSurface.forward("train") + Loss.forward + loss.backward()
+    (tests/golden/make_golden_grad.py, CPU, its real modules) vs the HIP training forward, the loss mirror and
+    ImplicitSurface.backward_render: the loss value, every parameter gradient of the implicit surface and the sparse feature
+    rows' gradients, for the full finetune-mode loss (colour, eikonal, sparse, smooth, mfc, depth, pseudo-depth, pseudo-SDF)."""
+    from bench import model_conf
+    from surf_amd import conf, ops
+    from surf_amd.implicit_surface import ImplicitSurface, SceneVolumes
+    from surf_amd.losses import Loss
+    from surf_amd.training import LEAVES
+    from tests.golden.make_golden_grad import COS_ANNEAL, SEED, STEP
+    from tests.golden.make_golden_train import LOSS_CONF
+    d = dev()
+    gg = golden_grads
+    model = ImplicitSurface(model_conf(CFG["n_samples"], "f32"))
+    model.load_state_dict({k[len("implicit_surface."):]: v for k, v in weights.items() if k.startswith("implicit_surface.")})
+    model = model.to(d)
+    sc = SceneVolumes.from_device_layouts(gpu_scene["mvol"], gpu_scene["sv"].vols, gpu_scene["sv"].tables, gpu_scene["feats_t4"],
+                                          gpu_scene["imgs_t4"], gpu_scene["cams"])
+    R = scene["rays_o"].shape[0]
+    near, far = scene["near"].repeat(R, 1), scene["far"].repeat(R, 1)
+    torch.manual_seed(SEED)
+    preds = model.render_scene(scene["rays_o"].to(d), scene["rays_d"].to(d), near.to(d), far.to(d), sc, COS_ANNEAL, patch_warp=True,
+                               step=STEP)
+    preds["pseudo_sdf"] = model.pseudo_sdf(gg["pseudo_pts"].to(d), sc)
+    preds["ncc"] = ops.lncc(preds["ref_gray_val"].contiguous(), preds["sampled_gray_val"].contiguous())
+    rel_close(preds["color_fine"], gg["color_fine"], 1e-3, 2e-5)
+    rel_close(preds["pseudo_sdf"], gg["pseudo_sdf"], 0, 1e-4)
+    rel_close(preds["smooth_error"].reshape(1), gg["smooth_error"], 2e-3, 1e-3)
+    leaves = {k: preds[k].detach().clone().requires_grad_(True) for k in LEAVES + ("pseudo_sdf",)}
+    targets = {k[len("target_"):]: v.to(d) for k, v in gg.items() if k.startswith("target_")}
+    with torch.enable_grad():
+        lo = Loss(conf.from_dict(LOSS_CONF))({**preds, **leaves}, targets, step=STEP, mode="val")
+        lo["loss"].backward()
+    rel_close(lo["loss"].detach().reshape(1), gg["loss"], 1e-3, 1e-4)
+    g = {k: v.grad for k, v in leaves.items()}
+    dvols = model.backward_render(g["color_fine"], g["render_depth"], float(g["gradient_error"]), g["sparse_sdf"], g["ncc"],
+                                  g_smooth_error=float(g["smooth_error"]), g_pseudo_sdf=g["pseudo_sdf"])
+    n = 0
+    for name, p_ in model.named_parameters():
+        ref = gg["grad/" + name]
+        assert p_.grad is not None, name
+        if name == "color_network.s":         # ill-conditioned in fp32 on both sides (test_blend_backward_matches_autograd)
+            assert abs(float(p_.grad) - float(ref)) <= 0.35 * abs(float(ref)) + 1e-6
+            continue
+        rel_close(p_.grad, ref, 5e-3, 5e-4 * float(ref.abs().max()) + 1e-7)
+        n += 1
+    assert n >= 7 * 3 + 1 + 20
+    for lvl in range(4):
+        ref = gg[f"grad_vol{lvl}"]
+        rel_close(dvols[lvl], ref, 5e-3, 5e-4 * float(ref.abs().max()))
+
+
 def test_adam_steps_on_the_implicit_surface_reduce_the_loss(scene, weights, gpu_scene):
     """A few optimiser steps driven by the HIP backward kernels alone: colour L1 + eikonal + sparse terms of losses/loss.py
     through torch autograd on the per-ray outputs, then backward_render, then Adam on every parameter of the implicit surface
