@@ -69,3 +69,9 @@ def golden_train():
 def golden_grads():
     """The reference's own loss.backward() through its own render (tests/golden/make_golden_grad.py)."""
     return load_npz("train_grads.npz")
+
+
+@pytest.fixture(scope="session")
+def golden_vgrads():
+    """The reference's autograd through its own FPN / cost volume / sparse2dense / matching field / compute_ptloss."""
+    return load_npz("volume_grads.npz")

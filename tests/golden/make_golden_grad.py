@@ -67,7 +67,74 @@ def main():
         out[f"grad_vol{lvl}"] = v.grad.detach()
     G.ONLY.clear()
     G.npz("train_grads.npz", **out)
-    print("loss", float(lo["loss"]), {k: float(torch.as_tensor(v)) for k, v in lo.items() if k != "loss"})
+    print("loss", float(lo["loss"].detach()))
+    volume_side(FeatureNetwork, Volume, MatchingField, conf, scene, weights, fpn, pipe)
+
+
+def volume_side(FeatureNetwork, Volume, MatchingField, conf, scene, weights, fpn, pipe):
+    """volume_grads.npz: the reference's autograd through its own volume-build modules, one piece at a time (the sparse U-Net
+    needs torchsparse and cannot be run): FPN parameters, the cost volume (feature maps + agg_mlp), sparse2dense, the matching
+    field's depth maps (train-mode jitter, views 0 / src_idx), compute_ptloss - for seeded upstream gradients, which are stored."""
+    import numpy as np
+    from models.losses.photometric_loss import compute_ptloss
+    out = {}
+    intrs, c2ws = scene["intrs"], scene["c2ws"]
+    g = torch.Generator().manual_seed(2024)
+    # ---- FPN (feature_network.py:158-178)
+    fnet = FeatureNetwork(conf["feature_network"]).train()
+    fnet.load_state_dict({k[len("feature_network."):]: v for k, v in weights.items() if k.startswith("feature_network.")})
+    outs = fnet(scene["imgs"])                                       # coarse -> fine
+    ups = [torch.randn(o.shape, generator=g) for o in outs]
+    sum((o * u).sum() for o, u in zip(outs, ups)).backward()
+    for i, u in enumerate(ups):
+        out[f"fpn_up{i}"] = u
+    for name, p in fnet.named_parameters():
+        out["fpn_grad/" + name] = p.grad.detach()
+    # ---- cost volume (volume.py:54-97), stages 0 and 2
+    vol = Volume(conf["volume"]).train()
+    vol.load_state_dict({k[len("volume."):]: v for k, v in weights.items() if k.startswith("volume.")})
+    base = np.array(conf["volume"].get_list("base_volume_dim"))
+    for stage in (0, 2):
+        vol.zero_grad()
+        vol.volume_dim = base * 2 ** stage
+        vol.voxel_size = (vol.bounding[:, 1] - vol.bounding[:, 0]) / (vol.volume_dim - 1)
+        feats = [fpn[f"out{i}"].clone().requires_grad_(True) for i in range(4)]
+        coords = pipe[f"s{stage}_coords"].float()
+        cv, _ = vol.back_proj_multiscale(feats, coords, intrs, c2ws, stage)
+        up = torch.randn(cv.shape, generator=g)
+        (cv * up).sum().backward()
+        out[f"cv{stage}_up"] = up
+        for i, f in enumerate(feats):
+            out[f"cv{stage}_gfeat{i}"] = f.grad.detach() if f.grad is not None else torch.zeros_like(f)
+        for name, p in vol.named_parameters():
+            out[f"cv{stage}_grad/" + name] = p.grad.detach().clone()
+    # ---- sparse2dense (volume.py:99-121), stage 1 on top of stage 0's matching volume
+    vol.volume_dim = base * 2
+    vol.voxel_size = (vol.bounding[:, 1] - vol.bounding[:, 0]) / (vol.volume_dim - 1)
+    logit = pipe["s1_reg_out"][:, :1].clone().requires_grad_(True)
+    prev = pipe["s0_mvol"][None, None].clone().requires_grad_(True)
+    dense, _ = vol.sparse2dense(logit, pipe["s1_coords"].float(), prev)
+    up = torch.randn(dense.shape, generator=g)
+    (dense * up).sum().backward()
+    out.update(s2d_up=up[0, 0], s2d_glogit=logit.grad[:, 0].detach(), s2d_gprev=prev.grad[0, 0].detach())
+    # ---- matching field (matching_field.py:73-141), stage 1, train-mode jitter, views 0 and src_idx = 2
+    mf = MatchingField(conf["matching_field"]).train()
+    ipts = dict(scene)
+    ipts["src_idx"] = 2
+    ratios = list(G.MODEL_CONF["range_ratios"])
+    mv = pipe["s1_mvol"][None, None].clone().requires_grad_(True)
+    torch.manual_seed(31)
+    depths, _ = mf(ipts, mv, 1, ratios, list(pipe["s0_depths"]), perturb=True)
+    H, W = scene["imgs"].shape[-2:]
+    up0, up2 = torch.randn(H, W, generator=g), torch.randn(H, W, generator=g)
+    ((depths[0] * up0).sum() + (depths[2] * up2).sum()).backward()
+    out.update(mf_up0=up0, mf_up2=up2, mf_gmvol=mv.grad[0, 0].detach())
+    # ---- photometric term (losses/photometric_loss.py:54-125) w.r.t. the depth map
+    mask = (torch.rand(H, W, generator=g) > 0.15).float()
+    dep = pipe["s3_depths"][0].clone().requires_grad_(True)
+    compute_ptloss(dep, scene["imgs"], mask, intrs, c2ws).backward()
+    out.update(pt_mask=mask, pt_gdepth=dep.grad.detach())
+    G.npz("volume_grads.npz", **out)
 
 
 if __name__ == "__main__":

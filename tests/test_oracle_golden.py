@@ -271,3 +271,47 @@ def test_f2_oracle_autograd_equals_the_reference_loss_backward(scene, weights, g
     for lvl, v in enumerate(vols):
         ref = gg[f"grad_vol{lvl}"]
         assert float((v.grad - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-8, lvl
+
+
+def test_f2_oracle_autograd_equals_the_reference_autograd_on_the_volume_side(scene, weights, golden_fpn, golden_pipe, golden_vgrads):
+    """The checker of the volume-build backward kernels pinned piece by piece: autograd through the oracle's fpn_forward,
+    back_proj_multiscale, sparse2dense, matching_field and photometric_loss equals the reference's autograd through its own
+    modules (tests/golden/volume_grads.npz).  (The sparse U-Net cannot be pinned: torchsparse is absent.)"""
+    gv, gp = golden_vgrads, golden_pipe
+
+    def near(a, b, rel=2e-3):
+        assert float((a - b).abs().max()) <= rel * float(b.abs().max()) + 1e-8
+
+    sd = {k: v.clone().requires_grad_(True) for k, v in weights.items() if k.startswith("feature_network.") and v.is_floating_point()}
+    outs = O.fpn_forward(sd, scene["imgs"])
+    sum((o * gv[f"fpn_up{i}"]).sum() for i, o in enumerate(outs)).backward()
+    for k, v in sd.items():
+        near(v.grad, gv["fpn_grad/" + k[len("feature_network."):]], 5e-3)
+    for stage in (0, 2):
+        D = CFG["base_volume_dim"] * 2 ** stage
+        sdv = {k: v.clone().requires_grad_(True) for k, v in weights.items() if k.startswith("volume.agg_mlp")}
+        feats = [golden_fpn[f"out{i}"].clone().requires_grad_(True) for i in range(4)]
+        cv, _ = O.back_proj_multiscale(sdv, feats, gp[f"s{stage}_coords"].float(), D, scene["intrs"], scene["c2ws"], stage)
+        (cv * gv[f"cv{stage}_up"]).sum().backward()
+        for l in range(stage, 4):
+            near(feats[l].grad, gv[f"cv{stage}_gfeat{l}"])
+        for k in ("0.weight", "0.bias", "2.weight"):
+            near(sdv["volume.agg_mlp." + k].grad, gv[f"cv{stage}_grad/agg_mlp.{k}"])
+    D = CFG["base_volume_dim"] * 2
+    logit = gp["s1_reg_out"][:, 0].clone().requires_grad_(True)
+    prev = gp["s0_mvol"].clone().requires_grad_(True)
+    dense, _ = O.sparse2dense(logit, gp["s1_coords"], D, prev)
+    (dense * gv["s2d_up"]).sum().backward()
+    near(logit.grad, gv["s2d_glogit"], 1e-5)
+    near(prev.grad, gv["s2d_gprev"], 1e-4)
+    mv = gp["s1_mvol"].clone().requires_grad_(True)
+    torch.manual_seed(31)
+    dep = O.matching_field(scene["imgs"].shape[-2:], scene["intrs"], scene["c2ws"], scene["near_fars"], mv, 1, CFG["range_ratios"],
+                           CFG["n_samples_depths"], CFG["depth_res_levels"], list(gp["s0_depths"]), perturb=True, src_idx=2)
+    ((dep[0] * gv["mf_up0"]).sum() + (dep[2] * gv["mf_up2"]).sum()).backward()
+    near(mv.grad, gv["mf_gmvol"])
+    d3 = gp["s3_depths"][0].clone().requires_grad_(True)
+    O.photometric_loss(d3, scene["imgs"], gv["pt_mask"], scene["intrs"], scene["c2ws"], 0, 2)[0].backward()
+    ref = gv["pt_gdepth"]
+    bad = (d3.grad - ref).abs() > 2e-3 * ref.abs() + 2e-4 * float(ref.abs().max())
+    assert float(bad.float().mean()) < 2e-3, int(bad.sum())

@@ -451,3 +451,82 @@ def test_train_step_seven_views():
     assert len(model.last_voxels_per_stage) == 4 and min(model.last_voxels_per_stage) > 0
     moved = sum(1 for k, v in model.named_parameters() if v.requires_grad and float((v.detach() - before[k]).abs().max()) > 0)
     assert moved > 100
+
+
+# ---- against the REFERENCE's own autograd (tests/golden/volume_grads.npz, make_golden_grad.py) ---------------------------------
+def test_fpn_backward_equals_the_reference_autograd(scene, weights, golden_vgrads):
+    from surf_amd import conf
+    from surf_amd.feature_network import FeatureNetwork
+    d = dev()
+    gv = golden_vgrads
+    net = FeatureNetwork(conf.from_dict({"d_in": 3, "d_base": 8, "d_out": [4, 4, 4, 4]}))
+    net.load_state_dict({k[len("feature_network."):]: v for k, v in weights.items() if k.startswith("feature_network.")})
+    net = net.to(d)
+    tape = []
+    net(scene["imgs"].to(d), tape=tape)
+    net.backward(tape, [gv[f"fpn_up{i}"].permute(0, 2, 3, 1).contiguous().to(d) for i in range(4)])
+    n = 0
+    for name, p_ in net.named_parameters():
+        grad_close(p_.grad, gv["fpn_grad/" + name], 5e-3)
+        n += 1
+    assert n == 15
+
+
+@pytest.mark.parametrize("stage", [0, 2])
+def test_costvol_backward_equals_the_reference_autograd(scene, weights, golden_fpn, golden_pipe, golden_vgrads, stage):
+    from surf_amd import ops
+    d = dev()
+    gv = golden_vgrads
+    D = CFG["base_volume_dim"] * 2 ** stage
+    coords = golden_pipe[f"s{stage}_coords"].to(torch.int32).to(d).contiguous()
+    feats_t4 = [ops.pack_texel4(golden_fpn[f"out{i}"].to(d).contiguous()) for i in range(4)]
+    gfeats = [torch.zeros_like(f) for f in feats_t4]
+    g_agg = torch.zeros(49, device=d)
+    ops.costvol_backward(feats_t4, gfeats, stage, D, _cams(scene), ops.agg_mlp_host(weights), coords, gv[f"cv{stage}_up"].to(d).contiguous(), g_agg)
+    for l in range(4):
+        ref = gv[f"cv{stage}_gfeat{l}"]
+        if l < stage:
+            assert float(ref.abs().max()) == 0.0 and float(gfeats[l].abs().max()) == 0.0
+        else:
+            grad_close(gfeats[l].permute(0, 3, 1, 2), ref)
+    ref_agg = torch.cat([gv[f"cv{stage}_grad/agg_mlp.{k}"].reshape(-1) for k in ("0.weight", "0.bias", "2.weight")])
+    grad_close(g_agg[:48], ref_agg)
+
+
+def test_densify_matching_photometric_backward_equal_the_reference_autograd(scene, golden_pipe, golden_vgrads):
+    from surf_amd import conf, ops
+    from surf_amd.matching_field import MatchingField
+    d = dev()
+    gv, gp = golden_vgrads, golden_pipe
+    # sparse2dense, stage 1
+    D = CFG["base_volume_dim"] * 2
+    coords = gp["s1_coords"].to(torch.int32).to(d).contiguous()
+    rows = gp["s1_reg_out"].to(d).contiguous()
+    _, table = ops.densify(coords, rows, D, gp["s0_mvol"].to(d).contiguous())
+    g_rows = torch.zeros_like(rows)
+    g_prev = torch.zeros(D // 2, D // 2, D // 2, device=d)
+    ops.densify_backward(coords, table, gv["s2d_up"].to(d).contiguous(), g_rows, g_prev)
+    grad_close(g_rows[:, 0], gv["s2d_glogit"])
+    grad_close(g_prev, gv["s2d_gprev"])
+    # matching field, stage 1, jitter as the reference drew it (CPU generator, seed 31), views 0 and 2
+    H, W = scene["imgs"].shape[-2:]
+    nv = scene["intrs"].shape[0]
+    mf = MatchingField(conf.from_dict({"n_samples_depths": CFG["n_samples_depths"], "n_importance_depths": [0] * 4,
+                                       "up_sample_steps": [0] * 4, "depth_res_levels": CFG["depth_res_levels"]}))
+    lvl = CFG["depth_res_levels"][1]
+    torch.manual_seed(31)
+    jitter = mf.draw_jitter(nv, (H // lvl) * (W // lvl), 2, 2).to(d).contiguous()
+    G = torch.zeros(nv, H, W)
+    G[0], G[2] = gv["mf_up0"], gv["mf_up2"]
+    dm = ops.matching_depth_backward(gp["s1_mvol"].to(d).contiguous(), _cams(scene), scene["near_fars"], H, W, lvl,
+                                     CFG["n_samples_depths"][1], G.to(d).contiguous(), gp["s0_depths"].to(d).contiguous(),
+                                     CFG["range_ratios"][1], CFG["range_ratios"][0], jitter=jitter, views=(0, 2))
+    grad_close(dm, gv["mf_gmvol"])
+    # photometric term
+    imgs_t4 = ops.pack_texel4(scene["imgs"].to(d).contiguous())
+    gd = ops.photometric_loss_backward(gp["s3_depths"][0].to(d).contiguous(), imgs_t4, gv["pt_mask"].to(d).contiguous(),
+                                       ops.Cameras(scene["intrs"], scene["c2ws"]), 0, 2, 1.0).cpu()
+    ref = gv["pt_gdepth"]
+    scale = float(ref.abs().max())
+    bad = (gd - ref).abs() > 5e-3 * ref.abs() + 1e-3 * scale
+    assert float(bad.float().mean()) < 5e-3, int(bad.sum())
