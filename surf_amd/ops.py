@@ -5,7 +5,6 @@ current stream.  Nothing here computes on the CPU except the one-off weight re-l
 the library) and 4x4 camera inversions.
 """
 import ctypes
-import math
 
 import numpy as np
 import torch
