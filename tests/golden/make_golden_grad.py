@@ -65,6 +65,17 @@ def main():
         out["grad/" + name] = (p.grad if p.grad is not None else torch.zeros_like(p)).detach()
     for lvl, v in enumerate(vols_r):
         out[f"grad_vol{lvl}"] = v.grad.detach()
+    # ---- the smooth (H.1) term alone (weight 1e-4 in the loss above: its share of those gradients is below their tolerance)
+    for p_ in isurf.parameters():
+        p_.grad = None
+    vols_s = [v.detach().clone().requires_grad_(True) for v in vols_r]
+    torch.manual_seed(SEED)
+    outs_s = isurf("train", ipts, mvol, vols_s, tabs_r, masks_r, feats_r, feats_r, COS_ANNEAL, STEP)
+    outs_s["smooth_error"].backward()
+    for name, p_ in isurf.named_parameters():
+        out["smooth_grad/" + name] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).detach()
+    for lvl, v in enumerate(vols_s):
+        out[f"smooth_grad_vol{lvl}"] = (v.grad if v.grad is not None else torch.zeros_like(v)).detach()
     G.ONLY.clear()
     G.npz("train_grads.npz", **out)
     print("loss", float(lo["loss"].detach()))

@@ -1073,6 +1073,19 @@ def test_training_backward_equals_the_reference_loss_backward(scene, weights, gp
     for lvl in range(4):
         ref = gg[f"grad_vol{lvl}"]
         rel_close(dvols[lvl], ref, 5e-3, 5e-4 * float(ref.abs().max()))
+    # the smooth (H.1) term alone (weight 1e-4 above): surf_sdf_smooth_backward against the reference's triple backward
+    for p_ in model.parameters():
+        p_.grad = None
+    zc = torch.zeros_like(g["color_fine"])
+    dv = model.backward_render(zc, None, 0.0, None, None, g_smooth_error=1.0)
+    for l in range(7):
+        for part in ("weight_g", "weight_v", "bias"):
+            name = f"sdf_network.lin{l}.{part}"
+            ref = gg["smooth_grad/" + name]
+            rel_close(dict(model.named_parameters())[name].grad, ref, 5e-3, 1e-3 * float(ref.abs().max()) + 1e-6)
+    for lvl in range(4):
+        ref = gg[f"smooth_grad_vol{lvl}"]
+        rel_close(dv[lvl], ref, 5e-3, 1e-3 * float(ref.abs().max()))
 
 
 def test_adam_steps_on_the_implicit_surface_reduce_the_loss(scene, weights, gpu_scene):

@@ -271,6 +271,22 @@ def test_f2_oracle_autograd_equals_the_reference_loss_backward(scene, weights, g
     for lvl, v in enumerate(vols):
         ref = gg[f"grad_vol{lvl}"]
         assert float((v.grad - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-8, lvl
+    # the smooth (H.1) term alone: the reference's triple backward vs autograd through the oracle's closed form
+    for v in list(sd.values()) + vols:
+        v.grad = None
+    o2 = O.render(sd, scene["rays_o"], scene["rays_d"], near, far, mvol, vols, tabs, masks, feats, scene["imgs"], scene["intrs"],
+                  scene["c2ws"], CFG["n_samples"], CFG["sample_ranges"], CFG["n_depth"], COS_ANNEAL, patch_warp=True)
+    o2["smooth_error"].backward()
+    for l in range(7):
+        for part in ("weight_g", "weight_v", "bias"):
+            name = f"sdf_network.lin{l}.{part}"
+            ref, got = gg["smooth_grad/" + name], sd["implicit_surface." + name].grad
+            got = torch.zeros_like(ref) if got is None else got
+            assert float((got - ref).abs().max()) <= 3e-3 * float(ref.abs().max()) + 1e-6, name
+    for lvl, v in enumerate(vols):
+        ref = gg[f"smooth_grad_vol{lvl}"]
+        assert float(ref.abs().max()) > 0
+        assert float((v.grad - ref).abs().max()) <= 3e-3 * float(ref.abs().max()) + 1e-7, lvl
 
 
 def test_f2_oracle_autograd_equals_the_reference_autograd_on_the_volume_side(scene, weights, golden_fpn, golden_pipe, golden_vgrads):
