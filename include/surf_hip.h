@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 26
+#define SURF_ABI_VERSION 27
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -179,6 +179,14 @@ int surf_blend_backward(const float* pts, const int32_t* idx, int64_t n, const f
  */
 int surf_lncc(const float* ref, const float* src, int64_t n_rays, int n_src, int patch_elems, int channels, float* out,
               void* stream);
+
+/*
+ * Backward of surf_lncc: the autograd of compute_LNCC2 (models/losses/ncc.py:7-51) under loss.backward() (runner.py:163).
+ * g_out (n_rays): upstream gradient of the per-ray value; g_ref (1, n_rays, P, C) and g_src (n_src, n_rays, P, C): gradients
+ * of the two patch stacks (fully written: zero for the views outside the two smallest of a ray).
+ */
+int surf_lncc_backward(const float* ref, const float* src, const float* g_out, int64_t n_rays, int n_src, int patch_elems,
+                       int channels, float* g_ref, float* g_src, void* stream);
 
 /*
  * Per-pixel terms of the photometric loss of one depth map (training).  Replaces compute_ptloss + SSIM

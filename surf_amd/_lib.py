@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
 # must equal SURF_ABI_VERSION of include/surf_hip.h (tests/test_host_modules.py compares the two texts); lib() refuses a
 # library built from another header
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -52,6 +52,7 @@ SIGNATURES = {
     "surf_lncc_jvp": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "surf_crossing_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_lncc": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "surf_lncc_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "surf_sdf_smooth_packed_floats": (c_i64, []),
     "surf_sdf_smooth_pack_weights": (c_int, [c_ptr, c_ptr, c_ptr]),
     "surf_sdf_smooth": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
@@ -135,16 +136,24 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with surf_amd/csrc/build.sh (or __graft_entry__.build()). "
                 "There is no CPU fallback for the SuRF hot path.")
-        _lib = ctypes.CDLL(LIB_PATH)
+        cand = ctypes.CDLL(LIB_PATH)
+        rebuild = "rebuild with surf_amd/csrc/build.sh (or __graft_entry__.build())"
+        try:                                  # the version first: a stale library lacks newer symbols and would otherwise
+            cand.surf_abi_version.restype = c_int         # die with a bare AttributeError in the binding loop below
+            cand.surf_abi_version.argtypes = []
+            got = cand.surf_abi_version()
+        except AttributeError:
+            raise RuntimeError(f"{LIB_PATH} exports no surf_abi_version: not a surf_hip library; {rebuild}") from None
+        if got != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} reports ABI version {got}, this binding is written for {ABI_VERSION}: {rebuild}")
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(_lib, name)  # AttributeError here = header/library mismatch
+            try:
+                fn = getattr(cand, name)
+            except AttributeError:
+                raise RuntimeError(f"{LIB_PATH} (ABI {got}) lacks {name}, which include/surf_hip.h declares: {rebuild}") from None
             fn.restype = res
             fn.argtypes = args
-        got = _lib.surf_abi_version()
-        if got != ABI_VERSION:
-            _lib = None
-            raise RuntimeError(f"{LIB_PATH} reports ABI version {got}, this binding is written for {ABI_VERSION}: "
-                               "rebuild with surf_amd/csrc/build.sh")
+        _lib = cand                           # cached only when fully bound
     return _lib
 
 

@@ -1,0 +1,203 @@
+"""torch.autograd layer over the HIP forward / backward kernel pairs: what makes `loss.backward()` work.
+
+The reference trains with plain autograd (runner.py:152-165):
+
+    outputs = self.model(self.mode, inputs, cos_anneal_ratio=..., step=...)     # DistributedDataParallel(SuRF), runner.py:102
+    loss = self.loss(outputs, inputs, step)["loss"]
+    self.optimizer.zero_grad(); loss.backward(); self.optimizer.step()
+
+The kernels keep no graph, so a train-mode `SuRF.forward` with autograd enabled is recorded as TWO graph nodes whose
+backward passes are the HIP backward kernels:
+
+  `_Build`  (volume-building models)  parameters of feature_network / volume.agg_mlp / reg_network
+            -> per-stage rows [logit | 7 features], FPN maps (texel4), depth_stage{s}, depth_src_stage{s}
+            backward = SuRF.backward_volumes (matching field -> densify -> sparse U-Net -> cost volume -> FPN)
+  `_Render` parameters of implicit_surface (+ the per-stage rows, + the FPN maps)
+            -> color_fine, render_depth, gradient_error, sparse_sdf, smooth_error, ref_gray_val, sampled_gray_val, pseudo_sdf
+            backward = ImplicitSurface.backward_render (composite -> SDF / blend backward, patch tangents)
+
+Autograd's engine sums the two consumers of the FPN maps (cost volumes and the colour path) and of the rows, runs
+`_Render.backward` first and `_Build.backward` once every depth / row / map gradient has arrived; the parameter gradients
+are RETURNED (grads.GradSink), so AccumulateGrad - and DistributedDataParallel's bucket hooks behind it - see them: the
+implicit-surface bucket is all-reduced over RCCL while the volume-build backward still runs.  Everything that the
+reference detaches (voxel selections, z-sampling from the matching volume, normals and feature maps of the patch warp,
+`mid_inside_sphere`, `valid_mask`) is returned as plain tensors.
+
+`lncc` / `photometric_loss` give the two HIP loss terms of `surf_amd.losses.Loss` a backward as well; a caller that keeps
+the reference's own `Loss` (torch ops on the outputs) needs nothing else.
+"""
+import torch
+
+from . import ops
+from .grads import GradSink
+
+RENDER_KEYS = ("color_fine", "render_depth", "gradient_error", "sparse_sdf", "smooth_error", "ref_gray_val", "sampled_gray_val")
+
+
+def _scalar(g):
+    """Upstream gradient of a scalar output as a python float (the kernels take it by value)."""
+    return 0.0 if g is None else float(g)
+
+
+class _Render(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, isurf, cfg, *tensors):
+        """tensors = implicit-surface parameters (cfg["n_params"]) + sparse rows fine -> coarse (cfg["n_rows"], (N_s, 7 or 8))
+        + FPN maps fine -> coarse (the rest, may be none; cfg["feat_layout"]: "t4" texel4 (nv,h,w,4) or "nchw"): graph inputs
+        only - cfg["run"]() renders from the prepared scene and returns (outputs dict, record of the forward); the
+        non-differentiable outputs are handed back through cfg["holder"]."""
+        ctx.set_materialize_grads(False)
+        out, rec = cfg["run"]()
+        n_params, n_rows = cfg["n_params"], cfg["n_rows"]
+        ctx.isurf, ctx.rec = isurf, rec
+        ctx.n_params, ctx.n_rows, ctx.n_feats = n_params, n_rows, len(tensors) - n_params - n_rows
+        ctx.params = tensors[:n_params]
+        ctx.row_widths = [int(t.shape[1]) for t in tensors[n_params:n_params + n_rows]]
+        ctx.feat_layout = cfg.get("feat_layout", "t4")
+        keys = RENDER_KEYS + (("pseudo_sdf",) if "pseudo_sdf" in out else ())
+        ctx.keys = keys
+        cfg["holder"].update({k: v for k, v in out.items() if k not in keys})
+        cfg["holder"]["_keys"] = keys
+        return tuple(out[k] for k in keys)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        g = dict(zip(ctx.keys, gouts))
+        isurf, rec = ctx.isurf, ctx.rec
+        if rec is None:
+            raise RuntimeError("the render of this forward was already differentiated (its record is freed after one backward)")
+        sink = GradSink()
+        scene = rec["scene"]
+        first_feat = 2 + ctx.n_params + ctx.n_rows
+        want_feats = ctx.n_feats > 0 and any(ctx.needs_input_grad[first_feat:])
+        gfeats = [torch.zeros_like(f) for f in scene.feats_t4] if want_feats else None
+        patches = (g["ref_gray_val"], g["sampled_gray_val"])
+        dvols = isurf.backward_render(g["color_fine"], g["render_depth"], _scalar(g["gradient_error"]), g["sparse_sdf"], None,
+                                      gfeats_t4=gfeats, g_smooth_error=_scalar(g["smooth_error"]), g_pseudo_sdf=g.get("pseudo_sdf"),
+                                      g_patches=None if patches == (None, None) else patches, ctx=rec, sink=sink)
+        ctx.rec = None
+        rows = []
+        for dv, w in zip(dvols, ctx.row_widths):                   # (N_s, 7) -> the input's own width ([logit | 7] rows: logit 0)
+            if w == 8:
+                full = torch.zeros(dv.shape[0], 8, dtype=dv.dtype, device=dv.device)
+                full[:, 1:] = dv
+                dv = full
+            rows.append(dv)
+        feats = [None] * ctx.n_feats
+        if want_feats:
+            feats = [gf.permute(0, 3, 1, 2)[:, :4].contiguous() if ctx.feat_layout == "nchw" else gf for gf in gfeats]
+        return (None, None) + tuple(sink.get(p) for p in ctx.params) + tuple(rows) + tuple(feats)
+
+
+class _Build(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, mode, ipts, holder, *params):
+        ctx.set_materialize_grads(False)
+        outputs, volumes, tables, mvol, features, cams, tape = model.run_build(mode, ipts, record=True)
+        ctx.model, ctx.tape, ctx.params = model, tape, params
+        n = model.num_stage
+        ctx.n = n
+        holder.update(tables=tables, mvol=mvol, cams=cams)
+        depths = [outputs[f"depth_stage{s}"] for s in range(n)] + [outputs[f"depth_src_stage{s}"][...] for s in range(n)]
+        return tuple(volumes) + tuple(features) + tuple(depths)
+
+    @staticmethod
+    def backward(ctx, *g):
+        n, model, tape = ctx.n, ctx.model, ctx.tape
+        if tape is None:
+            raise RuntimeError("the volume build of this forward was already differentiated (its tapes are freed after one backward)")
+        g_rows, g_feats, g_dep, g_src = g[:n], g[n:2 * n], g[2 * n:3 * n], g[3 * n:4 * n]
+        sink = GradSink()
+        gfeats = [torch.zeros_like(f) if gf is None else gf.contiguous().clone() for f, gf in zip(tape["feats"], g_feats)]
+        model.backward_volumes(list(g_rows[::-1]), {s: (g_dep[s], g_src[s]) for s in range(n)}, tape=tape, gfeats=gfeats, sink=sink)
+        ctx.tape = None
+        return (None, None, None, None) + tuple(sink.get(p) for p in ctx.params)
+
+
+def differentiable_forward(model, mode, ipts, cos_anneal_ratio=1.0, step=None):
+    """`SuRF.forward` in train mode with a graph (see the module docstring).  Same output dictionary as the plain path."""
+    isurf = model.implicit_surface
+    outputs = {}
+    if model.has_vol:                                                   # surf.py:149-156: rows = the per-scene parameters
+        scene = model._frozen_scene(ipts)
+        rows = list(model.volumes)[::-1]                                # fine -> coarse
+        feats = []
+    else:
+        holder = {}
+        bparams = [p for m in (model.feature_network, model.volume, model.reg_network) for p in m.parameters() if p.requires_grad]
+        res = _Build.apply(model, mode, ipts, holder, *bparams)
+        n = model.num_stage
+        volumes, features = list(res[:n]), list(res[n:2 * n])
+        for s in range(n):
+            outputs[f"depth_stage{s}"] = res[2 * n + s]
+            outputs[f"depth_src_stage{s}"] = res[3 * n + s]
+        with torch.no_grad():
+            scene = model.build_scene(mode, ipts, [v.detach() for v in volumes], holder["tables"], holder["mvol"],
+                                      [f.detach() for f in features], holder["cams"], step)
+        rows, feats = volumes[::-1], features[::-1]
+    outputs.update(_render_node(isurf, lambda: model.run_render(mode, ipts, scene, cos_anneal_ratio, step), rows, feats, "t4"))
+    return outputs
+
+
+def _render_node(isurf, run_render, rows, feats, feat_layout):
+    rparams = [p for p in isurf.parameters() if p.requires_grad]
+    holder = {}
+
+    def run():
+        out = run_render()
+        rec, isurf._ctx = isurf._ctx, None          # the node owns the record of this forward (freed after its backward)
+        return out, rec
+
+    cfg = dict(run=run, holder=holder, n_params=len(rparams), n_rows=len(rows), feat_layout=feat_layout)
+    res = _Render.apply(isurf, cfg, *rparams, *rows, *feats)
+    outputs = {k: v for k, v in holder.items() if k != "_keys"}
+    outputs.update(dict(zip(holder["_keys"], res)))
+    return outputs
+
+
+def differentiable_render(isurf, run_render, volumes, features):
+    """`ImplicitSurface.forward` in train mode with a graph, for a caller that owns the volume build (the
+    reference's models/surf.py with this ImplicitSurface swapped in): `volumes` = the reference's (N_s, 7) rows fine ->
+    coarse and `features` = its NCHW FPN maps fine -> coarse, both with their torch autograd history; their gradients flow
+    back into the reference's own modules.  run_render() -> the plain outputs of the train-mode render."""
+    return _render_node(isurf, run_render, list(volumes), list(features), "nchw")
+
+
+class _Lncc(torch.autograd.Function):
+    """compute_LNCC2 (losses/ncc.py:7-51) = surf_lncc, backward surf_lncc_backward."""
+
+    @staticmethod
+    def forward(ctx, ref, src):
+        ref, src = ref.float().contiguous(), src.float().contiguous()
+        ctx.save_for_backward(ref, src)
+        return ops.lncc(ref, src)
+
+    @staticmethod
+    def backward(ctx, g):
+        ref, src = ctx.saved_tensors
+        g_ref, g_src = ops.lncc_backward(ref, src, g)
+        return g_ref, g_src
+
+
+def lncc(ref_gray_val, sampled_gray_val):
+    return _Lncc.apply(ref_gray_val, sampled_gray_val)
+
+
+class _Photometric(torch.autograd.Function):
+    """compute_ptloss (losses/photometric_loss.py:54-125) of one depth map = surf_ptloss_terms, backward surf_ptloss_backward."""
+
+    @staticmethod
+    def forward(ctx, depth, imgs_t4, mask, cams, ref_idx, topk):
+        depth = depth.float().contiguous()
+        ctx.save_for_backward(depth, imgs_t4, mask)
+        ctx.cams, ctx.ref_idx, ctx.topk = cams, ref_idx, topk
+        return ops.photometric_loss(depth, imgs_t4, mask, cams, ref_idx=ref_idx, topk=topk)
+
+    @staticmethod
+    def backward(ctx, g):
+        depth, imgs_t4, mask = ctx.saved_tensors
+        return ops.photometric_loss_backward(depth, imgs_t4, mask, ctx.cams, ctx.ref_idx, ctx.topk, upstream=g), None, None, None, None, None
+
+
+def photometric_loss(depth, imgs_t4, mask, cams, ref_idx=0, topk=2):
+    return _Photometric.apply(depth, imgs_t4, mask, cams, ref_idx, topk)

@@ -1,8 +1,11 @@
 """Multi-GPU plumbing of the hot path.  Inference shards by scene: scenes are independent, every rank
 renders its own share, there is NO data-path collective.  torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in
 the CPU tests) is only used for the barrier / max-over-ranks timing of bench.py, to gather small per-scene result records
-and - training (runner.py:102,163: DDP) - for the gradient all-reduce of `all_reduce_gradients`: the backward kernels do
-not run under autograd, so the averaging DDP does in its hooks is one explicit bucketed all-reduce after `SuRF.backward`."""
+and for training (runner.py:102,163).  A train-mode forward is differentiable (surf_amd.autograd), so
+`torch.nn.parallel.DistributedDataParallel(model)` works as in the reference: it broadcasts rank 0's parameters and buffers
+when it wraps the model, rank 0's BatchNorm running statistics at every forward, and averages the gradients in its bucket
+hooks during `loss.backward()`.  `all_reduce_gradients` + `broadcast_module_state` are the same two duties in explicit
+form for a step that does not wrap the model (surf_amd.training, bench.py)."""
 import os
 
 import torch
@@ -81,3 +84,23 @@ def all_reduce_gradients(params, bucket_bytes=25 << 20):
             off += p.numel()
             p.grad = g.clone() if p.grad is None else p.grad.copy_(g)
     return len(buckets)
+
+
+
+def broadcast_module_state(module, src=0, buffers_only=False):
+    """Make every rank's parameters and buffers (BatchNorm running statistics) equal to rank `src`'s - what
+    DistributedDataParallel does when it wraps a model (parameters + buffers once) and at every forward (buffers,
+    `broadcast_buffers=True`, runner.py:102).  Without it replicas started from different seeds, or a checkpoint loaded on
+    rank 0 only, stay different forever under a gradient-only all-reduce.  Call once before the first step and with
+    `buffers_only=True` before evaluation / checkpointing (or every step, like DDP).  Returns the number of tensors sent."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    tensors = list(module.buffers()) if buffers_only else list(module.parameters()) + list(module.buffers())
+    n = 0
+    with torch.no_grad():
+        for t in tensors:
+            if not torch.is_tensor(t) or t.numel() == 0:
+                continue
+            dist.broadcast(t.data, src=src)
+            n += 1
+    return n

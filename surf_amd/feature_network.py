@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .grads import accumulate
 
 
 class _Conv(nn.Module):
@@ -97,13 +98,13 @@ class FeatureNetwork(nn.Module):
             tape.append(dict(enc=enc_rec, dec=dec_rec, dec_out=dec))
         return outs[::-1]
 
-    def backward(self, tape, g_outs_c2f):
+    def backward(self, tape, g_outs_c2f, sink=None):
         """Reverse sweep: g_outs_c2f = gradients of the four texel4 outputs (coarse -> fine, like forward's return value).
-        ACCUMULATES into the `.grad` of every convolution weight.  Input gradients reuse the forward kernels (stride 1: the
+        ACCUMULATES into the `.grad` of every convolution weight (or into `sink`, a grads.GradSink).  Input gradients reuse the forward kernels (stride 1: the
         flipped, transposed kernel; stride 2 <-> transposed convolution), weight gradients `surf_conv3x3_wgrad`, the
         InstanceNorm + ReLU (+ skip) backward `surf_bn_relu_backward` per view."""
         def acc(p, g):
-            p.grad = g.to(p.dtype) if p.grad is None else p.grad + g.to(p.dtype)
+            accumulate(p, g, sink)
 
         def flipT(w):
             """Conv2d weight (Cout, Cin, 3, 3) -> the packed kernel [ky][kx][Cout][Cin] of its input gradient (stride 1)."""

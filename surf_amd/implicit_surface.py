@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .grads import accumulate
 
 
 class _WNLinear(nn.Module):
@@ -303,7 +304,7 @@ class ImplicitSurface(nn.Module):
 
     @torch.no_grad()
     def backward_render(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None, gfeats_t4=None,
-                        g_smooth_error=0.0, g_pseudo_sdf=None):
+                        g_smooth_error=0.0, g_pseudo_sdf=None, g_patches=None, ctx=None, sink=None):
         """Partial backward of the last training forward (`render_scene(patch_warp=True)`), SURVEY 8f-f2: given the loss's
         gradients w.r.t. `color_fine` (R,3), `render_depth` (R), `gradient_error` (scalar), `sparse_sdf` ((1024 + R*S),1) and
         the per-ray patch NCC (R,1) (= compute_LNCC2 of ref_gray_val / sampled_gray_val, the mfc term),
@@ -315,19 +316,34 @@ class ImplicitSurface(nn.Module):
         gfeats_t4 (fine -> coarse, like the scene's feature maps): accumulates the colour path's gradient into the FPN maps
         (generalisation training).  g_smooth_error (scalar): the smooth (H.1) term, through surf_sdf_smooth_backward (reverse
         over a forward with value, two tangents and their mixed tangent).  g_pseudo_sdf (n_pseudo, 1): the pseudo_sdf output
-        (`ImplicitSurface.pseudo_sdf` after the training forward).  The volume build's backward is SuRF.backward_volumes."""
-        c = self._ctx
+        (`ImplicitSurface.pseudo_sdf` after the training forward).  The volume build's backward is SuRF.backward_volumes.
+        g_patches = (d loss / d ref_gray_val, d loss / d sampled_gray_val) - what autograd hands back when the loss consumed
+        the patch stacks themselves (the reference's Loss: compute_LNCC2 in torch, losses/loss.py:43): contracted with the
+        patches' tangents along the ray into d loss / d z0 (the patches depend on the network through z0 alone,
+        implicit_surface.py:217-245).  ctx: the record of the forward to differentiate (default: the module's last one);
+        sink: a grads.GradSink that receives the parameter gradients instead of `.grad` (surf_amd.autograd)."""
+        c = ctx if ctx is not None else self._ctx
         st, act, scene = c["st"], c["act"], c["scene"]
         dev = c["sdf"].device
         inv_s = self.deviation_network.inv_s()
+        if g_color is None:
+            g_color = torch.zeros(c["rays_d"].shape[0], 3, dtype=torch.float32, device=dev)
         d_sdf, d_grad, d_col, d_is = ops.composite_backward(c["sdf"], c["grad"], c["col"], st, c["rays_d"], inv_s, c["anneal"], scene.cams,
                                                         g_color.float().contiguous(),
                                                         None if g_depth is None else g_depth.float().contiguous(),
                                                         eik_scale=float(g_gradient_error) / (c["eik_den"] + 1e-5))
-        if g_ncc is not None:
+        if g_ncc is not None or g_patches is not None:
             ref, src, ref_t, src_t = ops.patch_warp_tangent(c["pts0"], c["rays_d"], c["g0"], c["maps"], scene.cams)
-            _, dncc = ops.lncc_jvp(ref, src, ref_t, src_t)
-            ops.crossing_backward(c["sdf"], st["vmask"], st["mid_z"], st["z_vals"].max(), g_ncc.reshape(-1).float() * dncc, d_sdf)
+            g_z0 = torch.zeros(ref.shape[1], dtype=torch.float32, device=dev)
+            if g_ncc is not None:
+                _, dncc = ops.lncc_jvp(ref, src, ref_t, src_t)
+                g_z0 += g_ncc.reshape(-1).float() * dncc
+            if g_patches is not None:
+                if g_patches[0] is not None:
+                    g_z0 += (g_patches[0].float() * ref_t).sum(dim=(0, 2, 3))
+                if g_patches[1] is not None:
+                    g_z0 += (g_patches[1].float() * src_t).sum(dim=(0, 2, 3))
+            ops.crossing_backward(c["sdf"], st["vmask"], st["mid_z"], st["z_vals"].max(), g_z0, d_sdf)
         idx = act.long()
         ybar = d_sdf[idx]
         pts = st["pts"][idx]
@@ -355,23 +371,23 @@ class ImplicitSurface(nn.Module):
                 res["weight"][l] = res["weight"][l] + rs["weight"][l]
                 res["bias"][l] = res["bias"][l] + rs["bias"][l]
             res["volumes"] = [a_ + b_ for a_, b_ in zip(res["volumes"], rs["volumes"])]
-        with torch.enable_grad():                             # weight norm: W = g v / |v|_row (sdf_network.py:88-89)
-            for l in range(7):
-                lin = getattr(self.sdf_network, f"lin{l}")
-                W = lin.weight_v * (lin.weight_g / torch.linalg.norm(lin.weight_v, dim=1, keepdim=True))
-                W.backward(res["weight"][l])
-                lin.bias.grad = res["bias"][l] if lin.bias.grad is None else lin.bias.grad + res["bias"][l]
+        for l in range(7):           # weight norm W = g v / |v|_row (sdf_network.py:88-89), its backward in closed form:
+            lin = getattr(self.sdf_network, f"lin{l}")          # dg = <dW, v>/|v|,  dv = (g/|v|) (dW - (dg/|v|) v)
+            v, g, dW = lin.weight_v.detach().float(), lin.weight_g.detach().float(), res["weight"][l]
+            nrm = torch.linalg.norm(v, dim=1, keepdim=True)
+            dg = (dW * v).sum(dim=1, keepdim=True) / nrm
+            accumulate(lin.weight_g, dg, sink)
+            accumulate(lin.weight_v, (g / nrm) * (dW - (dg / nrm) * v), sink)
+            accumulate(lin.bias, res["bias"][l], sink)
         cn = dict(self.color_network.named_parameters())     # raw parameter buffer in state_dict order, built on the device
         raw_w = torch.cat([cn[k].detach().reshape(-1).float() for k in ops.BLEND_KEYS]).contiguous()
         gb = ops.blend_backward(st["pts"], act, d_col, scene.feats_t4, scene.imgs_t4, scene.cams, raw_w, gfeats_t4=gfeats_t4)
         for name, p in self.color_network.named_parameters():
-            gp = gb[name].reshape(p.shape).to(p.dtype)
-            p.grad = gp if p.grad is None else p.grad + gp
+            accumulate(p, gb[name], sink)
         var = self.deviation_network.variance
         raw = float(torch.exp(var.detach() * 10.0))
         dvar = d_is * 10.0 * inv_s if 1e-6 < raw < 1e6 else torch.zeros((), device=dev)
-        dvar = dvar.to(var.device).reshape(var.shape)
-        var.grad = dvar if var.grad is None else var.grad + dvar
+        accumulate(var, dvar, sink)
         return [g[:, :7].contiguous() for g in res["volumes"]]
 
     def draw_jitter(self, n_rays, ref_chunk=None):
@@ -474,18 +490,36 @@ class ImplicitSurface(nn.Module):
 
     def forward(self, mode, ipts, matching_volume, volumes, sparse_idxes, mask_volumes, features, match_features,
                 cos_anneal_ratio=1.0, step=None):
+        """implicit_surface.py:404-436 with the reference's argument list (volumes (N_s, 7) rows, int64 index tables and NCHW
+        feature maps, all fine -> coarse), for a models/surf.py that swaps this class in.  In train mode
+        with autograd enabled the outputs carry grad_fn and `volumes` / `features` receive their gradients
+        (surf_amd.autograd.differentiable_render)."""
         rays_o, rays_d = ipts["rays_o"], ipts["rays_d"]
         near, far = ipts["near"], ipts["far"]
         if near.shape[0] == 1:
             near = near.repeat(rays_o.shape[0], 1)
             far = far.repeat(rays_o.shape[0], 1)
-        scene = self.scene(matching_volume, volumes, sparse_idxes, mask_volumes, features, ipts["imgs"], ipts["intrs"],
-                           ipts["c2ws"])
-        if mode == "val":
-            outputs = self.validate(rays_o, rays_d, near, far, scene, ipts["bound_min"], ipts["bound_max"], ipts["hw"],
-                                    cos_anneal_ratio, step)
-        else:
-            outputs = self.render_scene(rays_o, rays_d, near, far, scene, cos_anneal_ratio)
-        if "pseudo_pts" in ipts:  # implicit_surface.py:425-434
-            outputs["pseudo_sdf"] = self.pseudo_sdf(ipts["pseudo_pts"], scene)
-        return outputs
+        with torch.no_grad():
+            scene = self.scene(matching_volume, volumes, sparse_idxes, mask_volumes, features, ipts["imgs"], ipts["intrs"],
+                               ipts["c2ws"])
+            if match_features is not None and mode != "val":
+                scene.match_feats_t4 = [ops.pack_texel4(f.detach().float().contiguous()) for f in match_features]
+            if mode == "val":
+                outputs = self.validate(rays_o, rays_d, near, far, scene, ipts["bound_min"], ipts["bound_max"], ipts["hw"],
+                                        cos_anneal_ratio, step)
+                if "pseudo_pts" in ipts:  # implicit_surface.py:425-434
+                    outputs["pseudo_sdf"] = self.pseudo_sdf(ipts["pseudo_pts"], scene)
+                return outputs
+
+        def run():
+            out = self.render_scene(rays_o, rays_d, near, far, scene, cos_anneal_ratio, patch_warp=True, step=step)
+            if "pseudo_pts" in ipts:
+                out["pseudo_sdf"] = self.pseudo_sdf(ipts["pseudo_pts"], scene)
+            return out
+
+        graph_inputs = list(self.parameters()) + list(volumes) + list(features)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in graph_inputs):
+            from . import autograd
+            return autograd.differentiable_render(self, run, volumes, features)
+        with torch.no_grad():
+            return run()

@@ -1,18 +1,18 @@
 """Host-side mirror of the reference's training loss (models/losses/loss.py:10-111).
 
 Same constructor keys (`confs/surf.conf:49-63`), same `forward(preds, targets, step, mode)` and the same output dictionary.
-Most terms are scalar reductions of the hot path's outputs; the two with real work run in HIP: the local NCC of the
-surface patches (`compute_LNCC2`, losses/ncc.py:7-51 -> `surf_lncc`, csrc/lncc.hip) and the per-stage photometric term
-(`compute_ptloss`, losses/photometric_loss.py:54-125: inverse warping of the source images by the matching-field depths,
-SSIM + smooth-L1 + gradient -> `surf_ptloss_terms`, csrc/ptloss.hip).  The scalar terms are plain torch ops on the hot
-path's outputs: `surf_amd.training` differentiates them with torch autograd on leaf copies of those outputs and feeds the
-results to the HIP backward kernels; the two HIP terms have their own backward entries (`surf_lncc_jvp`,
-`surf_ptloss_backward`).
+Most terms are scalar reductions of the hot path's outputs (plain torch ops: autograd differentiates them); the two with
+real work run in HIP and carry their own backward (`surf_amd.autograd`): the local NCC of the surface patches
+(`compute_LNCC2`, losses/ncc.py:7-51 -> `surf_lncc` / `surf_lncc_backward`, csrc/lncc.hip) and the per-stage photometric
+term (`compute_ptloss`, losses/photometric_loss.py:54-125: inverse warping of the source images by the matching-field depths,
+SSIM + smooth-L1 + gradient -> `surf_ptloss_terms` / `surf_ptloss_backward`, csrc/ptloss.hip).  `loss["loss"].backward()` on
+the outputs of a train-mode `SuRF.forward` therefore fills every `.grad` (runner.py:158-163); the reference's own `Loss`
+(torch throughout) works on those outputs as well.
 """
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import autograd, ops
 
 
 class Loss(nn.Module):
@@ -40,8 +40,7 @@ class Loss(nn.Module):
         anneal = min(1.0, step / 2)                                                                          # loss.py:37
         sparse_loss = torch.exp(-preds["sparse_sdf"].abs() * self.sparse_scale_factor).mean() * anneal
         smooth_loss = preds["smooth_error"].mean()
-        # (R,1); a caller that wants d loss / d ncc (training.finetune_step) passes the values in as a leaf
-        ncc = preds["ncc"] if "ncc" in preds else ops.lncc(preds["ref_gray_val"].contiguous(), preds["sampled_gray_val"].contiguous())
+        ncc = preds["ncc"] if "ncc" in preds else autograd.lncc(preds["ref_gray_val"], preds["sampled_gray_val"])
         ncc_mask = vm * preds["mid_inside_sphere"]
         mfc_loss = 0.5 * ((ncc * ncc_mask).sum(dim=0) / (ncc_mask.sum(dim=0) + 1e-8)).squeeze(-1)
 
@@ -54,9 +53,8 @@ class Loss(nn.Module):
             src_idx = int(targets["src_idx"])
             mask_ref, mask_src = targets["mask_ref"].float().contiguous(), targets["mask_src"].float().contiguous()
             for i in range(n):
-                ref_photo = ops.photometric_loss(preds[f"depth_stage{i}"].float().contiguous(), imgs_t4, mask_ref, cams)
-                src_photo = ops.photometric_loss(preds[f"depth_src_stage{i}"].float().contiguous(), imgs_t4, mask_src, cams,
-                                                 ref_idx=src_idx, topk=1)
+                ref_photo = autograd.photometric_loss(preds[f"depth_stage{i}"], imgs_t4, mask_ref, cams)
+                src_photo = autograd.photometric_loss(preds[f"depth_src_stage{i}"], imgs_t4, mask_src, cams, ref_idx=src_idx, topk=1)
                 photo_loss = photo_loss + (ref_photo + src_photo) * self.stage_weights[i]
                 pa = self._masked_l1(preds[f"depth_stage{i}"], targets["pseudo_depth_ref"], targets["pseudo_depth_ref"] > 0)
                 spa = self._masked_l1(preds[f"depth_src_stage{i}"], targets["pseudo_depth_src"], targets["pseudo_depth_src"] > 0)

@@ -704,6 +704,20 @@ def lncc(ref_gray_val, sampled_gray_val):
     return out
 
 
+def lncc_backward(ref_gray_val, sampled_gray_val, g_ncc):
+    """(d/d ref_gray_val, d/d sampled_gray_val) of sum_r g_ncc[r] * compute_LNCC2(ref, src)[r] (surf_lncc_backward)."""
+    _chk(ref_gray_val, torch.float32, "ref_gray_val")
+    _chk(sampled_gray_val, torch.float32, "sampled_gray_val")
+    nsrc, R, P, C = sampled_gray_val.shape
+    g = _chk(g_ncc.reshape(-1).float().contiguous(), torch.float32, "g_ncc")
+    assert g.shape[0] == R
+    g_ref, g_src = torch.empty_like(ref_gray_val), torch.empty_like(sampled_gray_val)
+    if R > 0:
+        _lib.check(_lib.lib().surf_lncc_backward(_p(ref_gray_val), _p(sampled_gray_val), _p(g), R, int(nsrc), int(P), int(C),
+                                                 _p(g_ref), _p(g_src), _stream()), "surf_lncc_backward")
+    return g_ref, g_src
+
+
 # ------------------------------------------------------------------------------------------------
 # volume build (surf.py:80-131)
 # ------------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .grads import accumulate
 
 
 class _SpConv3d(nn.Module):
@@ -121,14 +122,15 @@ class SparseCostRegNet(nn.Module):
             tape.append(dict(lin=True, x=x, feats=feats))
         return out, x
 
-    def backward(self, tape, d_out, d_mid=None):
+    def backward(self, tape, d_out, d_mid=None, sink=None):
         """Reverse sweep over a tape recorded by a train-mode forward: gradients of sum(out d_out) + sum(mid d_mid) are
-        ACCUMULATED into the `.grad` of every convolution kernel, BatchNorm weight / bias and out_lin.weight; returns the
+        ACCUMULATED into the `.grad` (or into `sink`, a grads.GradSink) of every convolution kernel, BatchNorm weight / bias and
+        out_lin.weight; returns the
         gradient of `feats` (N, d_in).  Each block: BatchNorm(batch statistics) + ReLU + skip backward (surf_bn_relu_backward),
         then the convolution's input gradient as a sparse convolution on the swapped lattices and its kernel gradient
         (ops.spconv_backward)."""
         def acc(p, g):
-            p.grad = g.to(p.dtype) if p.grad is None else p.grad + g.to(p.dtype)
+            accumulate(p, g, sink)
 
         last = tape[-1]
         assert last.get("lin"), "tape: recorded by SparseCostRegNet.forward(..., tape=[])"

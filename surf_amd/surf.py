@@ -1,17 +1,19 @@
 """Drop-in for models/surf.py SuRF: same constructor, parameter names, ``forward(mode, ipts, cos_anneal_ratio,
 step)`` and output keys; every stage runs in the HIP kernels of libsurf_hip.so.
 
-Inference semantics (``mode == "val"`` or a no-grad ``"train"`` forward without the loss-only outputs).  Not
-implemented (they belong to SURVEY row f2): autograd through the kernels and the train-mode jitter of the matching
-field (``perturb=True`` in ``build_volumes``).  ``render.perturb > 0`` (the per-ray jitter of ``ImplicitSurface.render``,
-active in ``val`` too) is supported, and so is the per-scene volume API of finetuning (``has_vol`` / ``init_volumes`` /
-``get_params_vol`` / ``load_params_vol``, surf.py:47-78): the volumes are frozen once and every later forward renders from
-them without touching the FPN or the sparse U-Nets (their optimisation itself is row f2).
+``mode == "val"`` (and any forward under ``torch.no_grad()``) is the inference path.  A train-mode forward with autograd
+enabled returns outputs that carry ``grad_fn`` (``surf_amd.autograd``: two ``torch.autograd.Function`` nodes, the volume
+build + FPN and the render, whose backward passes are the HIP backward kernels), so the reference's own loop -
+``loss = Loss(outputs, inputs, step)["loss"]; loss.backward(); optimizer.step()`` (runner.py:155-165) - and
+``DistributedDataParallel(model)`` (runner.py:102) work unchanged.  ``render.perturb > 0`` (the per-ray jitter of
+``ImplicitSurface.render``, active in ``val`` too) is supported, and so is the per-scene volume API of finetuning
+(``has_vol`` / ``init_volumes`` / ``get_params_vol`` / ``load_params_vol``, surf.py:47-78).
 """
 import torch
 import torch.nn as nn
 
 from . import ops
+from .grads import accumulate
 from .feature_network import FeatureNetwork
 from .implicit_surface import ImplicitSurface, SceneVolumes
 from .matching_field import MatchingField
@@ -98,7 +100,8 @@ class SuRF(nn.Module):
                  g_pseudo_sdf=None):
         """Partial backward of the last train-mode forward (row f2): `.grad` of every implicit-surface parameter and, in
         finetune mode (has_vol), of the per-scene feature volumes - what surf.py:36-45 hands the optimiser there.  See
-        ImplicitSurface.backward_render for the chain; the volume build / FPN backward is `backward_volumes`."""
+        ImplicitSurface.backward_render for the chain; the volume build / FPN backward is `backward_volumes`.  (The explicit
+        form of what `loss.backward()` does through surf_amd.autograd.)"""
         gfeats = None
         if getattr(self, "_train_tape", None) is not None:       # volume-building model: the colour path's share of d FPN maps
             self._train_tape["gfeats"] = [torch.zeros_like(f) for f in self._train_tape["feats"]]      # coarse -> fine
@@ -107,36 +110,44 @@ class SuRF(nn.Module):
                                                       g_smooth_error=g_smooth_error, g_pseudo_sdf=g_pseudo_sdf)
         if self.has_vol:
             for p, g in zip(self.volumes, dvols[::-1]):          # volumes are kept coarse -> fine
-                g = g.to(p.dtype)
-                p.grad = g if p.grad is None else p.grad + g
+                accumulate(p, g)
         return dvols
 
-    def backward_volumes(self, row_grads_f2c, g_depths=None):
+    def backward_volumes(self, row_grads_f2c, g_depths=None, tape=None, gfeats=None, sink=None):
         """Backward of the volume build + FPN of the last `forward("train", ..., record=True)` (surf.py:80-131 under
-        loss.backward()): row_grads_f2c = d loss / d the stages' feature rows (N_s, 7), fine -> coarse (what
-        ImplicitSurface.backward_render returns); g_depths = {stage: (d loss / d depth_stage{s} (H,W) or None,
-        d loss / d depth_src_stage{s} or None)}.  Accumulates `.grad` of every parameter of reg_network, volume.agg_mlp and
-        feature_network.  Per stage, fine -> coarse: matching-field backward -> densify backward (-> the coarser matching
-        volume) -> sparse U-Net backward -> cost-volume backward (-> FPN maps, agg_mlp) and the parent-feature scatter
-        (-> the coarser stage's `mid` rows); then the FPN backward on the maps' total gradient (cost volumes + the colour
-        path's share that `SuRF.backward` accumulated).  Not differentiable: the voxel selections, the detached depths."""
-        t = self._train_tape
+        loss.backward()): row_grads_f2c = d loss / d the stages' feature rows, fine -> coarse, (N_s, 7) (what
+        ImplicitSurface.backward_render returns) or (N_s, 8) = [logit | 7 features] rows, None = no gradient; g_depths =
+        {stage: (d loss / d depth_stage{s} (H,W) or None, d loss / d depth_src_stage{s} or None)}.  Accumulates `.grad` of
+        every parameter of reg_network, volume.agg_mlp and feature_network (or fills `sink`, a grads.GradSink).  Per stage,
+        fine -> coarse: matching-field backward -> densify backward (-> the coarser matching volume) -> sparse U-Net backward
+        -> cost-volume backward (-> FPN maps, agg_mlp) and the parent-feature scatter (-> the coarser stage's `mid` rows);
+        then the FPN backward on the maps' total gradient (cost volumes + the colour path's share: `gfeats`, coarse -> fine,
+        or what `SuRF.backward` left in the tape).  Not differentiable: the voxel selections, the detached depths.
+        tape: the record to differentiate (default: the module's last one, consumed)."""
+        own = tape is None
+        t = self._train_tape if own else tape
         if t is None:
             raise RuntimeError("backward_volumes needs forward('train', ..., record=True) of a volume-building model first")
-        if not self.reg_network.training:
+        if not t.get("bn_train", self.reg_network.training):
             raise RuntimeError("backward_volumes: the sparse U-Net's tape is recorded in train mode (model.train())")
         feats, cams = t["feats"], t["cams"]
         dev = feats[0].device
         nv = feats[0].shape[0]
         H, W = t["hw"]
-        gfeats = t.pop("gfeats", None) or [torch.zeros_like(f) for f in feats]     # SuRF.backward leaves the colour path's share
+        if gfeats is None:                           # SuRF.backward leaves the colour path's share in the tape
+            gfeats = t.pop("gfeats", None) or [torch.zeros_like(f) for f in feats]
         g_agg = torch.zeros(49, dtype=torch.float32, device=dev)
         n = self.num_stage
         d_mvol, d_mid = None, None
         for s in range(n - 1, -1, -1):
             r = t["vol"][s]
             g_out = torch.zeros(r["coords"].shape[0], 8, dtype=torch.float32, device=dev)
-            g_out[:, 1:] = row_grads_f2c[n - 1 - s]
+            rg = row_grads_f2c[n - 1 - s]
+            if rg is not None:
+                if rg.shape[1] == 8:
+                    g_out += rg
+                else:
+                    g_out[:, 1:] = rg
             gd = (g_depths or {}).get(s, (None, None))
             if gd[0] is not None or gd[1] is not None:
                 g_full = torch.zeros(nv, H, W, dtype=torch.float32, device=dev)
@@ -152,14 +163,15 @@ class SuRF(nn.Module):
                     Dp = r["D"] // 2
                     d_prev = torch.zeros(Dp, Dp, Dp, dtype=torch.float32, device=dev)
                 ops.densify_backward(r["coords"], r["table"], d_mvol, g_out, d_prev)
-            d_reg_in = self.reg_network.nets[s].backward(r["reg_tape"], g_out, d_mid)
+            d_reg_in = self.reg_network.nets[s].backward(r["reg_tape"], g_out, d_mid, sink=sink)
             d_mid = self.volume.stage_backward(s, r["D"], feats, gfeats, cams, r["coords"], d_reg_in, g_agg, r.get("pidx"),
                                                r["n_parents"])
             d_mvol = d_prev
-        self.volume.assign_agg_grad(g_agg)
-        self.feature_network.backward(t["fpn"], gfeats)
+        self.volume.assign_agg_grad(g_agg, sink=sink)
+        self.feature_network.backward(t["fpn"], gfeats, sink=sink)
         self.last_voxels_per_stage = [int(r["coords"].shape[0]) for r in t["vol"]]
-        self._train_tape = None                     # the tapes hold every stage's activations (GBs at full size): one backward each
+        if own:
+            self._train_tape = None                 # the tapes hold every stage's activations (GBs at full size): one backward each
         return gfeats
 
     def _frozen_scene(self, ipts):
@@ -232,30 +244,41 @@ class SuRF(nn.Module):
         return outputs, volumes, tables, mvol
 
     @torch.no_grad()
-    def forward(self, mode, ipts, cos_anneal_ratio=1.0, step=None, record=False):
-        """record (train mode of a volume-building model): keep the tapes `backward_volumes` needs in `self._train_tape`."""
+    def run_build(self, mode, ipts, record=False):
+        """FPN + 4-stage volume build of one forward (surf.py:136-139).  Returns (depth outputs, volumes coarse -> fine
+        (N_s, 8) = [logit | 7 features], index tables, matching volume, texel4 feature maps coarse -> fine, cameras, tape or
+        None).  record: keep what `backward_volumes` needs."""
+        imgs, intrs, c2ws = ipts["imgs"], ipts["intrs"], ipts["c2ws"]
+        cams = ops._cams_ext(ops.Cameras(intrs, c2ws), intrs, c2ws)
+        fpn_tape, vol_tape = ([], []) if record else (None, None)
+        features = self.feature_network(imgs, tape=fpn_tape)                # texel4, coarse -> fine
+        outputs, volumes, tables, mvol = self.build_volumes(ipts, features, cams, perturb=(mode == "train"), tape=vol_tape,
+                                                            logit_override=getattr(self, "logit_override", None))  # surf.py:139
+        tape = None
+        if record:
+            tape = dict(fpn=fpn_tape, vol=vol_tape, feats=features, cams=cams, near_fars=ipts["near_fars"],
+                        hw=tuple(imgs.shape[-2:]), src_idx=int(ipts["src_idx"]) if "src_idx" in ipts else 0,
+                        bn_train=self.reg_network.training)
+        return outputs, volumes, tables, mvol, features, cams, tape
+
+    @torch.no_grad()
+    def build_scene(self, mode, ipts, volumes, tables, mvol, features, cams, step=None):
+        """SceneVolumes of a freshly built pyramid (kernel layouts, no re-packing) + the frozen matching FPN's maps of a
+        training forward (surf.py:141-148)."""
         imgs = ipts["imgs"]
-        self._train_tape = None
-        intrs, c2ws = ipts["intrs"], ipts["c2ws"]
-        if self.has_vol:                                                        # surf.py:149-156
-            outputs, scene = {}, self._frozen_scene(ipts)
-        else:
-            cams = ops._cams_ext(ops.Cameras(intrs, c2ws), intrs, c2ws)
-            fpn_tape, vol_tape = ([], []) if record else (None, None)
-            features = self.feature_network(imgs, tape=fpn_tape)                # texel4, coarse -> fine
-            outputs, volumes, tables, mvol = self.build_volumes(ipts, features, cams, perturb=(mode == "train"), tape=vol_tape,
-                                                                logit_override=getattr(self, "logit_override", None))  # surf.py:139
-            if record:
-                self._train_tape = dict(fpn=fpn_tape, vol=vol_tape, feats=features, cams=cams, near_fars=ipts["near_fars"],
-                                        hw=tuple(imgs.shape[-2:]), src_idx=int(ipts["src_idx"]) if "src_idx" in ipts else 0)
-            scene = SceneVolumes.from_device_layouts(mvol, [v[:, 1:] for v in volumes[::-1]], tables[::-1], features[::-1],
-                                                     ops.pack_texel4(imgs.detach().float().contiguous()), cams)
-            if mode != "val":                                                   # surf.py:141-148 (loss-only inputs)
-                if step is not None and step % 2 == 0:                          # refresh the frozen matching FPN
-                    self.match_feature_network.load_state_dict(self.feature_network.state_dict(), strict=True)
-                    for p in self.match_feature_network.parameters():
-                        p.requires_grad = False
-                scene.match_feats_t4 = self.match_feature_network(imgs)[::-1]
+        scene = SceneVolumes.from_device_layouts(mvol, [v[:, 1:] for v in volumes[::-1]], tables[::-1], features[::-1],
+                                                 ops.pack_texel4(imgs.detach().float().contiguous()), cams)
+        if mode != "val":                                                   # surf.py:141-148 (loss-only inputs)
+            if step is not None and step % 2 == 0:                          # refresh the frozen matching FPN
+                self.match_feature_network.load_state_dict(self.feature_network.state_dict(), strict=True)
+                for p in self.match_feature_network.parameters():
+                    p.requires_grad = False
+            scene.match_feats_t4 = self.match_feature_network(imgs)[::-1]
+        return scene
+
+    @torch.no_grad()
+    def run_render(self, mode, ipts, scene, cos_anneal_ratio=1.0, step=None):
+        """ImplicitSurface.forward on prepared SceneVolumes (surf.py:159)."""
         isurf = self.implicit_surface
         rays_o, rays_d = ipts["rays_o"], ipts["rays_d"]
         near, far = ipts["near"], ipts["far"]
@@ -263,11 +286,37 @@ class SuRF(nn.Module):
             near = near.repeat(rays_o.shape[0], 1)
             far = far.repeat(rays_o.shape[0], 1)
         if mode == "val":
-            surface = isurf.validate(rays_o, rays_d, near, far, scene, ipts["bound_min"], ipts["bound_max"], ipts["hw"],
-                                     cos_anneal_ratio, step, mesh_resolution=int(ipts.get("mesh_resolution", 512)))
-        else:
-            surface = isurf.render_scene(rays_o, rays_d, near, far, scene, cos_anneal_ratio, patch_warp=True, step=step)
-            if "pseudo_pts" in ipts:                                            # implicit_surface.py:425-434
-                surface["pseudo_sdf"] = isurf.pseudo_sdf(ipts["pseudo_pts"], scene)
-        outputs.update(surface)
-        return outputs
+            return isurf.validate(rays_o, rays_d, near, far, scene, ipts["bound_min"], ipts["bound_max"], ipts["hw"],
+                                  cos_anneal_ratio, step, mesh_resolution=int(ipts.get("mesh_resolution", 512)))
+        surface = isurf.render_scene(rays_o, rays_d, near, far, scene, cos_anneal_ratio, patch_warp=True, step=step)
+        if "pseudo_pts" in ipts:                                            # implicit_surface.py:425-434
+            surface["pseudo_sdf"] = isurf.pseudo_sdf(ipts["pseudo_pts"], scene)
+        return surface
+
+    def _wants_graph(self, mode, record=False):
+        """A train-mode forward records an autograd graph when autograd is on and something is trainable.  A volume-building
+        model must also be in train() mode, as runner.py:143 puts it: the sparse U-Net's backward kernels are those of
+        batch-statistics BatchNorm (an eval()-mode model forwards without a graph)."""
+        if mode == "val" or record or not torch.is_grad_enabled():
+            return False
+        if not self.has_vol and not self.reg_network.training:
+            return False
+        return any(p.requires_grad for p in self.parameters())
+
+    def forward(self, mode, ipts, cos_anneal_ratio=1.0, step=None, record=False):
+        """surf.py:133-163.  With autograd enabled a train-mode forward is differentiable (surf_amd.autograd): its outputs
+        carry grad_fn and `loss.backward()` runs the HIP backward kernels.  record=True (surf_amd.training's explicit step)
+        instead keeps the tapes on the module for `SuRF.backward` / `SuRF.backward_volumes` and returns plain tensors."""
+        if self._wants_graph(mode, record):
+            from . import autograd
+            return autograd.differentiable_forward(self, mode, ipts, cos_anneal_ratio, step)
+        with torch.no_grad():
+            self._train_tape = None
+            if self.has_vol:                                                    # surf.py:149-156
+                outputs, scene = {}, self._frozen_scene(ipts)
+            else:
+                outputs, volumes, tables, mvol, features, cams, tape = self.run_build(mode, ipts, record=record)
+                self._train_tape = tape
+                scene = self.build_scene(mode, ipts, volumes, tables, mvol, features, cams, step)
+            outputs.update(self.run_render(mode, ipts, scene, cos_anneal_ratio, step))
+            return outputs

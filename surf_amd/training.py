@@ -1,87 +1,67 @@
-"""One optimisation step of the reference's runner (runner.py:150-166), driven by the HIP backward kernels.
+"""One optimisation step of the reference's runner (runner.py:152-165) as a function.
 
-`finetune_step`: a has_vol model (surf.py:36-45's finetune parameter set): forward (`SuRF.forward("train")`), the loss's
-scalar terms through torch autograd on the per-ray outputs, `SuRF.backward` (surf_composite_backward -> surf_sdf_backward /
-surf_blend_backward), optimiser step.
-`train_step`: a volume-building model (generalisation training): the same, plus the per-stage depth terms (the masked L1
-terms through torch autograd on the depth maps, the photometric term through `surf_ptloss_backward`) and
-`SuRF.backward_volumes` (matching field -> densify -> sparse U-Net -> cost volume -> FPN), so that every parameter group of
-surf.py:36-45 receives its gradient.
+A train-mode `SuRF.forward` is differentiable (surf_amd.autograd: the HIP backward kernels behind two autograd nodes), so the
+step is the reference's own sequence - forward, `Loss`, `loss.backward()`, `optimizer.step()` - and runner.py needs no
+change to train with this package, with or without `DistributedDataParallel` (runner.py:102).  These helpers exist for
+callers that do not use the runner (bench.py, the tests):
 
-Differentiated terms: every term of losses/loss.py - colour, eikonal, sparse-SDF, smooth (H.1), rendered-depth, pseudo-SDF (the dataset's `pseudo_pts`), the patch-NCC
-term (`mfc_loss`), the per-stage photometric and pseudo-depth terms.
+`train_step`     a volume-building model (generalisation training, configs[3]): every parameter group of surf.py:36-45.
+`finetune_step`  a has_vol model (per-scene finetuning: implicit surface + the per-scene feature volumes).
+
+Both average the gradients over the ranks themselves when a process group is up and the model is NOT wrapped in
+DistributedDataParallel (`dist.all_reduce_gradients`: one flat bucket); under DDP its hooks have already done it.
+Differentiated terms: every term of losses/loss.py - colour, eikonal, sparse-SDF, smooth (H.1), rendered depth, pseudo-SDF,
+the patch-NCC term (`mfc_loss`), the per-stage photometric and pseudo-depth terms.
 """
 import torch
 
-from . import dist, ops
+from . import dist
 
-
-def _sync_gradients(optimizer):
-    """Data-parallel step (one process per GPU, runner.py's DDP): average the gradients over the ranks with bucketed
-    all-reduces (RCCL on GPUs, gloo in the CPU tests) before the optimiser step.  No-op for a single process."""
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-        dist.all_reduce_gradients([p for g in optimizer.param_groups for p in g["params"]])
-
+# the differentiable per-ray outputs of a train-mode forward (tests pin the backward kernels through leaf copies of these)
 LEAVES = ("color_fine", "render_depth", "gradient_error", "sparse_sdf", "ncc", "smooth_error")
 
 
-def _leaf_names(preds):
-    return LEAVES + (("pseudo_sdf",) if "pseudo_sdf" in preds else ())
+def _is_ddp(model):
+    return isinstance(model, torch.nn.parallel.DistributedDataParallel)
+
+
+def _sync_gradients(model, optimizer):
+    """Data-parallel step without DDP: average the gradients over the ranks (RCCL on GPUs, gloo in the CPU tests)."""
+    if _is_ddp(model):
+        return
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        dist.all_reduce_gradients([p for g in optimizer.param_groups for p in g["params"]])
+
+
+def _step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio, step, mode):
+    outputs = model("train", ipts, cos_anneal_ratio=cos_anneal_ratio, step=step)          # runner.py:155
+    out = loss_fn(outputs, targets, step=step, mode=mode)                                  # runner.py:159
+    optimizer.zero_grad(set_to_none=True)
+    out["loss"].backward()                                                                 # runner.py:163
+    _sync_gradients(model, optimizer)
+    optimizer.step()
+    return {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in out.items()}
 
 
 def finetune_step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio=1.0, step=0):
-    preds = model("train", ipts, cos_anneal_ratio, step)
-    preds["ncc"] = ops.lncc(preds["ref_gray_val"].contiguous(), preds["sampled_gray_val"].contiguous())
-    leaves = {k: preds[k].detach().clone().requires_grad_(True) for k in _leaf_names(preds)}
-    with torch.enable_grad():
-        out = loss_fn({**preds, **leaves}, targets, step=step, mode="finetune")      # any mode but "train": no per-stage terms
-        out["loss"].backward()
-    optimizer.zero_grad(set_to_none=True)
-    g = {k: v.grad for k, v in leaves.items()}
-    model.backward(g["color_fine"], g["render_depth"], 0.0 if g["gradient_error"] is None else float(g["gradient_error"]),
-                   g["sparse_sdf"], g["ncc"], 0.0 if g["smooth_error"] is None else float(g["smooth_error"]), g.get("pseudo_sdf"))
-    _sync_gradients(optimizer)
-    optimizer.step()
-    return {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in out.items()}
+    """runner.py:300-330 (finetune): any loss mode but "train" - no per-stage depth terms, the volumes are frozen structure."""
+    core = model.module if _is_ddp(model) else model
+    if not core.has_vol:
+        raise ValueError("finetune_step drives a has_vol model (SuRF.init_volumes / load_params_vol first)")
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        # the per-scene volumes are (N_s, 7) with N_s depending on the scene: ranks holding different scenes cannot average
+        # them (the reference finetunes in a single process, runner.py:62)
+        raise RuntimeError("finetune_step: per-scene volumes cannot be averaged over ranks; finetune in a single process")
+    return _step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio, step, "finetune")
 
 
 def train_step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio=1.0, step=0):
-    """runner.py:150-166 for a volume-building model in train mode (model.train(): BatchNorm batch statistics, matching-field
+    """runner.py:152-165 for a volume-building model in train mode (model.train(): BatchNorm batch statistics, matching-field
     jitter).  targets: what losses/loss.py reads in mode "train" (color, imgs, intrs, c2ws, src_idx, mask_ref / mask_src,
     pseudo_depth_ref / pseudo_depth_src, depth_ref / depth_src, ...)."""
-    if model.has_vol:
+    core = model.module if _is_ddp(model) else model
+    if core.has_vol:
         raise ValueError("train_step drives a volume-building model; use finetune_step for has_vol models")
-    preds = model("train", ipts, cos_anneal_ratio, step, record=True)
-    preds["ncc"] = ops.lncc(preds["ref_gray_val"].contiguous(), preds["sampled_gray_val"].contiguous())
-    n = model.num_stage
-    depth_keys = [f"depth_stage{i}" for i in range(n)] + [f"depth_src_stage{i}" for i in range(n)]
-    leaves = {k: preds[k].detach().clone().requires_grad_(True) for k in _leaf_names(preds) + tuple(depth_keys)}
-    with torch.enable_grad():
-        out = loss_fn({**preds, **leaves}, targets, step=step, mode="train")
-        out["loss"].backward()
-    optimizer.zero_grad(set_to_none=True)
-    g = {k: v.grad for k, v in leaves.items()}
-    # the photometric term is computed by HIP kernels outside autograd: its gradient w.r.t. the depth maps comes from
-    # surf_ptloss_backward, weighted like loss.py:60-66
-    imgs_t4 = ops.pack_texel4(targets["imgs"].float().contiguous())
-    cams = ops.Cameras(targets["intrs"], targets["c2ws"])
-    src_idx = int(targets["src_idx"])
-    mask_ref, mask_src = targets["mask_ref"].float().contiguous(), targets["mask_src"].float().contiguous()
-    g_depths = {}
-    for i in range(n):
-        w = float(loss_fn.ptloss_weight) * float(loss_fn.stage_weights[i])
-        g_ref, g_src = g[f"depth_stage{i}"], g[f"depth_src_stage{i}"]
-        if w != 0.0:
-            p_ref = ops.photometric_loss_backward(preds[f"depth_stage{i}"].float().contiguous(), imgs_t4, mask_ref, cams, 0, 2, w)
-            p_src = ops.photometric_loss_backward(preds[f"depth_src_stage{i}"].float().contiguous(), imgs_t4, mask_src, cams,
-                                                  src_idx, 1, w)
-            g_ref = p_ref if g_ref is None else g_ref + p_ref
-            g_src = p_src if g_src is None else g_src + p_src
-        g_depths[i] = (g_ref, g_src)
-    rows = model.backward(g["color_fine"], g["render_depth"], 0.0 if g["gradient_error"] is None else float(g["gradient_error"]),
-                          g["sparse_sdf"], g["ncc"], 0.0 if g["smooth_error"] is None else float(g["smooth_error"]),
-                          g.get("pseudo_sdf"))
-    model.backward_volumes(rows, g_depths)
-    _sync_gradients(optimizer)
-    optimizer.step()
-    return {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in out.items()}
+    if not core.training:
+        raise RuntimeError("train_step: call model.train() first (the sparse U-Net's backward is that of batch-statistics BatchNorm)")
+    return _step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio, step, "train")

@@ -5,6 +5,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from .grads import accumulate
 
 
 class Volume(nn.Module):
@@ -61,10 +62,9 @@ class Volume(nn.Module):
         d_mid = torch.zeros(n_parents, 8, dtype=torch.float32, device=d_reg_in.device)
         return ops.scatter_rows_add(d_reg_in, pidx, d_mid, shift=3, dst_off=8)
 
-    def assign_agg_grad(self, g_agg):
-        """Split the 49 floats of costvol_backward (w1 | b1 | w2 | b2) into agg_mlp's `.grad` (accumulating)."""
+    def assign_agg_grad(self, g_agg, sink=None):
+        """Split the 49 floats of costvol_backward (w1 | b1 | w2 | b2) into agg_mlp's `.grad` (accumulating) or `sink`."""
         parts = ((self.agg_mlp[0].weight, 0, 32), (self.agg_mlp[0].bias, 32, 40), (self.agg_mlp[2].weight, 40, 48),
                  (self.agg_mlp[2].bias, 48, 49))
         for p_, a, b in parts:
-            g = g_agg[a:b].reshape(p_.shape).to(p_.dtype)
-            p_.grad = g if p_.grad is None else p_.grad + g
+            accumulate(p_, g_agg[a:b], sink)

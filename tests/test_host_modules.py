@@ -154,7 +154,7 @@ def test_agg_mlp_gradient_split_and_step_helpers():
     assert host.shape == (49,)
     opt = torch.optim.SGD(vol.parameters(), lr=0.1)
     before = vol.agg_mlp[0].bias.grad.clone()
-    training._sync_gradients(opt)
+    training._sync_gradients(vol, opt)
     assert torch.equal(vol.agg_mlp[0].bias.grad, before)
 
 
