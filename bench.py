@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark of the SuRF hot path on MI355X: full-image render throughput (rays/s).
 
-    python bench.py --gpus N --steps K --warmup W [--workload dtu|tnt] [--scenes M]
+    python bench.py --gpus N --steps K --warmup W [--workload dtu|tnt|train] [--scenes M]
 
 One "step" = one pass of the render hot path (ray set-up -> SDF MLP + gradient -> multi-view blending ->
 NeuS compositing) over every pixel ray of the reference view of a synthetic multi-view scene
@@ -20,6 +20,10 @@ datasets/__init__.py:37-38 of the reference); without it every rank renders one 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (sdf_mlp) timed with HIP events on the launch
 stream inside the timed region; `roofline_kernels` lists the other contraction kernels; `cpu_baseline` is the CPU
 oracle (oracle/surf_oracle.py, a port of the reference algorithm) timed on this host on a bounded ray subset.
+`--workload train` (configs[3]) instead runs the data-parallel TRAINING step: every rank one scene + 512 rays per step
+through the reference's own sequence (forward, Loss, loss.backward(), Adam) with the model wrapped in
+DistributedDataParallel over RCCL; it reports training rays/s, steps/s, the all-reduce time of the gradient bucket alone
+and `roofline_kernels` for the heaviest backward kernels.
 `--dry` replaces the kernels by a sleep and RCCL by gloo: it exists so that tests/test_dist_gloo.py can drive this
 file's own N > 1 control flow on a CPU-only host; a dry line says so ("data": "dry-run") and is not a measurement.
 """
@@ -62,6 +66,10 @@ WORKLOADS = {
     # BASELINE.json configs[4]: Tanks&Temples, 7 views 1080p, 192 samples per ray
     "tnt": {"height": 1080, "width": 1920, "views": 7, "n_samples": "96,48,32,16",
             "metric": "rays/sec (1080x1920, 7-view, 192 samp/ray render, whole job)"},
+    # BASELINE.json configs[3]: surf.conf unsupervised training, data-parallel over the ranks (runner.py:102: DDP): one scene
+    # + 512 rays per rank and step; a step = forward (FPN, 4-stage volume build, render) + Loss + loss.backward() + Adam
+    "train": {"height": 576, "width": 800, "views": 5, "n_samples": "64,32,16,16",
+              "metric": "training rays/sec (surf.conf unsupervised training step, 5 views 576x800, 128 samp/ray, whole job)"},
 }
 RAY_CHUNK = 1 << 19      # rays per render call (bounds the per-sample buffers; 576x800 fits one call)
 
@@ -216,7 +224,7 @@ def volume_build_timing(args, dev):
     return res
 
 
-def training_step_setup(dev, H=576, W=800, nv=5, base_dim=88, rays=512, device_jitter=True):
+def training_step_setup(dev, H=576, W=800, nv=5, base_dim=88, rays=512, device_jitter=True, scene_seed=0):
     """A volume-building SuRF in train mode on the synthetic scene + the inputs / loss targets of one training step
     (runner.py:150-166).  Weights are random-init, so the analytic sphere logit replaces the U-Net's matching logit in the
     forward (as in volume_build_timing); the backward still runs through every kernel."""
@@ -228,9 +236,9 @@ def training_step_setup(dev, H=576, W=800, nv=5, base_dim=88, rays=512, device_j
     model.logit_override = synthetic.sphere_logit
     model.matching_field.device_jitter = device_jitter      # False: the reference's CPU-generator draw (host-bound)
     intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
-    imgs = synthetic.procedural_images(nv, H, W, 0, dev)
+    imgs = synthetic.procedural_images(nv, H, W, scene_seed, dev)
     rays_o, rays_d = synthetic.pixel_rays(intrs[0], c2ws[0], H, W, 1, dev)
-    sel = torch.randperm(rays_o.shape[0], device=dev)[:rays]
+    sel = torch.randperm(rays_o.shape[0], generator=torch.Generator().manual_seed(1000 + scene_seed))[:rays].to(dev)
     ipts = {"imgs": imgs, "intrs": intrs.to(dev), "c2ws": c2ws.to(dev), "near_fars": near_fars.to(dev),
             "near": near_fars[0, 0].reshape(1, 1).to(dev), "far": near_fars[0, 1].reshape(1, 1).to(dev),
             "rays_o": rays_o[sel].contiguous(), "rays_d": rays_d[sel].contiguous(), "src_idx": 1}
@@ -297,32 +305,223 @@ def mesh_grid_timing(model, scene, dev, resolution):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# --workload train: BASELINE configs[3], the data-parallel training step (runner.py:102,152-165)
+# ----------------------------------------------------------------------------------------------------------------------
+
+VALU_FP32_PEAK = 157.3      # TFLOP/s, MI355X_MICROARCH.md (vector fp32 = the fp32 matrix rate on this part)
+
+
+def train_kernel_rooflines(per_kernel):
+    """`roofline_kernels` entries of the training step's heaviest backward kernels from the HIP events recorded inside the
+    timed region (ops.kernel_events).  Algorithmic work per unit (DESIGN K12): spconv_wgrad<Ci,Co> per (output site, offset)
+    one table entry + one gathered C_i row (4 + 4 C_i B) and, per site, the dy row (4 C_o B / 27 per unit); costvol_bwd per
+    (voxel, view, level) 64 B of taps gathered + 64 B of float atomics; matching_depth_bwd per (ray, sample) 32 B of corners
+    read + 32 B of float atomics; sdf_bwd / sdf_smooth_bwd per sample 2x / 4x (forward + reverse) x 0.13 M MAC on the fp32 VALU."""
+    out = []
+    for name, rows in sorted(per_kernel.items(), key=lambda kv: -sum(r[0] for r in kv[1])):
+        ms = sum(r[0] for r in rows)                       # per step (all launches of the kernel)
+        units = sum(r[1] for r in rows)
+        e = {"kernel": name, "ms_per_step": ms, "launches_per_step": len(rows), "units_per_step": units}
+        if name.startswith("spconv_wgrad<"):
+            ci, co = (int(v) for v in name[len("spconv_wgrad<"):-1].split(","))
+            b = units * (4 + 4 * ci + 4 * co / 27.0)
+            e.update(bound="hbm", achieved=b / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", bytes_per_unit=4 + 4 * ci + 4 * co / 27.0)
+        elif name.startswith("spconv_dgrad<"):
+            ci, co = (int(v) for v in name[len("spconv_dgrad<"):-1].split(","))
+            b = units * (4 + 4 * ci + 4 * co / 27.0)
+            e.update(bound="hbm", achieved=b / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", bytes_per_unit=4 + 4 * ci + 4 * co / 27.0)
+        elif name == "costvol_bwd":
+            e.update(bound="hbm", achieved=units * 128.0 / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", bytes_per_unit=128)
+        elif name == "matching_depth_bwd":
+            e.update(bound="hbm", achieved=units * 64.0 / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", bytes_per_unit=64)
+        elif name in ("sdf_bwd", "sdf_smooth_bwd"):
+            f = (2 if name == "sdf_bwd" else 4) * 2 * 2 * 0.13e6
+            e.update(bound="valu", achieved=units * f / (ms * 1e-3) / 1e12, peak=VALU_FP32_PEAK, unit="TFLOP/s", flop_per_unit=f)
+        elif name == "blend_bwd":
+            f = 2 * 2 * 20e3
+            e.update(bound="valu", achieved=units * f / (ms * 1e-3) / 1e12, peak=VALU_FP32_PEAK, unit="TFLOP/s", flop_per_unit=f)
+        if "achieved" in e:
+            e["frac"] = e["achieved"] / e["peak"]
+        out.append(e)
+    return out
+
+
+class _DryTrainModel(torch.nn.Module):
+    """--dry: a CPU stand-in with SuRF's parameter count (1.41 M floats) and forward signature."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1410, 1000))
+
+    def forward(self, mode, inputs, cos_anneal_ratio=1.0, step=None):
+        time.sleep(0.002)
+        return {"color_fine": (self.w.sum() * 0.0 + inputs["x"]).reshape(1, 1)}
+
+
+def run_rank_train(args):
+    """N ranks x (one synthetic scene + `--rays` rays) per step, gradients averaged by DistributedDataParallel over RCCL -
+    the reference's own arrangement (scripts/run.sh:3, runner.py:102) on surf_amd's differentiable forward."""
+    from torch.nn.parallel import DistributedDataParallel
+    from surf_amd import dist as D
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = args.dry
+    if dry:
+        dev = torch.device("cpu")
+        D.init_from_env("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        D.init_from_env("nccl", dev)
+    if args.fail_rank == rank:
+        sys.exit(3)
+
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
+
+    H, W, nv, rays = args.height, args.width, args.views, args.rays
+    if dry:
+        model = _DryTrainModel()
+        inputs = {"x": torch.tensor(float(rank))}
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        loss_of = lambda outputs: outputs["color_fine"].sum()          # noqa: E731
+        ddp = DistributedDataParallel(model) if world > 1 else model
+    else:
+        from surf_amd import ops
+        model, ipts, targets, loss_fn, opt = training_step_setup(dev, H, W, nv, args.base_dim, rays=rays, scene_seed=rank)
+        inputs = {**targets, **ipts}                                    # the runner hands ONE dictionary to model and loss
+        loss_of = lambda outputs: loss_fn(outputs, inputs, 3.0)["loss"]  # noqa: E731
+        ddp = DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model      # runner.py:102
+
+    def step():                                                        # runner.py:155-164
+        outputs = ddp("train", inputs, cos_anneal_ratio=1.0, step=3.0)
+        loss = loss_of(outputs)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    sync()
+    D.barrier()
+    sync()
+    if not dry:
+        ops.kernel_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync()
+    D.barrier()
+    sync()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    events = []
+    if not dry:
+        events, ops.kernel_events = ops.kernel_events, None
+    # the gradient all-reduce alone: one flat bucket of the trainable parameters' size (DDP's single 5.6 MB bucket)
+    n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    allreduce_ms = None
+    if world > 1:
+        flat = torch.zeros(n_params, dtype=torch.float32, device=dev)
+        for _ in range(3):
+            torch.distributed.all_reduce(flat)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            torch.distributed.all_reduce(flat)
+        sync()
+        allreduce_ms = D.max_over_ranks((time.perf_counter() - t1) / 10 * 1e3, dev)
+    if rank == 0:
+        per_kernel = {}
+        for name, a, b, units in events:
+            per_kernel.setdefault(name, []).append((a.elapsed_time(b) / args.steps, units / args.steps))
+        rk = train_kernel_rooflines(per_kernel) if per_kernel else []
+        top = next((e for e in rk if "frac" in e), None)
+        result = {
+            "metric": WORKLOADS["train"]["metric"], "value": world * rays * args.steps / elapsed, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "none (dry run)" if dry else "f32", "data": "dry-run" if dry else "synthetic",
+            "config": {"workload": ("DRY RUN of the train control flow: no kernels executed" if dry else
+                                    f"training step: {nv} views {H}x{W}, {rays} rays x 128 samples and one synthetic scene per rank, "
+                                    f"{args.base_dim}^3 -> {args.base_dim * 8}^3 pyramid, every term of losses/loss.py, Adam"),
+                       "rays_per_rank_step": rays, "parallelism": f"ddp{world}" if world > 1 else "single",
+                       "trainable_parameters": n_params},
+            "steps_per_s": args.steps / elapsed, "gradient_allreduce_ms": allreduce_ms,
+            "loss": float(loss.detach()),
+            "roofline": None if top is None else {k: top[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac")} | {"traffic": None},
+            "roofline_kernels": rk,
+            "cpu_baseline": None,
+        }
+        if not dry:
+            result["voxels_per_stage"] = getattr(model, "last_voxels_per_stage", None)
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 # launcher: `python bench.py --gpus N` without a torch.distributed launcher
 # ----------------------------------------------------------------------------------------------------------------------
 
 
-def launch_ranks(n, argv):
-    """Start n ranks of this file as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on
+def launch_ranks(n, argv, timeout_s=1700.0):
+    """Start n ranks of this file as FRESH child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on
     127.0.0.1) and relay rank 0's stdout.  Runs before anything in this process has touched the GPU: the parent never
-    initialises HIP and nothing is exec'd from a process that has."""
+    initialises HIP and nothing is exec'd from a process that has.  Every rank's stdout / stderr goes to its own temporary
+    file (no pipe can fill up); when a rank exits non-zero, or `timeout_s` passes, the others - who would otherwise sit in
+    an RCCL collective until the caller's own limit - are killed (exactly the processes started here), and the failing
+    ranks' stderr tails are shown."""
+    import tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, logs = [], []
+    tmp = tempfile.mkdtemp(prefix="surf_bench_")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0)
+        fo, fe = open(os.path.join(tmp, f"rank{r}.out"), "w+"), open(os.path.join(tmp, f"rank{r}.err"), "w+")
+        logs.append((fo, fe))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=fo, stderr=fe, text=True))
+    t0, why = time.monotonic(), None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes):
+            why = "a rank failed"
+        elif time.monotonic() - t0 > timeout_s:
+            why = f"timeout after {timeout_s:.0f} s"
+        if why:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            codes = [p.wait() for p in procs]
+            break
+        time.sleep(0.2)
+
+    def tail(f, nbytes=3000):
+        f.flush()
+        f.seek(0)
+        return f.read()[-nbytes:]
+    sys.stdout.write(tail(logs[0][0], 1 << 24))
     sys.stdout.flush()
-    if any(codes):
-        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
-        return 1
-    return 0
+    bad = why is not None or any(codes)
+    if bad:
+        print(f"bench.py: rank exit codes {codes}" + (f" ({why}; the remaining ranks were killed)" if why else ""), file=sys.stderr)
+        for r, (fo, fe) in enumerate(logs):
+            if codes[r] != 0:
+                print(f"---- rank {r} stderr (tail) ----\n{tail(fe)}", file=sys.stderr)
+    for fo, fe in logs:
+        fo.close()
+        fe.close()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return 1 if bad else 0
 
 
 def parse_args(argv):
@@ -351,6 +550,9 @@ def parse_args(argv):
     ap.add_argument("--also", default="f16x2", help="comma list of further precisions timed after the headline run "
                                                     "(reported under other_precisions; '' = none)")
     ap.add_argument("--dry", action="store_true", help="control-flow test: no GPU, no kernels, gloo instead of RCCL")
+    ap.add_argument("--rank-timeout", type=float, default=1700.0, help="self-spawned ranks are killed after this many seconds")
+    ap.add_argument("--rays", type=int, default=512, help="--workload train: rays per rank and step (confs/surf.conf: 512)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="(tests) this rank exits 3 before the first barrier")
     args = ap.parse_args(argv)
     wl = WORKLOADS[args.workload]
     for k in ("height", "width", "views", "n_samples"):
@@ -363,7 +565,7 @@ def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(launch_ranks(args.gpus, argv))
+        sys.exit(launch_ranks(args.gpus, argv, args.rank_timeout))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with matching values "
@@ -385,6 +587,8 @@ class DryScene:
 
 
 def run_rank(args):
+    if args.workload == "train":
+        return run_rank_train(args)
     from surf_amd import dist as D
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -399,6 +603,8 @@ def run_rank(args):
         D.init_from_env("nccl", dev)          # RCCL; only the barrier, the MAX of the elapsed time and the record gather
     if torch.distributed.is_initialized():
         assert torch.distributed.get_world_size() == world == args.gpus
+    if args.fail_rank == rank:
+        sys.exit(3)
 
     def sync():
         if not dry:

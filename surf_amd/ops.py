@@ -20,6 +20,30 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# bench.py: a list that receives (name, start event, end event, algorithmic units) of the instrumented backward launches
+# (HIP events on the launch stream); None = no timing
+kernel_events = None
+
+
+class _timed:
+    """with _timed("costvol_bwd", units): ... - brackets the launches inside with a HIP event pair when a bench asked for it."""
+
+    def __init__(self, name, units=0):
+        self.name, self.units = name, units
+
+    def __enter__(self):
+        if kernel_events is not None:
+            self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if kernel_events is not None and exc[0] is None:
+            self.b.record()
+            kernel_events.append((self.name, self.a, self.b, self.units))
+        return False
+
+
 def _p(t):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
@@ -354,9 +378,10 @@ def sdf_backward(pts, ybar, gbar, volumes, packed, want_dvols=True):
     tb = torch.empty(6, n, 128, dtype=torch.float32, device=dev)
     tdb = torch.empty(6, n, 128, dtype=torch.float32, device=dev)
     dvols = [torch.zeros_like(v) for v in volumes.vols] if want_dvols else None
-    rc = _lib.lib().surf_sdf_backward(_p(pts), _p(ybar), _p(gbar), n, volumes._vp, volumes._tp, volumes._dp, volumes.n,
-                                      _ptr_array(dvols) if dvols is not None else None, _p(packed), _p(in_v), _p(in_d), _p(tb),
-                                      _p(tdb), _stream())
+    with _timed("sdf_bwd", n):
+        rc = _lib.lib().surf_sdf_backward(_p(pts), _p(ybar), _p(gbar), n, volumes._vp, volumes._tp, volumes._dp, volumes.n,
+                                          _ptr_array(dvols) if dvols is not None else None, _p(packed), _p(in_v), _p(in_d), _p(tb),
+                                          _p(tdb), _stream())
     _lib.check(rc, "surf_sdf_backward")
     shapes = [(128, 27), (128, 156), (101, 156), (128, 156), (128, 156), (128, 156), (129, 156)]
     dW, db = [], []
@@ -386,8 +411,9 @@ def sdf_smooth_backward(pts, sbar, volumes, packed, want_dvols=True):
     xin = torch.empty(7, 4, n, 160, dtype=torch.float32, device=dev)
     ab = torch.empty(6, 4, n, 128, dtype=torch.float32, device=dev)
     dvols = [torch.zeros_like(v) for v in volumes.vols] if want_dvols else None
-    rc = _lib.lib().surf_sdf_smooth_backward(_p(pts), _p(sbar), n, volumes._vp, volumes._tp, volumes._dp, volumes.n,
-                                             _ptr_array(dvols) if dvols is not None else None, _p(packed), _p(xin), _p(ab), _stream())
+    with _timed("sdf_smooth_bwd", n):
+        rc = _lib.lib().surf_sdf_smooth_backward(_p(pts), _p(sbar), n, volumes._vp, volumes._tp, volumes._dp, volumes.n,
+                                                 _ptr_array(dvols) if dvols is not None else None, _p(packed), _p(xin), _p(ab), _stream())
     _lib.check(rc, "surf_sdf_smooth_backward")
     shapes = [(128, 27), (128, 156), (101, 156), (128, 156), (128, 156), (128, 156), (129, 156)]
     dW, db = [], []
@@ -446,10 +472,11 @@ def blend_backward(pts, active_idx, gcolor, feats_t4, imgs_t4, cams, raw_weights
     if n > 0:
         hw = (ctypes.c_int * 8)(*[int(v) for f in feats_t4 for v in f.shape[1:3]])
         intr16 = np.ascontiguousarray(cams.intrs.reshape(cams.nv, -1))
-        rc = _lib.lib().surf_blend_backward(_p(pts), _p(active_idx), n, _p(gcolor), _ptr_array(list(feats_t4)), hw, _p(imgs_t4),
-                                            cams.nv, _np_ptr(intr16), _np_ptr(cams.w2c), _np_ptr(cams.c2w), _p(raw_weights),
-                                            _p(rows), _p(ds), _p(color),
-                                            None if gfeats_t4 is None else _ptr_array(list(gfeats_t4)), _stream())
+        with _timed("blend_bwd", n * V):
+            rc = _lib.lib().surf_blend_backward(_p(pts), _p(active_idx), n, _p(gcolor), _ptr_array(list(feats_t4)), hw, _p(imgs_t4),
+                                                cams.nv, _np_ptr(intr16), _np_ptr(cams.w2c), _np_ptr(cams.c2w), _p(raw_weights),
+                                                _p(rows), _p(ds), _p(color),
+                                                None if gfeats_t4 is None else _ptr_array(list(gfeats_t4)), _stream())
         _lib.check(rc, "surf_blend_backward")
     flat = rows[:n].reshape(-1, ROW)
     for name, cin, cout, c_in, c_ad in _BLEND_LAYERS:
@@ -853,11 +880,13 @@ def matching_depth_backward(mvol, cams, near_fars, H, W, res_level, n, g_full, p
     g_lr = torch.empty(cams.nv, h, w, dtype=torch.float32, device=dev)
     if dmvol is None:
         dmvol = torch.zeros_like(mvol)
-    rc = _lib.lib().surf_matching_depth_backward(_p(mvol), int(mvol.shape[0]), cams.nv, _np_ptr(cams.kinv), _np_ptr(cams.c2w),
-                                                 _np_ptr(cams.rinv), _np_ptr(nf), H, W, h, w, _p(lin_x), _p(lin_y), _p(lin_n),
-                                                 int(n), _p(pre_depths), ctypes.c_float(float(ratio_cur)),
-                                                 ctypes.c_float(float(ratio_prev)), _p(jitter), _p(g_full), int(views[0]), int(views[1]),
-                                                 _p(g_lr), _p(dmvol), _stream())
+    n_views = len(set(int(v) for v in views))
+    with _timed("matching_depth_bwd", n_views * h * w * int(n) * (1 if pre_depths is None else 2)):
+        rc = _lib.lib().surf_matching_depth_backward(_p(mvol), int(mvol.shape[0]), cams.nv, _np_ptr(cams.kinv), _np_ptr(cams.c2w),
+                                                     _np_ptr(cams.rinv), _np_ptr(nf), H, W, h, w, _p(lin_x), _p(lin_y), _p(lin_n),
+                                                     int(n), _p(pre_depths), ctypes.c_float(float(ratio_cur)),
+                                                     ctypes.c_float(float(ratio_prev)), _p(jitter), _p(g_full), int(views[0]), int(views[1]),
+                                                     _p(g_lr), _p(dmvol), _stream())
     _lib.check(rc, "surf_matching_depth_backward")
     return dmvol
 
@@ -894,9 +923,10 @@ def costvol_backward(feats_t4_c2f, gfeats_t4_c2f, stage, D, cams, agg, coords, g
     hw = (ctypes.c_int * 8)(*[int(v) for f in feats_t4_c2f for v in f.shape[1:3]])
     agg = np.ascontiguousarray(agg, dtype=np.float32)
     ws = torch.empty(_lib.lib().surf_costvol_backward_workspace_floats(), dtype=torch.float32, device=g.device)
-    rc = _lib.lib().surf_costvol_backward(_p(coords), _p(g), coords.shape[0], int(D), _ptr_array(feats_t4_c2f),
-                                          _ptr_array(gfeats_t4_c2f), hw, int(stage), cams.nv, _np_ptr(cams.intrs),
-                                          _np_ptr(cams.w2c), _np_ptr(agg), _p(ws), _p(g_agg), _stream())
+    with _timed("costvol_bwd", int(coords.shape[0]) * cams.nv * (4 - int(stage))):
+        rc = _lib.lib().surf_costvol_backward(_p(coords), _p(g), coords.shape[0], int(D), _ptr_array(feats_t4_c2f),
+                                              _ptr_array(gfeats_t4_c2f), hw, int(stage), cams.nv, _np_ptr(cams.intrs),
+                                              _np_ptr(cams.w2c), _np_ptr(agg), _p(ws), _p(g_agg), _stream())
     _lib.check(rc, "surf_costvol_backward")
 
 
@@ -1030,16 +1060,18 @@ def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight,
     _chk(dy, torch.float32, "dy")
     cin, cout = int(weight.shape[1]), int(weight.shape[2])
     wt = weight.transpose(1, 2).contiguous()                        # (27, Cout, Cin)
-    if mode == SUBM:
-        dx = spconv(dy, out_table, in_coords, SUBM, wt.flip(0).contiguous())
-    elif mode == DOWN:
-        dx = spconv(dy, out_table, in_coords, UP, wt)
-    else:
-        dx = spconv(dy, out_table, in_coords, DOWN, wt)
+    with _timed(f"spconv_dgrad<{cout},{cin}>", int(in_coords.shape[0]) * 27):
+        if mode == SUBM:
+            dx = spconv(dy, out_table, in_coords, SUBM, wt.flip(0).contiguous())
+        elif mode == DOWN:
+            dx = spconv(dy, out_table, in_coords, UP, wt)
+        else:
+            dx = spconv(dy, out_table, in_coords, DOWN, wt)
     dW = torch.zeros_like(weight)
     if out_coords.shape[0] > 0 and x.shape[0] > 0:
-        rc = _lib.lib().surf_spconv_wgrad(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords), out_coords.shape[0],
-                                          int(mode), _p(dy), cout, _p(dW), _stream())
+        with _timed(f"spconv_wgrad<{cin},{cout}>", int(out_coords.shape[0]) * 27):
+            rc = _lib.lib().surf_spconv_wgrad(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords), out_coords.shape[0],
+                                              int(mode), _p(dy), cout, _p(dW), _stream())
         _lib.check(rc, "surf_spconv_wgrad")
     return dx, dW
 

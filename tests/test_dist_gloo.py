@@ -139,3 +139,33 @@ def test_gradient_all_reduce_two_ranks(tmp_path):
     assert res["buckets"] == 2                       # [8400 B] (alone: it exceeds the 4096-byte bucket), [44 B + 64 B]
     assert abs(res["g0"] - 1.5) < 1e-6 and abs(res["g2"] - 0.5) < 1e-6
     assert all(abs(a - 1.5 * k) < 1e-6 for k, a in enumerate(res["g1"]))
+
+
+def test_bench_train_workload_two_ranks_ddp_dry():
+    """`python bench.py --workload train --gpus 2` (BASELINE configs[3]): two fresh ranks, the model wrapped in
+    DistributedDataParallel (gloo here, RCCL on GPUs), the runner's step sequence, one line with training rays/s, steps/s
+    and the all-reduce time of the gradient bucket."""
+    import json
+    res = subprocess.run([sys.executable, BENCH, "--workload", "train", "--gpus", "2", "--dry", "--steps", "3", "--warmup", "1"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["scaling"] == "weak" and r["data"] == "dry-run"
+    assert r["config"]["parallelism"] == "ddp2" and r["config"]["rays_per_rank_step"] == 512
+    assert r["gradient_allreduce_ms"] > 0 and r["config"]["trainable_parameters"] == 1410000
+    assert abs(r["value"] - 2 * 512 * r["steps_per_s"]) < 1e-6 * r["value"]
+
+
+def test_bench_kills_the_surviving_ranks_when_one_dies():
+    """A rank that exits before the first barrier must not leave the others waiting in a collective until the caller's own
+    limit: the launcher kills exactly the processes it started, reports the exit codes and returns non-zero - quickly."""
+    import time
+    for workload in ("dtu", "train"):
+        t0 = time.monotonic()
+        res = subprocess.run([sys.executable, BENCH, "--workload", workload, "--gpus", "2", "--dry", "--steps", "2", "--warmup", "0",
+                              "--fail-rank", "1"], env=_clean_env(), capture_output=True, text=True, timeout=120)
+        assert res.returncode == 1, (workload, res.returncode, res.stderr[-1000:])
+        assert "rank exit codes" in res.stderr and "killed" in res.stderr
+        assert time.monotonic() - t0 < 60
