@@ -39,21 +39,41 @@ def update_faces(vertices, faces, keep):
     return np.asarray(vertices)[used], remap[faces]
 
 
+def _mask_coverage(mask, px, py):
+    """Bilinear sample (align_corners=True pixel coordinates, zeros outside) of a non-negative (h, w) mask at float pixel
+    positions: > 0 exactly where one of the four neighbouring texels with a non-zero weight is set."""
+    h, w = mask.shape
+    x0, y0 = torch.floor(px), torch.floor(py)
+    fx, fy = px - x0, py - y0
+    total = torch.zeros_like(px)
+    for dy, wy in ((0, 1.0 - fy), (1, fy)):
+        for dx, wx in ((0, 1.0 - fx), (1, fx)):
+            xi, yi = x0.long() + dx, y0.long() + dy
+            ok = (xi >= 0) & (xi < w) & (yi >= 0) & (yi < h)
+            total += torch.where(ok, mask[yi.clamp(0, h - 1), xi.clamp(0, w - 1)] * wx * wy, torch.zeros_like(px))
+    return total
+
+
 @torch.no_grad()
 def clean_mesh_by_mask(vertices, faces, masks, intrs, c2ws, min_nb_visible=1):
-    """utils/clean_mesh.py:9-34.  masks (nv,h,w) bool / float tensors; returns the face keep-mask (F,) bool."""
-    points = torch.as_tensor(np.asarray(vertices), dtype=torch.float32).permute(1, 0)
-    nv, h, w = masks.shape
-    pts_cam = torch.matmul(c2ws.inverse(), torch.cat([points, torch.ones_like(points[:1])], dim=0)[None])[:, :3]
-    pts_img = torch.matmul(intrs[:, :3, :3], pts_cam)
-    pts_xy = pts_img[:, :2] / torch.clamp(pts_img[:, 2:], 1e-8)
-    pts_xy[:, 0] = 2 * pts_xy[:, 0] / (w - 1) - 1
-    pts_xy[:, 1] = 2 * pts_xy[:, 1] / (h - 1) - 1
-    in_mask = (pts_xy.abs() <= 1).all(dim=1) & (pts_img[:, -1] > 1e-8)
-    grid = torch.clamp(pts_xy.permute(0, 2, 1).unsqueeze(1), -10, 10)
-    warp_mask = F.grid_sample(masks.unsqueeze(1).float(), grid, align_corners=True).reshape(nv, -1)
-    valid = ((warp_mask > 0) * in_mask).sum(dim=0) > min_nb_visible
-    return valid[torch.as_tensor(np.asarray(faces), dtype=torch.long)].all(dim=-1).numpy()
+    """The visual-hull test of utils/clean_mesh.py:9-34: a vertex counts as seen by a view when it lies in front of the camera,
+    projects inside the image and onto a set texel of that view's (dilated) mask (bilinear footprint); a face survives when
+    each of its vertices is seen by MORE than `min_nb_visible` views.  masks (nv,h,w) bool / float tensors; returns the face
+    keep-mask (F,) bool (the caller applies it: Trimesh.update_faces)."""
+    xyz1 = torch.cat([torch.as_tensor(np.asarray(vertices), dtype=torch.float32),
+                      torch.ones(len(vertices), 1, dtype=torch.float32)], dim=1)                   # (V, 4)
+    n_seen = torch.zeros(len(vertices), dtype=torch.long)
+    for mask, K, c2w in zip(masks.float(), intrs, c2ws):
+        h, w = mask.shape
+        uvw = (xyz1 @ torch.inverse(c2w).T)[:, :3] @ K[:3, :3].T                                    # homogeneous pixel coordinates
+        depth = uvw[:, 2]
+        px, py = uvw[:, 0] / depth.clamp(min=1e-8), uvw[:, 1] / depth.clamp(min=1e-8)
+        inside = (px >= 0) & (px <= w - 1) & (py >= 0) & (py <= h - 1) & (depth > 1e-8)
+        far = 10.0 * max(h, w)                         # keep the index arithmetic finite for points far outside the image
+        on_mask = _mask_coverage(mask, px.clamp(-far, far), py.clamp(-far, far)) > 0
+        n_seen += (inside & on_mask).long()
+    vertex_ok = n_seen > min_nb_visible
+    return vertex_ok[torch.as_tensor(np.asarray(faces), dtype=torch.long)].all(dim=-1).numpy()
 
 
 def face_components(faces, min_len):
