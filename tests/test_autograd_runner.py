@@ -235,6 +235,12 @@ def test_runner_sequence_on_the_full_model_equals_the_explicit_backward(scene):
         if not p.requires_grad:
             continue
         ref = p.grad if p.grad is not None else torch.zeros_like(p)
+        if n == "volume.agg_mlp.2.bias":
+            # the view softmax is shift invariant: this gradient is zero in exact arithmetic and atomics-order rounding noise
+            # in both runs (tests/test_volume_backward.py::test_volume_build_backward_end_to_end)
+            w2 = float(model.volume.agg_mlp[2].weight.grad.abs().max())
+            assert float(got[n].abs().max()) < 1e-3 * w2 and float(ref.abs().max()) < 1e-3 * w2
+            continue
         scale = max(float(ref.abs().max()), 1e-8)
         worst.append((float((got[n] - ref).abs().max()) / scale, n))
     worst.sort(reverse=True)

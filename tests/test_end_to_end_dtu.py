@@ -1,0 +1,116 @@
+"""GPU, rows f3 + a17 + f1 + f4 in one chain: a synthetic scene written in DTU's own file formats -> surf_amd.datasets.get_loader
+-> SuRF.forward("val") (FPN, 4-stage volume build, render, 128^3 lattice + marching cubes) -> mesh_io.export_mesh with the
+item's scale_mat -> evaluation.dtu_eval.evaluate_scan against an analytic ground truth with a KNOWN Chamfer distance.
+
+The SDF network's geometric initialisation is a sphere of radius ~0.5 in the normalised frame whatever the feature volumes
+hold (sdf_network.py:62-86 zeroes the feature columns), so the exported mesh is a sphere of known centre (scale_mat's
+translation) and measurable radius r in world units; the ground-truth "scan" is the sphere of radius r + delta around the
+same centre, for which accuracy = completeness = delta."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from tests.test_datasets import _ring_cams, _write_cam
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_scene(root, H=96, W=128, n_views=4):
+    from surf_amd.datasets import mvs_io
+    g = np.random.default_rng(11)
+    for sub in ("Cameras", "Rectified_raw/scan24", "Depths_raw/scan24", "Pseudo_depths/scan24", "Pseudo_points"):
+        os.makedirs(root / sub)
+    K = np.array([[2892.33, 0, 823.2], [0, 2883.18, 619.07], [0, 0, 1.0]])
+    for v, w2c in enumerate(_ring_cams(n_views)):
+        _write_cam(root / "Cameras" / f"{v:08d}_cam.txt", w2c, K, 425.0, 2.5)
+        yy, xx = np.mgrid[:H, :W]
+        img = np.stack([0.5 + 0.5 * np.sin(0.11 * xx + 0.07 * yy + v), 0.5 + 0.5 * np.sin(0.05 * xx - 0.13 * yy + 2 * v),
+                        0.5 + 0.5 * np.cos(0.09 * xx + 0.03 * yy)], axis=-1)
+        Image.fromarray((img * 255).astype(np.uint8)).save(root / "Rectified_raw/scan24" / f"rect_{v + 1:03d}_3_r5000.png")
+        Image.fromarray(np.full((H, W), 255, np.uint8)).save(root / "Depths_raw/scan24" / f"depth_visual_{v:04d}.png")
+        mvs_io.write_pfm(root / "Depths_raw/scan24" / f"depth_map_{v:04d}.pfm", np.full((H, W), 600.0, np.float32))
+        mvs_io.write_pfm(root / "Pseudo_depths/scan24" / f"{v:08d}.pfm", np.full((H, W), 600.0, np.float32))
+    (root / "Cameras" / "pair.txt").write_text(f"{n_views}\n" + "".join(
+        f"{r}\n{n_views - 1} " + " ".join(f"{s} 1.0" for s in range(n_views) if s != r) + "\n" for r in range(n_views)))
+    with open(root / "Pseudo_points" / "mvsnet024_l3.ply", "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex 2500\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+        for p in g.standard_normal((2500, 3)) * 40:
+            f.write(" ".join(f"{v:.5f}" for v in p) + "\n")
+
+
+def test_dtu_files_to_chamfer(tmp_path):
+    from scipy.io import savemat
+    from bench import surf_conf
+    from surf_amd import conf, mesh_io, synthetic
+    from surf_amd.datasets import get_loader
+    from surf_amd.evaluation import dtu_eval
+    from surf_amd.surf import SuRF
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    H, W = 96, 128
+    root = tmp_path / "dtu"
+    _write_scene(root, H, W)
+    dconf = conf.from_dict({"dataset_name": "DTUDataset", "data_dir": str(root), "scene": ["scan24"], "ref_view": [1], "light_idx": [3],
+                            "num_src_view": 2, "val_res_level": 2, "factor": 1.0, "interval_scale": 1, "num_interval": 192,
+                            "img_hw": [H, W], "total_views": 4})
+    loader, _, dataset = get_loader(dconf, "val", False, num_workers=0)
+    assert len(dataset) == 1
+    np.random.seed(0)
+    item = next(iter(loader))
+    inputs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in item.items()}             # runner.py's tocuda
+    inputs["mesh_resolution"] = 128
+
+    torch.manual_seed(0)
+    mcfg = surf_conf(base_dim=16)
+    model = SuRF(conf.from_dict(mcfg)).to(dev).eval()
+    model.logit_override = synthetic.sphere_logit          # untrained U-Nets: a surface-concentrated pyramid like a trained one's
+    with torch.no_grad():
+        out = model("val", inputs, cos_anneal_ratio=1.0, step=0)                                  # runner.py:216
+    h, w = H // 2, W // 2
+    assert out["img_fine"].shape == (h, w, 3) and out["normal_img"].shape == (h, w, 3) and out["render_depth"].shape == (h, w)
+    assert np.isfinite(out["img_fine"]).all() and out["depth_stage3"].shape == (H, W)
+    v, t = out["vertices"], out["triangles"]
+    assert len(v) > 1000 and len(t) > 2000
+    r_norm = np.linalg.norm(v, axis=1)
+    assert abs(float(r_norm.mean()) - 0.5) < 0.05 and float(r_norm.std()) < 0.02                  # the geometric-init sphere
+    # the central ray of the reference view hits that sphere: rendered depth ~ |camera centre| - radius
+    c = item["c2ws"][0, :3, 3].norm().item()
+    centre_depth = float(out["render_depth"][h // 2, w // 2])
+    assert abs(centre_depth - (c - float(r_norm.mean()))) < 0.15 * c, (centre_depth, c)
+
+    # ---- runner.py:231-240: world-frame PLY ----
+    mesh_path = tmp_path / "exp" / "meshes" / "final" / "scan24.ply"
+    vw = mesh_io.export_mesh(str(mesh_path), v, t, item["scale_mat"])
+    S = item["scale_mat"].double().numpy()
+    centre_w, radius_scale = S[:3, 3], float(np.linalg.norm(S[:3, 0]))
+    r_world = float(np.linalg.norm(vw - centre_w[None], axis=1).mean())
+    assert abs(r_world - radius_scale * float(r_norm.mean())) < 1e-3 * r_world
+
+    # ---- DTU evaluation files for "scan 24": the scan is the sphere of radius r + delta ----
+    delta = 6.0
+    ev = tmp_path / "dtu_eval"
+    os.makedirs(ev / "ObsMask")
+    os.makedirs(ev / "Points" / "stl")
+    g = np.random.default_rng(3)
+    d = g.standard_normal((40000, 3))
+    stl = centre_w[None] + (r_world + delta) * d / np.linalg.norm(d, axis=1, keepdims=True)
+    with open(ev / "Points" / "stl" / "stl024_total.ply", "w") as f:
+        f.write(f"ply\nformat ascii 1.0\nelement vertex {len(stl)}\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
+        for p in stl:
+            f.write(" ".join(f"{x:.4f}" for x in p) + "\n")
+    lo, hi = centre_w - 2 * r_world, centre_w + 2 * r_world
+    res = 4.0 * r_world / 63
+    savemat(ev / "ObsMask" / "ObsMask24_10.mat", {"ObsMask": np.ones((64, 64, 64), np.uint8), "BB": np.stack([lo, hi]).astype(np.float32),
+                                                  "Res": np.float32(res)})
+    savemat(ev / "ObsMask" / "Plane24.mat", {"P": np.array([[0.0, 0.0, 1.0, -(lo[2] - 1.0)]])})       # everything is above it
+    density = r_world / 60.0
+    d2s, s2d, overall = dtu_eval.evaluate_scan(str(mesh_path), str(ev), 24, downsample_density=density, patch_size=60,
+                                               max_dist=20, rng=np.random.default_rng(0))
+    # accuracy: every mesh point is delta from the larger sphere; completeness: every scan point is delta (+ sampling
+    # spacing of the thinned mesh cloud) from the mesh
+    assert abs(d2s - delta) < 0.6, d2s
+    assert delta - 0.6 < s2d < delta + 0.6 + density, s2d
+    assert abs(overall - 0.5 * (d2s + s2d)) < 1e-9
