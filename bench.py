@@ -313,33 +313,37 @@ VALU_FP32_PEAK = 157.3      # TFLOP/s, MI355X_MICROARCH.md (vector fp32 = the fp
 
 def train_kernel_rooflines(per_kernel):
     """`roofline_kernels` entries of the training step's heaviest backward kernels from the HIP events recorded inside the
-    timed region (ops.kernel_events).  Algorithmic work per unit (DESIGN K12): spconv_wgrad<Ci,Co> per (output site, offset)
-    one table entry + one gathered C_i row (4 + 4 C_i B) and, per site, the dy row (4 C_o B / 27 per unit); costvol_bwd per
-    (voxel, view, level) 64 B of taps gathered + 64 B of float atomics; matching_depth_bwd per (ray, sample) 32 B of corners
-    read + 32 B of float atomics; sdf_bwd / sdf_smooth_bwd per sample 2x / 4x (forward + reverse) x 0.13 M MAC on the fp32 VALU."""
+    timed region (ops.kernel_events).  Algorithmic work per unit (DESIGN K12):
+      spconv_wgrad<Ci,Co>  per EXISTING (output site, offset) pair one gathered C_i row (4 C_i B); per output site the 27 table
+                           entries (108 B) and the dy row (4 C_o B).  The pairs are counted on the device (ops.spconv_backward)
+      spconv_dgrad<Ci,Co>  the same sparse convolution on the swapped lattices + the output row written (4 C_o B per site)
+      costvol_bwd          per (voxel, view, level) 64 B of taps gathered + 64 B of float atomics
+      matching_depth_bwd   per (ray, sample) 32 B of corners read + 32 B of float atomics
+      sdf_bwd / sdf_smooth_bwd   per sample 2x / 4x (forward + reverse) x 0.13 M MAC on the fp32 VALU
+      blend_bwd            per (sample, view) forward recomputed + reverse ~ 20 K MAC each on the fp32 VALU."""
     out = []
     for name, rows in sorted(per_kernel.items(), key=lambda kv: -sum(r[0] for r in kv[1])):
         ms = sum(r[0] for r in rows)                       # per step (all launches of the kernel)
-        units = sum(r[1] for r in rows)
-        e = {"kernel": name, "ms_per_step": ms, "launches_per_step": len(rows), "units_per_step": units}
-        if name.startswith("spconv_wgrad<"):
-            ci, co = (int(v) for v in name[len("spconv_wgrad<"):-1].split(","))
-            b = units * (4 + 4 * ci + 4 * co / 27.0)
-            e.update(bound="hbm", achieved=b / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", bytes_per_unit=4 + 4 * ci + 4 * co / 27.0)
-        elif name.startswith("spconv_dgrad<"):
-            ci, co = (int(v) for v in name[len("spconv_dgrad<"):-1].split(","))
-            b = units * (4 + 4 * ci + 4 * co / 27.0)
-            e.update(bound="hbm", achieved=b / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", bytes_per_unit=4 + 4 * ci + 4 * co / 27.0)
-        elif name == "costvol_bwd":
-            e.update(bound="hbm", achieved=units * 128.0 / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", bytes_per_unit=128)
-        elif name == "matching_depth_bwd":
-            e.update(bound="hbm", achieved=units * 64.0 / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", bytes_per_unit=64)
-        elif name in ("sdf_bwd", "sdf_smooth_bwd"):
-            f = (2 if name == "sdf_bwd" else 4) * 2 * 2 * 0.13e6
-            e.update(bound="valu", achieved=units * f / (ms * 1e-3) / 1e12, peak=VALU_FP32_PEAK, unit="TFLOP/s", flop_per_unit=f)
-        elif name == "blend_bwd":
-            f = 2 * 2 * 20e3
-            e.update(bound="valu", achieved=units * f / (ms * 1e-3) / 1e12, peak=VALU_FP32_PEAK, unit="TFLOP/s", flop_per_unit=f)
+        e = {"kernel": name, "ms_per_step": ms, "launches_per_step": len(rows)}
+        if name.startswith("spconv_"):
+            ci, co = (int(v) for v in name[name.index("<") + 1:-1].split(","))
+            pairs, sites = sum(r[1]["pairs"] for r in rows), sum(r[1]["sites"] for r in rows)
+            b = pairs * 4.0 * ci + sites * (108.0 + 4.0 * co)
+            e.update(bound="hbm", achieved=b / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", pairs_per_step=pairs,
+                     sites_per_step=sites, algorithmic_bytes_per_step=b)
+        else:
+            units = sum(r[1] for r in rows)
+            e["units_per_step"] = units
+            if name == "costvol_bwd":
+                e.update(bound="hbm", achieved=units * 128.0 / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", bytes_per_unit=128)
+            elif name == "matching_depth_bwd":
+                e.update(bound="hbm", achieved=units * 64.0 / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", bytes_per_unit=64)
+            elif name in ("sdf_bwd", "sdf_smooth_bwd"):
+                f = (2 if name == "sdf_bwd" else 4) * 2 * 2 * 0.13e6
+                e.update(bound="valu", achieved=units * f / (ms * 1e-3) / 1e12, peak=VALU_FP32_PEAK, unit="TFLOP/s", flop_per_unit=f)
+            elif name == "blend_bwd":
+                f = 2 * 2 * 20e3
+                e.update(bound="valu", achieved=units * f / (ms * 1e-3) / 1e12, peak=VALU_FP32_PEAK, unit="TFLOP/s", flop_per_unit=f)
         if "achieved" in e:
             e["frac"] = e["achieved"] / e["peak"]
         out.append(e)
@@ -436,7 +440,11 @@ def run_rank_train(args):
     if rank == 0:
         per_kernel = {}
         for name, a, b, units in events:
-            per_kernel.setdefault(name, []).append((a.elapsed_time(b) / args.steps, units / args.steps))
+            if isinstance(units, dict):
+                units = {k: float(v) / args.steps for k, v in units.items()}
+            else:
+                units = units / args.steps
+            per_kernel.setdefault(name, []).append((a.elapsed_time(b) / args.steps, units))
         rk = train_kernel_rooflines(per_kernel) if per_kernel else []
         top = next((e for e in rk if "frac" in e), None)
         result = {

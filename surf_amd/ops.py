@@ -1060,7 +1060,13 @@ def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight,
     _chk(dy, torch.float32, "dy")
     cin, cout = int(weight.shape[1]), int(weight.shape[2])
     wt = weight.transpose(1, 2).contiguous()                        # (27, Cout, Cin)
-    with _timed(f"spconv_dgrad<{cout},{cin}>", int(in_coords.shape[0]) * 27):
+    pairs = 0
+    if kernel_events is not None and out_coords.shape[0] > 0 and x.shape[0] > 0:
+        # bench only: the number of (output site, offset) pairs that exist = the forward convolution of an all-ones
+        # 8-channel input with a constant kernel (1/8), summed; a device scalar, read after the timed region
+        ones = torch.ones(x.shape[0], 8, dtype=torch.float32, device=x.device)
+        pairs = spconv(ones, in_table, out_coords, mode, torch.full((27, 8, 8), 0.125, dtype=torch.float32, device=x.device))[:, 0].sum()
+    with _timed(f"spconv_dgrad<{cout},{cin}>", {"pairs": pairs, "sites": int(in_coords.shape[0])}):
         if mode == SUBM:
             dx = spconv(dy, out_table, in_coords, SUBM, wt.flip(0).contiguous())
         elif mode == DOWN:
@@ -1069,7 +1075,7 @@ def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight,
             dx = spconv(dy, out_table, in_coords, DOWN, wt)
     dW = torch.zeros_like(weight)
     if out_coords.shape[0] > 0 and x.shape[0] > 0:
-        with _timed(f"spconv_wgrad<{cin},{cout}>", int(out_coords.shape[0]) * 27):
+        with _timed(f"spconv_wgrad<{cin},{cout}>", {"pairs": pairs, "sites": int(out_coords.shape[0])}):
             rc = _lib.lib().surf_spconv_wgrad(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords), out_coords.shape[0],
                                               int(mode), _p(dy), cout, _p(dW), _stream())
         _lib.check(rc, "surf_spconv_wgrad")

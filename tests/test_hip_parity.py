@@ -363,9 +363,11 @@ def test_fpn_matches_golden(scene, weights, golden_fpn):
 
 
 def test_surf_forward_end_to_end_vs_oracle(scene):
-    """Row a17: SuRF.forward('val') (FPN -> 4-stage volume build with the sparse U-Net -> render) against the oracle
-    pipeline with the same seeded weights.  Voxel keep/drop decisions are thresholded, so a handful of voxels may
-    flip between fp32 implementations: sets and images are compared with a small outlier allowance."""
+    """Row a17: SuRF.forward('val') (FPN -> 4-stage volume build with the sparse U-Net -> render -> lattice + marching cubes)
+    against the oracle with the same seeded weights, STRICTLY: the voxel keep / drop decisions are thresholded, so instead of
+    allowing outliers the oracle is run stage by stage on the model's own upstream tensors (teacher forcing) - every stage's
+    outputs must then agree at the path's tolerances with zero outliers - and the decisions themselves are counted: the
+    oracle's kept set on the same candidates may differ from the model's by at most a handful of threshold flips."""
     from surf_amd import conf
     from surf_amd.surf import SuRF
     from tests.golden.make_golden import MODEL_CONF
@@ -387,27 +389,64 @@ def test_surf_forward_end_to_end_vs_oracle(scene):
     ipts["mesh_resolution"] = 32
     out = model("val", ipts, 1.0)
     torch.cuda.synchronize()
-
-    feats = O.fpn_forward(sd, scene["imgs"])
-    ocfg = {"range_ratios": cfg["range_ratios"], "base_volume_dim": 8, "n_samples_depths": [128, 64, 32, 16],
-            "depth_res_levels": [4, 2, 2, 1]}
-    ref = O.build_volumes(sd, scene, feats, ocfg)
-    for s in range(4):
-        dref = ref["depths"][s][0]
-        got = out[f"depth_stage{s}"].cpu()
-        frac = float(((got - dref).abs() < 2e-3).float().mean())
-        assert frac > 0.97, (s, frac)
-    R = scene["rays_o"].shape[0]
-    near, far = scene["near"].repeat(R, 1), scene["far"].repeat(R, 1)
-    rr = O.render(sd, scene["rays_o"], scene["rays_d"], near, far, ref["matching_volume"], ref["volumes"][::-1],
-                  ref["tables"][::-1], ref["masks"][::-1], feats[::-1], scene["imgs"], scene["intrs"], scene["c2ws"],
-                  cfg["implicit_surface"]["render"]["n_samples"], [1.0, 0.4, 0.1, 0.01], 256, 1.0)
-    ok = ((out["color_fine"] - rr["color_fine"]).abs().max(dim=1).values < 2e-3).float().mean()
-    assert float(ok) > 0.95, float(ok)
-    okd = ((torch.from_numpy(out["render_depth"]).reshape(-1) - rr["render_depth"]).abs() < 2e-3).float().mean()
-    assert float(okd) > 0.95, float(okd)
     assert out["img_fine"].shape == (7, 8, 3) and out["normal_img"].shape == (7, 8, 3)
     assert out["vertices"].shape[1] == 3 and out["triangles"].shape[1] == 3
+
+    # the intermediates of that (deterministic) forward
+    with torch.no_grad():
+        feats_t4 = model.feature_network(ipts["imgs"])
+        trace = {}
+        outs2, volumes, tables, mvol = model.build_volumes(ipts, feats_t4, trace=trace)
+    for s in range(4):
+        assert torch.equal(outs2[f"depth_stage{s}"], out[f"depth_stage{s}"]), s
+    feats_ref = O.fpn_forward(sd, scene["imgs"])                                      # coarse -> fine, NCHW
+    feats_got = [f.permute(0, 3, 1, 2).cpu().contiguous() for f in feats_t4]
+    for a, b in zip(feats_got, feats_ref):
+        rel_close(a, b, 1e-3, 1e-4)
+    ratios, n_dep, lvls = cfg["range_ratios"], [128, 64, 32, 16], [4, 2, 2, 1]
+    base_range = (scene["far"] - scene["near"]).squeeze()
+    total_flips = 0
+    for s in range(4):
+        t = trace[s]
+        D = t["D"]
+        coords = t["coords"].cpu().float()
+        # ---- the keep decisions on the model's own candidates
+        if s == 0:
+            cand = O.init_coords(D)
+        else:
+            cand, _ = O.up_sample(t["parents"].cpu().float(), torch.zeros(t["parents"].shape[0], 1))
+            pre = [x.cpu() for x in t["pre_depths"]]
+            cand = cand[O.depth_filtering(pre, cand, D, scene["intrs"], scene["c2ws"], base_range * ratios[s])]
+        _, keep = O.back_proj_multiscale(sd, feats_got, cand, D, scene["intrs"], scene["c2ws"], s)
+        k_ref = set(O._coord_key(cand[keep].long(), D).tolist())
+        k_got = set(O._coord_key(coords.long(), D).tolist())
+        flips = len(k_ref ^ k_got)
+        total_flips += flips
+        assert flips <= max(2, len(k_ref) // 2000), (s, flips, len(k_ref))
+        # ---- every stage output on the model's own inputs: zero outliers
+        reg_in = t["reg_in"].cpu()
+        cv, _ = O.back_proj_multiscale(sd, feats_got, coords, D, scene["intrs"], scene["c2ws"], s)
+        rel_close(reg_in[:, :8], cv, 1e-3, 2e-5)
+        o_ref, _ = O.sparse_unet(sd, reg_in, coords.long(), D, s)
+        rel_close(t["out"], o_ref, 1e-3, 1e-4)
+        prev = trace[s - 1]["mvol"].cpu() if s > 0 else None
+        m_ref, _ = O.sparse2dense(t["out"].cpu()[:, 0], coords, D, prev)
+        rel_close(t["mvol"], m_ref, 1e-4, 2e-5)
+        assert torch.equal(t["table"].cpu().long(), O.get_index(coords, D))
+        d_ref = O.matching_field((H, W), scene["intrs"], scene["c2ws"], scene["near_fars"], t["mvol"].cpu(), s, ratios, n_dep, lvls,
+                                 None if s == 0 else [x.cpu() for x in t["pre_depths"]])
+        rel_close(t["depths"], torch.stack(d_ref), 1e-3, 5e-5)
+    assert total_flips <= 4, total_flips
+    # ---- the render on the model's own pyramid
+    R = scene["rays_o"].shape[0]
+    near, far = scene["near"].repeat(R, 1), scene["far"].repeat(R, 1)
+    tabs = [tb.cpu().long() for tb in tables[::-1]]
+    rr = O.render(sd, scene["rays_o"], scene["rays_d"], near, far, mvol.cpu(), [v[:, 1:].cpu() for v in volumes[::-1]], tabs,
+                  [(tb >= 0).float() for tb in tabs], feats_got[::-1], scene["imgs"], scene["intrs"], scene["c2ws"],
+                  cfg["implicit_surface"]["render"]["n_samples"], [1.0, 0.4, 0.1, 0.01], 256, 1.0)
+    rel_close(out["color_fine"], rr["color_fine"], 1e-3, 1e-3 * float(rr["color_fine"].abs().max()))
+    rel_close(torch.from_numpy(out["render_depth"]).reshape(-1), rr["render_depth"], 1e-3, 1e-3)
+    rel_close(torch.from_numpy(out["sdf_depth"]).reshape(-1), rr["sdf_depth"].reshape(-1), 1e-3, 1e-3)
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 1.0), ("f16x2", 4.0)])
@@ -1064,7 +1103,11 @@ def test_training_backward_equals_the_reference_loss_backward(scene, weights, gp
     for name, p_ in model.named_parameters():
         ref = gg["grad/" + name]
         assert p_.grad is not None, name
-        if name == "color_network.s":         # ill-conditioned in fp32 on both sides (test_blend_backward_matches_autograd)
+        if name == "color_network.s":
+            # the golden value is the reference's fp32 autograd, itself ~30 % away from the float64 value of the same
+            # expression (a_v = ex_v - min_u ex_u cancels 5 of fp32's 7 digits; test_blend_backward_matches_autograd uses the
+            # float64 oracle as arbiter, tests/test_oracle_golden.py::test_color_network_s_gradient_conditioning measures the
+            # conditioning): only the order of magnitude and the sign can be pinned against THIS number
             assert abs(float(p_.grad) - float(ref)) <= 0.35 * abs(float(ref)) + 1e-6
             continue
         rel_close(p_.grad, ref, 5e-3, 5e-4 * float(ref.abs().max()) + 1e-7)
@@ -1152,10 +1195,19 @@ def test_blend_backward_matches_autograd(weights, gpu_scene, golden_render, scen
         ref = v.grad if v.grad is not None else torch.zeros_like(v)
         got = res[name].reshape(ref.shape)
         if name == "s":
-            # d/ds goes through (ex_v - min_u ex_u) with ex = exp(|s| (cos - 1)) ~ 0.99 for every view: a difference of
-            # nearly equal fp32 numbers (1e-5 apart), ill-conditioned in the reference's own fp32 autograd too
-            # (per-sample values agree to 1e-3 on 90 % of the samples, scripts/dbg_blend_bwd.py)
-            assert abs(float(got) - float(ref)) <= 0.35 * abs(float(ref)) + 1e-5
+            # d/ds goes through a_v = ex_v - min_u ex_u with ex = exp(|s| (cos - 1)) ~ 0.99 for every view: differences of
+            # fp32 numbers 1e-5 apart, i.e. <= 3 significant digits per sample.  The arbiter is the same oracle in float64
+            # (`s_fp64` below): on this fixture the reference's OWN fp32 autograd is ~30 % away from it, and moving every
+            # cosine by one fp32 ulp moves the fp32 result by more than that distance (tests/test_oracle_golden.py::
+            # test_color_network_s_gradient_conditioning shows both on the CPU).  The HIP gradient has to be at least as
+            # close to the float64 value as the reference's fp32 one is.
+            sd64 = {k: v.detach().double().requires_grad_(True) for k, v in weights.items() if k.startswith(prefix)}
+            rf64, rd64, mv64 = O.lookup_feature(pts[idx.long()].double(), scene["imgs"].double(), scene["intrs"].double(),
+                                                scene["c2ws"].double(), [f.double() for f in c["feats"]])
+            (O.blending(sd64, rf64, rd64, mv64) * gcolor[idx.long()].double()).sum().backward()
+            s_fp64 = float(sd64[prefix + "s"].grad)
+            err_ref32, err_hip = abs(float(ref) - s_fp64), abs(float(got) - s_fp64)
+            assert err_hip <= max(1.2 * err_ref32, 2e-2 * abs(s_fp64)), (float(got), float(ref), s_fp64)
             continue
         rel_close(got, ref, 2e-3, 2e-4 * max(float(ref.abs().max()), 1e-2))    # (rgb_fc.4.bias: the softmax gradients sum to 0)
 
