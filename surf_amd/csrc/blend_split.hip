@@ -79,12 +79,7 @@ struct BPolBf3 {
     asm volatile("" : "+v"(u));  // keep the packed value: the residuals below come from its two halves
     return u;
   }
-  static __device__ __forceinline__ void split(float a, float b, uint32_t (&p)[NP]) {
-    p[0] = pack2(a, b);
-    const float ra = a - __builtin_bit_cast(float, p[0] << 16), rb = b - __builtin_bit_cast(float, p[0] & 0xffff0000u);
-    p[1] = pack2(ra, rb);
-    p[2] = pack2(ra - __builtin_bit_cast(float, p[1] << 16), rb - __builtin_bit_cast(float, p[1] & 0xffff0000u));
-  }
+  static __device__ __forceinline__ void split(float a, float b, uint32_t (&p)[NP]) { surf_split3_bf16(a, b, p); }
   static __device__ __forceinline__ void mma(f32x16& acc, const u32x4 (&a)[NP], const FragT<NP>& b) {
 #define SURF_MF(x, y) \
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[x]), __builtin_bit_cast(bf16x8, b.p[y]), acc, 0, 0, 0)

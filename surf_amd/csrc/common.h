@@ -13,6 +13,45 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// ---- exact three-way bf16 split of a pair of fp32 values (a = a1 + a2 + a3, 8 + 8 + 8 significant bits, RNE residuals) ----
+// used by every kernel that runs fp32 contractions on the bf16 matrix pipe (sdf_mlp_split, blend_split, spconv_mfma).
+// p[k] packs piece k of (a, b) as (lo, hi) halves.  The residual a - float(piece) is ONE instruction:
+// v_dot2c_f32_bf16 acc, piece_pair, (-1, 0)  computes acc + piece.lo * -1 + piece.hi * 0 with fp32 accumulation - exact,
+// because a - bf16(a) is representable (scripts/microbench/dot2_residual.hip checks it bit for bit against the
+// shift-and-subtract form, v_lshlrev / v_and + v_sub = two instructions).  7 VALU per pair instead of 11.
+#ifndef SURF_SPLIT_DOT2
+#define SURF_SPLIT_DOT2 1
+#endif
+typedef __bf16 surf_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t surf_pack2_bf16(float a, float b) {
+  surf_bf16x2 v;
+  v[0] = (__bf16)a;
+  v[1] = (__bf16)b;
+  uint32_t u = __builtin_bit_cast(uint32_t, v);
+  asm volatile("" : "+v"(u));  // keep the packed value: the residuals below come from its two halves
+  return u;
+}
+__device__ __forceinline__ void surf_residual_bf16(uint32_t packed, float a, float b, float& ra, float& rb) {
+#if SURF_SPLIT_DOT2
+  surf_bf16x2 lo, hi;
+  lo[0] = (__bf16)(-1.0f); lo[1] = (__bf16)0.0f;
+  hi[0] = (__bf16)0.0f; hi[1] = (__bf16)(-1.0f);
+  ra = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(surf_bf16x2, packed), lo, a, false);
+  rb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(surf_bf16x2, packed), hi, b, false);
+#else
+  ra = a - __builtin_bit_cast(float, packed << 16);
+  rb = b - __builtin_bit_cast(float, packed & 0xffff0000u);
+#endif
+}
+__device__ __forceinline__ void surf_split3_bf16(float a, float b, uint32_t (&p)[3]) {
+  float ra, rb, ra2, rb2;
+  p[0] = surf_pack2_bf16(a, b);
+  surf_residual_bf16(p[0], a, b, ra, rb);
+  p[1] = surf_pack2_bf16(ra, rb);
+  surf_residual_bf16(p[1], ra, rb, ra2, rb2);
+  p[2] = surf_pack2_bf16(ra2, rb2);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -46,12 +46,7 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
   return u;
 }
 // exact three-way split of a pair: a = p0.lo + p1.lo + p2.lo (+ < 2^-24 |a|), same for b in the high halves
-__device__ __forceinline__ void split3(float a, float b, uint32_t (&p)[3]) {
-  p[0] = pack2(a, b);
-  const float ra = a - __builtin_bit_cast(float, p[0] << 16), rb = b - __builtin_bit_cast(float, p[0] & 0xffff0000u);
-  p[1] = pack2(ra, rb);
-  p[2] = pack2(ra - __builtin_bit_cast(float, p[1] << 16), rb - __builtin_bit_cast(float, p[1] & 0xffff0000u));
-}
+__device__ __forceinline__ void split3(float a, float b, uint32_t (&p)[3]) { surf_split3_bf16(a, b, p); }
 
 template <int CIN, int COUT>
 struct Shape {
