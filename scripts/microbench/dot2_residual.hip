@@ -28,9 +28,12 @@ __device__ __forceinline__ void split_shift(float a, float b, uint32_t (&p)[3]) 
   p[2] = pack2(ra - __builtin_bit_cast(float, p[1] << 16), rb - __builtin_bit_cast(float, p[1] & 0xffff0000u));
 }
 __device__ __forceinline__ void split_dot2(float a, float b, uint32_t (&p)[3]) {
-  bf16x2 lo, hi;
-  lo[0] = (__bf16)(-1.0f); lo[1] = (__bf16)0.0f;
-  hi[0] = (__bf16)0.0f; hi[1] = (__bf16)(-1.0f);
+  // the packed constants (-1, 0) / (0, -1) in registers the compiler cannot see through: written as bf16x2 literals hipcc
+  // turns (-1, 0) into the inline constant -1.0, which the hardware expands to 0xBF800000 = (0, -1) (first run of this file:
+  // every residual_lo came out as a - piece.hi)
+  uint32_t lo_u = 0x0000bf80u, hi_u = 0xbf800000u;
+  asm volatile("" : "+v"(lo_u), "+v"(hi_u));
+  const bf16x2 lo = __builtin_bit_cast(bf16x2, lo_u), hi = __builtin_bit_cast(bf16x2, hi_u);
   p[0] = pack2(a, b);
   const float ra = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p[0]), lo, a, false);
   const float rb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, p[0]), hi, b, false);

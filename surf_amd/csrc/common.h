@@ -15,12 +15,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- exact three-way bf16 split of a pair of fp32 values (a = a1 + a2 + a3, 8 + 8 + 8 significant bits, RNE residuals) ----
 // used by every kernel that runs fp32 contractions on the bf16 matrix pipe (sdf_mlp_split, blend_split, spconv_mfma).
-// p[k] packs piece k of (a, b) as (lo, hi) halves.  The residual a - float(piece) is ONE instruction:
-// v_dot2c_f32_bf16 acc, piece_pair, (-1, 0)  computes acc + piece.lo * -1 + piece.hi * 0 with fp32 accumulation - exact,
-// because a - bf16(a) is representable (scripts/microbench/dot2_residual.hip checks it bit for bit against the
-// shift-and-subtract form, v_lshlrev / v_and + v_sub = two instructions).  7 VALU per pair instead of 11.
+// p[k] packs piece k of (a, b) as (lo, hi) halves; the residual a - float(piece) is a shift / mask + a subtraction (11 VALU
+// per pair in all).  Tried in round 3 and NOT used (SURF_SPLIT_DOT2 = 1): the residual as ONE v_dot2c_f32_bf16
+// (acc + piece.lo * -1 + piece.hi * 0; 7 VALU per pair).  Two findings (scripts/microbench/dot2_residual.hip, same-box A/B of
+// bench.py): the instruction is not full rate - blend 43.1 vs 41.6 ms, SDF 129.9 vs 128.9 ms, 53 vs 45 ns per dependent
+// split - and hipcc encodes the packed constant (-1, 0) as the inline constant -1.0, which the hardware expands to
+// 0xBF800000 = (0, -1): the constant must be kept out of the inline-constant path (an opaque register).
 #ifndef SURF_SPLIT_DOT2
-#define SURF_SPLIT_DOT2 1
+#define SURF_SPLIT_DOT2 0
 #endif
 typedef __bf16 surf_bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t surf_pack2_bf16(float a, float b) {
@@ -33,11 +35,10 @@ __device__ __forceinline__ uint32_t surf_pack2_bf16(float a, float b) {
 }
 __device__ __forceinline__ void surf_residual_bf16(uint32_t packed, float a, float b, float& ra, float& rb) {
 #if SURF_SPLIT_DOT2
-  surf_bf16x2 lo, hi;
-  lo[0] = (__bf16)(-1.0f); lo[1] = (__bf16)0.0f;
-  hi[0] = (__bf16)0.0f; hi[1] = (__bf16)(-1.0f);
-  ra = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(surf_bf16x2, packed), lo, a, false);
-  rb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(surf_bf16x2, packed), hi, b, false);
+  uint32_t lo = 0x0000bf80u, hi = 0xbf800000u;          // (-1, 0) and (0, -1) as packed bf16 pairs
+  asm volatile("" : "+v"(lo), "+v"(hi));                // not an inline constant: see above
+  ra = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(surf_bf16x2, packed), __builtin_bit_cast(surf_bf16x2, lo), a, false);
+  rb = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(surf_bf16x2, packed), __builtin_bit_cast(surf_bf16x2, hi), b, false);
 #else
   ra = a - __builtin_bit_cast(float, packed << 16);
   rb = b - __builtin_bit_cast(float, packed & 0xffff0000u);
