@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 27
+#define SURF_ABI_VERSION 28
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -155,6 +155,11 @@ int surf_crossing_backward(const float* sdf, const uint8_t* vmask, const float* 
 int64_t surf_colgram_workspace_floats(int64_t rows, int M, int N);
 int surf_colgram(const float* A, int ldA, int M, const float* X, int ldX, int N, int64_t rows, int with_sum, int accumulate,
                  float* workspace, float* out, void* stream);
+/* The same with a precision policy: 0 = fp32-equivalent (surf_colgram: fp32 FMAs for rows < 4096, otherwise the matrix cores with an
+ * exact three-way bf16 operand split and fp32 accumulation), 1 = operands rounded to ONE bf16 piece, fp32 accumulation (the
+ * weight-gradient reductions of `train.precision = bf16`, BASELINE configs[3]). */
+int surf_colgram_p(const float* A, int ldA, int M, const float* X, int ldX, int N, int64_t rows, int with_sum, int accumulate,
+                   int precision, float* workspace, float* out, void* stream);
 
 /*
  * Backward of the blending network w.r.t. its parameters for an upstream gradient of the per-sample colour (gcolor, indexed

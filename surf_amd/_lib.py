@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
 # must equal SURF_ABI_VERSION of include/surf_hip.h (tests/test_host_modules.py compares the two texts); lib() refuses a
 # library built from another header
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -48,6 +48,7 @@ SIGNATURES = {
     "surf_blend_backward": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_colgram_workspace_floats": (c_i64, [c_i64, c_int, c_int]),
     "surf_colgram": (c_int, [c_ptr, c_int, c_int, c_ptr, c_int, c_int, c_i64, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    "surf_colgram_p": (c_int, [c_ptr, c_int, c_int, c_ptr, c_int, c_int, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "surf_patch_warp_tangent": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_lncc_jvp": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
     "surf_crossing_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),

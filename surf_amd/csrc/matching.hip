@@ -179,83 +179,131 @@ __device__ __forceinline__ void trilinear_scatter(float* __restrict__ vol, int D
 // depth = cosz sum_k z_k softmax(rho)_k with the z_k constants (the bands come from detached depths, matching_field.py:104):
 //   d rho_k = g cosz w_k (z_k - E),  E = depth / cosz;  each d rho_k is scattered through the trilinear taps of its sample.
 // Eight lanes per ray, lane j = corner (dx, dy, dz) = (j >> 2, (j >> 1) & 1, j & 1) of every sample: the corner values meet by
-// three xor-shuffles (rho), and in the scatter the two z-corners of a row are adjacent lanes AND adjacent floats, so one request
-// carries 8 contiguous bytes (float atomics run at the memory side at a per-request rate; one lane per ray = 64 scattered
-// requests per instruction was 1.8x slower).  Pass 1 recomputes the softmax statistics (m, den), pass 2 the weights: nothing was
-// stored per sample in the forward.  `views`: the views that carry gradient (0 and src_idx), one grid slice each.
+// three xor-shuffles (rho).  Pass 1 recomputes the softmax statistics (m, den), pass 2 the weights: nothing was stored per
+// sample in the forward.  `views`: the views that carry gradient (0 and src_idx), one grid slice each.
+//
+// The scatter is what bounds this kernel: float atomics are served at the memory side at a per-REQUEST rate (~2-3 10^10 /s
+// chip-wide, MI355X_MICROARCH.md "Global float atomics"), and a trilinear scatter issues one request per z-pair of corners
+// (round 2: 324 M requests per training step = 12 of the kernel's 14 ms).  Round 3: a workgroup owns an 8 x 4 PATCH of
+// low-resolution pixels (not a 32 x 1 strip) - neighbouring rays of a patch walk the same voxel cells, 0.35-0.7 voxels apart -
+// and accumulates its scatter in an LDS hash table keyed by the z-pair of the cell (open addressing, linear probing; ds_add_f32
+// for the values); the table is flushed once, two adjacent lanes per entry so that a request still carries the 8 contiguous
+// bytes of a z-pair.  Entries that do not find a slot within MAX_PROBE steps go to global memory directly (never observed on
+// the bench scene: a patch touches ~1 K pairs, the table holds 2 K).  Summation order changes (it was already atomic-ordered).
+constexpr int MB_TX = 8, MB_TY = 4;            // rays per workgroup: 8 x 4 patch x 8 lanes = 256 threads
+#ifndef SURF_MB_SLOT_BITS
+#define SURF_MB_SLOT_BITS 11
+#endif
+constexpr int MB_SLOT_BITS = SURF_MB_SLOT_BITS, MB_SLOTS = 1 << MB_SLOT_BITS, MB_MAX_PROBE = 32;   // 24 KB of LDS: six workgroups per CU
+
+__device__ __forceinline__ void mb_accumulate(int* __restrict__ keys, float* __restrict__ vals, int64_t off, float gv,
+                                              float* __restrict__ dmvol) {
+  const int key = (int)(off >> 1), half = (int)(off & 1);
+  unsigned hsh = ((unsigned)key * 2654435761u) >> (32 - MB_SLOT_BITS);
+#pragma unroll 1
+  for (int probe = 0; probe < MB_MAX_PROBE; ++probe) {
+    const int slot = (int)((hsh + probe) & (MB_SLOTS - 1));
+    int cur = keys[slot];
+    if (cur == -1) cur = atomicCAS(&keys[slot], -1, key), cur = cur == -1 ? key : cur;
+    if (cur == key) {
+      atomicAdd(&vals[2 * slot + half], gv);
+      return;
+    }
+  }
+  atomicAdd(dmvol + off, gv);                                    // table (locally) full
+}
+
 __global__ __launch_bounds__(256) void matching_depth_bwd_kernel(MatchArgs a, const float* __restrict__ g_lr, float* __restrict__ dmvol,
                                                                  int view0, int view1) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t per_view = (int64_t)a.h * a.w;
-  const int j = (int)(t & 7);
-  const int64_t r = t >> 3;                          // ray slot; an octet never straddles the bound below
-  if (r >= per_view * 2) return;
-  const int v = r < per_view ? view0 : view1;
-  if (v < 0) return;
-  const int p = (int)(r % per_view);
-  const int64_t i = (int64_t)v * per_view + p;
-  const float g = g_lr[i];
-  if (g == 0.f) return;                              // octet-uniform
-  const float px = a.lin_x[p % a.w], py = a.lin_y[p / a.w];
-  const float* Ki = a.Kinv[v];
-  float cx = Ki[0] * px + Ki[1] * py + Ki[2];
-  float cy = Ki[3] * px + Ki[4] * py + Ki[5];
-  float cz_ = Ki[6] * px + Ki[7] * py + Ki[8];
-  const float nrm = sqrtf(cx * cx + cy * cy + cz_ * cz_);
-  cx /= nrm; cy /= nrm; cz_ /= nrm;
-  const float* R = a.R[v];
-  const float dx = R[0] * cx + R[1] * cy + R[2] * cz_;
-  const float dy = R[3] * cx + R[4] * cy + R[5] * cz_;
-  const float dz = R[6] * cx + R[7] * cy + R[8] * cz_;
-  const float* Ri = a.Rinv[v];
-  const float cosz = Ri[6] * dx + Ri[7] * dy + Ri[8] * dz;
-  const float ox = a.t[v][0], oy = a.t[v][1], oz = a.t[v][2];
-  const float n0 = a.nearv[v], f0 = a.farv[v];
-  float lo[2], hi[2];
-  int nb = 1;
-  lo[0] = n0; hi[0] = f0; lo[1] = n0; hi[1] = f0;
-  if (a.pre) {
-    const float pre = a.pre[((int64_t)v * a.H + (int)py) * a.W + (int)px];
-    const float zc = pre / cosz;
-    band(zc, ((f0 - n0) * a.ratio_cur) / 2.0f, n0, f0, lo[0], hi[0]);
-    band(zc, ((f0 - n0) * a.ratio_prev) / 2.0f, n0, f0, lo[1], hi[1]);
-    nb = 2;
+  __shared__ int keys[MB_SLOTS];
+  __shared__ float vals[2 * MB_SLOTS];
+  for (int e = threadIdx.x; e < MB_SLOTS; e += 256) {
+    keys[e] = -1;
+    vals[2 * e] = 0.f;
+    vals[2 * e + 1] = 0.f;
   }
-  const int cdx = j >> 2, cdy = (j >> 1) & 1, cdz = j & 1;
-  const int D = a.D;
-  float m = -INFINITY, den = 0.f, num = 0.f;
-  for (int pass = 0; pass < 2; ++pass) {
-    const float E = pass ? num / den : 0.f;
-    for (int b = 0; b < nb; ++b) {
-      const float rng = hi[b] - lo[b];
-      const float shift = a.jitter ? a.jitter[i * 2 + b] * rng / (float)a.n : 0.f;
-      for (int k = 0; k < a.n; ++k) {
-        float z = lo[b] + rng * a.lin_n[k];
-        if (a.jitter) z = z + shift;
-        const float qx = unnorm_acf(ox + dx * z, D), qy = unnorm_acf(oy + dy * z, D), qz = unnorm_acf(oz + dz * z, D);
-        const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
-        const float tx = qx - fx, ty = qy - fy, tz = qz - fz;
-        const int xi = (int)fx + cdx, yi = (int)fy + cdy, zi = (int)fz + cdz;
-        const float wgt = (cdx ? tx : 1.0f - tx) * (cdy ? ty : 1.0f - ty) * (cdz ? tz : 1.0f - tz);
-        const bool ok = (xi >= 0) & (xi < D) & (yi >= 0) & (yi < D) & (zi >= 0) & (zi < D);
-        const int64_t off = ((int64_t)xi * D + yi) * D + zi;
-        float rho = ok ? a.mvol[off] * wgt : 0.f;
-        rho += __shfl_xor(rho, 1);
-        rho += __shfl_xor(rho, 2);
-        rho += __shfl_xor(rho, 4);
-        if (pass == 0) {
-          const float mn = fmaxf(m, rho);
-          const float sc = expf(m - mn), e = expf(rho - mn);
-          den = den * sc + e;
-          num = num * sc + e * z;
-          m = mn;
-        } else {
-          const float wk = expf(rho - m) / den;
-          const float gv = g * cosz * wk * (z - E) * wgt;
-          if (ok && gv != 0.f) atomicAdd(dmvol + off, gv);
+  __syncthreads();
+  const int tiles_x = (a.w + MB_TX - 1) / MB_TX, tiles_y = (a.h + MB_TY - 1) / MB_TY;
+  const int tile = (int)(blockIdx.x % (unsigned)(tiles_x * tiles_y));
+  const int v = blockIdx.x / (unsigned)(tiles_x * tiles_y) == 0 ? view0 : view1;
+  const int j = (int)(threadIdx.x & 7);
+  const int r = (int)(threadIdx.x >> 3);               // ray of the patch
+  const int pxi = (tile % tiles_x) * MB_TX + (r & (MB_TX - 1)), pyi = (tile / tiles_x) * MB_TY + r / MB_TX;
+  const int64_t per_view = (int64_t)a.h * a.w;
+  bool live = v >= 0 && pxi < a.w && pyi < a.h;
+  const int p = live ? pyi * a.w + pxi : 0;
+  const int64_t i = (int64_t)(v < 0 ? 0 : v) * per_view + p;
+  const float g = live ? g_lr[i] : 0.f;
+  live = live && g != 0.f;                               // octet-uniform
+  if (live) {
+    const float px = a.lin_x[pxi], py = a.lin_y[pyi];
+    const float* Ki = a.Kinv[v];
+    float cx = Ki[0] * px + Ki[1] * py + Ki[2];
+    float cy = Ki[3] * px + Ki[4] * py + Ki[5];
+    float cz_ = Ki[6] * px + Ki[7] * py + Ki[8];
+    const float nrm = sqrtf(cx * cx + cy * cy + cz_ * cz_);
+    cx /= nrm; cy /= nrm; cz_ /= nrm;
+    const float* R = a.R[v];
+    const float dx = R[0] * cx + R[1] * cy + R[2] * cz_;
+    const float dy = R[3] * cx + R[4] * cy + R[5] * cz_;
+    const float dz = R[6] * cx + R[7] * cy + R[8] * cz_;
+    const float* Ri = a.Rinv[v];
+    const float cosz = Ri[6] * dx + Ri[7] * dy + Ri[8] * dz;
+    const float ox = a.t[v][0], oy = a.t[v][1], oz = a.t[v][2];
+    const float n0 = a.nearv[v], f0 = a.farv[v];
+    float lo[2], hi[2];
+    int nb = 1;
+    lo[0] = n0; hi[0] = f0; lo[1] = n0; hi[1] = f0;
+    if (a.pre) {
+      const float pre = a.pre[((int64_t)v * a.H + (int)py) * a.W + (int)px];
+      const float zc = pre / cosz;
+      band(zc, ((f0 - n0) * a.ratio_cur) / 2.0f, n0, f0, lo[0], hi[0]);
+      band(zc, ((f0 - n0) * a.ratio_prev) / 2.0f, n0, f0, lo[1], hi[1]);
+      nb = 2;
+    }
+    const int cdx = j >> 2, cdy = (j >> 1) & 1, cdz = j & 1;
+    const int D = a.D;
+    float m = -INFINITY, den = 0.f, num = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+      const float E = pass ? num / den : 0.f;
+      for (int b = 0; b < nb; ++b) {
+        const float rng = hi[b] - lo[b];
+        const float shift = a.jitter ? a.jitter[i * 2 + b] * rng / (float)a.n : 0.f;
+        for (int k = 0; k < a.n; ++k) {
+          float z = lo[b] + rng * a.lin_n[k];
+          if (a.jitter) z = z + shift;
+          const float qx = unnorm_acf(ox + dx * z, D), qy = unnorm_acf(oy + dy * z, D), qz = unnorm_acf(oz + dz * z, D);
+          const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
+          const float tx = qx - fx, ty = qy - fy, tz = qz - fz;
+          const int xi = (int)fx + cdx, yi = (int)fy + cdy, zi = (int)fz + cdz;
+          const float wgt = (cdx ? tx : 1.0f - tx) * (cdy ? ty : 1.0f - ty) * (cdz ? tz : 1.0f - tz);
+          const bool ok = (xi >= 0) & (xi < D) & (yi >= 0) & (yi < D) & (zi >= 0) & (zi < D);
+          const int64_t off = ((int64_t)xi * D + yi) * D + zi;
+          float rho = ok ? a.mvol[off] * wgt : 0.f;
+          rho += __shfl_xor(rho, 1);
+          rho += __shfl_xor(rho, 2);
+          rho += __shfl_xor(rho, 4);
+          if (pass == 0) {
+            const float mn = fmaxf(m, rho);
+            const float sc = expf(m - mn), e = expf(rho - mn);
+            den = den * sc + e;
+            num = num * sc + e * z;
+            m = mn;
+          } else {
+            const float wk = expf(rho - m) / den;
+            const float gv = g * cosz * wk * (z - E) * wgt;
+            if (ok && gv != 0.f) mb_accumulate(keys, vals, off, gv, dmvol);
+          }
         }
       }
     }
+  }
+  __syncthreads();
+  // flush: lanes 2e, 2e + 1 own the two z-halves of entry e: adjacent lanes, adjacent floats
+  for (int e = threadIdx.x; e < 2 * MB_SLOTS; e += 256) {
+    const int key = keys[e >> 1];
+    const float val = vals[e];
+    if (key >= 0 && val != 0.f) atomicAdd(dmvol + 2 * (int64_t)key + (e & 1), val);
   }
 }
 
@@ -320,8 +368,10 @@ extern "C" int surf_matching_depth_backward(const float* mvol, int D, int nv, co
   hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, dim3((unsigned)((n_full + 255) / 256)), dim3(256), 0, st, g_full, nv, h, w, H,
                      W, g_lr);
   if (view0 < 0 || view0 >= nv || view1 >= nv) return SURF_E_ARG;
-  const int64_t n_thr = (int64_t)h * w * 2 * 8;     // two view slices x eight lanes per ray
-  hipLaunchKernelGGL(matching_depth_bwd_kernel, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, st, a, g_lr, dmvol, view0,
-                     view1 == view0 ? -1 : view1);
+  if ((int64_t)D * D * D > 0x7fffffffLL) return SURF_E_LIMIT;    // 31-bit cell keys in the workgroup's LDS table (D <= 1290)
+  const int64_t tiles = (int64_t)((w + MB_TX - 1) / MB_TX) * ((h + MB_TY - 1) / MB_TY);
+  const bool two = view1 >= 0 && view1 != view0;
+  hipLaunchKernelGGL(matching_depth_bwd_kernel, dim3((unsigned)(tiles * (two ? 2 : 1))), dim3(256), 0, st, a, g_lr, dmvol, view0,
+                     two ? view1 : -1);
   return surf_check_launch();
 }

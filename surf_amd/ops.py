@@ -428,9 +428,29 @@ def sdf_smooth_backward(pts, sbar, volumes, packed, want_dvols=True):
     return {"weight": dW, "bias": db, "volumes": dvols}
 
 
-def colgram(A, X, with_sum=False, out=None):
+# precision of the weight-gradient reductions (surf_colgram_p): 0 = fp32-equivalent, 1 = operands rounded to bf16 (fp32
+# accumulate).  Set through `set_train_precision` (conf key `train_precision` of the model / bench --train-precision).
+TRAIN_PRECISIONS = {"fp32": 0, "bf16": 1}
+colgram_precision = 0
+
+
+def set_train_precision(name):
+    """Reduced-precision policy of the TRAINING step (BASELINE configs[3] "bf16").  "fp32" (default):
+    every backward reduction fp32-equivalent.  "bf16": the operands of the weight-gradient reductions dW = adj^T in (the
+    per-sample adjoint and input rows written by surf_sdf_backward / surf_sdf_smooth_backward / surf_blend_backward and the
+    sparse U-Net's out_lin) are rounded to bf16 on load and multiplied on the matrix cores with fp32 accumulation.  Master
+    weights, optimiser state, the forward, the adjoint propagation itself and every gather / scatter kernel stay fp32."""
+    global colgram_precision
+    if name not in TRAIN_PRECISIONS:
+        raise ValueError(f"train precision must be one of {sorted(TRAIN_PRECISIONS)}, got {name!r}")
+    colgram_precision = TRAIN_PRECISIONS[name]
+    return name
+
+
+def colgram(A, X, with_sum=False, out=None, precision=None):
     """out (M, N [+1]) = A^T [X | 1] for row-major 2-D views A (rows, M), X (rows, N) that share contiguous rows (column
-    slices of a wider buffer are fine: the row stride is taken from the view).  `out` given: accumulated into."""
+    slices of a wider buffer are fine: the row stride is taken from the view).  `out` given: accumulated into.
+    precision: None = the module's training policy (`set_train_precision`), 0 = fp32-equivalent, 1 = bf16 operands."""
     assert A.dim() == 2 and X.dim() == 2 and A.shape[0] == X.shape[0] and A.stride(1) == 1 and X.stride(1) == 1
     assert A.dtype == torch.float32 and X.dtype == torch.float32 and A.is_cuda and X.is_cuda
     rows, M, N = int(A.shape[0]), int(A.shape[1]), int(X.shape[1])
@@ -440,9 +460,10 @@ def colgram(A, X, with_sum=False, out=None):
     if rows == 0:
         return out if acc else out.zero_()
     ws = torch.empty(_lib.lib().surf_colgram_workspace_floats(rows, M, N), dtype=torch.float32, device=A.device)
-    rc = _lib.lib().surf_colgram(_p(A), int(A.stride(0)), M, _p(X), int(X.stride(0)), N, rows, int(with_sum), int(acc), _p(ws),
-                                 _p(out), _stream())
-    _lib.check(rc, "surf_colgram")
+    with _timed("colgram", rows * M * (N + (1 if with_sum else 0))):
+        rc = _lib.lib().surf_colgram_p(_p(A), int(A.stride(0)), M, _p(X), int(X.stride(0)), N, rows, int(with_sum), int(acc),
+                                       int(colgram_precision if precision is None else precision), _p(ws), _p(out), _stream())
+    _lib.check(rc, "surf_colgram_p")
     return out
 
 

@@ -1252,7 +1252,8 @@ def test_finetune_steps_train_volumes_and_networks(scene):
     assert float((model.implicit_surface.color_network.base_fc[0].weight.detach() - w0).abs().max()) > 0
 
 
-@pytest.mark.parametrize("rows,M,N", [(5000, 33, 57), (1, 1, 4), (1025, 64, 63), (3333, 128, 156), (2048, 101, 27)])
+@pytest.mark.parametrize("rows,M,N", [(5000, 33, 57), (1, 1, 4), (1025, 64, 63), (3333, 128, 156), (2048, 101, 27),
+                                      (60864, 128, 156), (4096, 8, 8), (100003, 101, 159), (70001, 64, 37), (243456, 32, 33)])
 def test_colgram_matches_matmul(rows, M, N):
     """surf_colgram (the weight / bias reductions of the backward kernels) on column slices of wider buffers, with the
     ones column and in accumulate mode, against float64 matmul."""
@@ -1267,6 +1268,13 @@ def test_colgram_matches_matmul(rows, M, N):
     out2 = ops.colgram(A, X, with_sum=True, out=out.clone())
     rel_close(out2, 2 * ref, 1e-4, 2e-4 * float(ref.abs().max()))
     rel_close(ops.colgram(A, X), ref[:, :N], 1e-4, 1e-4 * float(ref.abs().max()))
+    # train.precision = bf16: operands rounded to one bf16 piece (2^-9 relative each), fp32 accumulation on the matrix cores;
+    # the reference of THAT arithmetic is the matmul of the rounded operands
+    out_b = ops.colgram(A, X, with_sum=True, precision=1)
+    Ab, Xb = A.to(torch.bfloat16).double(), X.to(torch.bfloat16).double()
+    ref_b = (Ab.t() @ torch.cat([Xb, torch.ones(rows, 1, dtype=torch.float64, device=d)], dim=1)).float()
+    rel_close(out_b, ref_b, 1e-4, 1e-4 * float(ref.abs().max()))
+    assert float((out_b - ref).abs().max()) <= 2e-2 * float(ref.abs().max()) + 1e-3 * (rows ** 0.5)
 
 
 def test_mfc_backward_pieces_match_autograd(scene, gpu_scene, golden_train, golden_fpn):
