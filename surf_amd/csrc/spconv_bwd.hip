@@ -6,6 +6,8 @@
 // the dy rows sit in LDS and every thread owns 4 x 2 register blocks of that offset's slice (thin layers: one block on a
 // 1/G share of the tile's sites; 0.75 LDS words per FMA instead of 2), accumulated in registers over the workgroup's tiles and added to dW with one float atomic per
 // entry and workgroup.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -127,6 +129,189 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgArgs a) {
   }
 }
 
+// ---- thin layers (C_in + C_out <= 48: the finest lattices, millions of sites), round 3 --------------------------------------
+// The kernel above sweeps the output sites once per kernel offset: 27 passes over coords / dy and 27 gathers of 64-byte rows
+// per site (15 GB per 5 M-site call, 3 TB/s: memory bound).  Neighbouring sites share almost all of their 27 neighbours - the
+// 8 children of a parent reference 64 cells 216 times - so here a workgroup takes a tile of 128 consecutive sites ONCE:
+//   B  every (site, offset) neighbour is looked up in the index table and its row id entered into an LDS hash set;
+//   C  the DISTINCT rows of the tile (typically ~450 of 3,456 references) are loaded into LDS once;
+//   D  every thread owns (offset k, 4 x 2 block of the (C_in, C_out) slice) pairs - 27 (C_in / 4)(C_out / 2) of them over 256
+//      threads - and walks the tile's 128 sites for each: x row from the LDS cache, dy row from LDS, 8 FMAs; its accumulators
+//      stay in registers across all tiles of the workgroup (no cross-thread reduction) and are added to dW once at the end.
+// Traffic per site: 12 B coords + 4 C_out B dy + 108 B of table entries + ~4 distinct rows, instead of 27 x (16 + 4 C_out + 4 C_in p).
+// A tile that references more distinct rows than the cache holds is processed in rounds over windows of the row list
+// (coarse lattices listed along z: 3 x 3 x 130 cells); a reference that finds the hash set full is served by its own thread with
+// global float atomics (> 2,048 distinct rows in one tile: practically never).  Used for the submanifold and transposed (up) convolutions, whose sites share
+// neighbours; a stride-2 (down) convolution's 3^3 windows hardly overlap - there the kernel above is faster (1.9 vs 6.2 ms per
+// step on <8,16>) and stays in use.
+template <int CIN, int COUT>
+struct ThinCfg {
+  static constexpr int TS = CIN <= 16 ? 128 : 64;       // sites per tile (C_in = 32: the row cache holds fewer rows)
+  static constexpr int NB = (CIN / 4) * (COUT / 2);
+  static constexpr int NPAIR = 27 * NB;
+  static constexpr int PER = (NPAIR + 255) / 256;
+  static constexpr int CAP = CIN <= 16 ? 512 : 320;     // distinct neighbour rows cached per tile
+  static constexpr int HS = 2048;                       // hash slots (>= the distinct rows of any realistic tile)
+  static constexpr int XS = CIN + 4, DS = COUT + 2;
+  static constexpr int NJ = (27 * TS + 255) / 256;      // (site, offset) references per thread
+};
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void spconv_wgrad_thin_kernel(WgArgs a) {
+  typedef ThinCfg<CIN, COUT> C;
+  constexpr int TS = C::TS, XS = C::XS, DS = C::DS, CAP = C::CAP, HS = C::HS, PER = C::PER, NJ = C::NJ;
+  __shared__ __attribute__((aligned(16))) float xs[(CAP + 1) * XS];   // row CAP = zeros (absent neighbour)
+  __shared__ __attribute__((aligned(16))) float ds[TS * DS];
+  __shared__ int hkey[HS];
+  __shared__ unsigned short hidx[HS];
+  __shared__ unsigned short nbr[27 * TS];
+  __shared__ int rowlist[HS];
+  __shared__ int n_rows;
+  const int D = a.Din;
+  const int p = threadIdx.x;
+  const int64_t n_tiles = (a.n_out + TS - 1) / TS;
+  // this thread's (offset, block) pairs
+  int kk[PER], ci0[PER], co0[PER];
+  float acc[PER][4][2];
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    const int q = p + 256 * e;
+    const int qq = q < C::NPAIR ? q : 0;
+    kk[e] = qq / C::NB;
+    const int blk = qq % C::NB;
+    ci0[e] = (blk / (COUT / 2)) * 4;
+    co0[e] = (blk % (COUT / 2)) * 2;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) acc[e][qd][0] = acc[e][qd][1] = 0.f;
+  }
+  for (int e = p; e < XS; e += 256) xs[CAP * XS + e] = 0.f;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // ---- A: reset the set, stage dy
+    for (int e = p; e < HS; e += 256) hkey[e] = -1;
+    if (p == 0) n_rows = 0;
+    for (int e = p; e < TS * COUT; e += 256) {
+      const int s_ = e / COUT, c = e % COUT;
+      const int64_t i = tile * TS + s_;
+      ds[s_ * DS + c] = i < a.n_out ? a.dy[i * COUT + c] : 0.f;
+    }
+    __syncthreads();
+    // ---- B1: reference q = p + 256 j = (offset q / TS, site q % TS): table lookup, row id into the hash set
+    int my_row[NJ], my_slot[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {                                // all table lookups first: independent loads in flight together
+      const int q = p + 256 * j;
+      const int k = q / TS, st = q % TS;
+      const int64_t si = tile * TS + st;
+      int row = -1;
+      if (k < 27 && si < a.n_out) {
+        const int cx = a.out_coords[si * 3 + 0], cy = a.out_coords[si * 3 + 1], cz = a.out_coords[si * 3 + 2];
+        const int ox = k % 3 - 1, oy = (k / 3) % 3 - 1, oz = k / 9 - 1;
+        int x, y, z;
+        bool ok = true;
+        if (a.mode == MODE_SUBM) { x = cx + ox; y = cy + oy; z = cz + oz; }
+        else if (a.mode == MODE_DOWN) { x = 2 * cx + ox; y = 2 * cy + oy; z = 2 * cz + oz; }
+        else {
+          const int tx = cx - ox, ty = cy - oy, tz = cz - oz;
+          ok = ((tx | ty | tz) & 1) == 0;
+          x = tx >> 1; y = ty >> 1; z = tz >> 1;
+        }
+        ok = ok && x >= 0 && x < D && y >= 0 && y < D && z >= 0 && z < D;
+        if (ok) row = a.in_table[((int64_t)x * D + y) * D + z];
+      }
+      my_row[j] = row;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {                                // then the set insertions
+      const int row = my_row[j];
+      int slot = -1;
+      if (row >= 0) {
+        unsigned hsh = ((unsigned)row * 2654435761u) >> 21;
+#pragma unroll 1
+        for (int probe = 0; probe < 48; ++probe) {
+          const int s_ = (int)((hsh + probe) & (HS - 1));
+          int cur = hkey[s_];
+          if (cur == -1) { cur = atomicCAS(&hkey[s_], -1, row); if (cur == -1) cur = row; }
+          if (cur == row) { slot = s_; break; }
+        }
+      }
+      my_slot[j] = slot;
+    }
+    __syncthreads();
+    // ---- B2: dense indices for the distinct rows
+    for (int e = p; e < HS; e += 256) {
+      const int key = hkey[e];
+      if (key >= 0) {
+        const int idx = atomicAdd(&n_rows, 1);
+        hidx[e] = (unsigned short)idx;
+        rowlist[idx] = key;
+      }
+    }
+    __syncthreads();
+    // ---- B3: references -> dense row indices.  A reference that found no slot (a full set: > 2,048 distinct rows in one tile)
+    // is served here and now by its own thread with C_in C_out global float atomics: always correct, practically never taken
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int q = p + 256 * j;
+      const int k = q / TS, st = q % TS;
+      if (k < 27) {
+        int ref = 0xffff;                                         // absent
+        if (my_row[j] >= 0) {
+          if (my_slot[j] >= 0) ref = (int)hidx[my_slot[j]];
+          else {
+            float* dst = a.dW + (int64_t)k * CIN * COUT;
+            const float* xr = a.x + (int64_t)my_row[j] * CIN;
+            for (int ci = 0; ci < CIN; ++ci) {
+              const float xv = xr[ci];
+              for (int co = 0; co < COUT; ++co) atomicAdd(dst + ci * COUT + co, xv * ds[st * DS + co]);
+            }
+          }
+        }
+        nbr[q] = (unsigned short)ref;
+      }
+    }
+    // ---- C + D in rounds of CAP cached rows (one round unless the tile references more distinct rows than the cache holds)
+    const int total = n_rows;
+    for (int base = 0; base < total || base == 0; base += CAP) {
+      const int nr = total - base < CAP ? total - base : CAP;
+      if (base > 0) __syncthreads();                              // the previous round's reads of xs
+      for (int e = p; e < nr * (CIN / 4); e += 256) {
+        const int idx = e / (CIN / 4), c4 = e % (CIN / 4);
+        *reinterpret_cast<f32x4*>(xs + idx * XS + c4 * 4) =
+            *reinterpret_cast<const f32x4*>(a.x + (int64_t)rowlist[base + idx] * CIN + c4 * 4);
+      }
+      __syncthreads();
+#pragma unroll 2
+      for (int t = 0; t < TS; ++t) {
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+          const int idx = (int)nbr[kk[e] * TS + t] - base;
+          const int ref = (unsigned)idx < (unsigned)CAP ? idx : CAP;        // outside this round's window (or absent): zeros
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + ref * XS + ci0[e]);
+          const float d0 = ds[t * DS + co0[e]], d1 = ds[t * DS + co0[e] + 1];
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd) {
+            acc[e][qd][0] = fmaf(xv[qd], d0, acc[e][qd][0]);
+            acc[e][qd][1] = fmaf(xv[qd], d1, acc[e][qd][1]);
+          }
+        }
+      }
+      if (total == 0) break;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int e = 0; e < PER; ++e) {
+    if (p + 256 * e < C::NPAIR) {
+      float* dst = a.dW + (int64_t)kk[e] * CIN * COUT;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          if (acc[e][qd][r] != 0.f) atomicAdd(dst + (ci0[e] + qd) * COUT + co0[e] + r, acc[e][qd][r]);
+    }
+  }
+}
+
 }  // namespace
 
 #define WG_CASES(X) X(8, 8) X(16, 8) X(8, 16) X(16, 16) X(16, 32) X(32, 32) X(32, 64) X(64, 64) X(64, 32) X(32, 16)
@@ -136,13 +321,20 @@ extern "C" int surf_spconv_wgrad(const float* x, int cin, const int32_t* in_tabl
   if (!x || !in_table || !out_coords || !dy || !dW || n_out <= 0 || D_in < 1 || mode < 0 || mode > 2) return SURF_E_ARG;
   WgArgs a;
   a.x = x; a.in_table = in_table; a.Din = D_in; a.out_coords = out_coords; a.n_out = n_out; a.mode = mode; a.dy = dy; a.dW = dW;
-  const int ts = (cin + cout <= 48) ? 256 : 64;
+  const bool thin = cin + cout <= 48 && mode != MODE_DOWN && !getenv("SURF_WGRAD_CLASSIC");    // (env: A/B timing of the round-2 kernel)
+  const int ts = thin ? 128 : ((cin + cout <= 48) ? 256 : 64);
   const int64_t tiles = (n_out + ts - 1) / ts;
   const unsigned grid = (unsigned)(tiles < 1024 ? tiles : 1024);
-#define X(CI, CO)                                                                                              \
-  if (cin == CI && cout == CO) {                                                                               \
-    hipLaunchKernelGGL((spconv_wgrad_kernel<CI, CO>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);        \
-    return surf_check_launch();                                                                                \
+#define X(CI, CO)                                                                                                \
+  if (cin == CI && cout == CO) {                                                                                 \
+    if constexpr (CI + CO <= 48) {                                                                               \
+      if (thin) {                                                                                                \
+        hipLaunchKernelGGL((spconv_wgrad_thin_kernel<CI, CO>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); \
+        return surf_check_launch();                                                                              \
+      }                                                                                                          \
+    }                                                                                                            \
+    hipLaunchKernelGGL((spconv_wgrad_kernel<CI, CO>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);          \
+    return surf_check_launch();                                                                                  \
   }
   WG_CASES(X)
 #undef X

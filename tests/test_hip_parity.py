@@ -1370,3 +1370,56 @@ def test_spconv_backward_matches_autograd(cin, cout):
         dx, dW = ops.spconv_backward(x.to(d), args[0], args[1], args[2], args[3], mode, w.to(d), dy.to(d))
         rel_close(dx, xr.grad, 1e-4, 1e-5 * float(xr.grad.abs().max()))
         rel_close(dW, wr.grad, 1e-4, 2e-5 * float(wr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 8), (8, 8), (16, 16), (32, 16), (16, 32)])
+def test_spconv_wgrad_thin_kernel_row_cache_and_its_overflow(cin, cout):
+    """The thin-layer weight-gradient kernel (csrc/spconv_bwd.hip: 128-site tiles, distinct neighbour rows cached in LDS through a
+    hash set).  Two lattices: children-ordered sites of a dense band (neighbours shared between sites, the cache's normal case)
+    and 64 isolated sites spaced three cells apart in a fully occupied lattice - 1,728 DISTINCT neighbour rows in the tile, more
+    than the cache holds (512 / 320 rows: the tile is processed in rounds) - and, with 128 such sites (3,456 distinct rows), more
+    than the hash set (2,048 slots) holds, so that the direct path runs too.  Against float64."""
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(7 * cin + cout)
+
+    def reference(x, table, out_coords, dy, D):
+        dW = torch.zeros(27, cin, cout, dtype=torch.float64)
+        oc = out_coords.long()
+        for k in range(27):
+            off = torch.tensor([k % 3 - 1, (k // 3) % 3 - 1, k // 9 - 1])
+            nb = oc + off
+            ok = ((nb >= 0) & (nb < D)).all(dim=1)
+            rows = torch.full((oc.shape[0],), -1, dtype=torch.long)
+            nbc = nb.clamp(0, D - 1)
+            rows[ok] = table[nbc[ok, 0], nbc[ok, 1], nbc[ok, 2]].long()
+            sel = rows >= 0
+            dW[k] = x[rows[sel]].double().t() @ dy[sel].double()
+        return dW.float()
+
+    # (a) a dense band in children order
+    D = 24
+    par = (torch.rand(D // 2, D // 2, D // 2, generator=g) < 0.5).nonzero()
+    offs = torch.tensor([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)])
+    coords = (par[:, None, :] * 2 + offs[None]).reshape(-1, 3).to(torch.int32).contiguous()
+    # (b) isolated sites in a full lattice
+    D2 = 16
+    full = torch.stack(torch.meshgrid(torch.arange(D2), torch.arange(D2), torch.arange(D2), indexing="ij"), dim=-1).reshape(-1, 3)
+    iso = torch.stack(torch.meshgrid(torch.arange(1, 13, 3), torch.arange(1, 13, 3), torch.arange(1, 13, 3), indexing="ij"),
+                      dim=-1).reshape(-1, 3).to(torch.int32).contiguous()
+    assert iso.shape[0] == 64
+    D3 = 26
+    full3 = torch.stack(torch.meshgrid(torch.arange(D3), torch.arange(D3), torch.arange(D3), indexing="ij"), dim=-1).reshape(-1, 3)
+    iso3 = torch.stack(torch.meshgrid(torch.arange(1, 25, 3), torch.arange(1, 13, 3), torch.arange(1, 13, 3), indexing="ij"),
+                       dim=-1).reshape(-1, 3).to(torch.int32).contiguous()
+    assert iso3.shape[0] == 128
+    for in_coords, out_coords, Dd in ((coords, coords, D), (full.to(torch.int32).contiguous(), iso, D2),
+                                      (full3.to(torch.int32).contiguous(), iso3, D3)):
+        table = ops.table_from_coords(in_coords.to(d), Dd)
+        x = torch.randn(in_coords.shape[0], cin, generator=g)
+        dy = torch.randn(out_coords.shape[0], cout, generator=g)
+        w = torch.zeros(27, cin, cout)
+        _, dW = ops.spconv_backward(x.to(d), table, in_coords.to(d), ops.table_from_coords(out_coords.to(d), Dd), out_coords.to(d),
+                                    ops.SUBM, w.to(d), dy.to(d))
+        ref = reference(x, table.cpu(), out_coords, dy, Dd)
+        rel_close(dW, ref, 1e-4, 2e-5 * float(ref.abs().max()))
