@@ -224,7 +224,7 @@ def volume_build_timing(args, dev):
     return res
 
 
-def training_step_setup(dev, H=576, W=800, nv=5, base_dim=88, rays=512, device_jitter=True, scene_seed=0):
+def training_step_setup(dev, H=576, W=800, nv=5, base_dim=88, rays=512, device_jitter=True, scene_seed=0, precision="fp32"):
     """A volume-building SuRF in train mode on the synthetic scene + the inputs / loss targets of one training step
     (runner.py:150-166).  Weights are random-init, so the analytic sphere logit replaces the U-Net's matching logit in the
     forward (as in volume_build_timing); the backward still runs through every kernel."""
@@ -232,7 +232,7 @@ def training_step_setup(dev, H=576, W=800, nv=5, base_dim=88, rays=512, device_j
     from surf_amd.losses import Loss
     from surf_amd.surf import SuRF
     torch.manual_seed(0)
-    model = SuRF(conf.from_dict(surf_conf(base_dim))).to(dev).train()
+    model = SuRF(conf.from_dict(dict(surf_conf(base_dim), train_precision=precision))).to(dev).train()
     model.logit_override = synthetic.sphere_logit
     model.matching_field.device_jitter = device_jitter      # False: the reference's CPU-generator draw (host-bound)
     intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
@@ -257,22 +257,32 @@ def training_step_setup(dev, H=576, W=800, nv=5, base_dim=88, rays=512, device_j
 
 
 def training_step_timing(args, dev, steps=3):
-    """Wall time of one full training step (forward with tapes -> loss -> HIP backward of the render, the 4-stage volume
-    build and the FPN -> Adam) on the bench scene, reported beside the render metric."""
-    from surf_amd import training
-    model, ipts, targets, loss_fn, opt = training_step_setup(dev, args.height, args.width, args.views, args.base_dim)
-    for _ in range(2):
-        out = training.train_step(model, ipts, targets, loss_fn, opt, 1.0, 3)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out = training.train_step(model, ipts, targets, loss_fn, opt, 1.0, 3)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    return {"ms_per_step": ms, "rays": int(ipts["rays_o"].shape[0]), "samples_per_ray": 128,
-            "voxels_per_stage": model.last_voxels_per_stage,
-            "loss": out["loss"], "what": "forward (FPN, volume build, render) + loss + HIP backward of all of it + Adam; "
-                                         "every term of losses/loss.py; matching-field jitter on the device generator"}
+    """Wall time of one full training step (runner.py:152-165: forward -> Loss -> loss.backward() = the HIP backward of the
+    render, the 4-stage volume build and the FPN -> Adam) on the bench scene, reported beside the render metric,
+    for both training-precision policies."""
+    from surf_amd import ops, training
+    res = {}
+    for precision in ("fp32", "bf16"):
+        model, ipts, targets, loss_fn, opt = training_step_setup(dev, args.height, args.width, args.views, args.base_dim,
+                                                                 precision=precision)
+        for _ in range(2):
+            out = training.train_step(model, ipts, targets, loss_fn, opt, 1.0, 3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = training.train_step(model, ipts, targets, loss_fn, opt, 1.0, 3)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        res[precision] = {"ms_per_step": ms, "loss": out["loss"]}
+        voxels = model.last_voxels_per_stage
+        rays = int(ipts["rays_o"].shape[0])
+        del model, opt
+    ops.set_train_precision("fp32")
+    return {"ms_per_step": res["fp32"]["ms_per_step"], "rays": rays, "samples_per_ray": 128, "voxels_per_stage": voxels,
+            "loss": res["fp32"]["loss"], "train_precision_bf16": res["bf16"],
+            "what": "forward (FPN, volume build, render) + loss + loss.backward() (HIP backward of all of it) + Adam; every term of "
+                    "losses/loss.py; matching-field jitter on the device generator; train_precision_bf16: the same step with the "
+                    "weight-gradient reductions on bf16 operands (model conf train_precision = bf16)"}
 
 
 def mesh_grid_timing(model, scene, dev, resolution):
@@ -394,7 +404,8 @@ def run_rank_train(args):
         ddp = DistributedDataParallel(model) if world > 1 else model
     else:
         from surf_amd import ops
-        model, ipts, targets, loss_fn, opt = training_step_setup(dev, H, W, nv, args.base_dim, rays=rays, scene_seed=rank)
+        model, ipts, targets, loss_fn, opt = training_step_setup(dev, H, W, nv, args.base_dim, rays=rays, scene_seed=rank,
+                                                                 precision=args.train_precision)
         inputs = {**targets, **ipts}                                    # the runner hands ONE dictionary to model and loss
         loss_of = lambda outputs: loss_fn(outputs, inputs, 3.0)["loss"]  # noqa: E731
         ddp = DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model      # runner.py:102
@@ -451,11 +462,14 @@ def run_rank_train(args):
             "metric": WORKLOADS["train"]["metric"], "value": world * rays * args.steps / elapsed, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "none (dry run)" if dry else "f32", "data": "dry-run" if dry else "synthetic",
+            "dtype": "none (dry run)" if dry else ("f32" if args.train_precision == "fp32" else
+                                                   "f32 (weight-gradient reductions: bf16 operands, fp32 accumulate)"),
+            "data": "dry-run" if dry else "synthetic",
             "config": {"workload": ("DRY RUN of the train control flow: no kernels executed" if dry else
                                     f"training step: {nv} views {H}x{W}, {rays} rays x 128 samples and one synthetic scene per rank, "
                                     f"{args.base_dim}^3 -> {args.base_dim * 8}^3 pyramid, every term of losses/loss.py, Adam"),
                        "rays_per_rank_step": rays, "parallelism": f"ddp{world}" if world > 1 else "single",
+                       "train_precision": args.train_precision,
                        "trainable_parameters": n_params},
             "steps_per_s": args.steps / elapsed, "gradient_allreduce_ms": allreduce_ms,
             "loss": float(loss.detach()),
@@ -560,6 +574,8 @@ def parse_args(argv):
     ap.add_argument("--dry", action="store_true", help="control-flow test: no GPU, no kernels, gloo instead of RCCL")
     ap.add_argument("--rank-timeout", type=float, default=1700.0, help="self-spawned ranks are killed after this many seconds")
     ap.add_argument("--rays", type=int, default=512, help="--workload train: rays per rank and step (confs/surf.conf: 512)")
+    ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16"],
+                    help="training-backward policy (model conf key train_precision): bf16 = weight-gradient reductions on bf16 operands")
     ap.add_argument("--fail-rank", type=int, default=-1, help="(tests) this rank exits 3 before the first barrier")
     args = ap.parse_args(argv)
     wl = WORKLOADS[args.workload]
@@ -729,7 +745,8 @@ def run_rank(args):
         per_kernel.setdefault(name, []).append(a.elapsed_time(b))
     kernel_ms = {k: sum(v) / len(v) for k, v in per_kernel.items()}         # average per launch
     launches_per_step = {k: len(v) / args.steps for k, v in per_kernel.items()}
-    active = sum(active_log) / len(active_log)                                # active samples per sdf / blend launch
+    # active samples per sdf / blend launch (device-side counts of the render calls, read after the timed region)
+    active = sum(int(x) for x in active_log) / len(active_log)
 
     # ---- the other SDF precisions on the same scene (N = 1 only; after the timed region, reported separately) ----
     others = {}

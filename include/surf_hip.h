@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 28
+#define SURF_ABI_VERSION 29
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -115,6 +115,16 @@ int surf_sdf_pack_weights_f16(const float* const* h_W, const float* const* h_b, 
 int surf_sdf_mlp_f16x2(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_vols,
                        const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* sdf,
                        float* grad, void* scratch, void* stream);
+
+/* Both split kernels with the number of `idx` entries read from DEVICE memory (d_n[0] <= n_capacity = entries allocated for idx):
+ * the launch that follows surf_compact needs no host round trip for the count ("replaced by device-side counters").
+ * Grid and scratch are sized by the capacity; rows beyond d_n[0] are not touched. */
+int surf_sdf_mlp_bf16x3_dn(const float* pts, const int32_t* idx, int64_t n_capacity, const int32_t* d_n, const float* const* h_vols,
+                           const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* sdf,
+                           float* grad, void* scratch, void* stream);
+int surf_sdf_mlp_f16x2_dn(const float* pts, const int32_t* idx, int64_t n_capacity, const int32_t* d_n, const float* const* h_vols,
+                          const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* sdf,
+                          float* grad, void* scratch, void* stream);
 
 /*
  * Second-order term of the SDF network (training): grad (n,3) (optional) and smooth (n,3) = H.1, the row sums of the
@@ -267,6 +277,11 @@ int surf_blend_split(const float* pts, const uint8_t* mask, const int32_t* idx, 
                      const int* h_hw, int n_level, const float* imgs, int nv, const float* h_intrs, const float* h_w2c,
                      const float* h_c2w, const void* blend_w, int precision, float* color, uint8_t* n_valid, void* scratch,
                      void* stream);
+/* ... with the number of idx entries read from device memory, as surf_sdf_mlp_bf16x3_dn. */
+int surf_blend_split_dn(const float* pts, const int32_t* idx, int64_t n_capacity, const int32_t* d_n, const float* const* h_feats,
+                        const int* h_hw, int n_level, const float* imgs, int nv, const float* h_intrs, const float* h_w2c,
+                        const float* h_c2w, const void* blend_w, int precision, float* color, uint8_t* n_valid, void* scratch,
+                        void* stream);
 
 /*
  * NeuS SDF -> alpha compositing, zero-crossing depth and per-ray reductions.

@@ -169,6 +169,7 @@ struct BlendArgs {
   const uint8_t* mask;
   const int32_t* idx;  // optional list of point indices (n entries)
   int64_t n;
+  const int32_t* n_dev;  // optional device-side count (<= n = capacity of idx)
   const float* feats[4];
   int hw[8];
   const float* imgs;
@@ -361,7 +362,8 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
   const int NS = a.nv - 1;
   const int64_t wave_id = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * WPB;
-  const int64_t n_tiles = (a.n + TILE - 1) / TILE;
+  const int64_t n_pts = a.n_dev ? (int64_t)*a.n_dev : a.n;
+  const int64_t n_tiles = (n_pts + TILE - 1) / TILE;
   float* slot = a.scratch + wave_id * slot_floats(NS);
   const float* scal = reinterpret_cast<const float*>(lds + scal_off<P::BB>());
   const float s_abs = scal[0], b_vis = scal[1], b_vis2 = scal[2], b_rgb4 = scal[3];
@@ -375,9 +377,9 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
 
   for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
     const int64_t slot_i = tile * TILE + j;
-    const int64_t sc = slot_i < a.n ? slot_i : a.n - 1;
+    const int64_t sc = slot_i < n_pts ? slot_i : n_pts - 1;
     const int64_t i = a.idx ? (int64_t)a.idx[sc] : sc;
-    const bool active = (slot_i < a.n) && (!a.mask || a.mask[i] != 0);
+    const bool active = (slot_i < n_pts) && (!a.mask || a.mask[i] != 0);
     if (__ballot(active) == 0ull) continue;
     const float px = a.pts[i * 3 + 0], py = a.pts[i * 3 + 1], pz = a.pts[i * 3 + 2];
 
@@ -810,16 +812,16 @@ extern "C" int64_t surf_blend_split_scratch_bytes(int64_t n_points, int nv) {
   return (int64_t)grid_blocks(n_points) * WPB * slot_floats(nv - 1) * (int64_t)sizeof(float);
 }
 
-extern "C" int surf_blend_split(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n,
-                                const float* const* h_feats, const int* h_hw, int n_level, const float* imgs, int nv,
-                                const float* h_intrs, const float* h_w2c, const float* h_c2w, const void* blend_w,
-                                int precision, float* color, uint8_t* n_valid, void* scratch, void* stream) {
+static int blend_split_impl(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const int32_t* d_n,
+                            const float* const* h_feats, const int* h_hw, int n_level, const float* imgs, int nv,
+                            const float* h_intrs, const float* h_w2c, const float* h_c2w, const void* blend_w,
+                            int precision, float* color, uint8_t* n_valid, void* scratch, void* stream) {
   if (!pts || !h_feats || !h_hw || !imgs || !h_intrs || !h_w2c || !h_c2w || !blend_w || !color || !scratch) return SURF_E_ARG;
   if (n <= 0 || nv < 2) return SURF_E_ARG;
   if (n_level != 4 || nv > SURF_MAX_VIEWS) return SURF_E_LIMIT;  // d_feature = 16 = 4 levels x 4 channels
   if (precision != BPolBf3::ID && precision != BPolH2::ID && precision != BPolF32::ID) return SURF_E_ARG;
   BlendArgs a;
-  a.pts = pts; a.mask = mask; a.idx = idx; a.n = n; a.imgs = imgs; a.w = (const unsigned char*)blend_w; a.color = color;
+  a.pts = pts; a.mask = mask; a.idx = idx; a.n = n; a.n_dev = d_n; a.imgs = imgs; a.w = (const unsigned char*)blend_w; a.color = color;
   a.n_valid = n_valid;
   a.scratch = (float*)scratch;
   a.nv = nv;
@@ -840,4 +842,23 @@ extern "C" int surf_blend_split(const float* pts, const uint8_t* mask, const int
   if (precision == BPolBf3::ID) return launch<BPolBf3>(a, (hipStream_t)stream);
   if (precision == BPolH2::ID) return launch<BPolH2>(a, (hipStream_t)stream);
   return launch<BPolF32>(a, (hipStream_t)stream);
+}
+
+extern "C" int surf_blend_split(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n,
+                                const float* const* h_feats, const int* h_hw, int n_level, const float* imgs, int nv,
+                                const float* h_intrs, const float* h_w2c, const float* h_c2w, const void* blend_w,
+                                int precision, float* color, uint8_t* n_valid, void* scratch, void* stream) {
+  return blend_split_impl(pts, mask, idx, n, nullptr, h_feats, h_hw, n_level, imgs, nv, h_intrs, h_w2c, h_c2w, blend_w, precision,
+                          color, n_valid, scratch, stream);
+}
+
+// The same with the number of idx entries read from DEVICE memory (d_n[0] <= n_capacity): no host round trip between the
+// compaction and this launch.
+extern "C" int surf_blend_split_dn(const float* pts, const int32_t* idx, int64_t n_capacity, const int32_t* d_n,
+                                   const float* const* h_feats, const int* h_hw, int n_level, const float* imgs, int nv,
+                                   const float* h_intrs, const float* h_w2c, const float* h_c2w, const void* blend_w,
+                                   int precision, float* color, uint8_t* n_valid, void* scratch, void* stream) {
+  if (!idx || !d_n) return SURF_E_ARG;
+  return blend_split_impl(pts, nullptr, idx, n_capacity, d_n, h_feats, h_hw, n_level, imgs, nv, h_intrs, h_w2c, h_c2w, blend_w,
+                          precision, color, n_valid, scratch, stream);
 }

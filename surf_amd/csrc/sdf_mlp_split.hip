@@ -390,7 +390,8 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
   c.sl = __builtin_amdgcn_make_buffer_rsrc((void*)a.scratch, 0, (GRAD && !(SURF_X_NOSCRATCH & 2)) ? 0x7fffffff : 0, 0x00020000);
   const int64_t wave_id = (int64_t)blockIdx.x * WPB + c.wave;
   c.svoff = (int)(wave_id * (SCR_SLOT * 4)) + c.lane * 16;
-  const int64_t n_tiles = (a.n + TILE - 1) / TILE;
+  const int64_t n_pts = a.n_dev ? (int64_t)*a.n_dev : a.n;
+  const int64_t n_tiles = (n_pts + TILE - 1) / TILE;
   const int64_t n_rounds = (n_tiles + WPB - 1) / WPB;
 
   // stream prologue: chunks 0 .. NS-2 (later rounds inherit them from the last chunks of the round before)
@@ -406,9 +407,9 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
   for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
     const int64_t tile = round * WPB + c.wave;
     const int64_t slot0 = tile * TILE + (c.lane & 31);
-    const int64_t sc = slot0 < a.n ? slot0 : a.n - 1;
+    const int64_t sc = slot0 < n_pts ? slot0 : n_pts - 1;
     const int64_t i = a.idx ? (int64_t)a.idx[sc] : sc;
-    const bool active = (slot0 < a.n) && (!a.mask || a.mask[i] != 0);
+    const bool active = (slot0 < n_pts) && (!a.mask || a.mask[i] != 0);
     const float px = a.pts[i * 3 + 0], py = a.pts[i * 3 + 1], pz = a.pts[i * 3 + 2];
 
     Frag ef[2], pf[2];
@@ -692,13 +693,13 @@ int pack_weights(const float* const* h_W, const float* const* h_b, unsigned char
 template <class P>
 int launch(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_vols,
            const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* sdf, float* grad,
-           void* scratch, void* stream) {
+           void* scratch, void* stream, const int32_t* d_n) {
   if (!pts || !h_vols || !h_tables || !h_dims || !packed || !sdf) return SURF_E_ARG;
   if (n <= 0 || n_vol <= 0) return SURF_E_ARG;
   if (n_vol > SURF_MAX_STAGES) return SURF_E_LIMIT;
   if (grad && !scratch) return SURF_E_ARG;
   SdfArgs a;
-  a.pts = pts; a.mask = mask; a.idx = idx; a.n = n; a.packed = (const unsigned char*)packed; a.sdf = sdf; a.grad = grad;
+  a.pts = pts; a.mask = mask; a.idx = idx; a.n = n; a.n_dev = d_n; a.packed = (const unsigned char*)packed; a.sdf = sdf; a.grad = grad;
   a.scratch = (float*)scratch;
   for (int s = 0; s < SURF_MAX_STAGES; ++s) {
     a.vols[s] = s < n_vol ? h_vols[s] : h_vols[0];
@@ -742,7 +743,15 @@ extern "C" int surf_sdf_pack_weights_bf16(const float* const* h_W, const float* 
 extern "C" int surf_sdf_mlp_bf16x3(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n,
                                    const float* const* h_vols, const int32_t* const* h_tables, const int* h_dims, int n_vol,
                                    const void* packed, float* sdf, float* grad, void* scratch, void* stream) {
-  return launch<PolBf3>(pts, mask, idx, n, h_vols, h_tables, h_dims, n_vol, packed, sdf, grad, scratch, stream);
+  return launch<PolBf3>(pts, mask, idx, n, h_vols, h_tables, h_dims, n_vol, packed, sdf, grad, scratch, stream, nullptr);
+}
+// The same with the number of idx entries read from DEVICE memory (d_n[0] <= n = capacity of idx): the launch that follows a
+// compaction needs no host round trip for the count (device-side counters instead of host syncs).
+extern "C" int surf_sdf_mlp_bf16x3_dn(const float* pts, const int32_t* idx, int64_t n_capacity, const int32_t* d_n,
+                                     const float* const* h_vols, const int32_t* const* h_tables, const int* h_dims, int n_vol,
+                                     const void* packed, float* sdf, float* grad, void* scratch, void* stream) {
+  if (!idx || !d_n) return SURF_E_ARG;
+  return launch<PolBf3>(pts, nullptr, idx, n_capacity, h_vols, h_tables, h_dims, n_vol, packed, sdf, grad, scratch, stream, d_n);
 }
 
 extern "C" int64_t surf_sdf_f16_packed_bytes(void) { return stream_bytes<PolH2>() + TAIL_FLOATS * 4; }
@@ -753,5 +762,13 @@ extern "C" int surf_sdf_pack_weights_f16(const float* const* h_W, const float* c
 extern "C" int surf_sdf_mlp_f16x2(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n,
                                   const float* const* h_vols, const int32_t* const* h_tables, const int* h_dims, int n_vol,
                                   const void* packed, float* sdf, float* grad, void* scratch, void* stream) {
-  return launch<PolH2>(pts, mask, idx, n, h_vols, h_tables, h_dims, n_vol, packed, sdf, grad, scratch, stream);
+  return launch<PolH2>(pts, mask, idx, n, h_vols, h_tables, h_dims, n_vol, packed, sdf, grad, scratch, stream, nullptr);
+}
+// The same with the number of idx entries read from DEVICE memory (d_n[0] <= n = capacity of idx): the launch that follows a
+// compaction needs no host round trip for the count (device-side counters instead of host syncs).
+extern "C" int surf_sdf_mlp_f16x2_dn(const float* pts, const int32_t* idx, int64_t n_capacity, const int32_t* d_n,
+                                    const float* const* h_vols, const int32_t* const* h_tables, const int* h_dims, int n_vol,
+                                    const void* packed, float* sdf, float* grad, void* scratch, void* stream) {
+  if (!idx || !d_n) return SURF_E_ARG;
+  return launch<PolH2>(pts, nullptr, idx, n_capacity, h_vols, h_tables, h_dims, n_vol, packed, sdf, grad, scratch, stream, d_n);
 }

@@ -204,7 +204,8 @@ struct SdfArgs {
   const float* pts;
   const uint8_t* mask;
   const int32_t* idx;
-  int64_t n;
+  int64_t n;            // entries of idx / points (capacity when n_dev is set)
+  const int32_t* n_dev;  // optional device-side count (<= n): no host round trip between the compaction and this launch
   const float* vols[SURF_MAX_STAGES];
   const int32_t* tables[SURF_MAX_STAGES];
   int dims[SURF_MAX_STAGES];

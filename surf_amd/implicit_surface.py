@@ -102,7 +102,12 @@ class SingleVarianceNetwork(nn.Module):
         self.register_parameter("variance", nn.Parameter(torch.tensor(float(init_val))))
 
     def inv_s(self):
-        return float(torch.exp(self.variance.detach() * 10.0).clamp(1e-6, 1e6))
+        """exp(10 v) clipped, as a python float (the kernels take it by value).  One device read per parameter VERSION, not
+        per render call: an inference loop never syncs on it after the first call."""
+        key = (self.variance._version, self.variance.data_ptr())
+        if getattr(self, "_inv_s_cache", None) is None or self._inv_s_cache[0] != key:
+            self._inv_s_cache = (key, float(torch.exp(self.variance.detach() * 10.0).clamp(1e-6, 1e6)))
+        return self._inv_s_cache[1]
 
 
 class SceneVolumes:
@@ -259,17 +264,24 @@ class ImplicitSurface(nn.Module):
         st = timed("ray_setup", lambda: ops.ray_setup(rays_o, rays_d, near.float(), far.float(), scene.mvol, scene.sv,
                                                       self.n_samples, self.sample_ranges, self.n_depth, jitter=jitter,
                                                       want_z=patch_warp))
-        act = timed("compact", lambda: ops.compact(st["vmask"]))      # masked-in samples, ray-major order
-        sdf, grad = timed("sdf_mlp", lambda: ops.sdf_mlp(st["pts"], scene.sv, sdf_w, mask=st["vmask"], active_idx=act))
+        # masked-in samples, ray-major order.  Inference with the split kernels keeps the count on the device (no host sync
+        # between the compaction and the two MLP kernels); a training forward needs the exact-size list for its backward
+        n_act = None
+        if patch_warp or self.sdf_precision == "f32" or self.blend_precision == "f32":
+            act = timed("compact", lambda: ops.compact(st["vmask"]))
+        else:
+            act, n_act = timed("compact", lambda: ops.compact_counted(st["vmask"]))
+        sdf, grad = timed("sdf_mlp", lambda: ops.sdf_mlp(st["pts"], scene.sv, sdf_w, mask=st["vmask"], active_idx=act,
+                                                         active_count=n_act))
         col, nvalid = timed("blend", lambda: ops.blend(st["pts"], scene.feats_t4, scene.imgs_t4, scene.cams, blend_w,
-                                                       mask=st["vmask"], active_idx=act))
+                                                       mask=st["vmask"], active_idx=act, active_count=n_act))
         out = timed("composite", lambda: ops.composite(sdf, grad, col, nvalid, st, rays_d, self.deviation_network.inv_s(),
                                                        float(cos_anneal_ratio), scene.cams, per_sample=per_sample,
                                                        want_z0=patch_warp))
-        if ev is not None:
-            self.last_active_samples = int(act.shape[0])
+        if ev is not None:                                  # bench.py only: the count for the roofline arithmetic
+            self.last_active_samples = int(act.shape[0]) if n_act is None else n_act
             if self.active_samples_log is not None:
-                self.active_samples_log.append(int(act.shape[0]))
+                self.active_samples_log.append(self.last_active_samples)
         R, S = st["mid_z"].shape
         eik = out.pop("eik").sum(dim=0)
         out["gradient_error"] = eik[0] / (eik[1] + 1e-5)

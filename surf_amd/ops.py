@@ -294,9 +294,11 @@ def _sdf_scratch(n, device, precision="f32"):
     return buf
 
 
-def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True, compact_active=True, active_idx=None):
+def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True, compact_active=True, active_idx=None, active_count=None):
     """sdf_network.py:95-141 at n points.  Returns (sdf (n,), grad (n,3) or None); masked-out rows are
-    left at sdf=100 / grad=0 (what render_core substitutes, implicit_surface.py:93,99)."""
+    left at sdf=100 / grad=0 (what render_core substitutes, implicit_surface.py:93,99).
+    active_count (with active_idx from compact_counted, split kernels only): the number of valid entries of active_idx as a
+    DEVICE tensor - the kernel reads it there, no host sync."""
     _chk(pts, torch.float32, "pts")
     precision = sdf_packed_precision(packed)    # which kernel the packed weights were laid out for
     _chk(packed, torch.float32 if precision == "f32" else torch.uint8, "packed weights")
@@ -321,6 +323,15 @@ def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True, compact_active=True
             return sdf, grad
     scratch = _sdf_scratch(n_eval, dev, precision) if want_grad else None
     name = {"f32": "surf_sdf_mlp", "bf16x3": "surf_sdf_mlp_bf16x3", "f16x2": "surf_sdf_mlp_f16x2"}[precision]
+    if active_count is not None:
+        if precision == "f32" or active_idx is None:
+            raise ValueError("active_count needs active_idx and one of the split kernels (bf16x3 / f16x2)")
+        _chk(active_count, torch.int32, "active_count")
+        fn = getattr(_lib.lib(), name + "_dn")
+        rc = fn(_p(pts), _p(idx), n_eval, _p(active_count), volumes._vp, volumes._tp, volumes._dp, volumes.n, _p(packed), _p(sdf),
+                _p(grad), _p(scratch), _stream())
+        _lib.check(rc, name + "_dn")
+        return sdf, grad
     fn = getattr(_lib.lib(), name)
     rc = fn(_p(pts), _p(None if idx is not None else mask), _p(idx), n_eval, volumes._vp, volumes._tp, volumes._dp, volumes.n,
             _p(packed), _p(sdf), _p(grad), _p(scratch), _stream())
@@ -522,7 +533,7 @@ class Cameras:
         self.rot_ref = np.ascontiguousarray(torch.inverse(c2w_cpu[0, :3, :3]).numpy())
 
 
-def blend(pts, feats_t4, imgs_t4, cams, packed, mask=None, compact_active=True, active_idx=None):
+def blend(pts, feats_t4, imgs_t4, cams, packed, mask=None, compact_active=True, active_idx=None, active_count=None):
     """projector.py:501-556 + blending_network.py:69-118.  feats_t4: list fine -> coarse of (nv,H,W,4).
     Returns (color (n,3), n_valid (n) uint8); masked-out rows are zero."""
     _chk(pts, torch.float32, "pts")
@@ -544,6 +555,8 @@ def blend(pts, feats_t4, imgs_t4, cams, packed, mask=None, compact_active=True, 
     if n_eval == 0:
         return color, nvalid
     precision = blend_packed_precision(packed)     # which kernel the packed weights were laid out for
+    if precision == "f32" and active_count is not None:
+        raise ValueError("active_count needs one of the split blend kernels")
     if precision == "f32":
         rc = _lib.lib().surf_blend(_p(pts), _p(None if idx is not None else mask), _p(idx), n_eval, fp, hw, len(feats_t4),
                                    _p(imgs_t4), cams.nv, _np_ptr(cams.intrs), _np_ptr(cams.w2c), _np_ptr(cams.c2w), _p(packed),
@@ -555,9 +568,15 @@ def blend(pts, feats_t4, imgs_t4, cams, packed, mask=None, compact_active=True, 
         if scratch is None or scratch.numel() < need:
             scratch = torch.empty(need, dtype=torch.uint8, device=dev)
             _scratch_cache[key] = scratch
-        rc = _lib.lib().surf_blend_split(_p(pts), _p(None if idx is not None else mask), _p(idx), n_eval, fp, hw, len(feats_t4),
-                                         _p(imgs_t4), cams.nv, _np_ptr(cams.intrs), _np_ptr(cams.w2c), _np_ptr(cams.c2w),
-                                         _p(packed), _BLEND_ID[precision], _p(color), _p(nvalid), _p(scratch), _stream())
+        if active_count is not None:           # the count stays on the device (compact_counted)
+            _chk(active_count, torch.int32, "active_count")
+            rc = _lib.lib().surf_blend_split_dn(_p(pts), _p(idx), n_eval, _p(active_count), fp, hw, len(feats_t4), _p(imgs_t4),
+                                                cams.nv, _np_ptr(cams.intrs), _np_ptr(cams.w2c), _np_ptr(cams.c2w), _p(packed),
+                                                _BLEND_ID[precision], _p(color), _p(nvalid), _p(scratch), _stream())
+        else:
+            rc = _lib.lib().surf_blend_split(_p(pts), _p(None if idx is not None else mask), _p(idx), n_eval, fp, hw, len(feats_t4),
+                                             _p(imgs_t4), cams.nv, _np_ptr(cams.intrs), _np_ptr(cams.w2c), _np_ptr(cams.c2w),
+                                             _p(packed), _BLEND_ID[precision], _p(color), _p(nvalid), _p(scratch), _stream())
     _lib.check(rc, "surf_blend" if precision == "f32" else f"surf_blend_split({precision})")
     return color, nvalid
 
@@ -826,6 +845,20 @@ def compact(flags):
     total = torch.empty(1, dtype=torch.int32, device=dev)
     _lib.check(_lib.lib().surf_compact(_p(flags), n, _p(ws), _p(idx), _p(total), _stream()), "surf_compact")
     return idx[:int(total.item())]
+
+
+def compact_counted(flags):
+    """compact without the host round trip: (idx (n,) int32 of which the first `count` entries are the ascending indices of
+    the set flags, count (1,) int32 ON THE DEVICE).  For consumers that read the count from device memory (sdf_mlp / blend
+    with `active_count`)."""
+    _chk(flags, torch.uint8, "flags")
+    n = flags.numel()
+    dev = flags.device
+    ws = torch.empty(_lib.lib().surf_compact_workspace_ints(n), dtype=torch.int32, device=dev)
+    idx = torch.empty(n, dtype=torch.int32, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().surf_compact(_p(flags), n, _p(ws), _p(idx), _p(total), _stream()), "surf_compact")
+    return idx, total
 
 
 def gather_rows(src, idx, shift=0, dst=None, dst_off=0):

@@ -39,6 +39,11 @@ class SuRF(nn.Module):
                 p.requires_grad = False
         self.implicit_surface = ImplicitSurface(confs["implicit_surface"])
         self._vol_scene = None                     # kernel-layout copy of the frozen volumes (per view subset)
+        # optional key (ours): reduced-precision policy of the training backward, BASELINE configs[3] ("fp32" | "bf16", see
+        # ops.set_train_precision: which tensors may be bf16); applied process-wide at every train-mode forward of this model
+        self.train_precision = confs.get_string("train_precision", "fp32")
+        if self.train_precision not in ops.TRAIN_PRECISIONS:
+            raise ValueError(f"train_precision must be one of {sorted(ops.TRAIN_PRECISIONS)}, got {self.train_precision!r}")
 
     def get_optim_params(self, lr_conf):
         """surf.py:36-45 (parameter groups; training itself is row f2)."""
@@ -307,6 +312,8 @@ class SuRF(nn.Module):
         """surf.py:133-163.  With autograd enabled a train-mode forward is differentiable (surf_amd.autograd): its outputs
         carry grad_fn and `loss.backward()` runs the HIP backward kernels.  record=True (surf_amd.training's explicit step)
         instead keeps the tapes on the module for `SuRF.backward` / `SuRF.backward_volumes` and returns plain tensors."""
+        if mode != "val":
+            ops.set_train_precision(self.train_precision)
         if self._wants_graph(mode, record):
             from . import autograd
             return autograd.differentiable_forward(self, mode, ipts, cos_anneal_ratio, step)

@@ -32,7 +32,7 @@ def rel_close(a, b, rtol, atol, what=""):
     assert not bool(bad.any()), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max().item():.3e}"
 
 
-def _check_against_reference_backward(named_params, vol_grads_f2c, gg):
+def _check_against_reference_backward(named_params, vol_grads_f2c, gg, param_tol=5e-4):
     n = 0
     for name, p_ in named_params:
         ref = gg["grad/" + name]
@@ -40,7 +40,7 @@ def _check_against_reference_backward(named_params, vol_grads_f2c, gg):
         if name == "color_network.s":          # see test_color_network_s_gradient_is_conditioned_like_this (test_hip_parity.py)
             assert abs(float(p_.grad) - float(ref)) <= 0.35 * abs(float(ref)) + 1e-6
             continue
-        rel_close(p_.grad, ref, 5e-3, 5e-4 * float(ref.abs().max()) + 1e-7, name)
+        rel_close(p_.grad, ref, 5e-3, param_tol * float(ref.abs().max()) + 1e-7, name)
         n += 1
     assert n >= 7 * 3 + 1 + 20
     for lvl in range(4):
@@ -118,8 +118,13 @@ def test_module_swap_train_forward_equals_the_reference_loss_backward(scene, wei
     assert float((isurf.sdf_network.lin3.weight_v.detach() - before).abs().max()) > 0
 
 
-def test_runner_sequence_on_a_has_vol_model_equals_the_reference_loss_backward(scene, weights, golden_fpn, golden_pipe, golden_grads):
-    """runner.py:152-164 verbatim on surf_amd.surf.SuRF (finetune parameter set: implicit surface + per-scene volumes)."""
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_runner_sequence_on_a_has_vol_model_equals_the_reference_loss_backward(scene, weights, golden_fpn, golden_pipe, golden_grads,
+                                                                               precision):
+    """runner.py:152-164 verbatim on surf_amd.surf.SuRF (finetune parameter set: implicit surface + per-scene volumes).
+    precision = the model conf's `train_precision`: "bf16" (BASELINE configs[3]) rounds the operands of the weight-gradient
+    reductions to bf16 (fp32 accumulate) - the reference's gradients are then reproduced to 2 % of each tensor's largest entry
+    instead of 0.05 %; loss, forward and the feature rows' gradients are untouched by the policy."""
     from surf_amd import conf
     from surf_amd.losses import Loss
     from surf_amd.surf import SuRF
@@ -128,7 +133,7 @@ def test_runner_sequence_on_a_has_vol_model_equals_the_reference_loss_backward(s
     from tests.golden.make_golden_train import LOSS_CONF
     d = dev()
     gg = golden_grads
-    cfg = dict(MODEL_CONF, has_vol=True)
+    cfg = dict(MODEL_CONF, has_vol=True, train_precision=precision)
     cfg["implicit_surface"] = dict(cfg["implicit_surface"])
     cfg["implicit_surface"]["render"] = dict(cfg["implicit_surface"]["render"], sdf_precision="f32", blend_precision="f32", perturb=0.0)
     model = SuRF(conf.from_dict(cfg)).to(d)
@@ -157,7 +162,11 @@ def test_runner_sequence_on_a_has_vol_model_equals_the_reference_loss_backward(s
     assert bool(torch.isfinite(psnr))
     rel_close(loss.detach().reshape(1), gg["loss"], 1e-3, 1e-4, "loss")
     named = [(n[len("implicit_surface."):], p) for n, p in model.named_parameters() if n.startswith("implicit_surface.")]
-    _check_against_reference_backward(named, [p.grad for p in list(model.volumes)[::-1]], gg)
+    try:
+        _check_against_reference_backward(named, [p.grad for p in list(model.volumes)[::-1]], gg, param_tol=5e-4 if precision == "fp32" else 2e-2)
+    finally:
+        from surf_amd import ops
+        ops.set_train_precision("fp32")
     optimizer.step()
 
 

@@ -1423,3 +1423,44 @@ def test_spconv_wgrad_thin_kernel_row_cache_and_its_overflow(cin, cout):
                                     ops.SUBM, w.to(d), dy.to(d))
         ref = reference(x, table.cpu(), out_coords, dy, Dd)
         rel_close(dW, ref, 1e-4, 2e-5 * float(ref.abs().max()))
+
+
+def test_inference_render_keeps_the_active_count_on_the_device(scene, weights, gpu_scene):
+    """SURVEY 8b "no hidden syncs ... replaced by device-side counters": an inference render_scene with the split kernels hands
+    the compaction's count to the SDF / blend kernels in device memory (surf_sdf_mlp_bf16x3_dn / surf_blend_split_dn) and reads
+    the variance parameter once per version - the second call of a loop runs under torch's sync-debug mode without tripping
+    it - and the results are bit-identical to the host-count path."""
+    from bench import model_conf
+    from surf_amd import ops
+    from surf_amd.implicit_surface import ImplicitSurface, SceneVolumes
+    d = dev()
+    model = ImplicitSurface(model_conf(CFG["n_samples"], "bf16x3", "bf16x3"))
+    model.load_state_dict({k[len("implicit_surface."):]: v for k, v in weights.items() if k.startswith("implicit_surface.")})
+    model = model.to(d)
+    sc = SceneVolumes.from_device_layouts(gpu_scene["mvol"], gpu_scene["sv"].vols, gpu_scene["sv"].tables, gpu_scene["feats_t4"],
+                                          gpu_scene["imgs_t4"], gpu_scene["cams"])
+    R = scene["rays_o"].shape[0]
+    ro, rd = scene["rays_o"].to(d), scene["rays_d"].to(d)
+    near, far = scene["near"].repeat(R, 1).to(d), scene["far"].repeat(R, 1).to(d)
+    out0 = model.render_scene(ro, rd, near, far, sc, 1.0, per_sample=False)          # warms the weight / inv_s caches
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out1 = model.render_scene(ro, rd, near, far, sc, 1.0, per_sample=False)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    # the host-count path on the same inputs
+    st = ops.ray_setup(ro, rd, near, far, sc.mvol, sc.sv, model.n_samples, model.sample_ranges, model.n_depth)
+    act = ops.compact(st["vmask"])
+    idx_c, n_c = ops.compact_counted(st["vmask"])
+    assert int(n_c) == act.shape[0] and torch.equal(idx_c[:act.shape[0]], act)
+    sdf_w, blend_w = model.packed_weights(d)
+    sdf_a, grad_a = ops.sdf_mlp(st["pts"], sc.sv, sdf_w, mask=st["vmask"], active_idx=act)
+    sdf_b, grad_b = ops.sdf_mlp(st["pts"], sc.sv, sdf_w, mask=st["vmask"], active_idx=idx_c, active_count=n_c)
+    assert torch.equal(sdf_a, sdf_b) and torch.equal(grad_a, grad_b)
+    col_a, nv_a = ops.blend(st["pts"], sc.feats_t4, sc.imgs_t4, sc.cams, blend_w, mask=st["vmask"], active_idx=act)
+    col_b, nv_b = ops.blend(st["pts"], sc.feats_t4, sc.imgs_t4, sc.cams, blend_w, mask=st["vmask"], active_idx=idx_c, active_count=n_c)
+    assert torch.equal(col_a, col_b) and torch.equal(nv_a, nv_b)
+    for k in ("color_fine", "render_depth", "sdf_depth"):
+        assert torch.equal(out0[k], out1[k]), k
