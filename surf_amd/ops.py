@@ -243,6 +243,21 @@ def blend_packed_precision(packed):
 # ------------------------------------------------------------------------------------------------
 
 
+_linspace_cache = {}
+
+
+def _linspace_dev(lo, hi, n, dev):
+    """torch.linspace computed on the CPU - like the reference, whose sample fractions are CPU linspaces moved to the device
+    (implicit_surface.py:271, matching_field.py:31) - and kept on the device: one host-to-device copy per (lo, hi, n), not one
+    per call (a pageable copy is a synchronising operation)."""
+    key = (float(lo), float(hi), int(n), str(dev))
+    t = _linspace_cache.get(key)
+    if t is None:
+        t = torch.linspace(float(lo), float(hi), int(n), dtype=torch.float32).to(dev)
+        _linspace_cache[key] = t
+    return t
+
+
 def ray_setup(rays_o, rays_d, near, far, mvol, volumes, n_samples, sample_ranges, n_depth, want_z=False, jitter=None):
     """implicit_surface.py:268-311 + :72-86.  Returns dict(mid_z, dists, pts, vmask[, z_vals]).
     jitter: None (render.perturb = 0) or (R, n_stage) float32 on the device = the `torch.rand([R, 1]) - 0.5` draws of
@@ -259,8 +274,11 @@ def ray_setup(rays_o, rays_d, near, far, mvol, volumes, n_samples, sample_ranges
     if jitter is not None:
         _chk(jitter, torch.float32, "jitter")
         assert tuple(jitter.shape) == (R, len(n_samples)), jitter.shape
-    lin_depth = torch.linspace(0.0, 1.0, n_depth, dtype=torch.float32).to(dev)
-    lin_s = torch.cat([torch.linspace(0.0, 1.0, int(n), dtype=torch.float32) for n in n_samples]).to(dev)
+    lin_depth = _linspace_dev(0.0, 1.0, n_depth, dev)
+    key = ("stages", tuple(int(n) for n in n_samples), str(dev))
+    lin_s = _linspace_cache.get(key)
+    if lin_s is None:
+        lin_s = _linspace_cache[key] = torch.cat([torch.linspace(0.0, 1.0, int(n), dtype=torch.float32) for n in n_samples]).to(dev)
     out = {
         "mid_z": torch.empty(R, S, dtype=torch.float32, device=dev),
         "dists": torch.empty(R, S, dtype=torch.float32, device=dev),
@@ -900,9 +918,9 @@ def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, r
     _chk(mvol, torch.float32, "matching volume")
     dev = mvol.device
     h, w = H // res_level, W // res_level
-    lin_x = torch.linspace(0, W - 1, w).to(dev)
-    lin_y = torch.linspace(0, H - 1, h).to(dev)
-    lin_n = torch.linspace(0.0, 1.0, n).to(dev)
+    lin_x = _linspace_dev(0, W - 1, w, dev)
+    lin_y = _linspace_dev(0, H - 1, h, dev)
+    lin_n = _linspace_dev(0.0, 1.0, n, dev)
     nf = np.ascontiguousarray(near_fars.detach().to("cpu", torch.float32).numpy())
     lr = torch.empty(cams.nv, h, w, dtype=torch.float32, device=dev)
     full = torch.empty(cams.nv, H, W, dtype=torch.float32, device=dev)
@@ -927,9 +945,9 @@ def matching_depth_backward(mvol, cams, near_fars, H, W, res_level, n, g_full, p
     dev = mvol.device
     h, w = H // res_level, W // res_level
     assert tuple(g_full.shape) == (cams.nv, H, W)
-    lin_x = torch.linspace(0, W - 1, w).to(dev)
-    lin_y = torch.linspace(0, H - 1, h).to(dev)
-    lin_n = torch.linspace(0.0, 1.0, n).to(dev)
+    lin_x = _linspace_dev(0, W - 1, w, dev)
+    lin_y = _linspace_dev(0, H - 1, h, dev)
+    lin_n = _linspace_dev(0.0, 1.0, n, dev)
     nf = np.ascontiguousarray(near_fars.detach().to("cpu", torch.float32).numpy())
     g_lr = torch.empty(cams.nv, h, w, dtype=torch.float32, device=dev)
     if dmvol is None:
