@@ -286,7 +286,7 @@ __device__ __forceinline__ void load_sprime(const Ctx& c, int layer, int tile, f
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     if (ls >= 0) dst[g] = *reinterpret_cast<const f32x4*>(c.lds_s + ls * 4096 + g * 1024);
-    else dst[g] = bload(c.sl, c.svoff, layer * 16384 + (tile * 4 + g) * 1024);
+    else dst[g] = bload_scratch(c.sl, c.svoff, layer * 16384 + (tile * 4 + g) * 1024);
   }
 }
 template <class P, int L, int T, bool CONVERT>
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
       f32x4 Jq[12];  // feature Jacobian: DEEP fetches it under the last chunk
       if (P::DEEPJ) {
 #pragma unroll
-        for (int g = 0; g < 12; ++g) Jq[g] = bload(c.sl, c.svoff, SCR_S * 4 + g * 1024);
+        for (int g = 0; g < 12; ++g) Jq[g] = bload_scratch(c.sl, c.svoff, SCR_S * 4 + g * 1024);
       }
       {
         f32x4 unused[4];
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
           float Jf[24];
 #pragma unroll
           for (int g = 0; g < 6; ++g) {
-            const f32x4 v = P::DEEPJ ? Jq[6 * sl + g] : bload(c.sl, c.svoff, SCR_S * 4 + (6 * sl + g) * 1024);
+            const f32x4 v = P::DEEPJ ? Jq[6 * sl + g] : bload_scratch(c.sl, c.svoff, SCR_S * 4 + (6 * sl + g) * 1024);
             Jf[4 * g + 0] = v[0]; Jf[4 * g + 1] = v[1]; Jf[4 * g + 2] = v[2]; Jf[4 * g + 3] = v[3];
           }
 #pragma unroll

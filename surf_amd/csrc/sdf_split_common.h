@@ -218,11 +218,23 @@ struct SdfArgs {
 __device__ __forceinline__ f32x4 bload(rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+// Cache policy of the softplus' / Jacobian scratch round trip (written once, read once ~40 us later by the same wave):
+// SURF_X_SCRATCH_NT bit 0: stores non-temporal, bit 1: loads non-temporal (timing experiment of round 3).
+#ifndef SURF_X_SCRATCH_NT
+#define SURF_X_SCRATCH_NT 0
+#endif
+__device__ __forceinline__ f32x4 bload_scratch(rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, (SURF_X_SCRATCH_NT & 2) ? 2 : 0));
+}
 // 16-byte scratch store.  gfx950: a VALU write to the data VGPRs right after `buffer_store_dwordx4 ... sN offen` corrupts
 // lanes 12-15 of every 16 (see sdf_mlp.hip).  Store and pad are ONE asm statement so that nothing - not the scheduler,
 // not a register-allocator copy or reload - can land between them.
 __device__ __forceinline__ void bstore(rsrc_t r, int voff, int soff, f32x4 v) {
+#if SURF_X_SCRATCH_NT & 1
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+#else
   asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(r), "s"(soff) : "memory");
+#endif
 }
 
 template <class P>
