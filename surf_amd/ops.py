@@ -45,6 +45,7 @@ class _timed:
 
 
 def _p(t):
+    t = getattr(t, "tensor", t)            # PackedBlend
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
 
@@ -216,25 +217,50 @@ def blend_pack_weights_split_host(raw, precision):
     return out
 
 
+class PackedBlend:
+    """The LDS image of a split blend kernel together with the precision it was laid out for.  The f16x2 and f32lds images have
+    the SAME size, so the layout cannot be recovered from the bytes: it travels with them explicitly (an attribute on the
+    tensor, as in round 2, is lost by clone() / to() / a state-dict round trip and the f32lds image then ran through the f16x2
+    kernel without any error)."""
+    __slots__ = ("tensor", "precision")
+
+    def __init__(self, tensor, precision):
+        if precision not in _BLEND_ID:
+            raise ValueError(f"blend precision must be one of {sorted(_BLEND_ID)}")
+        if tensor.dtype != torch.uint8 or tensor.numel() != _lib.lib().surf_blend_split_packed_bytes(_BLEND_ID[precision]):
+            raise ValueError(f"not a {precision} image of surf_blend_pack_weights_split")
+        self.tensor, self.precision = tensor, precision
+
+    def to(self, device):
+        return PackedBlend(self.tensor.to(device), self.precision)
+
+    @property
+    def device(self):
+        return self.tensor.device
+
+
 def blend_pack_weights(sd, device, prefix="implicit_surface.color_network.", precision="f32"):
-    """Packed BlendingNetwork weights for the blend kernel of `precision` (fp32 tensor: blend.hip; bytes: blend_split.hip)."""
+    """Packed BlendingNetwork weights for the blend kernel of `precision` (fp32 tensor: blend.hip; PackedBlend: blend_split.hip)."""
     raw = blend_raw_weights(sd, prefix)
     if precision == "f32":
         return torch.from_numpy(blend_pack_weights_host(raw)).to(device)
-    packed = torch.from_numpy(blend_pack_weights_split_host(raw, precision)).to(device)
-    packed.surf_precision = precision          # the f16x2 and f32lds images have the same size: carry the name along
-    return packed
+    return PackedBlend(torch.from_numpy(blend_pack_weights_split_host(raw, precision)).to(device), precision)
 
 
 def blend_packed_precision(packed):
+    """Which blend kernel a packed weight object belongs to.  Raw byte tensors are accepted only where the size identifies
+    the layout; an ambiguous size raises instead of guessing."""
+    if isinstance(packed, PackedBlend):
+        return packed.precision
     if packed.dtype == torch.float32:
         return "f32"
-    if getattr(packed, "surf_precision", None) in _BLEND_ID:
-        return packed.surf_precision
     if packed.dtype == torch.uint8:
-        for precision, pid in _BLEND_ID.items():
-            if packed.numel() == _lib.lib().surf_blend_split_packed_bytes(pid):
-                return precision
+        hits = [precision for precision, pid in _BLEND_ID.items() if packed.numel() == _lib.lib().surf_blend_split_packed_bytes(pid)]
+        if len(hits) == 1:
+            return hits[0]
+        if len(hits) > 1:
+            raise ValueError(f"a {packed.numel()}-byte blend image fits the layouts {hits}: pass the PackedBlend that "
+                             "blend_pack_weights returned (it carries the precision)")
     raise ValueError("packed blend weights: not an output of surf_blend_pack_weights / surf_blend_pack_weights_split")
 
 

@@ -170,3 +170,25 @@ def test_backward_entry_points_fail_loudly_without_a_recorded_forward():
     model._train_tape = None
     with _pytest.raises(RuntimeError, match="record=True"):
         model.backward_volumes([torch.zeros(1, 7)] * 4)
+
+
+def test_packed_blend_image_carries_its_precision():
+    """The f16x2 and f32lds LDS images of the split blend kernel have the same size: the layout travels with the bytes
+    (ops.PackedBlend), a raw byte tensor of an ambiguous size is refused instead of guessed, a wrong-sized one is refused."""
+    import pytest as _pytest
+    import torch
+    from surf_amd import _lib, ops
+    L = _lib.lib()
+    sizes = {p: L.surf_blend_split_packed_bytes(pid) for p, pid in ops._BLEND_ID.items()}
+    assert sizes["f16x2"] == sizes["f32lds"] != sizes["bf16x3"]
+    raw16 = torch.zeros(sizes["f16x2"], dtype=torch.uint8)
+    for precision in ("f16x2", "f32lds"):
+        pk = ops.PackedBlend(raw16, precision)
+        assert ops.blend_packed_precision(pk) == precision and ops.blend_packed_precision(pk.to("cpu")) == precision
+    with _pytest.raises(ValueError, match="fits the layouts"):
+        ops.blend_packed_precision(raw16)
+    assert ops.blend_packed_precision(torch.zeros(sizes["bf16x3"], dtype=torch.uint8)) == "bf16x3"
+    with _pytest.raises(ValueError):
+        ops.PackedBlend(raw16, "bf16x3")
+    with _pytest.raises(ValueError):
+        ops.blend_packed_precision(torch.zeros(17, dtype=torch.uint8))
