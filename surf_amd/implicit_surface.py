@@ -269,6 +269,11 @@ class ImplicitSurface(nn.Module):
         n_act = None
         if patch_warp or self.sdf_precision == "f32" or self.blend_precision == "f32":
             act = timed("compact", lambda: ops.compact(st["vmask"]))
+            if patch_warp and act.shape[0] == 0:
+                # implicit_surface.py:88-89: a training batch without a single masked-in sample still sends its first ten points
+                # through the networks (their compositing weights stay zero: voxel_mask is unchanged) - sparse_sdf then holds
+                # ten real SDF values and the graph stays connected.  (Inference outputs do not depend on it.)
+                act = torch.arange(min(10, st["vmask"].numel()), dtype=torch.int32, device=dev)
         else:
             act, n_act = timed("compact", lambda: ops.compact_counted(st["vmask"]))
         sdf, grad = timed("sdf_mlp", lambda: ops.sdf_mlp(st["pts"], scene.sv, sdf_w, mask=st["vmask"], active_idx=act,

@@ -367,3 +367,41 @@ def test_lncc_backward_matches_autograd(golden_train):
             assert scale > 0
             rel_close(a, b, 1e-3, 2e-5 * scale, nm)
         assert int((src.grad.abs().sum(dim=(2, 3)) > 0).sum(dim=0).max()) <= 2
+
+
+def test_a_batch_that_misses_the_volume_still_trains(scene, weights, golden_fpn, golden_pipe):
+    """implicit_surface.py:88-89: when no sample of the batch is masked in, the reference sends the first ten points through the
+    networks anyway (voxel_mask itself stays zero, so their compositing weights are zero): sparse_sdf holds ten real SDF values
+    instead of the placeholder 100 and loss.backward() has a graph to walk.  Rays pointing away from the volume: the forward's
+    ten values equal the oracle's SDF at those points, the colour is zero, the backward fills finite gradients."""
+    from bench import model_conf
+    from surf_amd import ops
+    from surf_amd.implicit_surface import ImplicitSurface
+    d = dev()
+    isurf = ImplicitSurface(model_conf(CFG["n_samples"], "f32")).train()
+    isurf.load_state_dict({k[len("implicit_surface."):]: v for k, v in weights.items() if k.startswith("implicit_surface.")})
+    isurf = isurf.to(d)
+    vols, tabs, masks, mvol = pipeline_views(golden_pipe)
+    vols_d = [v.to(d).clone().requires_grad_(True) for v in vols]
+    feats = [golden_fpn[f"out{i}"].to(d) for i in range(4)][::-1]
+    ipts = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    ipts["rays_o"] = scene["rays_o"].to(d) + 50.0                       # far outside [-1, 1]^3 and looking away
+    torch.manual_seed(0)
+    outs = isurf("train", ipts, mvol.to(d)[None, None], vols_d, [t.to(d) for t in tabs], [m.to(d) for m in masks], feats, feats, 1.0, 3)
+    R = scene["rays_o"].shape[0]
+    S = sum(CFG["n_samples"])
+    ss = outs["sparse_sdf"].detach().cpu().reshape(-1)[1024:]
+    assert ss.shape[0] == R * S
+    assert float((ss[10:] - 100.0).abs().max()) == 0.0 and float((ss[:10] - 100.0).abs().min()) > 1.0
+    assert float(outs["color_fine"].detach().abs().max()) == 0.0 and float(outs["smooth_error"].detach()) == 0.0
+    # the oracle's SDF at those ten points (all their feature lookups are empty: outside every table)
+    st = ops.ray_setup(ipts["rays_o"].float().contiguous(), ipts["rays_d"].float().contiguous(), ipts["near"].repeat(R, 1).float(),
+                       ipts["far"].repeat(R, 1).float(), mvol.to(d).contiguous(), ops.SparseVolumes([v.to(d) for v in vols], [t.to(d) for t in tabs]),
+                       CFG["n_samples"], [1.0, 0.4, 0.1, 0.01], 256)
+    pts10 = st["pts"][:10].cpu()
+    sdf_ref = O.sdf_mlp(O.sdf_weights(weights), pts10, torch.zeros(10, 28))[0].reshape(-1)
+    rel_close(ss[:10], sdf_ref, 1e-4, 1e-4)
+    loss = torch.exp(-outs["sparse_sdf"].abs() * 0.01).mean() + outs["color_fine"].sum() + outs["gradient_error"]
+    loss.backward()
+    g = isurf.sdf_network.lin0.weight_v.grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
