@@ -212,20 +212,36 @@ class ImplicitSurface(nn.Module):
         return super().train(mode)
 
     def packed_weights(self, device):
+        """(SDF operand stream, blend LDS image) for the kernels of sdf_precision / blend_precision, cached per parameter version.
+        With the split kernels (the defaults) the images are built ON THE DEVICE from the live parameters (surf_amd.packing:
+        byte-identical to the C ABI's host packers, no device-to-host copy, no sync); the fp32-MFMA kernels use the host packers."""
         ver = tuple((p._version, p.data_ptr()) for p in self.parameters()) + (str(device), self.sdf_precision, self.blend_precision)
         if self._packed is None or self._packed[0] != ver:
-            sd = {k: v for k, v in self.state_dict().items()}
-            sdf_w = (ops.sdf_pack_weights(sd, device, "sdf_network.") if self.sdf_precision == "f32" else
-                     ops.sdf_pack_weights_split(sd, device, "sdf_network.", self.sdf_precision))
-            self._packed = (ver, sdf_w, ops.blend_pack_weights(sd, device, "color_network.", self.blend_precision))
+            from . import packing
+            on_device = next(self.parameters()).is_cuda and packing.supported(self.sdf_precision, self.blend_precision)
+            if on_device:
+                with torch.no_grad():
+                    sdf_w = packing.sdf_pack_split_device(self.sdf_network, self.sdf_precision)
+                    blend_w = packing.blend_pack_split_device(self.color_network, self.blend_precision)
+            else:
+                sd = {k: v for k, v in self.state_dict().items()}
+                sdf_w = (ops.sdf_pack_weights(sd, device, "sdf_network.") if self.sdf_precision == "f32" else
+                         ops.sdf_pack_weights_split(sd, device, "sdf_network.", self.sdf_precision))
+                blend_w = ops.blend_pack_weights(sd, device, "color_network.", self.blend_precision)
+            self._packed = (ver, sdf_w, blend_w)
         return self._packed[1], self._packed[2]
 
     def smooth_weights(self, device):
         """fp32 image of sdf_network for the second-order kernel (training only), cached with the other re-layouts."""
         self.packed_weights(device)                  # refreshes self._packed when parameters changed
         if len(self._packed) == 3:
-            sd = {k: v for k, v in self.state_dict().items()}
-            self._packed = self._packed + (ops.sdf_smooth_pack_weights(sd, device, "sdf_network."),)
+            if next(self.parameters()).is_cuda:
+                from . import packing
+                with torch.no_grad():
+                    sm = packing.sdf_pack_smooth_device(self.sdf_network)
+            else:
+                sm = ops.sdf_smooth_pack_weights({k: v for k, v in self.state_dict().items()}, device, "sdf_network.")
+            self._packed = self._packed + (sm,)
         return self._packed[3]
 
     def scene(self, matching_volume, volumes, sparse_idxes, mask_volumes, features, imgs, intrs, c2ws):

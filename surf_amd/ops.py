@@ -383,9 +383,8 @@ def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True, compact_active=True
     return sdf, grad
 
 
-def sdf_smooth_pack_weights(sd, device, prefix="implicit_surface.sdf_network."):
-    """fp32 image of the SDF network for surf_sdf_smooth (both orientations of every matrix)."""
-    layers = sdf_effective_weights(sd, prefix)
+def sdf_smooth_pack_weights_host(layers):
+    """[(W_l, b_l)] effective matrices -> fp32 image of the SDF network for surf_sdf_smooth (both orientations of every matrix)."""
     sdf_pack_weights_host(layers)  # shape validation only
     Ws = [_host_f32(W) for W, _ in layers]
     bs = [_host_f32(b) for _, b in layers]
@@ -394,7 +393,11 @@ def sdf_smooth_pack_weights(sd, device, prefix="implicit_surface.sdf_network."):
     wp = (ctypes.c_void_p * 7)(*[w.ctypes.data for w in Ws])
     bp = (ctypes.c_void_p * 7)(*[b.ctypes.data for b in bs])
     _lib.check(L.surf_sdf_smooth_pack_weights(wp, bp, _np_ptr(out)), "surf_sdf_smooth_pack_weights")
-    return torch.from_numpy(out).to(device)
+    return out
+
+
+def sdf_smooth_pack_weights(sd, device, prefix="implicit_surface.sdf_network."):
+    return torch.from_numpy(sdf_smooth_pack_weights_host(sdf_effective_weights(sd, prefix))).to(device)
 
 
 def sdf_smooth(pts, volumes, packed, active_idx=None, want_grad=False):

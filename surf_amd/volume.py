@@ -21,8 +21,14 @@ class Volume(nn.Module):
         self.agg_mlp = nn.Sequential(nn.Linear(4, 8), nn.ELU(inplace=True), nn.Linear(8, 1))
 
     def agg_host(self):
-        return np.concatenate([p.detach().to("cpu", torch.float32).numpy().reshape(-1) for p in
-                               (self.agg_mlp[0].weight, self.agg_mlp[0].bias, self.agg_mlp[2].weight, self.agg_mlp[2].bias)])
+        """The 49 floats of agg_mlp (w1 | b1 | w2 | b2) the cost-volume kernels take by value.  ONE device-to-host copy per
+        parameter version (the kernels of all four stages, forward and backward, share it), not four per call."""
+        ps = (self.agg_mlp[0].weight, self.agg_mlp[0].bias, self.agg_mlp[2].weight, self.agg_mlp[2].bias)
+        key = tuple((p._version, p.data_ptr()) for p in ps)
+        if getattr(self, "_agg_cache", None) is None or self._agg_cache[0] != key:
+            flat = torch.cat([p.detach().reshape(-1).float() for p in ps])
+            self._agg_cache = (key, flat.to("cpu").numpy().copy())
+        return self._agg_cache[1]
 
     def stage_inputs(self, stage, D, feats_c2f, cams, parents=None, parent_feats=None, depths=None, depth_range=None, saved=None):
         """up_sample + depth_filtering + back_proj_multiscale + the row selections of surf.py:97-109.

@@ -192,3 +192,42 @@ def test_packed_blend_image_carries_its_precision():
         ops.PackedBlend(raw16, "bf16x3")
     with _pytest.raises(ValueError):
         ops.blend_packed_precision(torch.zeros(17, dtype=torch.uint8))
+
+
+def test_device_packing_is_byte_identical_to_the_host_packers():
+    """surf_amd.packing builds the operand images of the split SDF / blend kernels and the fp32 image of the second-order
+    kernel with torch ops from the live parameters (on the device in production; the same ops on the CPU here).  The C ABI's
+    host packers are the definition: byte identity on random weights, for every split layout, incl. a negative `s`."""
+    import torch
+    from bench import model_conf
+    from surf_amd import ops, packing
+    from surf_amd.implicit_surface import ImplicitSurface
+    torch.manual_seed(3)
+    m = ImplicitSurface(model_conf([64, 32, 16, 16]))
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+        m.color_network.s.fill_(-0.37)
+    sd = dict(m.state_dict())
+    for prec in ("bf16x3", "f16x2"):
+        assert torch.equal(ops.sdf_pack_weights_split(sd, "cpu", "sdf_network.", prec), packing.sdf_pack_split_device(m.sdf_network, prec)), prec
+    assert torch.equal(ops.sdf_smooth_pack_weights(sd, "cpu", "sdf_network."), packing.sdf_pack_smooth_device(m.sdf_network))
+    for prec in ("bf16x3", "f16x2", "f32lds"):
+        a, b = ops.blend_pack_weights(sd, "cpu", "color_network.", prec), packing.blend_pack_split_device(m.color_network, prec)
+        assert b.precision == prec and torch.equal(a.tensor, b.tensor), prec
+    assert torch.equal(packing.blend_raw_device(m.color_network), torch.from_numpy(ops.blend_raw_weights({"implicit_surface.color_network." + k: v
+                       for k, v in m.color_network.state_dict().items()})))
+    assert packing.supported("bf16x3", "bf16x3") and not packing.supported("f32", "bf16x3")
+
+
+def test_agg_mlp_host_copy_is_cached_per_parameter_version():
+    import torch
+    from surf_amd import conf
+    from surf_amd.volume import Volume
+    vol = Volume(conf.from_dict({"base_volume_dim": [8, 8, 8]}))
+    a = vol.agg_host()
+    assert vol.agg_host() is a and a.shape == (49,)
+    with torch.no_grad():
+        vol.agg_mlp[2].bias.add_(1.0)
+    b = vol.agg_host()
+    assert b is not a and abs(float(b[48] - a[48]) - 1.0) < 1e-6
