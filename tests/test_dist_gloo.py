@@ -169,3 +169,45 @@ def test_bench_kills_the_surviving_ranks_when_one_dies():
         assert res.returncode == 1, (workload, res.returncode, res.stderr[-1000:])
         assert "rank exit codes" in res.stderr and "killed" in res.stderr
         assert time.monotonic() - t0 < 60
+
+
+STATE_WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import torch
+    from surf_amd import dist as D
+    rank, local_rank, world = D.init_from_env(backend="gloo")
+    torch.manual_seed(100 + rank)                       # replicas that start DIFFERENT (another seed, or a checkpoint loaded on rank 0 only)
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.BatchNorm1d(7), torch.nn.Linear(7, 2))
+    net(torch.randn(16, 5))                             # moves the BatchNorm running statistics, differently per rank
+    before = float(sum(p.detach().abs().sum() for p in net.parameters()) + sum(b.float().abs().sum() for b in net.buffers()))
+    n_all = D.broadcast_module_state(net, src=0)
+    after = float(sum(p.detach().abs().sum() for p in net.parameters()) + sum(b.float().abs().sum() for b in net.buffers()))
+    with torch.no_grad():
+        net[1].running_mean.add_(float(rank + 1))       # per-rank drift of the buffers during training
+    n_buf = D.broadcast_module_state(net, src=0, buffers_only=True)
+    rm = float(net[1].running_mean.sum())
+    print("RESULT " + json.dumps({"rank": rank, "before": before, "after": after, "n_all": n_all, "n_buf": n_buf, "rm": rm}))
+""") % ROOT
+
+
+def test_broadcast_module_state_makes_replicas_identical(tmp_path):
+    """dist.broadcast_module_state = what DistributedDataParallel does at wrap time (parameters + buffers from rank 0) and at
+    every forward (buffers), for a model that is not wrapped: ranks started from different seeds hold rank 0's state afterwards,
+    BatchNorm running statistics included."""
+    import json
+    script = tmp_path / "state_worker.py"
+    script.write_text(STATE_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(_clean_env(), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                                       MASTER_PORT=str(port))) for r in range(2)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
+    res = sorted((json.loads([ln for ln in o[0].splitlines() if ln.startswith("RESULT ")][-1][7:]) for o in outs), key=lambda r: r["rank"])
+    assert res[0]["before"] != res[1]["before"]
+    assert res[0]["after"] == res[1]["after"] == res[0]["before"]
+    assert res[0]["n_all"] == res[1]["n_all"] == 6 + 3 and res[0]["n_buf"] == 3      # 6 parameters + 3 BatchNorm buffers
+    assert res[0]["rm"] == res[1]["rm"]
