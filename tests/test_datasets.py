@@ -1,7 +1,8 @@
-"""Row f3: dataset readers on synthetic scenes written in the reference's file formats (MVSNet camera / pair files, PFM,
-PNG / JPG, PLY).  The real datasets and cv2 are absent, so agreement with the reference on real files is not pinned; what
-is checked is the file-format handling, the camera algebra (K, R, C recovered from a projection; the unit-sphere
-normalisation re-projects every point onto the same pixel) and the `ipts` contract (keys, shapes, ray geometry)."""
+"""Row f3: dataset readers.  Pinned against the reference's own readers: tests/golden/dataset_items.npz holds what
+datasets/dtu.py's and datasets/tanks.py's `__getitem__` returned for synthetic scenes written in the datasets' file formats
+(tests/golden/make_golden_dataset.py; cv2.resize, cv2.decomposeProjectionMatrix and plyfile stood in for).  Also checked on their
+own: the file-format handling (MVSNet camera / pair files, PFM, PNG / JPG, PLY), the camera algebra (K, R, C recovered from a
+projection; the unit-sphere normalisation re-projects every point onto the same pixel) and the `ipts` contract."""
 import os
 
 import numpy as np
@@ -65,49 +66,19 @@ def test_pfm_pair_cam_and_ply_files(tmp_path):
     assert np.array_equal(mvs_io.read_ply_points(tmp_path / "a.ply"), [[1, 2, 3], [4, 5, 6]])
 
 
-def _ring_cams(n, radius=600.0):
-    cams = []
-    for i in range(n):
-        a = 0.25 * (i - n // 2)
-        o = np.array([radius * np.sin(a), 20.0 * i, -radius * np.cos(a)])
-        z = -o / np.linalg.norm(o)
-        x = np.cross([0, 1.0, 0], z)
-        x /= np.linalg.norm(x)
-        y = np.cross(z, x)
-        c2w = np.eye(4)
-        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = x, y, z, o
-        cams.append(np.linalg.inv(c2w))
-    return cams
+from tests.golden.dtu_scene import ring_cams as _ring_cams  # noqa: E402
+from tests.golden.dtu_scene import write_dtu_scene
 
 
 def _write_cam(path, w2c, K, dmin, dint):
-    rows = "\n".join(" ".join(f"{v:.8f}" for v in r) for r in w2c)
-    krows = "\n".join(" ".join(f"{v:.8f}" for v in r) for r in K)
-    path.write_text(f"extrinsic\n{rows}\n\nintrinsic\n{krows}\n\n{dmin} {dint}\n")
+    from tests.golden.dtu_scene import write_cam
+    write_cam(str(path), w2c, K, dmin, dint)
 
 
 @pytest.fixture()
 def dtu_dir(tmp_path):
-    g = np.random.default_rng(5)
     root = tmp_path / "dtu"
-    for sub in ("Cameras", "Rectified_raw/scan24", "Depths_raw/scan24", "Pseudo_depths/scan24", "Pseudo_points"):
-        os.makedirs(root / sub)
-    K = np.array([[2892.33, 0, 823.2], [0, 2883.18, 619.07], [0, 0, 1.0]])
-    cams = _ring_cams(5)
-    for v, w2c in enumerate(cams):
-        _write_cam(root / "Cameras" / f"{v:08d}_cam.txt", w2c, K, 425.0, 2.5)
-        Image.fromarray((g.random((60, 80, 3)) * 255).astype(np.uint8)).save(root / "Rectified_raw/scan24" / f"rect_{v + 1:03d}_3_r5000.png")
-        mask = np.zeros((60, 80), np.uint8)
-        mask[10:50, 20:70] = 255
-        Image.fromarray(mask).save(root / "Depths_raw/scan24" / f"depth_visual_{v:04d}.png")
-        mvs_io.write_pfm(root / "Depths_raw/scan24" / f"depth_map_{v:04d}.pfm", 500 + 100 * g.random((60, 80)).astype(np.float32))
-        mvs_io.write_pfm(root / "Pseudo_depths/scan24" / f"{v:08d}.pfm", 500 + 100 * g.random((60, 80)).astype(np.float32))
-    (root / "Cameras" / "pair.txt").write_text("5\n" + "".join(
-        f"{r}\n4 " + " ".join(f"{s} 1.0" for s in range(5) if s != r) + "\n" for r in range(5)))
-    with open(root / "Pseudo_points" / "mvsnet024_l3.ply", "w") as f:
-        f.write("ply\nformat ascii 1.0\nelement vertex 3000\nproperty float x\nproperty float y\nproperty float z\nend_header\n")
-        for p in g.standard_normal((3000, 3)) * 50:
-            f.write(" ".join(f"{v:.5f}" for v in p) + "\n")
+    K, cams = write_dtu_scene(str(root))
     return root, K, cams
 
 
@@ -194,3 +165,57 @@ def test_tanks_item(tmp_path):
     assert float(it["masks"].min()) == 1.0 and float(it["depth_ref"].abs().max()) == 0.0
     with pytest.raises(NotImplementedError):
         get_loader(conf.from_dict({"dataset_name": "BMVSDataset"}), "val", False)
+
+
+def _compare_with_reference_item(item, gold, tag):
+    want_keys = {k.split("/")[1] for k in gold if k.startswith(tag + "/") and not k.startswith(tag + "/str/")}
+    want_strs = {k.split("/")[2]: k.split("/")[3] for k in gold if k.startswith(tag + "/str/")}
+    assert set(item) == want_keys | set(want_strs), set(item) ^ (want_keys | set(want_strs))
+    for k, v in want_strs.items():
+        assert item[k] == v
+    for k in sorted(want_keys):
+        ref, got = gold[f"{tag}/{k}"], item[k]
+        if not torch.is_tensor(got):
+            assert int(got) == int(ref), k
+            continue
+        assert got.dtype == ref.dtype and tuple(got.shape) == tuple(ref.shape), (k, got.dtype, ref.dtype, got.shape, ref.shape)
+        if got.dtype.is_floating_point:
+            assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6 * float(ref.abs().max() + 1)), (k, float((got - ref).abs().max()))
+        else:
+            assert torch.equal(got, ref), k
+
+
+@pytest.mark.parametrize("mode", ["val", "train"])
+def test_dtu_reader_equals_the_reference_reader(tmp_path, mode):
+    """Row f3 against the REFERENCE itself: tests/golden/dataset_items.npz holds what datasets/dtu.py's own
+    `DTUDataset.__getitem__` returned for the synthetic scene of tests/golden/dtu_scene.py (generated in the build container by
+    tests/golden/make_golden_dataset.py; cv2.resize / cv2.decomposeProjectionMatrix / plyfile stood in for, everything else the
+    reference's code).  surf_amd's reader, same files, same seeds: every tensor of the dictionary - cameras after the unit-sphere
+    normalisation, near / far, the seeded pixel draws, rays, colours / depths at the pixels, pseudo points - equals it, keys
+    and dtypes included."""
+    from tests.conftest import load_npz
+    from tests.golden.dtu_scene import DATASET_CONF, SEEDS
+    gold = load_npz("dataset_items.npz")
+    root = tmp_path / "dtu"
+    write_dtu_scene(str(root))
+    extra = {} if mode == "val" else {"n_rays": 96}
+    ds = DTUDataset(conf.from_dict(dict(DATASET_CONF, data_dir=str(root), **extra)), mode)
+    np.random.seed(SEEDS["numpy"])
+    torch.manual_seed(SEEDS["torch"])
+    _compare_with_reference_item(ds[0], gold, mode)
+
+
+@pytest.mark.parametrize("mode", ["val", "train"])
+def test_tanks_reader_equals_the_reference_reader(tmp_path, mode):
+    """The same for datasets/tanks.py's `TanksDataset.__getitem__` (BASELINE configs[4]'s reader): views with and without a mask
+    file, zero depths, the fixed src_idx."""
+    from tests.conftest import load_npz
+    from tests.golden.dtu_scene import SEEDS, TANKS_CONF, write_tanks_scene
+    gold = load_npz("dataset_items.npz")
+    root = tmp_path / "tnt"
+    write_tanks_scene(str(root))
+    extra = {} if mode == "val" else {"n_rays": 64}
+    ds = TanksDataset(conf.from_dict(dict(TANKS_CONF, data_dir=str(root), **extra)), mode)
+    np.random.seed(SEEDS["numpy"])
+    torch.manual_seed(SEEDS["torch"])
+    _compare_with_reference_item(ds[0], gold, "tanks_" + mode)
