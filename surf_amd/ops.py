@@ -424,7 +424,7 @@ def sdf_smooth(pts, volumes, packed, active_idx=None, want_grad=False):
 
 def sdf_backward(pts, ybar, gbar, volumes, packed, want_dvols=True):
     """Gradients of sum_n (ybar_n sdf_n + gbar_n . grad_n) w.r.t. the EFFECTIVE (weight-normed) matrices / biases of
-    lin0..lin6 and the sparse feature rows (surf_sdf_backward; the batch reductions are rocBLAS GEMMs through torch.matmul).
+    lin0..lin6 and the sparse feature rows (surf_sdf_backward; the batch reductions dW = adj^T in are surf_colgram_p: matrix cores).
     packed: sdf_smooth_pack_weights.  Returns {"weight": [7 tensors shaped like W_l], "bias": [7], "volumes": [per level (N_s,8)]}."""
     _chk(pts, torch.float32, "pts")
     _chk(ybar, torch.float32, "ybar")
@@ -533,7 +533,7 @@ _BLEND_LAYERS = [  # (state_dict prefix, in, out, IN column, ADJ column) of surf
 
 def blend_backward(pts, active_idx, gcolor, feats_t4, imgs_t4, cams, raw_weights, want_color=False, gfeats_t4=None):
     """Gradients of sum_n gcolor_n . colour_n w.r.t. the blending network's parameters (surf_blend_backward; the batch
-    reductions are small GEMMs through torch.matmul).  raw_weights: device tensor of blend_raw_weights(sd).
+    reductions are surf_colgram_p: matrix cores).  raw_weights: device tensor of blend_raw_weights(sd) (packing.blend_raw_device).
     gfeats_t4: four texel4 maps shaped like feats_t4 that accumulate the gradient of the sampled feature channels.
     Returns {state_dict name: gradient} (+ "_color": the recomputed colours of the active samples, if asked)."""
     _chk(pts, torch.float32, "pts")
