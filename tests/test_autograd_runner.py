@@ -405,3 +405,41 @@ def test_a_batch_that_misses_the_volume_still_trains(scene, weights, golden_fpn,
     loss.backward()
     g = isurf.sdf_network.lin0.weight_v.grad
     assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+
+
+def test_module_swap_feature_maps_receive_the_colour_paths_gradient(scene, weights, golden_fpn, golden_pipe):
+    """INTEGRATION.md 1 with a trainable FPN upstream: the NCHW feature maps the caller passes in (with autograd history) get the
+    blending network's share of the gradient back - the texel4 maps of surf_blend_backward, re-laid out - equal to what the
+    explicit chain (ImplicitSurface.backward_render with gfeats_t4) accumulates for the same upstream gradient."""
+    from bench import model_conf
+    from surf_amd.implicit_surface import ImplicitSurface
+    d = dev()
+    isurf = ImplicitSurface(model_conf(CFG["n_samples"], "f32")).train()
+    isurf.load_state_dict({k[len("implicit_surface."):]: v for k, v in weights.items() if k.startswith("implicit_surface.")})
+    isurf = isurf.to(d)
+    vols, tabs, masks, mvol = pipeline_views(golden_pipe)
+    vols_d = [v.to(d) for v in vols]
+    feats = [golden_fpn[f"out{i}"].to(d).clone().requires_grad_(True) for i in range(4)][::-1]
+    ipts = {k: (v.to(d) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    g = torch.Generator().manual_seed(9)
+    gc = torch.randn(scene["rays_o"].shape[0], 3, generator=g).to(d)
+    torch.manual_seed(0)
+    outs = isurf("train", ipts, mvol.to(d)[None, None], vols_d, [t.to(d) for t in tabs], [m.to(d) for m in masks], feats, feats, 1.0, 3)
+    (outs["color_fine"] * gc).sum().backward()
+    got = [f.grad for f in feats]
+    assert all(x is not None and float(x.abs().max()) > 0 for x in got)
+    # the explicit chain on an identical forward
+    with torch.no_grad():
+        torch.manual_seed(0)
+        sc = isurf.scene(mvol.to(d)[None, None], vols_d, [t.to(d) for t in tabs], None, [f.detach() for f in feats], ipts["imgs"],
+                         ipts["intrs"], ipts["c2ws"])
+        R = scene["rays_o"].shape[0]
+        isurf.render_scene(ipts["rays_o"], ipts["rays_d"], ipts["near"].repeat(R, 1), ipts["far"].repeat(R, 1), sc, 1.0,
+                           patch_warp=True, step=3)
+        gf = [torch.zeros_like(f) for f in sc.feats_t4]
+        for p_ in isurf.parameters():
+            p_.grad = None
+        isurf.backward_render(gc, gfeats_t4=gf)
+    for a, b in zip(got, gf):
+        ref = b.permute(0, 3, 1, 2)
+        rel_close(a, ref, 1e-4, 1e-5 * float(ref.abs().max()), "feature map gradient")
