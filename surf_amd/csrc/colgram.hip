@@ -104,10 +104,11 @@ typedef uint32_t cg_u32x4 __attribute__((ext_vector_type(4)));
 template <int NP>
 struct CgFrag { cg_u32x4 p[NP]; };
 
-template <int NP>
-__device__ __forceinline__ void cg_load_frag(const float* __restrict__ base, int ld, int64_t row0, int64_t row_end, int col, int ncols,
-                                             bool ones_col, int h, CgFrag<NP>& f) {
-  float v[8];
+// raw loads of one fragment (eight rows of this lane's column) and their conversion are separate steps, so that the loads of
+// k-step i + 1 are in flight while k-step i is split and multiplied (a wave runs only ~15 k-steps on a 60 K-row batch: without
+// the overlap every step exposed a full memory latency)
+__device__ __forceinline__ void cg_load_raw(const float* __restrict__ base, int ld, int64_t row0, int64_t row_end, int col, int ncols,
+                                            bool ones_col, int h, float (&v)[8]) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int64_t r = row0 + 8 * h + j;
@@ -118,6 +119,9 @@ __device__ __forceinline__ void cg_load_frag(const float* __restrict__ base, int
     }
     v[j] = x;
   }
+}
+template <int NP>
+__device__ __forceinline__ void cg_make_frag(const float (&v)[8], CgFrag<NP>& f) {
 #pragma unroll
   for (int pr = 0; pr < 4; ++pr) {
     if (NP == 3) {
@@ -149,16 +153,28 @@ __global__ __launch_bounds__(256) void colgram_mfma_kernel(const float* __restri
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float va[8], vx[NT][8];
+  cg_load_raw(A, ldA, r0, r1, 32 * mt + c, M, false, h, va);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    if (32 * t < NX) cg_load_raw(X, ldX, r0, r1, 32 * t + c, N, with_sum != 0, h, vx[t]);
   for (int64_t rb = r0; rb < r1; rb += 16) {
-    CgFrag<NP> fa;
-    cg_load_frag<NP>(A, ldA, rb, r1, 32 * mt + c, M, false, h, fa);
+    CgFrag<NP> fa, fx[NT];
+    cg_make_frag<NP>(va, fa);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (32 * t < NX) cg_make_frag<NP>(vx[t], fx[t]);
+    if (rb + 16 < r1) {                                         // next step's rows: issued before this step's products
+      cg_load_raw(A, ldA, rb + 16, r1, 32 * mt + c, M, false, h, va);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (32 * t < NX) cg_load_raw(X, ldX, rb + 16, r1, 32 * t + c, N, with_sum != 0, h, vx[t]);
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       if (32 * t < NX) {                                        // (uniform)
-        CgFrag<NP> fx;
-        cg_load_frag<NP>(X, ldX, rb, r1, 32 * t + c, N, with_sum != 0, h, fx);
 #define CG_MF(x, y) \
-  acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cg_bf16x8, fa.p[x]), __builtin_bit_cast(cg_bf16x8, fx.p[y]), acc[t], 0, 0, 0)
+  acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(cg_bf16x8, fa.p[x]), __builtin_bit_cast(cg_bf16x8, fx[t].p[y]), acc[t], 0, 0, 0)
         if (NP == 3) {
           CG_MF(2 % NP, 0); CG_MF(0, 2 % NP); CG_MF(1 % NP, 1 % NP); CG_MF(1 % NP, 0); CG_MF(0, 1 % NP); CG_MF(0, 0);
         } else {

@@ -147,19 +147,22 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgArgs a) {
 template <int CIN, int COUT>
 struct ThinCfg {
   static constexpr int TS = CIN <= 16 ? 128 : 64;       // sites per tile (C_in = 32: the row cache holds fewer rows)
-  static constexpr int NB = (CIN / 4) * (COUT / 2);
+  // register block of a (offset, block) pair: 4 input x BC output channels.  4 x 4 where that still gives most threads a pair
+  // (one LDS index + two 16-byte reads per 16 FMAs), 4 x 2 otherwise (<8,8>: 108 pairs of 4 x 4 would idle 148 threads)
+  static constexpr int BC = (COUT % 4 == 0 && 27 * (CIN / 4) * (COUT / 4) >= 200) ? 4 : 2;
+  static constexpr int NB = (CIN / 4) * (COUT / BC);
   static constexpr int NPAIR = 27 * NB;
   static constexpr int PER = (NPAIR + 255) / 256;
   static constexpr int CAP = CIN <= 16 ? 512 : 320;     // distinct neighbour rows cached per tile
   static constexpr int HS = 2048;                       // hash slots (>= the distinct rows of any realistic tile)
-  static constexpr int XS = CIN + 4, DS = COUT + 2;
+  static constexpr int XS = CIN + 4, DS = COUT + 4;     // padded row strides (16-byte aligned vector reads)
   static constexpr int NJ = (27 * TS + 255) / 256;      // (site, offset) references per thread
 };
 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void spconv_wgrad_thin_kernel(WgArgs a) {
   typedef ThinCfg<CIN, COUT> C;
-  constexpr int TS = C::TS, XS = C::XS, DS = C::DS, CAP = C::CAP, HS = C::HS, PER = C::PER, NJ = C::NJ;
+  constexpr int TS = C::TS, XS = C::XS, DS = C::DS, CAP = C::CAP, HS = C::HS, PER = C::PER, NJ = C::NJ, BC = C::BC;
   __shared__ __attribute__((aligned(16))) float xs[(CAP + 1) * XS];   // row CAP = zeros (absent neighbour)
   __shared__ __attribute__((aligned(16))) float ds[TS * DS];
   __shared__ int hkey[HS];
@@ -172,17 +175,19 @@ __global__ __launch_bounds__(256) void spconv_wgrad_thin_kernel(WgArgs a) {
   const int64_t n_tiles = (a.n_out + TS - 1) / TS;
   // this thread's (offset, block) pairs
   int kk[PER], ci0[PER], co0[PER];
-  float acc[PER][4][2];
+  float acc[PER][4][BC];
 #pragma unroll
   for (int e = 0; e < PER; ++e) {
     const int q = p + 256 * e;
     const int qq = q < C::NPAIR ? q : 0;
     kk[e] = qq / C::NB;
     const int blk = qq % C::NB;
-    ci0[e] = (blk / (COUT / 2)) * 4;
-    co0[e] = (blk % (COUT / 2)) * 2;
+    ci0[e] = (blk / (COUT / BC)) * 4;
+    co0[e] = (blk % (COUT / BC)) * BC;
 #pragma unroll
-    for (int qd = 0; qd < 4; ++qd) acc[e][qd][0] = acc[e][qd][1] = 0.f;
+    for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+      for (int r = 0; r < BC; ++r) acc[e][qd][r] = 0.f;
   }
   for (int e = p; e < XS; e += 256) xs[CAP * XS + e] = 0.f;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -287,12 +292,18 @@ __global__ __launch_bounds__(256) void spconv_wgrad_thin_kernel(WgArgs a) {
           const int idx = (int)nbr[kk[e] * TS + t] - base;
           const int ref = (unsigned)idx < (unsigned)CAP ? idx : CAP;        // outside this round's window (or absent): zeros
           const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + ref * XS + ci0[e]);
-          const float d0 = ds[t * DS + co0[e]], d1 = ds[t * DS + co0[e] + 1];
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd) {
-            acc[e][qd][0] = fmaf(xv[qd], d0, acc[e][qd][0]);
-            acc[e][qd][1] = fmaf(xv[qd], d1, acc[e][qd][1]);
+          float dv[BC];
+          if constexpr (BC == 4) {
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(ds + t * DS + co0[e]);
+            dv[0] = d4[0]; dv[1] = d4[1]; dv[2] = d4[2]; dv[3] = d4[3];
+          } else {
+            dv[0] = ds[t * DS + co0[e]];
+            dv[1] = ds[t * DS + co0[e] + 1];
           }
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd)
+#pragma unroll
+            for (int r = 0; r < BC; ++r) acc[e][qd][r] = fmaf(xv[qd], dv[r], acc[e][qd][r]);
         }
       }
       if (total == 0) break;
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(256) void spconv_wgrad_thin_kernel(WgArgs a) {
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd)
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < BC; ++r)
           if (acc[e][qd][r] != 0.f) atomicAdd(dst + (ci0[e] + qd) * COUT + co0[e] + r, acc[e][qd][r]);
     }
   }
