@@ -439,7 +439,11 @@ __device__ __forceinline__ void bilinear_texel4_scatter_coop(float* __restrict__
         for (int dy = 0; dy < 2; ++dy) {
           const int yi = y0 + dy;
           const float v = wxg * (dy ? ty : 1.0f - ty);
+#ifndef SURF_X_CV_NOATOMIC   // timing experiment only (wrong results): how much of costvol_bwd is the scatter
           if ((yi >= 0) & (yi < H) && v != 0.f) atomicAdd(map + ((int64_t)yi * W + xi) * 4 + c, v);
+#else
+          if ((yi >= 0) & (yi < H) && v == 12345.f) map[0] = v;
+#endif
         }
       }
     }
