@@ -66,3 +66,29 @@ def test_config5_seven_views_192_samples():
 
 def test_reference_default_136_samples_five_views():
     _check(*_run(5, 48, 64, [64, 32, 24, 16], 4))
+
+
+def test_bench_train_workload_line_on_one_gpu():
+    """BASELINE configs[3] at reduced size: `python bench.py --workload train` (the data-parallel training step as the bench runs
+    it; N = 1 here, the same code path that DistributedDataParallel wraps for N > 1) prints ONE well-formed line: training rays/s,
+    steps/s, per-kernel rooflines of the backward kernels from HIP events inside the timed region, a finite loss."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "train", "--steps", "2", "--warmup", "1", "--height", "96",
+                          "--width", "128", "--base-dim", "16", "--rays", "128"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["scaling"] == "weak" and r["data"] == "synthetic" and r["unit"] == "rays/s"
+    assert r["config"]["rays_per_rank_step"] == 128 and r["config"]["parallelism"] == "single" and r["config"]["train_precision"] == "fp32"
+    assert abs(r["value"] - 128 * r["steps_per_s"]) < 1e-6 * r["value"] and r["loss"] == r["loss"]
+    names = {e["kernel"] for e in r["roofline_kernels"]}
+    assert {"costvol_bwd", "matching_depth_bwd", "sdf_bwd", "blend_bwd", "colgram"} <= names
+    assert any(n.startswith("spconv_wgrad<") for n in names)
+    top = r["roofline"]
+    assert top is not None and top["bound"] in ("hbm", "valu") and 0 < top["frac"]
