@@ -16,8 +16,8 @@
 // a workgroup (one per SIMD) run in lockstep over an LDS image of it: one chunk = all k-steps x pieces of one 32-row
 // output tile, a ring of three slots filled by LDS-DMA (buffer_load ... lds) two chunks ahead, cyclically across rounds
 // and retired by counted s_waitcnt vmcnt(N) (no scratch-memory spills allowed: see build.sh).
-// Softplus, operand splitting and scratch stores of output tile t are issued between the MFMAs of tile t+1, as a
-// two-stage pipeline across k-steps (softplus of pair q beside the split of pair q-1).
+// Softplus, operand splitting and scratch stores of output tile t are issued between the MFMAs of tile t+1: cut into slots
+// of <= ~24 issue cycles and dealt out over the MFMA gaps by a compile-time plan (sdf_split_common.h, "conversion slots").
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -47,6 +47,8 @@ struct Ctx {
 #endif
   rsrc_t wr, sr, sl, tr;  // packed stream, scratch (stores / loads), fp32 tail
   int lane, lane16, h, svoff, wave;
+  int dma_voff;       // lane * 16 + wave * 1024: this wavefront's 1 KB block of every 4 KB DMA piece
+  uint32_t dma_lds;   // LDS address of the ring + wave * 1024 (made opaque once per round: see the round loop)
   char* lds;    // the ring
   char* lds_s;  // this wavefront's softplus' slices + lane * 16
 };
@@ -62,11 +64,13 @@ template <class P> constexpr int n_dma(int ci) { return (P::CH.ks[ci] * P::NP + 
 template <class P, int NS, int CI>
 __device__ __forceinline__ void stage_dma_piece(const Ctx& c, int k) {  // blocks wave + 4 k of chunk CI
   constexpr int OFF = P::CH.off[CI];
-  // blocks past the end of a chunk read into the next one / out of range (= 0) and land in the unused tail of the slot
-  const int blk = c.wave + 4 * k;
+  // blocks past the end of a chunk read into the next one / out of range (= 0) and land in the unused tail of the slot.
+  // The wave's share of the address sits in the offset VGPR / the per-round LDS base, so that the scalar offset is a
+  // compile-time constant: with `wave` inside it the ~330 distinct offsets of a round were loop-invariant SGPR values that
+  // the compiler hoisted out of the round loop and spilled to VGPR lanes (v_readlane + 5 wait states in front of every DMA).
   __builtin_amdgcn_raw_ptr_buffer_load_lds(
-      c.wr, (__attribute__((address_space(3))) void*)(c.lds + (CI % NS) * slot_bytes<P>() + blk * 1024), 16, c.lane16,
-      OFF + blk * 1024, 0, 0);
+      c.wr, (__attribute__((address_space(3))) void*)(uintptr_t)(c.dma_lds + ((CI % NS) * slot_bytes<P>() + k * 4096)), 16, c.dma_voff,
+      OFF + k * 4096, 0, 0);
 }
 template <class P, int NS, int CI>
 __device__ __forceinline__ void stage_dma(const Ctx& c) {
@@ -131,11 +135,13 @@ __device__ __forceinline__ void stage_barrier() {
   asm volatile("; surf_ring_window %1\n\ts_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N), "n"(P::nslot(GRAD) - 2) : "memory");
 }
 
-// One chunk: NKS k-steps read from its LDS slot; B fragments come from bsel(ks); fn(ks) = VALU work to interleave.
-template <class P, bool GRAD, int CI, int NCH, class BSel, class F>
-__device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F fn) {
+// One chunk: NKS k-steps of P::NM MFMAs read from its LDS slot; B fragments come from bsel(ks).  After MFMA m of k-step ks
+// (gap g = ks * NM + m) come, pinned by a scheduling barrier: the LDS read of piece m of the next k-step's A fragment, the
+// conversion slots the plan PL puts there (slot(s), in order) and the DMA pieces it puts there.
+template <class P, bool GRAD, int CI, int NCH, class PL, class BSel, class F>
+__device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F slot) {
   constexpr int NKS = P::CH.ks[CI];
-  constexpr int NP = P::NP;
+  constexpr int NP = P::NP, NM = P::NM;
   constexpr int NS = P::nslot(GRAD);
   const char* rd = c.lds + (CI % NS) * slot_bytes<P>() + c.lane16;
   typename P::Acc acc;
@@ -144,6 +150,7 @@ __device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F fn) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc.v[q][r] = 0.f;
   constexpr int PF = P::PF;  // A fragments are read PF k-steps ahead of their MFMAs
+  static_assert(PF == 1, "the gap plan places the reads of k-step ks + 1 behind the MFMAs of k-step ks");
   u32x4 a_q[PF + 1][NP];
 #pragma unroll
   for (int d = 0; d < PF; ++d)
@@ -151,105 +158,193 @@ __device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F fn) {
     for (int p = 0; p < NP; ++p)
       if (d < NKS) a_q[d][p] = *reinterpret_cast<const u32x4*>(rd + (d * NP + p) * 1024);
   constexpr int NXT = (CI + NS - 1) % NCH, ND = n_dma<P>(NXT);
+  static_assert(ND <= MAX_DMA && NKS * NM <= MAX_GAPS, "GapPlan sizes");
   if (NKS == 0 && !SURF_X_NODMA) stage_dma<P, NS, NXT>(c);  // padding chunk: nothing to hide the DMA issue behind
   __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    if (ks + PF < NKS) {
-#pragma unroll
-      for (int p = 0; p < NP; ++p)
-        if (!SURF_X_NOLDS) a_q[(ks + PF) % (PF + 1)][p] = *reinterpret_cast<const u32x4*>(rd + ((ks + PF) * NP + p) * 1024);
-    }
-    if (!SURF_X_NOMMA) P::mma(acc, a_q[SURF_X_NOLDS ? 0 : ks % (PF + 1)], bsel(ks));
-    else acc.v[0][ks % 16] += __builtin_bit_cast(float, bsel(ks).p[0][0]) + __builtin_bit_cast(float, a_q[ks % (PF + 1)][0][0]);
-    fn(ks);
-#pragma unroll
-    for (int k = 0; k < ND; ++k)  // this wave's DMA pieces of chunk CI+2, spread over the k-steps behind their MFMAs
-      if (!SURF_X_NODMA && k * NKS / (ND > 0 ? ND : 1) == ks) stage_dma_piece<P, NS, NXT>(c, k);
-#if SURF_SDF_SGB > 0
-    // order of this k-step's instructions: every MFMA is followed by SURF_SDF_SGB VALU operations (conversion work of
-    // the previous tile) and the LDS reads of the next k-step's A pieces, so that the matrix pipe never waits behind a
-    // run of VALU work and the VALU never idles behind a run of dependent MFMAs
-#pragma unroll
-    for (int m = 0; m < (NP == 3 ? 6 : 3); ++m) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, SURF_SDF_SGB, 0);
-      if (m < NP) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  static_for<0, NKS>([&](auto ksc) __attribute__((always_inline)) {
+    constexpr int ks = decltype(ksc)::value;
+    const FragT<NP>& b = bsel(ks);
+    static_for<0, NM>([&](auto mc) __attribute__((always_inline)) {
+      constexpr int m = decltype(mc)::value, g = ks * NM + m;
+      if (!SURF_X_NOMMA) {
+        P::mma_one(acc, a_q[SURF_X_NOLDS ? 0 : ks % (PF + 1)], b, m);
+        // An MFMA is a pure value to the compiler: instruction selection is free to linearise it anywhere between its
+        // operands and its use (it sank whole k-steps below their gaps' scheduling barriers, with the A pieces spilled to
+        // scratch memory meanwhile).  Passing the accumulator through an empty volatile statement ties it to this gap.
+        if (SURF_SDF_PINS & 2) asm volatile("" : "+v"(acc.v[m & (P::NA - 1)]));
+      } else if (m == 0) {
+        acc.v[0][ks % 16] += __builtin_bit_cast(float, b.p[0][0]) + __builtin_bit_cast(float, a_q[ks % (PF + 1)][0][0]);
+      }
+      if constexpr (m < NP && ks + PF < NKS)
+        if (!SURF_X_NOLDS) a_q[(ks + PF) % (PF + 1)][m] = *reinterpret_cast<const u32x4*>(rd + ((ks + PF) * NP + m) * 1024);
+      static_for<PL::v.first[g], PL::v.first[g + 1]>(slot);
+      static_for<0, ND>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (PL::v.dma_gap[k] == g)
+          if (!SURF_X_NODMA) stage_dma_piece<P, NS, NXT>(c, k);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  });
   SURF_T(CI < N_FWD_CHUNKS ? 1 : 3);
   stage_barrier<P, GRAD, CI, NCH>();
   SURF_T(7);
   return P::finish(acc);
 }
+template <class P, bool GRAD, int CI, int NCH> constexpr int chunk_dma() { return n_dma<P>((CI + P::nslot(GRAD) - 1) % NCH); }
 
 
 // ---- forward tile (layer L, tile T) -----------------------------------------------------------------------------------
 // hin/hout: fragments of the 128 hidden activations: index 2*tile + s.  `raw` = pre-activations of the tile finished
-// before this one; they are converted under this tile's MFMAs (two elements per k-step).
+// before this one; they are converted under this tile's MFMAs as two woven streams of mini-phases (sdf_split_common.h,
+// "conversion slots").  Per pair of elements:
+//   u | e = 2^-|u| | 1 + e | log2 | max(t, 0) | h | pack, value, subtract (x NP - 1) | pack: fragment dwords and, every second
+//   pair, the 16-byte store of four exponent arguments u for the reverse sweep
+// and for the tiles of layer 5 (LAST: h feeds lin6's row 0, h' w6 is the reverse sweep's first delta)
+//   u | e | 1 + e | log2 | max | h | y0 += w6 h ( | 1 / (1 + e) | t >= 0 ? 1 : e | h' w6 | split as above ).
+template <class P, bool GRAD, bool LAST>
+constexpr MiniProg fwd_prog() {
+  constexpr int scale = Scales<P>::W != 1.0f ? 8 : 0;
+  MiniProg mp{};
+  mini_add(mp, K_ARG, 0, 8);
+  mini_add(mp, K_EXP, 0, 16);
+  mini_add(mp, K_ADD1, 0, 8);
+  mini_add(mp, K_LOG, 0, 16);
+  mini_add(mp, K_MAX, 0, 8 + scale);
+  mini_add(mp, K_FMA, 0, 8);
+  if (LAST) {
+    mini_add(mp, K_Y0, 0, 8);
+    if (GRAD) {
+      mini_add(mp, K_RCP, 0, 16);
+      mini_add(mp, K_SEL, 0, 16);
+      mini_add(mp, K_SIG, 0, 16);
+      mini_add_split(mp, P::NP);
+    }
+  } else {
+    mini_add_split(mp, P::NP);
+  }
+  return mp;
+}
+template <class P, bool GRAD, int L, int T>
+struct FwdPlan {
+  static constexpr int CI = fwd_chunk(L, T), NKS = P::CH.ks[CI], NG = NKS * P::NM;
+  static constexpr bool LAST = (L == 5 && T > 0), CONV = !(L == 0 && T == 0);
+  static constexpr MiniProg mini = fwd_prog<P, GRAD, LAST>();
+  static constexpr SlotProg prog = CONV ? weave(mini, 8, (GRAD && !LAST) ? 8 : 0) : SlotProg{};
+  // T == 0 (L >= 1) converts tile 3 of the layer below into hin[6] (pairs 0..3) and hin[7], which this very chunk multiplies
+  // in its last two k-steps (layer 3, 101 inputs: hin[6] in the last one, hin[7] not at all)
+  static constexpr int DEADLINE = (T == 0 && L >= 1) ? (NKS - 1) * P::NM : NG;
+  static constexpr GapPlan v = plan_gaps(NKS, P::NM, P::NP, chunk_dma<P, GRAD, CI, n_chunks<P>(GRAD)>(), DEADLINE, prog);
+  static_assert(!(T == 0 && L >= 1) || pair_done_gap(v, prog, 3, NG) < (fwd_nl(L) + 6) * P::NM, "hin[6] is multiplied before it is complete");
+};
 template <class P, bool GRAD, int L, int T>
 __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>* hin, FragT<P::NP>* hout,
                                          const FragT<P::NP> (&ef)[2], const FragT<P::NP> (&pf)[2], FragT<P::NP>* dfr,
                                          float& y0) {
   typedef FragT<P::NP> Frag;
+  typedef FwdPlan<P, GRAD, L, T> PL;
   constexpr int CI = fwd_chunk(L, T);
   constexpr int NEk = fwd_ne(L), NL = fwd_nl(L);
-  constexpr bool LAST = (L == 5 && T > 0);          // previous tile belongs to layer 5: feeds lin6 row 0 directly
-  constexpr bool CONV = !(L == 0 && T == 0);         // there is a previous tile to convert
+  constexpr bool LAST = PL::LAST;  // previous tile belongs to layer 5: feeds lin6 row 0 directly
+  constexpr bool CONV = PL::CONV;  // there is a previous tile to convert
   constexpr int STORES = (GRAD && CONV && !LAST) ? 4 : 0;
+  constexpr float inv_w = 1.0f / Scales<P>::W;
+  // destination of the converted tile: (L, T - 1) in hout, or for T == 0 tile 3 of the layer below in hin
+  constexpr int dst_tile = T == 0 ? 3 : T - 1, s_layer = T == 0 ? L - 1 : L;
+  Frag* const dst = LAST ? dfr : ((T == 0 && L > 0) ? hin : hout);
   const f32x16 prev = raw;
   f32x4 w6[4];
   if (LAST) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) w6[g] = bload(c.tr, c.h * 256, (TAIL_W6H * 4) + ((T - 1) * 4 + g) * 16);
   }
-  f32x4 sbuf = {0.f, 0.f, 0.f, 0.f};
-  // element pair (2q, 2q+1) of the previous tile, in two stages so that two independent dependency chains (the
-  // transcendental chain of pair q and the split chain of pair q-1) are available to interleave with each k-step's MFMAs
-  f32x2 pend_h = {0.f, 0.f}, pend_s = {0.f, 0.f};
-  auto stage_a = [&](int q) __attribute__((always_inline)) {
-    const f32x2 t2 = {prev[2 * q], prev[2 * q + 1]};
-    softplus_pair<GRAD>(t2, 1.0f / Scales<P>::W, pend_h, pend_s);
-  };
-  auto stage_b = [&](int q, Frag* dst, int dst_tile, int s_layer) __attribute__((always_inline)) {
-    const f32x2 hv = pend_h, sv = pend_s;
-    const int el = 2 * q;
-    if (LAST) {
-      const float w0 = w6[el >> 2][el & 3], w1 = w6[(el + 1) >> 2][(el + 1) & 3];
-      y0 = fmaf(w0, hv[0], y0);
-      y0 = fmaf(w1, hv[1], y0);
-      if (GRAD)
-        frag_set_pair<P>(dfr[2 * dst_tile + (el >> 3)], (el & 7) >> 1, sv[0] * (w0 * Scales<P>::D), sv[1] * (w1 * Scales<P>::D));
-    } else {
-      frag_set_pair<P>(dst[2 * dst_tile + (el >> 3)], (el & 7) >> 1, hv[0], hv[1]);
-      sbuf[el & 3] = sv[0];
-      sbuf[(el & 3) + 1] = sv[1];
-      if (GRAD && (el & 3) == 2) {
-        const int ls = lds_slice<P>(s_layer, dst_tile);  // (compile-time at every call site)
-        if (ls >= 0) *reinterpret_cast<f32x4*>(c.lds_s + ls * 4096 + (el >> 2) * 1024) = sbuf;
-        else bstore(c.sr, c.svoff, s_layer * 16384 + (dst_tile * 4 + (el >> 2)) * 1024, sbuf);
+  f32x4 sbuf[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // exponent arguments of pairs (4k, 4k + 1) / (4k + 2, 4k + 3)
+  MiniState<P::NP> st[2] = {};
+  auto slot = [&](auto sc) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
+    constexpr int q = PL::prog.q[s], j = PL::prog.j[s], kind = PL::mini.kind[j], i = PL::mini.arg[j], el = 2 * q;
+    MiniState<P::NP>& S = st[q & 1];
+    const f32x2 t2 = {prev[el], prev[el + 1]};
+    const f32x2 w2 = {LAST ? w6[el >> 2][el & 3] : 0.f, LAST ? w6[(el + 1) >> 2][(el + 1) & 3] : 0.f};
+    if constexpr (kind == K_ARG) {
+      S.u[0] = t2[0] * (144.269504088896341f * inv_w);  // 100 log2(e) t   (element by element: no packed fp32 beside MFMAs)
+      S.u[1] = t2[1] * (144.269504088896341f * inv_w);
+      slot_pin(S.u);
+    } else if constexpr (kind == K_EXP) {
+      slot_pin(S.u);
+      S.e[0] = SURF_X_NOSOFTPLUS ? S.u[0] : __builtin_amdgcn_exp2f(-__builtin_fabsf(S.u[0]));
+      S.e[1] = SURF_X_NOSOFTPLUS ? S.u[1] : __builtin_amdgcn_exp2f(-__builtin_fabsf(S.u[1]));
+      slot_pin(S.e);
+    } else if constexpr (kind == K_ADD1) {
+      slot_pin(S.e);
+      S.d[0] = S.e[0] + 1.0f;
+      S.d[1] = S.e[1] + 1.0f;
+      slot_pin(S.d);
+    } else if constexpr (kind == K_LOG) {
+      slot_pin(S.d);
+      S.l[0] = SURF_X_NOSOFTPLUS ? S.d[0] : __builtin_amdgcn_logf(S.d[0]);
+      S.l[1] = SURF_X_NOSOFTPLUS ? S.d[1] : __builtin_amdgcn_logf(S.d[1]);
+      slot_pin(S.l);
+    } else if constexpr (kind == K_MAX) {
+      S.m[0] = __builtin_amdgcn_fmed3f(t2[0], 0.0f, 3.0e38f);  // max(t, 0) without the canonicalising extra v_max
+      S.m[1] = __builtin_amdgcn_fmed3f(t2[1], 0.0f, 3.0e38f);
+      if (inv_w != 1.0f) {
+        S.m[0] *= inv_w;
+        S.m[1] *= inv_w;
       }
-    }
-  };
-  auto fn = [&](int ks) __attribute__((always_inline)) {
-    if (L == 0) {
-      if (T > 0 && ks < 2) {  // only two k-steps per tile in layer 0: four pairs each
+      slot_pin(S.m);
+    } else if constexpr (kind == K_FMA) {  // h = max(t, 0) + ln(1 + e) / 100
+      slot_pin(S.l, S.m);
+      S.val[0] = fmaf(S.l[0], 0.69314718055994531f * 0.01f, S.m[0]);
+      S.val[1] = fmaf(S.l[1], 0.69314718055994531f * 0.01f, S.m[1]);
+      slot_pin(S.val);
+      if (!LAST) {
+        sbuf[q >> 1 & 1][el & 3] = S.u[0];
+        sbuf[q >> 1 & 1][(el & 3) + 1] = S.u[1];
+      }
+    } else if constexpr (kind == K_Y0) {
+      slot_pin(S.val);
+      y0 = fmaf(w2[0], S.val[0], y0);
+      y0 = fmaf(w2[1], S.val[1], y0);
+      slot_pin(y0);
+    } else if constexpr (kind == K_RCP) {
+      slot_pin(S.d);
+      S.r[0] = __builtin_amdgcn_rcpf(S.d[0]);
+      S.r[1] = __builtin_amdgcn_rcpf(S.d[1]);
+      slot_pin(S.r);
+    } else if constexpr (kind == K_SEL) {  // h' = (t >= 0 ? 1 : e) / (1 + e)
+      slot_pin(S.e);
+      S.sel[0] = t2[0] >= 0.0f ? 1.0f : S.e[0];
+      S.sel[1] = t2[1] >= 0.0f ? 1.0f : S.e[1];
+      slot_pin(S.sel);
+    } else if constexpr (kind == K_SIG) {
+      slot_pin(S.r, S.sel);
+      S.val[0] = (S.sel[0] * S.r[0]) * (w2[0] * Scales<P>::D);
+      S.val[1] = (S.sel[1] * S.r[1]) * (w2[1] * Scales<P>::D);
+      slot_pin(S.val);
+    } else if constexpr (kind == K_PACK) {
+      slot_pin(S.val);
+      S.pc[i] = SURF_X_NOSPLIT ? __builtin_bit_cast(uint32_t, S.val[i & 1]) : P::pack(S.val);
+      slot_pin(S.pc[i]);
+      if (i == P::NP - 1) {
+        Frag& f = dst[2 * dst_tile + (el >> 3)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          stage_a(4 * ks + u);
-          stage_b(4 * ks + u, hout, T - 1, 0);
+        for (int k = 0; k < P::NP; ++k) f.p[k][(el & 7) >> 1] = S.pc[k];
+        if (GRAD && !LAST && (el & 3) == 2) {
+          const int ls = lds_slice<P>(s_layer, dst_tile);  // (compile-time at every call site)
+          if (ls >= 0) *reinterpret_cast<f32x4*>(c.lds_s + ls * 4096 + (el >> 2) * 1024) = sbuf[q >> 1 & 1];
+          else bstore(c.sr, c.svoff, s_layer * 16384 + (dst_tile * 4 + (el >> 2)) * 1024, sbuf[q >> 1 & 1]);
         }
       }
-    } else {
-      // T == 0: tile 3 of the previous layer; its fragments 6 / 7 are complete after k-steps 4 / 8 and first needed
-      // by hidden k-steps 6 / 7 at positions >= 8 / 9
-      if (ks >= 1 && ks <= 8) {
-        if (T == 0) stage_b(ks - 1, hin, 3, L - 1);
-        else stage_b(ks - 1, hout, T - 1, L);
-      }
-      if (ks < 8) stage_a(ks);  // (a third stage - exp | log, rcp | split - measured no faster)
+    } else if constexpr (kind == K_EXPAND) {
+      slot_pin(S.pc[i]);
+      S.x = SURF_X_NOSPLIT ? S.val : P::expand(S.pc[i]);
+      slot_pin(S.x);
+    } else if constexpr (kind == K_SUB) {
+      slot_pin(S.val, S.x);
+      S.val[0] -= S.x[0];
+      S.val[1] -= S.x[1];
+      slot_pin(S.val);
     }
   };
   auto bsel = [&](int ks) __attribute__((always_inline)) -> const Frag& {
@@ -258,7 +353,7 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
     return hin[ks - NL];
   };
   static_assert((lds_slice<P>(T == 0 ? L - 1 : L, T == 0 ? 3 : T - 1) >= 0 ? 0 : STORES) == vm_post<P, GRAD>(CI) && (LAST ? 4 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
-  raw = run_chunk<P, GRAD, CI, n_chunks<P>(GRAD)>(c, bsel, fn);
+  raw = run_chunk<P, GRAD, CI, n_chunks<P>(GRAD), PL>(c, bsel, slot);
 }
 
 template <class P, bool GRAD, int L>
@@ -289,41 +384,88 @@ __device__ __forceinline__ void load_sprime(const Ctx& c, int layer, int tile, f
     else dst[g] = bload_scratch(c.sl, c.svoff, layer * 16384 + (tile * 4 + g) * 1024);
   }
 }
+// mini-phases of the reverse sweep, per pair of elements of the finished G tile:
+//   2^-u | 1 + 2^-u | 1 / that (= h') | delta = h' G | pack, value, subtract (x NP - 1) | pack: fragment dwords
+template <class P>
+constexpr MiniProg bwd_prog() {
+  MiniProg mp{};
+  mini_add(mp, K_EXPN, 0, 16);
+  mini_add(mp, K_ADD1, 0, 8);
+  mini_add(mp, K_RCP, 0, 16);
+  mini_add(mp, K_MULG, 0, 8 + (Scales<P>::W != 1.0f ? 8 : 0));
+  mini_add_split(mp, P::NP);
+  return mp;
+}
+template <class P, int L, int T, bool CONVERT>
+struct BwdPlan {
+  static constexpr int CI = bwd_chunk(L, T), NKS = P::CH.ks[CI];
+  static constexpr MiniProg mini = bwd_prog<P>();
+  static constexpr SlotProg prog = CONVERT ? weave(mini, 8, 0) : SlotProg{};
+  static constexpr GapPlan v = plan_gaps(NKS, P::NM, P::NP, chunk_dma<P, true, CI, n_chunks<P>(true)>(), NKS * P::NM, prog);
+};
 template <class P, int L, int T, bool CONVERT>
 __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, const BwdPend& prev,
                                            f32x4 (&s_load)[4]) {
   typedef FragT<P::NP> Frag;
+  typedef BwdPlan<P, L, T, CONVERT> PL;
   constexpr int CI = bwd_chunk(L, T);
-  constexpr int NKS = bwd_ks(L);
   constexpr int SL = sprime_layer(P::DEEP, L, T);
   constexpr int NG = SL >= 0 ? sprime_groups(SL, sprime_tile(P::DEEP, L, T)) : 0;
   static_assert((SL >= 0 && lds_slice<P>(SL, sprime_tile(P::DEEP, L, T)) >= 0 ? 0 : NG) + ((L == 0 && P::DEEPJ) ? 12 : 0) == vm_pre<P>(CI),
                 "vmcnt bookkeeping");
   if (SL >= 0) load_sprime<P, NG>(c, SL, sprime_tile(P::DEEP, L, T), s_load);
-  // two stages, as in the forward tiles: the product of pair q and the split of pair q-1 share a k-step
-  f32x2 pend = {0.f, 0.f};
-  auto mul = [&](int q) __attribute__((always_inline)) {
-    const int el = 2 * q;
+  MiniState<P::NP> st[2] = {};
+  auto slot = [&](auto sc) __attribute__((always_inline)) {
+    constexpr int s = decltype(sc)::value;
     constexpr float inv_w = 1.0f / Scales<P>::W;  // G arrives x W_SCALE x D_SCALE, deltas are kept x D_SCALE
-    pend[0] = prev.s[el >> 2][el & 3] * prev.G[el];
-    pend[1] = prev.s[(el + 1) >> 2][(el + 1) & 3] * prev.G[el + 1];
-    if (inv_w != 1.0f) pend = pend * inv_w;
-  };
-  auto put = [&](int q) __attribute__((always_inline)) {
-    const int el = 2 * q;
-    frag_set_pair<P>(dout[2 * (T - 1) + (el >> 3)], (el & 7) >> 1, pend[0], pend[1]);
-  };
-  auto fn = [&](int ks) __attribute__((always_inline)) {
-    if (CONVERT) {
-      if (ks >= 1) put(ks - 1);
-      mul(ks);
-      if (ks == NKS - 1) {  // drain: the last one or two pairs
-        put(ks);
-        if (NKS == 7) { mul(7); put(7); }
+    constexpr int q = PL::prog.q[s], j = PL::prog.j[s], kind = PL::mini.kind[j], i = PL::mini.arg[j], el = 2 * q;
+    MiniState<P::NP>& S = st[q & 1];
+    if constexpr (kind == K_EXPN) {
+      const f32x2 u = {prev.s[el >> 2][el & 3], prev.s[(el + 1) >> 2][(el + 1) & 3]};  // exponent arguments (forward K_ARG)
+      S.e[0] = SURF_X_NOSOFTPLUS ? u[0] : __builtin_amdgcn_exp2f(-u[0]);
+      S.e[1] = SURF_X_NOSOFTPLUS ? u[1] : __builtin_amdgcn_exp2f(-u[1]);
+      slot_pin(S.e);
+    } else if constexpr (kind == K_ADD1) {
+      slot_pin(S.e);
+      S.d[0] = S.e[0] + 1.0f;
+      S.d[1] = S.e[1] + 1.0f;
+      slot_pin(S.d);
+    } else if constexpr (kind == K_RCP) {  // h' = 1 / (1 + 2^-u): see sigma_pair
+      slot_pin(S.d);
+      S.r[0] = SURF_X_NOSOFTPLUS ? S.d[0] : __builtin_amdgcn_rcpf(S.d[0]);
+      S.r[1] = SURF_X_NOSOFTPLUS ? S.d[1] : __builtin_amdgcn_rcpf(S.d[1]);
+      slot_pin(S.r);
+    } else if constexpr (kind == K_MULG) {
+      slot_pin(S.r);
+      S.val[0] = S.r[0] * prev.G[el];
+      S.val[1] = S.r[1] * prev.G[el + 1];
+      if (inv_w != 1.0f) {
+        S.val[0] *= inv_w;
+        S.val[1] *= inv_w;
       }
+      slot_pin(S.val);
+    } else if constexpr (kind == K_PACK) {
+      slot_pin(S.val);
+      S.pc[i] = SURF_X_NOSPLIT ? __builtin_bit_cast(uint32_t, S.val[i & 1]) : P::pack(S.val);
+      slot_pin(S.pc[i]);
+      if (i == P::NP - 1) {
+        Frag& f = dout[2 * (T - 1) + (el >> 3)];
+#pragma unroll
+        for (int k = 0; k < P::NP; ++k) f.p[k][(el & 7) >> 1] = S.pc[k];
+      }
+    } else if constexpr (kind == K_EXPAND) {
+      slot_pin(S.pc[i]);
+      S.x = SURF_X_NOSPLIT ? S.val : P::expand(S.pc[i]);
+      slot_pin(S.x);
+    } else if constexpr (kind == K_SUB) {
+      slot_pin(S.val, S.x);
+      S.val[0] -= S.x[0];
+      S.val[1] -= S.x[1];
+      slot_pin(S.val);
     }
   };
-  return run_chunk<P, true, CI, n_chunks<P>(true)>(c, [&](int ks) __attribute__((always_inline)) -> const Frag& { return din[ks]; }, fn);
+  return run_chunk<P, true, CI, n_chunks<P>(true), PL>(
+      c, [&](int ks) __attribute__((always_inline)) -> const Frag& { return din[ks]; }, slot);
 }
 template <class P, int L, int T>
 __device__ __forceinline__ void bwd_hidden_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, BwdPend& pend) {
@@ -360,10 +502,14 @@ __device__ __forceinline__ void bwd_layer(const Ctx& c, const FragT<P::NP>* din,
 
 // empty chunks at the end of the gradient stream (n_chunks): their only content is the DMA issue and the barrier
 template <class P, int CI>
+struct PadPlan {
+  static constexpr GapPlan v = plan_gaps(0, P::NM, P::NP, chunk_dma<P, true, CI, n_chunks<P>(true)>(), 0, SlotProg{});
+};
+template <class P, int CI>
 __device__ __forceinline__ void pad_chunks(const Ctx& c, const FragT<P::NP>* any) {
   if constexpr (CI < n_chunks<P>(true)) {
-    run_chunk<P, true, CI, n_chunks<P>(true)>(
-        c, [&](int ks) __attribute__((always_inline)) -> const FragT<P::NP>& { return any[0]; }, [&](int) __attribute__((always_inline)) {});
+    run_chunk<P, true, CI, n_chunks<P>(true), PadPlan<P, CI>>(
+        c, [&](int ks) __attribute__((always_inline)) -> const FragT<P::NP>& { return any[0]; }, [&](auto) __attribute__((always_inline)) {});
     pad_chunks<P, CI + 1>(c, any);
   }
 }
@@ -384,6 +530,8 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
   c.lane16 = c.lane * 16;
   c.lds = lds;
   c.lds_s = lds + NS * slot_bytes<P>() + c.wave * (NSL * 4096) + c.lane16;
+  c.dma_voff = c.lane16 + c.wave * 1024;
+  c.dma_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds + c.wave * 1024;
   c.wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, stream_bytes<P>(), 0x00020000);
   c.tr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.packed + stream_bytes<P>()), 0, TAIL_FLOATS * 4, 0x00020000);
   c.sr = __builtin_amdgcn_make_buffer_rsrc((void*)a.scratch, 0, (GRAD && !(SURF_X_NOSCRATCH & 1)) ? 0x7fffffff : 0, 0x00020000);
@@ -405,6 +553,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
   for (int k = 0; k < 8; ++k) c.tacc[k] = 0;
 #endif
   for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
+    asm volatile("" : "+s"(c.dma_lds));  // not loop-invariant: the DMA addresses of a round are formed where they are used
     const int64_t tile = round * WPB + c.wave;
     const int64_t slot0 = tile * TILE + (c.lane & 31);
     const int64_t sc = slot0 < n_pts ? slot0 : n_pts - 1;
@@ -414,27 +563,32 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
 
     Frag ef[2], pf[2];
     float y0 = 0.f;
-    const SinCos3 base = sincos3(px, py, pz);
+    SinCos3 base;
     {
-      float phi[16], e[16];
+      float phi[16];
+      auto posenc = [&]() __attribute__((always_inline)) {
+        float e[16], je_unused[14];
+        base = sincos3(px, py, pz);
+        posenc_half(c.h, px, py, pz, base, e, je_unused, false);
+        e[14] = 1.0f;  // bias k-element (weights carry the bias there, lane half 0 only)
+        local_frags<P>(e, ef);
+      };
       if (SURF_X_NOGATHER) {
 #pragma unroll
         for (int ch = 0; ch < 16; ++ch) phi[ch] = px * (float)ch;
+        posenc();
       } else {
-        gather_features<GRAD>(a, c, px, py, pz, phi);
+        gather_features<GRAD>(a, c, px, py, pz, phi, posenc);
       }
+      f32x4 w6p[4];  // feature part of the last layer (all four loads first: the statements are emitted in source order)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {  // feature part of the last layer
-        const f32x4 w = bload(c.tr, c.h * 64, TAIL_W6P * 4 + g * 16);
+      for (int g = 0; g < 4; ++g) w6p[g] = bload(c.tr, c.h * 64, TAIL_W6P * 4 + g * 16);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          if (4 * g + q < 14) y0 = fmaf(w[q], phi[4 * g + q], y0);
-      }
-      float je_unused[14];
-      posenc_half(c.h, px, py, pz, base, e, je_unused, false);
-      e[14] = 1.0f;  // bias k-element (weights carry the bias there, lane half 0 only)
+          if (4 * g + q < 14) y0 = fmaf(w6p[g][q], phi[4 * g + q], y0);
       phi[14] = 1.0f;
-      local_frags<P>(e, ef);
       local_frags<P>(phi, pf);
     }
     SURF_T(0);
@@ -452,14 +606,17 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
     fwd_layer<P, GRAD, 5>(c, raw, hA, hB, ef, pf, dA, y0);
     SURF_T(1);
     {  // tile 3 of layer 5
+      f32x4 w6t[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) w6t[g] = bload(c.tr, c.h * 256, TAIL_W6H * 4 + (12 + g) * 16);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 w = bload(c.tr, c.h * 256, TAIL_W6H * 4 + (12 + g) * 16);
+        const f32x4 w = w6t[g];
         f32x2 hv[2], sv[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const f32x2 t2 = {raw[4 * g + 2 * q], raw[4 * g + 2 * q + 1]};
-          softplus_pair<GRAD>(t2, 1.0f / Scales<P>::W, hv[q], sv[q]);
+          softplus_pair<GRAD ? 1 : 0>(t2, 1.0f / Scales<P>::W, hv[q], sv[q]);
           y0 = fmaf(w[2 * q], hv[q][0], y0);
           y0 = fmaf(w[2 * q + 1], hv[q][1], y0);
           if (GRAD)
@@ -468,9 +625,9 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
         }
       }
     }
-    y0 += __shfl_xor(y0, 32);
     {
       const f32x4 b6 = bload(c.tr, 0, TAIL_B6 * 4);
+      y0 += __shfl_xor(y0, 32);
       y0 += b6[0];
     }
     if (active && c.h == 0) a.sdf[i] = y0;
@@ -480,11 +637,14 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
       f32x16 accE, accP;
 #pragma unroll
       for (int r = 0; r < 16; ++r) accE[r] = 0.f;
+      {
+        f32x4 w[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 w = bload(c.tr, c.h * 64, TAIL_W6P * 4 + g * 16);
+        for (int g = 0; g < 4; ++g) w[g] = bload(c.tr, c.h * 64, TAIL_W6P * 4 + g * 16);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) accP[4 * g + q] = w[q] * (Scales<P>::W * Scales<P>::D);
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) accP[4 * g + q] = w[g][q] * (Scales<P>::W * Scales<P>::D);
       }
       BwdPend pend = {};
       if (P::DEEP) load_sprime<P>(c, 4, 0, pend.sn);  // slice of the first hidden tile (5, 0)
@@ -703,7 +863,7 @@ int launch(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n,
   a.scratch = (float*)scratch;
   for (int s = 0; s < SURF_MAX_STAGES; ++s) {
     a.vols[s] = s < n_vol ? h_vols[s] : h_vols[0];
-    a.tables[s] = s < n_vol ? h_tables[s] : nullptr;
+    a.tables[s] = s < n_vol ? h_tables[s] : h_tables[0];  // absent levels: a valid address for gather_features' unconditional loads
     a.dims[s] = s < n_vol ? h_dims[s] : 0;
     if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
     if (s < n_vol && h_dims[s] > 1024) return SURF_E_LIMIT;  // 32-bit table indices (gather_features)

@@ -57,7 +57,7 @@ constexpr int TAIL_W6P = TAIL_W6H + 128;  // [h][16]
 constexpr int TAIL_B6 = TAIL_W6P + 32;
 constexpr int TAIL_FLOATS = TAIL_B6 + 4;
 
-// per-wave scratch slot (floats): softplus' of layers 0..4 + feature Jacobian (same layout as sdf_mlp.hip)
+// per-wave scratch slot (floats): softplus exponent arguments of layers 0..4 (sigma_pair) + feature Jacobian
 constexpr int SCR_S = 5 * 16 * 64 * 4;
 constexpr int SCR_J = 12 * 64 * 4;
 constexpr int SCR_SLOT = SCR_S + SCR_J;
@@ -72,6 +72,24 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int NP>
 struct FragT { u32x4 p[NP]; };  // B-operand fragments of a 16-wide k-step: NP pieces x 4 dwords (8 x 16 bit)
+
+// End of a slot: its results exist HERE.  VALU arithmetic is a pure value to the compiler, and instruction selection
+// linearises pure values wherever it likes between operands and use (the scheduling barriers only bind the machine scheduler
+// that runs afterwards): without the pin the tail of a slot drifts into the next gap's slot.
+#ifndef SURF_SDF_PINS
+#define SURF_SDF_PINS 2
+#endif
+#if SURF_SDF_PINS & 1
+__device__ __forceinline__ void slot_pin(f32x2& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void slot_pin(f32x2& a, f32x2& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void slot_pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void slot_pin(uint32_t& v) { asm volatile("" : "+v"(v)); }
+#else
+__device__ __forceinline__ void slot_pin(f32x2&) {}
+__device__ __forceinline__ void slot_pin(f32x2&, f32x2&) {}
+__device__ __forceinline__ void slot_pin(float&) {}
+__device__ __forceinline__ void slot_pin(uint32_t&) {}
+#endif
 
 // ---- precision policies ----------------------------------------------------------------------------------------------
 #ifndef SURF_X_NOGATHER  // timing experiments only (wrong results)
@@ -135,16 +153,25 @@ struct PolBf3 {
     return u;
   }
   static __device__ __forceinline__ void split(float a, float b, uint32_t (&p)[NP]) { surf_split3_bf16(a, b, p); }
+  // The same split as mini-phases (see "conversion slots"): piece = pack(v) (round to nearest even), its exact value back
+  // as two floats, v -= that.
+  static __device__ __forceinline__ uint32_t pack(f32x2 v) { return pack2(v[0], v[1]); }
+  static __device__ __forceinline__ f32x2 expand(uint32_t p) {
+    f32x2 x;
+    x[0] = __builtin_bit_cast(float, p << 16);
+    x[1] = __builtin_bit_cast(float, p & 0xffff0000u);
+    return x;
+  }
+  // MFMA m of a k-step (NM per k-step, smallest terms first): piece of A, piece of B
+  static constexpr int NM = 6;
+  static __device__ __forceinline__ void mma_one(Acc& acc, const u32x4 (&a)[NP], const FragT<NP>& b, int m) {
+    constexpr int X[6] = {2, 0, 1, 1, 0, 0}, Y[6] = {0, 2, 1, 0, 1, 0};
+    acc.v[m & (NA - 1)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[X[m]]), __builtin_bit_cast(bf16x8, b.p[Y[m]]),
+                                                                 acc.v[m & (NA - 1)], 0, 0, 0);
+  }
   static __device__ __forceinline__ void mma(Acc& acc, const u32x4 (&a)[NP], const FragT<NP>& b) {
-#define SURF_MF(q, x, y) \
-  acc.v[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[x]), __builtin_bit_cast(bf16x8, b.p[y]), acc.v[q], 0, 0, 0)
-    SURF_MF(0, 2, 0);  // smallest terms first
-    SURF_MF(NA - 1, 0, 2);
-    SURF_MF(0, 1, 1);
-    SURF_MF(NA - 1, 1, 0);
-    SURF_MF(0, 0, 1);
-    SURF_MF(NA - 1, 0, 0);
-#undef SURF_MF
+#pragma unroll
+    for (int m = 0; m < NM; ++m) mma_one(acc, a, b, m);
   }
   static __device__ __forceinline__ f32x16 finish(const Acc& acc) {
     if (NA == 1) return acc.v[0];
@@ -174,13 +201,20 @@ struct PolH2 {
     p[0] = __builtin_bit_cast(uint32_t, h);
     p[1] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, f16x2));
   }
+  static __device__ __forceinline__ uint32_t pack(f32x2 v) {
+    uint32_t p = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+    asm volatile("" : "+v"(p));
+    return p;
+  }
+  static __device__ __forceinline__ f32x2 expand(uint32_t p) { return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2); }
+  static constexpr int NM = 3;
+  static __device__ __forceinline__ void mma_one(Acc& acc, const u32x4 (&a)[NP], const FragT<NP>& b, int m) {
+    constexpr int X[3] = {1, 0, 0}, Y[3] = {0, 1, 0};
+    acc.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[X[m]]), __builtin_bit_cast(f16x8, b.p[Y[m]]), acc.v[0], 0, 0, 0);
+  }
   static __device__ __forceinline__ void mma(Acc& acc, const u32x4 (&a)[NP], const FragT<NP>& b) {
-#define SURF_MF(x, y) \
-  acc.v[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[x]), __builtin_bit_cast(f16x8, b.p[y]), acc.v[0], 0, 0, 0)
-    SURF_MF(1, 0);
-    SURF_MF(0, 1);
-    SURF_MF(0, 0);
-#undef SURF_MF
+#pragma unroll
+    for (int m = 0; m < NM; ++m) mma_one(acc, a, b, m);
   }
   static __device__ __forceinline__ f32x16 finish(const Acc& acc) { return acc.v[0]; }
 };
@@ -253,7 +287,12 @@ __device__ __forceinline__ void frag_set_pair(FragT<P::NP>& f, int pair /*0..3*/
 // softplus(beta = 100, threshold = 20) and its derivative for a pair of pre-activations given x ACC_SCALE, in the
 // overflow-free form  h = max(t, 0) + log(1 + exp(-|100 t|)) / 100,  h' = (t >= 0 ? 1 : exp(-|100 t|)) / (1 + exp(-|100 t|)),
 // which equals torch's thresholded softplus to fp32 rounding (the linear branch differs from it by < 2^-33 relative).
-template <bool WANT_S>
+// MODE 0: h only.  MODE 1: sv = h'.  MODE 2: sv = u = 100 log2(e) t, the exponent argument: the reverse sweep forms
+// h' = 1 / (1 + 2^-u) from it (sigma_pair) under ITS MFMAs.  The forward tiles are bound by the issue slots of their
+// conversion arithmetic (~42 issue cycles per 32-cycle MFMA with h' formed here, round-3 ISA count), the backward tiles
+// have slots to spare (~22), so the compare / select / reciprocal / multiply of h' move there; the scratch round trip
+// carries u instead of h' (same bytes).
+template <int MODE>
 __device__ __forceinline__ void softplus_pair(f32x2 acc, float acc_scale_inv, f32x2& hv, f32x2& sv) {
   if (SURF_X_NOSOFTPLUS) {
     hv = acc * acc_scale_inv;
@@ -274,30 +313,175 @@ __device__ __forceinline__ void softplus_pair(f32x2 acc, float acc_scale_inv, f3
   if (acc_scale_inv != 1.0f) m = m * acc_scale_inv;
   hv[0] = fmaf(l[0], 0.69314718055994531f * 0.01f, m[0]);
   hv[1] = fmaf(l[1], 0.69314718055994531f * 0.01f, m[1]);
-  if (WANT_S) {
+  if (MODE == 1) {
     f32x2 r, sel;
     r[0] = __builtin_amdgcn_rcpf(d[0]);
     r[1] = __builtin_amdgcn_rcpf(d[1]);
     sel[0] = acc[0] >= 0.0f ? 1.0f : e[0];
     sel[1] = acc[1] >= 0.0f ? 1.0f : e[1];
     sv = sel * r;
+  } else if (MODE == 2) {
+    sv = arg;
   }
 }
+// h' = 1 / (1 + 2^-u) of a stored exponent argument u = 100 log2(e) t (softplus_pair MODE 2).  No branch and no overflow
+// case: u << 0 gives 2^-u = inf and 1 / inf = 0, u >> 0 gives 2^-u = 0 and h' = 1; for u < 0 this is e / (1 + e) with
+// e = 2^u divided through by e, i.e. the same value as MODE 1 to fp32 rounding.
+__device__ __forceinline__ f32x2 sigma_pair(f32x2 u) {
+  if (SURF_X_NOSOFTPLUS) return u;
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(-u[0]);
+  e[1] = __builtin_amdgcn_exp2f(-u[1]);
+  const f32x2 d = e + 1.0f;
+  f32x2 r;
+  r[0] = __builtin_amdgcn_rcpf(d[0]);
+  r[1] = __builtin_amdgcn_rcpf(d[1]);
+  return r;
+}
+
+// ---- conversion slots ------------------------------------------------------------------------------------------------------
+// One wavefront per SIMD issues in order, and an MFMA that follows another within its 32 cycles holds the wave's issue until
+// the matrix pipe is free: only instructions that stand BETWEEN two MFMAs in program order run in the first one's shadow
+// (8 of the 32 cycles are the MFMA's own issue, plain VALU operations cost 4, transcendental ones 8, and so does every
+// `s_nop` the compiler has to put between a result and a use that follows it too closely: MI355X_MICROARCH.md, instruction
+// constants).  Measured on this kernel (round 3, half image): MFMA stream alone 36.3 ms, everything but the MFMAs 36.4 ms,
+// both 63.8 ms when the compiler places the conversion arithmetic (runs of 5-6 bare MFMAs, then clumps of 10-25 VALU
+// operations): the two hardly overlapped.  So the conversion work of a tile (softplus, operand split, stores) is cut into
+// MINI-PHASES of two independent instructions (the same step for the two elements of a pair, 8-16 issue cycles) whose
+// inputs were produced by an earlier mini-phase; the pairs of a tile form two streams (even / odd pairs, the odd one half a
+// pair behind), and a compile-time plan (plan_gaps) deals the woven sequence out over the MFMA gaps of the chunk it hides
+// under - at most one mini-phase of each stream per gap where the chunk is long enough, so that no instruction waits for
+// its neighbour - around the gaps' fixed contents (LDS reads of the next k-step's A pieces, LDS-DMA issue).  run_chunk pins
+// each gap with a scheduling barrier and every mini-phase pins its inputs and results (slot_pin).
+enum MiniKind : int {
+  K_ARG, K_EXP, K_ADD1, K_LOG, K_MAX, K_FMA,  // u = 100 log2(e) t | e = 2^-|u| | d = 1 + e | log2 d | max(t, 0) | h
+  K_Y0, K_RCP, K_SEL, K_SIG,                  // layer 5: y0 += w6 h | 1 / d | (t >= 0 ? 1 : e) | h' w6
+  K_EXPN, K_MULG,                             // reverse sweep: e = 2^-u | delta = G / d
+  K_PACK, K_EXPAND, K_SUB                     // operand split: piece i = pack(v) | its exact value | v -= that
+};
+constexpr int MAX_MINI = 24, MAX_SLOTS = 8 * MAX_MINI;
+struct MiniProg { int n; int kind[MAX_MINI]; int arg[MAX_MINI]; int cost[MAX_MINI]; };
+constexpr void mini_add(MiniProg& mp, int kind, int arg, int cost) {
+  mp.kind[mp.n] = kind; mp.arg[mp.n] = arg; mp.cost[mp.n] = cost; ++mp.n;
+}
+constexpr void mini_add_split(MiniProg& mp, int np) {
+  for (int i = 0; i < np; ++i) {
+    mini_add(mp, K_PACK, i, 4);
+    if (i + 1 < np) { mini_add(mp, K_EXPAND, i, 8); mini_add(mp, K_SUB, i, 8); }
+  }
+}
+// the woven sequence of a tile's `pairs` pairs: slot s = mini-phase j[s] of pair q[s] (stream q & 1)
+struct SlotProg { int n; int q[MAX_SLOTS]; int j[MAX_SLOTS]; int cost[MAX_SLOTS]; };
+constexpr SlotProg weave(MiniProg mp, int pairs, int store_cost) {
+  SlotProg sp{};
+  const int per = (pairs / 2) * mp.n, lag = mp.n | 1;  // stream B starts `lag` half-steps after stream A
+  int ia = 0, ib = 0;
+  while (ia < per || ib < per) {
+    const bool take_a = ib >= per || (ia < per && 2 * ia <= 2 * ib + lag);
+    const int i = take_a ? ia++ : ib++;
+    const int q = 2 * (i / mp.n) + (take_a ? 0 : 1), j = i % mp.n;
+    sp.q[sp.n] = q; sp.j[sp.n] = j;
+    sp.cost[sp.n] = mp.cost[j] + ((j == mp.n - 1 && (q & 1)) ? store_cost : 0);
+    ++sp.n;
+  }
+  return sp;
+}
+
+// Which slots run in which MFMA gap of a chunk.  Gap g = ks * NM + m follows MFMA m of k-step ks.
+constexpr int MAX_GAPS = MAX_KS * 6, MAX_DMA = 12;
+struct GapPlan {
+  int first[MAX_GAPS + 1];  // slots [first[g], first[g + 1]) run in gap g
+  int dma_gap[MAX_DMA];     // gap after which LDS-DMA piece k is issued
+  int cap, per_stream;      // what the plan needed: issue cycles per gap beside the MFMA itself (24 hide completely), mini-phases
+                            // of one stream per gap (1: no instruction of a gap depends on another one of it)
+};
+// nks k-steps of nm MFMAs; np LDS reads (A pieces of the next k-step, 8 cycles with the address copy) follow MFMAs 0..np-1
+// of every k-step but the last; n_dma DMA issues (descriptor offset + M0 + the load: ~12 cycles); slots in order, all of
+// them in gaps < deadline.
+constexpr GapPlan plan_gaps(int nks, int nm, int np, int n_dma, int deadline, SlotProg sp) {
+  GapPlan pl{};
+  const int ng = nks * nm;
+  int fixed[MAX_GAPS + 1] = {};
+  for (int ks = 0; ks + 1 < nks; ++ks)
+    for (int m = 0; m < np && m < nm; ++m) fixed[ks * nm + m] += 8;
+  for (int k = 0; k < n_dma; ++k) {
+    int g = 0;
+    if (ng > 0) g = n_dma <= nks ? ((k * nks) / n_dma) * nm + nm - 1 : (k * ng) / n_dma;
+    pl.dma_gap[k] = g;
+    fixed[g] += 12;
+  }
+  if (deadline > ng) deadline = ng;
+  int at[MAX_SLOTS] = {};
+  int cap = 24, per = 1;
+  for (bool done = sp.n == 0; !done;) {  // fewest mini-phases of one stream per gap first, then the smallest budget
+    for (cap = 24; cap <= 32 + 8 * per && !done; cap += 4) {
+      int g = 0, used = fixed[0], cnt[2] = {0, 0};
+      bool ok = true;
+      for (int s = 0; s < sp.n && ok; ++s) {
+        const int st = sp.q[s] & 1;
+        while ((used + sp.cost[s] > cap || cnt[st] >= per) && g + 1 < deadline) { ++g; used = fixed[g]; cnt[0] = cnt[1] = 0; }
+        if (used + sp.cost[s] > cap || cnt[st] >= per) ok = false;
+        at[s] = g;
+        used += sp.cost[s];
+        ++cnt[st];
+      }
+      done = ok;
+    }
+    if (!done) ++per;
+    else cap -= 4;
+    if (per > MAX_SLOTS) break;
+  }
+  for (int i = 0; i <= ng; ++i) {  // first[i] = number of slots placed in gaps < i
+    int n = 0;
+    for (int q = 0; q < sp.n; ++q) n += at[q] < i ? 1 : 0;
+    pl.first[i] = n;
+  }
+  pl.cap = cap;
+  pl.per_stream = per;
+  return pl;
+}
+// gap in which the last mini-phase of pair q runs
+constexpr int pair_done_gap(const GapPlan& pl, const SlotProg& sp, int q, int ng) {
+  int last = 0;
+  for (int s = 0; s < sp.n; ++s)
+    if (sp.q[s] == q) last = s;
+  int g = 0;
+  while (g < ng && pl.first[g + 1] <= last) ++g;
+  return g;
+}
+
+// compile-time loops: f(IC<LO>{}), ..., f(IC<HI - 1>{}).  (`#pragma unroll` loops whose bounds come out of the plan tables were
+// left as run-time loops over run-time register indices by the unroller.)
+template <int I> struct IC { static constexpr int value = I; };
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (LO < HI) {
+    f(IC<LO>{});
+    static_for<LO + 1, HI>(f);
+  }
+}
+
+// state of one stream of mini-phases
+template <int NP>
+struct MiniState { f32x2 u, e, d, l, m, r, sel, x, val; uint32_t pc[NP]; };
 
 // ---- gather / posenc (identical arithmetic to sdf_mlp.hip) -------------------------------------------------------------
 // Sparse trilinear gather of this lane half's two pyramid levels: phi[7 sl + ch], and (GRAD) the feature Jacobian of each
 // level straight to the wave's scratch slot (6 x 16 B per level: [ch][axis], 21 values + pad) to keep registers free.
-template <bool GRAD, class Ctx>
-__device__ __forceinline__ void gather_features(const SdfArgs& a, const Ctx& c, float px, float py, float pz, float (&phi)[16]) {
+// `mid()` runs between the issue of the row loads and their first use (the caller's positional encoding: a few hundred
+// instructions that need no memory).
+template <bool GRAD, class Ctx, class Mid>
+__device__ __forceinline__ void gather_features(const SdfArgs& a, const Ctx& c, float px, float py, float pz, float (&phi)[16], Mid mid) {
 #pragma unroll
   for (int ch = 0; ch < 16; ++ch) phi[ch] = 0.f;
   int rows[2][8];
   float tx[2], ty[2], tz[2], inv_vs[2];
 #pragma unroll
   for (int sl = 0; sl < 2; ++sl) {
-    const int st = 2 * c.h + sl;
-    const int D = a.dims[st];
-    const int32_t* __restrict__ table = a.tables[st];
+    // (selects between kernel arguments read with compile-time indices: `a.dims[2 * c.h + sl]` is a per-lane global load from
+    // the argument buffer, one more round trip in front of the table -> row chain)
+    const int D = c.h ? a.dims[2 + sl] : a.dims[sl];
+    const int32_t* __restrict__ table = c.h ? a.tables[2 + sl] : a.tables[sl];
     const float vs = 2.0f / ((float)D - 1.0f);
     inv_vs[sl] = 1.0f / vs;
     const float gx = (px + 1.0f) / vs, gy = (py + 1.0f) / vs, gz = (pz + 1.0f) / vs;
@@ -312,28 +496,41 @@ __device__ __forceinline__ void gather_features(const SdfArgs& a, const Ctx& c, 
       ys[d] = min(max(y0 + d, 0), D - 1);
       zs[d] = min(max(z0 + d, 0), D - 1);
     }
+    // unconditional loads (the launcher points the tables of absent levels at a valid one; their rows are discarded here):
+    // a load under `D > 0 ? .. : -1` becomes a branch, and sixteen branches are sixteen serialised round trips
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const unsigned xy = __umul24(__umul24(xs[k >> 2], D) + ys[(k >> 1) & 1], D);
-      rows[sl][k] = D > 0 ? table[xy + zs[k & 1]] : -1;
+      rows[sl][k] = table[D > 0 ? xy + zs[k & 1] : 0u];
     }
   }
 #pragma unroll
+  for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rows[sl][k] = (c.h ? a.dims[2 + sl] : a.dims[sl]) > 0 ? rows[sl][k] : -1;
+  // all 32 row loads of the two levels are in flight before the first of them is used (the kernels are compiled with source-
+  // order instruction selection, see build.sh: the order written here is the order issued)
+  f32x4 f0[2][8], f1[2][8];
+#pragma unroll
   for (int sl = 0; sl < 2; ++sl) {
-#ifdef SURF_GATHER_SEQUENTIAL  // one level's 16 row loads in flight at a time (kernels compiled for 256 registers)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    const float* __restrict__ vol = a.vols[2 * c.h + sl];
-    f32x4 f0[8], f1[8];
+    const float* __restrict__ vol = c.h ? a.vols[2 + sl] : a.vols[sl];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const f32x4* fr = reinterpret_cast<const f32x4*>(vol + (int64_t)max(rows[sl][k], 0) * 8);
-      f0[k] = fr[0];
-      f1[k] = fr[1];
+      f0[sl][k] = fr[0];
+      f1[sl][k] = fr[1];
     }
-    float Jl[24];
+  }
+  mid();
+  // The trilinear sums on explicit pairs of channels (v_pk_mul / v_pk_add_f32: two lanes of a register pair per instruction;
+  // the file is compiled without the SLP vectoriser, which would otherwise also pack the conversion arithmetic between the
+  // MFMAs, where a packed instruction costs ~15 cycles more than two plain ones - scripts/microbench/mfma_issue_model.hip).
+  // Pair p of a row = channels (2p, 2p + 1); channel 7 is the row's padding.
 #pragma unroll
-    for (int q = 0; q < 24; ++q) Jl[q] = 0.f;
+  for (int sl = 0; sl < 2; ++sl) {
+    f32x2 ph[4], Jx[4], Jy[4], Jz[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) ph[p] = Jx[p] = Jy[p] = Jz[p] = f32x2{0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int dx = k >> 2, dy = (k >> 1) & 1, dz = k & 1;
@@ -342,7 +539,7 @@ __device__ __forceinline__ void gather_features(const SdfArgs& a, const Ctx& c, 
       const float wy = dy ? ty[sl] : 1.0f - ty[sl];
       const float wz = dz ? tz[sl] : 1.0f - tz[sl];
       const float w = wx * wy * wz * ok;
-      const float f[7] = {f0[k][0], f0[k][1], f0[k][2], f0[k][3], f1[k][0], f1[k][1], f1[k][2]};
+      const f32x2 fp[4] = {{f0[sl][k][0], f0[sl][k][1]}, {f0[sl][k][2], f0[sl][k][3]}, {f1[sl][k][0], f1[sl][k][1]}, {f1[sl][k][2], f1[sl][k][3]}};
       float cx = 0.f, cy = 0.f, cz = 0.f;
       if (GRAD) {
         cx = ((dx ? 1.0f : -1.0f) * wy * wz) * (inv_vs[sl] * ok);
@@ -350,16 +547,26 @@ __device__ __forceinline__ void gather_features(const SdfArgs& a, const Ctx& c, 
         cz = ((dz ? 1.0f : -1.0f) * wx * wy) * (inv_vs[sl] * ok);
       }
 #pragma unroll
-      for (int ch = 0; ch < 7; ++ch) {
-        phi[7 * sl + ch] += f[ch] * w;
+      for (int p = 0; p < 4; ++p) {
+        ph[p] = ph[p] + fp[p] * w;
         if (GRAD) {
-          Jl[3 * ch + 0] += f[ch] * cx;
-          Jl[3 * ch + 1] += f[ch] * cy;
-          Jl[3 * ch + 2] += f[ch] * cz;
+          Jx[p] = Jx[p] + fp[p] * cx;
+          Jy[p] = Jy[p] + fp[p] * cy;
+          Jz[p] = Jz[p] + fp[p] * cz;
         }
       }
     }
+#pragma unroll
+    for (int ch = 0; ch < 7; ++ch) phi[7 * sl + ch] = ph[ch >> 1][ch & 1];
     if (GRAD) {
+      float Jl[24];
+#pragma unroll
+      for (int ch = 0; ch < 7; ++ch) {
+        Jl[3 * ch + 0] = Jx[ch >> 1][ch & 1];
+        Jl[3 * ch + 1] = Jy[ch >> 1][ch & 1];
+        Jl[3 * ch + 2] = Jz[ch >> 1][ch & 1];
+      }
+      Jl[21] = Jl[22] = Jl[23] = 0.f;
 #pragma unroll
       for (int g = 0; g < 6; ++g) {
         const f32x4 v = {Jl[4 * g], Jl[4 * g + 1], Jl[4 * g + 2], Jl[4 * g + 3]};
