@@ -6,7 +6,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-enum { K_FMA, K_CVT, K_LSHL, K_ANDLIT, K_ANDREG, K_SUB, K_SEQ, K_SEQ_REGMASK, K_EXPLOG };
+enum { K_FMA, K_CVT, K_LSHL, K_ANDLIT, K_ANDREG, K_SUB, K_SEQ, K_SEQ_REGMASK, K_EXPLOG, K_CVTBF, K_CVTBF_SDWA, K_FMAMIX, K_CVTPKF16, K_MED3, K_MUL, K_CNDMASK, K_AND_INPLACE, K_SUB_3OP, K_LSHL_INPLACE, K_FMA_3OP, K_CVT_INPLACE };
 template <int KIND>
 __device__ __forceinline__ void filler(float (&v)[16], unsigned (&u)[16], int n, unsigned mask) {
   const int i = n % 16, j = (n + 5) % 16;
@@ -16,6 +16,18 @@ __device__ __forceinline__ void filler(float (&v)[16], unsigned (&u)[16], int n,
   if (KIND == K_ANDLIT) asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(v[i]) : "v"(u[j]));
   if (KIND == K_ANDREG) asm volatile("v_and_b32 %0, %2, %1" : "=v"(v[i]) : "v"(u[j]), "v"(mask));
   if (KIND == K_SUB) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(v[i]) : "v"(v[j]));
+  if (KIND == K_AND_INPLACE) asm volatile("v_and_b32 %0, %1, %0" : "+v"(u[i]) : "v"(mask));
+  if (KIND == K_LSHL_INPLACE) asm volatile("v_lshlrev_b32 %0, 16, %0" : "+v"(u[i]));
+  if (KIND == K_SUB_3OP) asm volatile("v_sub_f32 %0, %1, %2" : "=v"(v[i]) : "v"(v[j]), "v"(v[(n + 9) % 16]));
+  if (KIND == K_FMA_3OP) asm volatile("v_fma_f32 %0, %1, %2, %2" : "=v"(v[i]) : "v"(v[j]), "v"(v[(n + 9) % 16]));
+  if (KIND == K_CVT_INPLACE) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(v[i]) : "v"(v[j]));
+  if (KIND == K_CVTBF) asm volatile("v_cvt_f32_bf16 %0, %1" : "=v"(v[i]) : "v"(u[j]));
+  if (KIND == K_CVTBF_SDWA) asm volatile("v_cvt_f32_bf16_sdwa %0, %1 src0_sel:WORD_1" : "=v"(v[i]) : "v"(u[j]));
+  if (KIND == K_FMAMIX) asm volatile("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v[i]) : "v"(u[j]));
+  if (KIND == K_CVTPKF16) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(u[i]) : "v"(v[i]), "v"(v[j]));
+  if (KIND == K_MED3) asm volatile("v_med3_f32 %0, %0, 0, %1" : "+v"(v[i]) : "v"(v[j]));
+  if (KIND == K_MUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(v[i]) : "v"(v[j]));
+  if (KIND == K_CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[i]) : "v"(v[j]) : "vcc");
   if (KIND == K_SEQ || KIND == K_SEQ_REGMASK) {  // stage n % 3 of the split of pair (2i, 2i+1), as three mini-phases
     const int st = n % 3, p = (n / 3) % 4;
     float &a = v[2 * p], &b = v[2 * p + 1], &xa = v[8 + 2 * p], &xb = v[9 + 2 * p];
@@ -81,13 +93,18 @@ template <int KIND>
 void sweep(float* out, const char* name) {
   printf("%-28s ns per MFMA gap [fillers only | mfma + fillers]:", name);
 #define ROW(NV) printf("  NV=%d %5.2f|%5.2f", NV, run<NV, KIND, false>(out), run<NV, KIND, true>(out))
-  ROW(0); ROW(2); ROW(3); ROW(4); ROW(5); ROW(6); ROW(8);
+  ROW(0); ROW(2); ROW(4); ROW(6);
 #undef ROW
   printf("\n");
 }
 int main() {
   float* out;
   (void)hipMalloc(&out, 512 * 256 * 4);
+  sweep<K_AND_INPLACE>(out, "v_and_b32 in place");
+  sweep<K_LSHL_INPLACE>(out, "v_lshlrev_b32 in place");
+  sweep<K_CVT_INPLACE>(out, "v_cvt_pk_bf16 in place");
+  sweep<K_SUB_3OP>(out, "v_sub_f32 dst != src");
+  sweep<K_FMA_3OP>(out, "v_fma_f32 dst != src");
   sweep<K_FMA>(out, "v_fma_f32");
   sweep<K_CVT>(out, "v_cvt_pk_bf16_f32");
   sweep<K_LSHL>(out, "v_lshlrev_b32 16");
@@ -97,5 +114,12 @@ int main() {
   sweep<K_SEQ>(out, "split mini-phases (literal)");
   sweep<K_SEQ_REGMASK>(out, "split mini-phases (reg mask)");
   sweep<K_EXPLOG>(out, "v_exp / v_add alternating");
+  sweep<K_CVTBF>(out, "v_cvt_f32_bf16");
+  sweep<K_CVTBF_SDWA>(out, "v_cvt_f32_bf16_sdwa WORD_1");
+  sweep<K_FMAMIX>(out, "v_fma_mix_f32 (f16 hi)");
+  sweep<K_CVTPKF16>(out, "v_cvt_pk_f16_f32");
+  sweep<K_MED3>(out, "v_med3_f32");
+  sweep<K_MUL>(out, "v_mul_f32");
+  sweep<K_CNDMASK>(out, "v_cndmask_b32");
   return 0;
 }

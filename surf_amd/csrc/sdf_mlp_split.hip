@@ -218,10 +218,10 @@ constexpr MiniProg fwd_prog() {
       mini_add(mp, K_RCP, 0, 16);
       mini_add(mp, K_SEL, 0, 16);
       mini_add(mp, K_SIG, 0, 16);
-      mini_add_split(mp, P::NP);
+      mini_add_split(mp, P::NP, P::FUSED_SUB);
     }
   } else {
-    mini_add_split(mp, P::NP);
+    mini_add_split(mp, P::NP, P::FUSED_SUB);
   }
   return mp;
 }
@@ -345,6 +345,8 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
       S.val[0] -= S.x[0];
       S.val[1] -= S.x[1];
       slot_pin(S.val);
+    } else if constexpr (kind == K_SUBP) {
+      S.val = SURF_X_NOSPLIT ? S.val : P::sub_piece(S.val, S.pc[i]);
     }
   };
   auto bsel = [&](int ks) __attribute__((always_inline)) -> const Frag& {
@@ -393,7 +395,7 @@ constexpr MiniProg bwd_prog() {
   mini_add(mp, K_ADD1, 0, 8);
   mini_add(mp, K_RCP, 0, 16);
   mini_add(mp, K_MULG, 0, 8 + (Scales<P>::W != 1.0f ? 8 : 0));
-  mini_add_split(mp, P::NP);
+  mini_add_split(mp, P::NP, P::FUSED_SUB);
   return mp;
 }
 template <class P, int L, int T, bool CONVERT>
@@ -462,6 +464,8 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
       S.val[0] -= S.x[0];
       S.val[1] -= S.x[1];
       slot_pin(S.val);
+    } else if constexpr (kind == K_SUBP) {
+      S.val = SURF_X_NOSPLIT ? S.val : P::sub_piece(S.val, S.pc[i]);
     }
   };
   return run_chunk<P, true, CI, n_chunks<P>(true), PL>(

@@ -162,6 +162,8 @@ struct PolBf3 {
     x[1] = __builtin_bit_cast(float, p & 0xffff0000u);
     return x;
   }
+  static constexpr bool FUSED_SUB = false;  // (no fp32 instruction reads a bf16 half in place)
+  static __device__ __forceinline__ f32x2 sub_piece(f32x2 v, uint32_t p) { return v - expand(p); }
   // MFMA m of a k-step (NM per k-step, smallest terms first): piece of A, piece of B
   static constexpr int NM = 6;
   static __device__ __forceinline__ void mma_one(Acc& acc, const u32x4 (&a)[NP], const FragT<NP>& b, int m) {
@@ -207,6 +209,15 @@ struct PolH2 {
     return p;
   }
   static __device__ __forceinline__ f32x2 expand(uint32_t p) { return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2); }
+  // v - (the two halves of p as floats), one v_fma_mix_f32 per element (an fp32 FMA that reads an fp16 half directly: no
+  // conversion instruction): fma(half, -1, v) is exact in the half and rounds once, like the subtraction it replaces.
+  static constexpr bool FUSED_SUB = true;
+  static __device__ __forceinline__ f32x2 sub_piece(f32x2 v, uint32_t p) {
+    f32x2 r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(p), "v"(v[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r[1]) : "v"(p), "v"(v[1]));
+    return r;
+  }
   static constexpr int NM = 3;
   static __device__ __forceinline__ void mma_one(Acc& acc, const u32x4 (&a)[NP], const FragT<NP>& b, int m) {
     constexpr int X[3] = {1, 0, 0}, Y[3] = {0, 1, 0};
@@ -357,17 +368,19 @@ enum MiniKind : int {
   K_ARG, K_EXP, K_ADD1, K_LOG, K_MAX, K_FMA,  // u = 100 log2(e) t | e = 2^-|u| | d = 1 + e | log2 d | max(t, 0) | h
   K_Y0, K_RCP, K_SEL, K_SIG,                  // layer 5: y0 += w6 h | 1 / d | (t >= 0 ? 1 : e) | h' w6
   K_EXPN, K_MULG,                             // reverse sweep: e = 2^-u | delta = G / d
-  K_PACK, K_EXPAND, K_SUB                     // operand split: piece i = pack(v) | its exact value | v -= that
+  K_PACK, K_EXPAND, K_SUB,                    // operand split: piece i = pack(v) | its exact value | v -= that
+  K_SUBP                                      // ... or both in one where an fp32 instruction reads the packed halves (f16x2)
 };
 constexpr int MAX_MINI = 24, MAX_SLOTS = 8 * MAX_MINI;
 struct MiniProg { int n; int kind[MAX_MINI]; int arg[MAX_MINI]; int cost[MAX_MINI]; };
 constexpr void mini_add(MiniProg& mp, int kind, int arg, int cost) {
   mp.kind[mp.n] = kind; mp.arg[mp.n] = arg; mp.cost[mp.n] = cost; ++mp.n;
 }
-constexpr void mini_add_split(MiniProg& mp, int np) {
+constexpr void mini_add_split(MiniProg& mp, int np, bool fused_sub) {
   for (int i = 0; i < np; ++i) {
     mini_add(mp, K_PACK, i, 4);
-    if (i + 1 < np) { mini_add(mp, K_EXPAND, i, 8); mini_add(mp, K_SUB, i, 8); }
+    if (i + 1 < np && fused_sub) mini_add(mp, K_SUBP, i, 8);
+    if (i + 1 < np && !fused_sub) { mini_add(mp, K_EXPAND, i, 8); mini_add(mp, K_SUB, i, 8); }
   }
 }
 // the woven sequence of a tile's `pairs` pairs: slot s = mini-phase j[s] of pair q[s] (stream q & 1)
