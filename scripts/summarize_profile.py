@@ -6,6 +6,11 @@ import glob
 import os
 import sys
 
+
+def newest(paths):
+    """gpurun merges every call's outputs into the same local directory: take the latest run's file"""
+    return max(paths, key=os.path.getmtime)
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -18,7 +23,7 @@ def ours(name):
     return "(anonymous namespace)::" in name and "at::" not in name and "rocprim" not in name
 
 
-f = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+f = newest(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")))
 rows = list(csv.DictReader(open(f)))
 with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w") as w:
     w.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-seconds 0 --train-step 0   (= the default bench command without its CPU-baseline leg and without the extra training-step timing, whose small launches of the same kernels would dilute the per-kernel averages; MI355X, {tag})\n")
@@ -38,7 +43,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_mfma"):
     fs = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))
     if not fs:
         continue
-    for row in csv.DictReader(open(fs[0])):
+    for row in csv.DictReader(open(newest(fs))):
         k = row["Kernel_Name"]
         if ours(k):
             short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]

@@ -8,6 +8,11 @@ import glob
 import os
 import sys
 
+
+def newest(paths):
+    """gpurun merges every call's outputs into the same local directory: take the latest run's file"""
+    return max(paths, key=os.path.getmtime)
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
@@ -21,7 +26,7 @@ def ours(name):
     return "(anonymous namespace)::" in name and "at::" not in name and "rocprim" not in name
 
 
-f = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+f = newest(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")))
 rows = list(csv.DictReader(open(f)))
 total = sum(int(r["TotalDurationNs"]) for r in rows)
 with open(os.path.join(dst, f"{tag}_train_kernel_stats.csv"), "w") as w:
@@ -45,7 +50,7 @@ for name in ("pmc_fetch", "pmc_write"):
     fs = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))
     if not fs:
         continue
-    for row in csv.DictReader(open(fs[0])):
+    for row in csv.DictReader(open(newest(fs))):
         k = row["Kernel_Name"]
         if ours(k):
             short = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]

@@ -30,7 +30,12 @@ __device__ __forceinline__ uint32_t surf_pack2_bf16(float a, float b) {
   v[0] = (__bf16)a;
   v[1] = (__bf16)b;
   uint32_t u = __builtin_bit_cast(uint32_t, v);
+#ifndef SURF_PACK_PIN
+#define SURF_PACK_PIN 1
+#endif
+#if SURF_PACK_PIN
   asm volatile("" : "+v"(u));  // keep the packed value: the residuals below come from its two halves
+#endif
   return u;
 }
 __device__ __forceinline__ void surf_residual_bf16(uint32_t packed, float a, float b, float& ra, float& rb) {
