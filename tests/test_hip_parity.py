@@ -506,6 +506,27 @@ def test_sdf_split_small_and_ragged_sizes(weights, gpu_scene, precision):
         assert bool((sm[1::2] == 100.0).all()) and bool((gm[1::2] == 0).all())
 
 
+@pytest.mark.parametrize("precision", ["bf16x3", "f16x2"])
+def test_sdf_split_absent_pyramid_levels(weights, gpu_scene, precision):
+    """Fewer than four sparse volumes (the C ABI allows 1..4; absent levels contribute zero features): the split kernels' gather
+    reads its index tables unconditionally and points the absent levels at a valid table - their rows must be discarded, exactly
+    as the fp32-MFMA kernel's `D > 0` select does."""
+    from surf_amd import ops
+    d = dev()
+    w = ops.sdf_pack_weights_split(weights, d, precision=precision)
+    sv = gpu_scene["sv"]
+    g = torch.Generator().manual_seed(9)
+    pts = ((torch.rand(5000, 3, generator=g) * 2 - 1) * 0.9).to(d).contiguous()
+    for n_vol in (1, 2, 3):
+        part = ops.SparseVolumes(sv.vols[:n_vol], sv.tables[:n_vol])
+        s0, g0 = ops.sdf_mlp(pts, part, gpu_scene["sdf_w"])
+        s, gr = ops.sdf_mlp(pts, part, w)
+        rel_close(s, s0, 0, 1e-5)
+        rel_close(gr, g0, 1e-4, 1e-4)
+    full, _ = ops.sdf_mlp(pts, sv, w)
+    assert float((full - s).abs().max()) > 1e-4          # (the fourth level does contribute on this scene)
+
+
 @pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x2"])
 def test_sdf_grid_matches_golden(weights, golden_pipe, golden_grid, precision):
     """Row a16: ImplicitSurface.sdf_grid / extract_geometry's lattice (implicit_surface.py:337-351: linspace axes,
