@@ -94,6 +94,13 @@ template <class P> constexpr int lds_slice(int layer, int tile) {  // index in t
   const int k = (4 - layer) * 4 + tile;
   return (layer <= 4 && layer >= 0 && k < P::LDS_SLICES) ? k : -1;
 }
+// ... and the next P::REG_SLICES of them in registers (RegSlices below): no memory operation at all
+template <class P> constexpr int reg_slice(int layer, int tile) {
+  const int k = (4 - layer) * 4 + tile - P::LDS_SLICES;
+  return (layer <= 4 && layer >= 0 && k >= 0 && k < P::REG_SLICES) ? k : -1;
+}
+template <class P> constexpr bool on_chip(int layer, int tile) { return lds_slice<P>(layer, tile) >= 0 || reg_slice<P>(layer, tile) >= 0; }
+template <class P> struct RegSlices { f32x4 v[P::REG_SLICES > 0 ? P::REG_SLICES : 1][4]; };
 // 16-byte groups of a softplus' slice that are read back: layer 2 has 101 rows, so the second half (k-step 7: rows
 // 112..127) of its tile 3 feeds nothing.  Loading it anyway would leave the loads to dead-code elimination, i.e. leave
 // the number of vector-memory operations of that chunk - which stage_barrier's vmcnt counts - to the optimiser.
@@ -104,7 +111,7 @@ template <class P> constexpr int vm_pre(int ci) {
   int l = 5, t = ci - N_FWD_CHUNKS;
   while (t >= BWD_NT[l]) { t -= BWD_NT[l]; --l; }
   if (l == 0) return P::DEEPJ ? 12 : 0;  // feature Jacobian for the epilogue
-  if (sprime_layer(P::DEEP, l, t) < 0 || lds_slice<P>(sprime_layer(P::DEEP, l, t), sprime_tile(P::DEEP, l, t)) >= 0) return 0;
+  if (sprime_layer(P::DEEP, l, t) < 0 || on_chip<P>(sprime_layer(P::DEEP, l, t), sprime_tile(P::DEEP, l, t))) return 0;
   return sprime_groups(sprime_layer(P::DEEP, l, t), sprime_tile(P::DEEP, l, t));
 }
 template <class P, bool GRAD> constexpr int vm_post(int ci) {
@@ -112,7 +119,7 @@ template <class P, bool GRAD> constexpr int vm_post(int ci) {
   const int l = ci / 4, t = ci % 4;
   if ((l == 0 && t == 0) || (l == 5 && t > 0)) return 0;
   // the slice stored under chunk (l, t): tile 3 of the layer below for t = 0, else (l, t - 1)
-  return lds_slice<P>(t == 0 ? l - 1 : l, t == 0 ? 3 : t - 1) >= 0 ? 0 : 4;
+  return on_chip<P>(t == 0 ? l - 1 : l, t == 0 ? 3 : t - 1) ? 0 : 4;
 }
 // Retire the DMA of chunk CI+1, issued during chunk CI-(NS-2): everything this wave issued in the chunks after that one
 // may stay in flight (operations between rounds are not counted, which only makes the wait stricter; that DMA's pieces are
@@ -240,7 +247,7 @@ struct FwdPlan {
 template <class P, bool GRAD, int L, int T>
 __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>* hin, FragT<P::NP>* hout,
                                          const FragT<P::NP> (&ef)[2], const FragT<P::NP> (&pf)[2], FragT<P::NP>* dfr,
-                                         float& y0) {
+                                         float& y0, RegSlices<P>& keep) {
   typedef FragT<P::NP> Frag;
   typedef FwdPlan<P, GRAD, L, T> PL;
   constexpr int CI = fwd_chunk(L, T);
@@ -331,8 +338,9 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
 #pragma unroll
         for (int k = 0; k < P::NP; ++k) f.p[k][(el & 7) >> 1] = S.pc[k];
         if (GRAD && !LAST && (el & 3) == 2) {
-          const int ls = lds_slice<P>(s_layer, dst_tile);  // (compile-time at every call site)
-          if (ls >= 0) *reinterpret_cast<f32x4*>(c.lds_s + ls * 4096 + (el >> 2) * 1024) = sbuf[q >> 1 & 1];
+          constexpr int ls = lds_slice<P>(s_layer, dst_tile), rs = reg_slice<P>(s_layer, dst_tile);
+          if constexpr (rs >= 0) keep.v[rs][el >> 2] = sbuf[q >> 1 & 1];
+          else if constexpr (ls >= 0) *reinterpret_cast<f32x4*>(c.lds_s + ls * 4096 + (el >> 2) * 1024) = sbuf[q >> 1 & 1];
           else bstore(c.sr, c.svoff, s_layer * 16384 + (dst_tile * 4 + (el >> 2)) * 1024, sbuf[q >> 1 & 1]);
         }
       }
@@ -354,18 +362,18 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
     if (ks < NL) return pf[ks - NEk];
     return hin[ks - NL];
   };
-  static_assert((lds_slice<P>(T == 0 ? L - 1 : L, T == 0 ? 3 : T - 1) >= 0 ? 0 : STORES) == vm_post<P, GRAD>(CI) && (LAST ? 4 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
+  static_assert((on_chip<P>(T == 0 ? L - 1 : L, T == 0 ? 3 : T - 1) ? 0 : STORES) == vm_post<P, GRAD>(CI) && (LAST ? 4 : 0) == vm_pre<P>(CI), "vmcnt bookkeeping");
   raw = run_chunk<P, GRAD, CI, n_chunks<P>(GRAD), PL>(c, bsel, slot);
 }
 
 template <class P, bool GRAD, int L>
 __device__ __forceinline__ void fwd_layer(const Ctx& c, f32x16& raw, FragT<P::NP>* hin, FragT<P::NP>* hout,
                                           const FragT<P::NP> (&ef)[2], const FragT<P::NP> (&pf)[2], FragT<P::NP>* dfr,
-                                          float& y0) {
-  fwd_tile<P, GRAD, L, 0>(c, raw, hin, hout, ef, pf, dfr, y0);
-  fwd_tile<P, GRAD, L, 1>(c, raw, hin, hout, ef, pf, dfr, y0);
-  fwd_tile<P, GRAD, L, 2>(c, raw, hin, hout, ef, pf, dfr, y0);
-  fwd_tile<P, GRAD, L, 3>(c, raw, hin, hout, ef, pf, dfr, y0);
+                                          float& y0, RegSlices<P>& keep) {
+  fwd_tile<P, GRAD, L, 0>(c, raw, hin, hout, ef, pf, dfr, y0, keep);
+  fwd_tile<P, GRAD, L, 1>(c, raw, hin, hout, ef, pf, dfr, y0, keep);
+  fwd_tile<P, GRAD, L, 2>(c, raw, hin, hout, ef, pf, dfr, y0, keep);
+  fwd_tile<P, GRAD, L, 3>(c, raw, hin, hout, ef, pf, dfr, y0, keep);
 }
 
 // ---- backward tiles ----------------------------------------------------------------------------------------------------
@@ -378,11 +386,12 @@ struct BwdPend {
   f32x4 sn[4];  // slice of the tile whose G is being computed now
 };
 template <class P, int NG = 4>
-__device__ __forceinline__ void load_sprime(const Ctx& c, int layer, int tile, f32x4 (&dst)[4]) {
-  const int ls = lds_slice<P>(layer, tile);
+__device__ __forceinline__ void load_sprime(const Ctx& c, int layer, int tile, f32x4 (&dst)[4], const RegSlices<P>& keep) {
+  const int ls = lds_slice<P>(layer, tile), rs = reg_slice<P>(layer, tile);
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    if (ls >= 0) dst[g] = *reinterpret_cast<const f32x4*>(c.lds_s + ls * 4096 + g * 1024);
+    if (rs >= 0) dst[g] = keep.v[rs][g];
+    else if (ls >= 0) dst[g] = *reinterpret_cast<const f32x4*>(c.lds_s + ls * 4096 + g * 1024);
     else dst[g] = bload_scratch(c.sl, c.svoff, layer * 16384 + (tile * 4 + g) * 1024);
   }
 }
@@ -407,15 +416,15 @@ struct BwdPlan {
 };
 template <class P, int L, int T, bool CONVERT>
 __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, const BwdPend& prev,
-                                           f32x4 (&s_load)[4]) {
+                                           f32x4 (&s_load)[4], const RegSlices<P>& keep) {
   typedef FragT<P::NP> Frag;
   typedef BwdPlan<P, L, T, CONVERT> PL;
   constexpr int CI = bwd_chunk(L, T);
   constexpr int SL = sprime_layer(P::DEEP, L, T);
   constexpr int NG = SL >= 0 ? sprime_groups(SL, sprime_tile(P::DEEP, L, T)) : 0;
-  static_assert((SL >= 0 && lds_slice<P>(SL, sprime_tile(P::DEEP, L, T)) >= 0 ? 0 : NG) + ((L == 0 && P::DEEPJ) ? 12 : 0) == vm_pre<P>(CI),
+  static_assert((SL >= 0 && on_chip<P>(SL, sprime_tile(P::DEEP, L, T)) ? 0 : NG) + ((L == 0 && P::DEEPJ) ? 12 : 0) == vm_pre<P>(CI),
                 "vmcnt bookkeeping");
-  if (SL >= 0) load_sprime<P, NG>(c, SL, sprime_tile(P::DEEP, L, T), s_load);
+  if (SL >= 0) load_sprime<P, NG>(c, SL, sprime_tile(P::DEEP, L, T), s_load, keep);
   MiniState<P::NP> st[2] = {};
   auto slot = [&](auto sc) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value;
@@ -472,10 +481,10 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
       c, [&](int ks) __attribute__((always_inline)) -> const Frag& { return din[ks]; }, slot);
 }
 template <class P, int L, int T>
-__device__ __forceinline__ void bwd_hidden_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, BwdPend& pend) {
+__device__ __forceinline__ void bwd_hidden_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, BwdPend& pend, const RegSlices<P>& keep) {
   const BwdPend prev = pend;
   f32x4 s_load[4] = {};
-  const f32x16 G = bwd_tile<P, L, T, (T > 0)>(c, din, dout, prev, s_load);
+  const f32x16 G = bwd_tile<P, L, T, (T > 0)>(c, din, dout, prev, s_load, keep);
   pend.G = G;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -489,18 +498,18 @@ __device__ __forceinline__ void bwd_hidden_tile(const Ctx& c, const FragT<P::NP>
 }
 template <class P, int L>
 __device__ __forceinline__ void bwd_layer(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, f32x16& accE,
-                                          f32x16& accP, BwdPend& pend) {
-  bwd_hidden_tile<P, L, 0>(c, din, dout, pend);
-  bwd_hidden_tile<P, L, 1>(c, din, dout, pend);
-  bwd_hidden_tile<P, L, 2>(c, din, dout, pend);
-  bwd_hidden_tile<P, L, 3>(c, din, dout, pend);
+                                          f32x16& accP, BwdPend& pend, const RegSlices<P>& keep) {
+  bwd_hidden_tile<P, L, 0>(c, din, dout, pend, keep);
+  bwd_hidden_tile<P, L, 1>(c, din, dout, pend, keep);
+  bwd_hidden_tile<P, L, 2>(c, din, dout, pend, keep);
+  bwd_hidden_tile<P, L, 3>(c, din, dout, pend, keep);
   const BwdPend prev = pend;
   if constexpr (L == 3) {
     f32x4 unused[4];
-    accE += bwd_tile<P, L, 4, true>(c, din, dout, prev, unused);
-    accP += bwd_tile<P, L, 5, false>(c, din, dout, prev, pend.sn);
+    accE += bwd_tile<P, L, 4, true>(c, din, dout, prev, unused, keep);
+    accP += bwd_tile<P, L, 5, false>(c, din, dout, prev, pend.sn, keep);
   } else {
-    accP += bwd_tile<P, L, 4, true>(c, din, dout, prev, pend.sn);
+    accP += bwd_tile<P, L, 4, true>(c, din, dout, prev, pend.sn, keep);
   }
 }
 
@@ -599,15 +608,16 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
 
     // ------------------------------------------------ forward ----------------------------------------------------
     Frag hA[8], hB[8], dA[8];
+    RegSlices<P> keep;
     f32x16 raw;
 #pragma unroll
     for (int r = 0; r < 16; ++r) raw[r] = 0.f;
-    fwd_layer<P, GRAD, 0>(c, raw, hA, hA, ef, pf, dA, y0);
-    fwd_layer<P, GRAD, 1>(c, raw, hA, hB, ef, pf, dA, y0);
-    fwd_layer<P, GRAD, 2>(c, raw, hB, hA, ef, pf, dA, y0);
-    fwd_layer<P, GRAD, 3>(c, raw, hA, hB, ef, pf, dA, y0);
-    fwd_layer<P, GRAD, 4>(c, raw, hB, hA, ef, pf, dA, y0);
-    fwd_layer<P, GRAD, 5>(c, raw, hA, hB, ef, pf, dA, y0);
+    fwd_layer<P, GRAD, 0>(c, raw, hA, hA, ef, pf, dA, y0, keep);
+    fwd_layer<P, GRAD, 1>(c, raw, hA, hB, ef, pf, dA, y0, keep);
+    fwd_layer<P, GRAD, 2>(c, raw, hB, hA, ef, pf, dA, y0, keep);
+    fwd_layer<P, GRAD, 3>(c, raw, hA, hB, ef, pf, dA, y0, keep);
+    fwd_layer<P, GRAD, 4>(c, raw, hB, hA, ef, pf, dA, y0, keep);
+    fwd_layer<P, GRAD, 5>(c, raw, hA, hB, ef, pf, dA, y0, keep);
     SURF_T(1);
     {  // tile 3 of layer 5
       f32x4 w6t[4];
@@ -651,12 +661,12 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
           for (int q = 0; q < 4; ++q) accP[4 * g + q] = w[g][q] * (Scales<P>::W * Scales<P>::D);
       }
       BwdPend pend = {};
-      if (P::DEEP) load_sprime<P>(c, 4, 0, pend.sn);  // slice of the first hidden tile (5, 0)
-      bwd_layer<P, 5>(c, dA, hA, accE, accP, pend);
-      bwd_layer<P, 4>(c, hA, dA, accE, accP, pend);
-      bwd_layer<P, 3>(c, dA, hA, accE, accP, pend);
-      bwd_layer<P, 2>(c, hA, dA, accE, accP, pend);
-      bwd_layer<P, 1>(c, dA, hA, accE, accP, pend);
+      if (P::DEEP) load_sprime<P>(c, 4, 0, pend.sn, keep);  // slice of the first hidden tile (5, 0)
+      bwd_layer<P, 5>(c, dA, hA, accE, accP, pend, keep);
+      bwd_layer<P, 4>(c, hA, dA, accE, accP, pend, keep);
+      bwd_layer<P, 3>(c, dA, hA, accE, accP, pend, keep);
+      bwd_layer<P, 2>(c, hA, dA, accE, accP, pend, keep);
+      bwd_layer<P, 1>(c, dA, hA, accE, accP, pend, keep);
       f32x4 Jq[12];  // feature Jacobian: DEEP fetches it under the last chunk
       if (P::DEEPJ) {
 #pragma unroll
@@ -664,7 +674,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
       }
       {
         f32x4 unused[4];
-        accE += bwd_tile<P, 0, 0, false>(c, hA, dA, pend, unused);
+        accE += bwd_tile<P, 0, 0, false>(c, hA, dA, pend, unused, keep);
       }
       pad_chunks<P, N_CHUNKS>(c, hA);
       SURF_T(3);

@@ -133,12 +133,24 @@ __device__ __forceinline__ void slot_pin(uint32_t&) {}
 #ifndef SURF_SDF_LDS_SLICES_H2
 #define SURF_SDF_LDS_SLICES_H2 5
 #endif
+// ... and in REGISTERS (16 per slice and lane) after those: what the gradient kernels' register files have left where the
+// slices are live (the end of the forward sweep and the first layers of the reverse one are not where the pressure peaks).
+// bf16x3: 11 (512 of 512 registers, no spill; 12 spill - build.sh refuses that build): 14 of the 20 slices never leave the CU.
+// f16x2: 15 (504 registers): all 20 stay on the CU and only the feature Jacobian still makes the round trip.
+// Measured (round 3, half image, same box): bf16x3 61.5 -> 58.6 ms with 10, f16x2 42.9 -> 37.7 ms with 15.
+#ifndef SURF_SDF_REG_SLICES_BF3
+#define SURF_SDF_REG_SLICES_BF3 11
+#endif
+#ifndef SURF_SDF_REG_SLICES_H2
+#define SURF_SDF_REG_SLICES_H2 15
+#endif
 
 struct PolBf3 {
   // NA: accumulator chains (two independent ones measured no faster); PF: k-steps of LDS read-ahead (2, 3: no faster)
   static constexpr int NP = 3, NA = 1, PF = 1;
   static constexpr int occ(bool) { return 1; }  // three-piece activations need the whole register file
   static constexpr int nslot(bool) { return SURF_SDF_NSLOT_BF3; }  // LDS ring length (36 KB slots)
+  static constexpr int REG_SLICES = SURF_SDF_REG_SLICES_BF3;
   static constexpr int LDS_SLICES = SURF_SDF_LDS_SLICES_BF3;       // softplus' slices per wavefront in the spare LDS (3 x 36 + 4 x 3 x 4 KB = 156 KB)
   static constexpr bool DEEP = true;   // backward softplus' reads two chunks ahead (registers to spare)
   static constexpr bool DEEPJ = true;  // feature Jacobian fetched under the last backward chunk
@@ -192,6 +204,7 @@ struct PolH2 {
   // in every launch, for a reason not understood; at 512 registers nothing spills and the screen is clean.
   static constexpr int occ(bool grad) { return grad ? 1 : 2; }
   static constexpr int nslot(bool grad) { return grad ? SURF_SDF_NSLOT_H2 : 3; }
+  static constexpr int REG_SLICES = SURF_SDF_REG_SLICES_H2;
   static constexpr int LDS_SLICES = SURF_SDF_LDS_SLICES_H2;        // 3 x 24 + 4 x 5 x 4 KB = 152 KB (gradient kernel: one workgroup per CU)  // 24 KB slots; two workgroups per CU forward-only
   static constexpr bool DEEP = true, DEEPJ = true;
   static constexpr ChunkTable CH = make_chunks(NP);
