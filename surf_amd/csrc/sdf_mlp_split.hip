@@ -213,7 +213,7 @@ template <class P, bool GRAD, bool LAST>
 constexpr MiniProg fwd_prog() {
   constexpr int scale = Scales<P>::W != 1.0f ? 8 : 0;
   MiniProg mp{};
-  mini_add(mp, K_ARG, 0, 8);
+  if (!P::PRESCALED) mini_add(mp, K_ARG, 0, 8);
   mini_add(mp, K_EXP, 0, 16);
   mini_add(mp, K_ADD1, 0, 8);
   mini_add(mp, K_LOG, 0, 16);
@@ -278,6 +278,7 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
       S.u[1] = t2[1] * (144.269504088896341f * inv_w);
       slot_pin(S.u);
     } else if constexpr (kind == K_EXP) {
+      if (P::PRESCALED) S.u = t2;  // the accumulators ARE the exponent arguments
       slot_pin(S.u);
       S.e[0] = SURF_X_NOSOFTPLUS ? S.u[0] : __builtin_amdgcn_exp2f(-__builtin_fabsf(S.u[0]));
       S.e[1] = SURF_X_NOSOFTPLUS ? S.u[1] : __builtin_amdgcn_exp2f(-__builtin_fabsf(S.u[1]));
@@ -302,8 +303,13 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
       slot_pin(S.m);
     } else if constexpr (kind == K_FMA) {  // h = max(t, 0) + ln(1 + e) / 100
       slot_pin(S.l, S.m);
-      S.val[0] = fmaf(S.l[0], 0.69314718055994531f * 0.01f, S.m[0]);
-      S.val[1] = fmaf(S.l[1], 0.69314718055994531f * 0.01f, S.m[1]);
+      if (P::PRESCALED) {  // z = max(u, 0) + log2(1 + 2^-|u|)
+        S.val[0] = S.m[0] + S.l[0];
+        S.val[1] = S.m[1] + S.l[1];
+      } else {
+        S.val[0] = fmaf(S.l[0], 0.69314718055994531f * 0.01f, S.m[0]);
+        S.val[1] = fmaf(S.l[1], 0.69314718055994531f * 0.01f, S.m[1]);
+      }
       slot_pin(S.val);
       if (!LAST) {
         sbuf[q >> 1 & 1][el & 3] = S.u[0];
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const f32x2 t2 = {raw[4 * g + 2 * q], raw[4 * g + 2 * q + 1]};
-          softplus_pair<GRAD ? 1 : 0>(t2, 1.0f / Scales<P>::W, hv[q], sv[q]);
+          softplus_pair<GRAD ? 1 : 0, P::PRESCALED>(t2, 1.0f / Scales<P>::W, hv[q], sv[q]);
           y0 = fmaf(w[2 * q], hv[q][0], y0);
           y0 = fmaf(w[2 * q + 1], hv[q][1], y0);
           if (GRAD)
@@ -777,6 +783,11 @@ int pack_weights(const float* const* h_W, const float* const* h_b, unsigned char
   const int in_dim[7] = {NE, 156, 156, 156, 156, 156, 156};
   const int out_dim[6] = {HID, HID, H2, HID, HID, HID};
   const float rsqrt2 = (float)(1.0 / sqrt(2.0));
+  // P::PRESCALED (see the policy): input columns and biases x c = 100 log2 e, row 0 of lin6 x ln 2 / 100, hidden columns as they
+  // are.  Every packed value stays ONE float product `weight * scale` (surf_amd/packing.py re-does exactly that on the device).
+  const float c_in = P::PRESCALED ? (float)(100.0 * 1.4426950408889634) : 1.0f;
+  const float c_in_rsqrt2 = P::PRESCALED ? (float)(100.0 * 1.4426950408889634 / sqrt(2.0)) : rsqrt2;
+  const float k_out = P::PRESCALED ? (float)(0.6931471805599453 / 100.0) : 1.0f;
   memset(out, 0, stream_bytes<P>() + TAIL_FLOATS * 4);
   auto put = [&](int chunk, int ks, int lane, int j, float v) {
     uint16_t p[NP];
@@ -801,11 +812,12 @@ int pack_weights(const float* const* h_W, const float* const* h_b, unsigned char
             if (ks < fwd_ne(l)) {
               const int cidx = 8 * ks + j;
               if (cidx < 14 && 14 * h + cidx < NE) col = (l == 3 ? H2 : 0) + 14 * h + cidx;
-              if (l == 3) scale = rsqrt2;
+              scale = l == 3 ? c_in_rsqrt2 : c_in;
               if (l == 0) is_bias = (cidx == 14 && h == 0);
             } else if (ks < fwd_nl(l)) {
               const int cidx = 8 * (ks - fwd_ne(l)) + j;
               if (cidx < 14) col = 128 + 14 * h + cidx;
+              scale = c_in;
               is_bias = (cidx == 14 && h == 0);
             } else {
               const int hk = ks - fwd_nl(l);
@@ -815,7 +827,7 @@ int pack_weights(const float* const* h_W, const float* const* h_b, unsigned char
             }
             float v = 0.f;
             if (col >= 0 && row < out_dim[l]) v = h_W[l][(int64_t)row * in_dim[l] + col] * scale;
-            if (is_bias && row < out_dim[l]) v = h_b[l][row];
+            if (is_bias && row < out_dim[l]) v = h_b[l][row] * c_in;
             put(ci, ks, lane, j, v);
           }
     }
@@ -844,9 +856,10 @@ int pack_weights(const float* const* h_W, const float* const* h_b, unsigned char
               if (l == 3) scale = rsqrt2;
             } else if (kind == 1) {
               if (r_row < 14 && ch < NE) col = (l == 3 ? H2 : 0) + ch;
-              if (l == 3) scale = rsqrt2;
+              scale = l == 3 ? c_in_rsqrt2 : c_in;
             } else {
               if (r_row < 14) col = 128 + ch;
+              scale = c_in;
             }
             float v = 0.f;
             if (col >= 0 && krow < out_dim[l]) v = h_W[l][(int64_t)krow * in_dim[l] + col] * scale;
@@ -857,7 +870,7 @@ int pack_weights(const float* const* h_W, const float* const* h_b, unsigned char
   float* tail = reinterpret_cast<float*>(out + stream_bytes<P>());
   auto hk = [](int tt, int r, int h) { return 32 * tt + (r & 3) + 8 * (r >> 2) + 4 * h; };
   for (int h = 0; h < 2; ++h) {
-    for (int s = 0; s < 64; ++s) tail[TAIL_W6H + h * 64 + s] = h_W[6][hk(s / 16, s % 16, h)];
+    for (int s = 0; s < 64; ++s) tail[TAIL_W6H + h * 64 + s] = h_W[6][hk(s / 16, s % 16, h)] * k_out;
     for (int s = 0; s < 14; ++s) tail[TAIL_W6P + h * 16 + s] = h_W[6][128 + 14 * h + s];
   }
   tail[TAIL_B6] = h_b[6][0];

@@ -135,11 +135,12 @@ __device__ __forceinline__ void slot_pin(uint32_t&) {}
 #endif
 // ... and in REGISTERS (16 per slice and lane) after those: what the gradient kernels' register files have left where the
 // slices are live (the end of the forward sweep and the first layers of the reverse one are not where the pressure peaks).
-// bf16x3: 11 (512 of 512 registers, no spill; 12 spill - build.sh refuses that build): 14 of the 20 slices never leave the CU.
+// bf16x3: 10 (500 of 512 registers; 11 fit exactly or spill 28 bytes depending on the surrounding code, 12 spill - build.sh
+// refuses such a build): 13 of the 20 slices never leave the CU.
 // f16x2: 15 (504 registers): all 20 stay on the CU and only the feature Jacobian still makes the round trip.
 // Measured (round 3, half image, same box): bf16x3 61.5 -> 58.6 ms with 10, f16x2 42.9 -> 37.7 ms with 15.
 #ifndef SURF_SDF_REG_SLICES_BF3
-#define SURF_SDF_REG_SLICES_BF3 11
+#define SURF_SDF_REG_SLICES_BF3 10
 #endif
 #ifndef SURF_SDF_REG_SLICES_H2
 #define SURF_SDF_REG_SLICES_H2 15
@@ -152,7 +153,10 @@ struct PolBf3 {
   static constexpr int nslot(bool) { return SURF_SDF_NSLOT_BF3; }  // LDS ring length (36 KB slots)
   static constexpr int REG_SLICES = SURF_SDF_REG_SLICES_BF3;
   static constexpr int LDS_SLICES = SURF_SDF_LDS_SLICES_BF3;       // softplus' slices per wavefront in the spare LDS (3 x 36 + 4 x 3 x 4 KB = 156 KB)
-  static constexpr bool DEEP = true;   // backward softplus' reads two chunks ahead (registers to spare)
+#ifndef SURF_SDF_DEEP_BF3
+#define SURF_SDF_DEEP_BF3 1
+#endif
+  static constexpr bool DEEP = SURF_SDF_DEEP_BF3;   // backward softplus' reads two chunks ahead (registers to spare)
   static constexpr bool DEEPJ = true;  // feature Jacobian fetched under the last backward chunk
   static constexpr ChunkTable CH = make_chunks(NP);
   struct Acc { f32x16 v[NA]; };
@@ -175,6 +179,12 @@ struct PolBf3 {
     return x;
   }
   static constexpr bool FUSED_SUB = false;  // (no fp32 instruction reads a bf16 half in place)
+  // The network runs in units of the softplus exponent: pre-activations u = 100 log2(e) t, activations z = y 100 / ln 2
+  // = max(u, 0) + log2(1 + 2^-|u|).  Because 100 log2(e) x ln(2) / 100 = 1, every hidden matrix is UNCHANGED (u' = W z + c b):
+  // the packer scales only the biases and the input (positional-encoding / feature) columns by c = 100 log2 e and row 0 of
+  // lin6 by ln 2 / 100 - and the kernel saves the multiply in front of every exponential (2 of ~25 instructions per pair).
+  // Not for f16x2: activations 144 times larger would leave the fp16 range at |y| > 454.
+  static constexpr bool PRESCALED = true;
   static __device__ __forceinline__ f32x2 sub_piece(f32x2 v, uint32_t p) { return v - expand(p); }
   // MFMA m of a k-step (NM per k-step, smallest terms first): piece of A, piece of B
   static constexpr int NM = 6;
@@ -225,6 +235,7 @@ struct PolH2 {
   // v - (the two halves of p as floats), one v_fma_mix_f32 per element (an fp32 FMA that reads an fp16 half directly: no
   // conversion instruction): fma(half, -1, v) is exact in the half and rounds once, like the subtraction it replaces.
   static constexpr bool FUSED_SUB = true;
+  static constexpr bool PRESCALED = false;
   static __device__ __forceinline__ f32x2 sub_piece(f32x2 v, uint32_t p) {
     f32x2 r;
     asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r[0]) : "v"(p), "v"(v[0]));
@@ -316,14 +327,14 @@ __device__ __forceinline__ void frag_set_pair(FragT<P::NP>& f, int pair /*0..3*/
 // conversion arithmetic (~42 issue cycles per 32-cycle MFMA with h' formed here, round-3 ISA count), the backward tiles
 // have slots to spare (~22), so the compare / select / reciprocal / multiply of h' move there; the scratch round trip
 // carries u instead of h' (same bytes).
-template <int MODE>
+template <int MODE, bool PRESCALED = false>
 __device__ __forceinline__ void softplus_pair(f32x2 acc, float acc_scale_inv, f32x2& hv, f32x2& sv) {
   if (SURF_X_NOSOFTPLUS) {
     hv = acc * acc_scale_inv;
     sv = acc * 0.5f;
     return;
   }
-  const f32x2 arg = acc * (144.269504088896341f * acc_scale_inv);  // 100 log2(e) t
+  const f32x2 arg = PRESCALED ? acc : acc * (144.269504088896341f * acc_scale_inv);  // 100 log2(e) t
   f32x2 e;
   e[0] = __builtin_amdgcn_exp2f(-__builtin_fabsf(arg[0]));
   e[1] = __builtin_amdgcn_exp2f(-__builtin_fabsf(arg[1]));
@@ -335,8 +346,12 @@ __device__ __forceinline__ void softplus_pair(f32x2 acc, float acc_scale_inv, f3
   m[0] = __builtin_amdgcn_fmed3f(acc[0], 0.0f, 3.0e38f);  // max(acc, 0) without the canonicalising extra v_max
   m[1] = __builtin_amdgcn_fmed3f(acc[1], 0.0f, 3.0e38f);
   if (acc_scale_inv != 1.0f) m = m * acc_scale_inv;
-  hv[0] = fmaf(l[0], 0.69314718055994531f * 0.01f, m[0]);
-  hv[1] = fmaf(l[1], 0.69314718055994531f * 0.01f, m[1]);
+  if (PRESCALED) {  // (policy PRESCALED: the activation in exponent units)
+    hv = m + l;
+  } else {
+    hv[0] = fmaf(l[0], 0.69314718055994531f * 0.01f, m[0]);
+    hv[1] = fmaf(l[1], 0.69314718055994531f * 0.01f, m[1]);
+  }
   if (MODE == 1) {
     f32x2 r, sel;
     r[0] = __builtin_amdgcn_rcpf(d[0]);

@@ -95,6 +95,7 @@ def _sdf_flat(isdf):
 def _sdf_split_map(precision):
     """(body map, tail map, NP, Scales<P>::W).  The logical order of the packed values - (k-step block, lane, k-slot) - is the
     same for both split policies, so the map is probed once with the bf16x3 packer (whose three pieces sum back exactly)."""
+    # (the coefficients differ: see below)
     key = ("sdf",)
     if key not in _MAPS:
         L = _lib.lib()
@@ -113,6 +114,26 @@ def _sdf_split_map(precision):
             return (ids.astype(np.float32) * c.astype(np.float32)).astype(np.float64)
         _MAPS[key] = (_Map(*_recover(runs[0][0], runs[1][0], n, prod)), _Map(*_recover(runs[0][1], runs[1][1], n, prod)))
     body, tail = _MAPS[key]
+    if precision == "f16x2":
+        # The bf16x3 kernel runs in units of the softplus exponent (sdf_split_common.h, PolBf3::PRESCALED): its packer scales the
+        # input columns and biases by c = 100 log2 e (c / sqrt 2 in the skip layer) and lin6's row 0 by ln 2 / 100; the f16x2
+        # packer does not.  Same gather, those factors taken out again (exact float constants of the host packer).
+        key2 = ("sdf", "f16x2")
+        if key2 not in _MAPS:
+            c = np.float64(np.float32(100.0 * 1.4426950408889634))
+            cr = np.float64(np.float32(100.0 * 1.4426950408889634 / np.sqrt(2.0)))
+            k = np.float64(np.float32(0.6931471805599453 / 100.0))
+            r2 = np.float64(np.float32(1.0 / np.sqrt(2.0)))
+
+            def plain(m):
+                coef = m.coef_np.copy()
+                coef[m.coef_np == c] = 1.0
+                coef[m.coef_np == cr] = r2
+                coef[m.coef_np == k] = 1.0
+                assert set(np.unique(coef)) <= {0.0, 1.0, r2}, "unexpected scale in the bf16x3 weight image"
+                return _Map(m.idx_np, coef)
+            _MAPS[key2] = (plain(body), plain(tail))
+        body, tail = _MAPS[key2]
     # Scales<P>::W: the exact power of two the f16x2 packer applies before the split
     return body, tail, {"bf16x3": 3, "f16x2": 2}[precision], {"bf16x3": 1.0, "f16x2": 256.0}[precision]
 

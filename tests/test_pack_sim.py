@@ -343,10 +343,15 @@ def sim_sdf_split(packed, pts, phi_full, jphi_full, precision):
             out.append(acc)
         return np.concatenate(out, 1)
 
+    # bf16x3 runs in units of the softplus exponent (PolBf3::PRESCALED): the accumulators are u = 100 log2(e) t, the
+    # activations z = max(u, 0) + log2(1 + 2^-|u|) = y 100 / ln 2, and the packer has scaled biases / input columns / lin6
+    def softplus_exp_units(u):
+        return np.maximum(u, 0) + np.log2(1 + np.exp2(-np.abs(u))), 1.0 / (1.0 + np.exp2(-u))
+    act = softplus_exp_units if precision == "bf16x3" else softplus
     Sg, h = [], None
     for l in range(6):
         t = fwd_layer(l, h)
-        h, sv = softplus(t)
+        h, sv = act(t)
         if l < 5:
             Sg.append(sv)
     w6h = S_.tail[:128].reshape(2, 64)[H]
