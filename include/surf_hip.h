@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 29
+#define SURF_ABI_VERSION 30
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -99,7 +99,9 @@ int surf_sdf_mlp(const float* pts, const uint8_t* mask, const int32_t* idx, int6
  * as surf_sdf_mlp; `packed` is the output of the matching surf_sdf_pack_weights_* (…_packed_bytes() bytes, device copy),
  * `scratch` >= …_scratch_bytes(n).
  *   bf16x3: every fp32 operand is split exactly into three bf16 pieces and six partial products are accumulated
- *           (dropped terms <= 2^-23 per product): fp32-equivalent results.
+ *           (dropped terms <= 2^-23 per product): fp32-equivalent results.  The packed image is opaque: the kernel works in
+ *           units of the softplus exponent (biases and input columns x 100 log2 e, lin6's row 0 x ln 2 / 100, hidden matrices
+ *           as they are), so an image is only meaningful to the kernel of the same library build.
  *   f16x2:  two fp16 pieces per operand (22 significant bits, second piece scaled by 2^11), three partial products:
  *           operand error <= 2^-22; activations must stay below 65504 in magnitude.  The fast path.
  */
