@@ -311,6 +311,23 @@ template <class P> constexpr int lds_bytes() { return image_bytes<P::BB>(); }
 // unrolled form and no spills at two wavefronts per SIMD.
 constexpr int SLOT_GROUPS = 5;
 constexpr int slot_floats(int ns) { return ns * SLOT_GROUPS * 64 * 4; }
+// The first lds_views<P>() source views of a tile are staged in the workgroup's spare LDS instead (5 KB per wavefront and
+// view behind the weight image: bf16x3 78 + 2 x 40 KB, f16x2 52 + 2 x 40, f32lds 104 + 40): each staged view is written once
+// and read three times (mean sweep, variance sweep, pass 2), and what does not leave the CU costs neither vector-memory
+// instructions nor - the SDF kernel's lesson of round 3 - the clock the chip sustains.
+#ifndef SURF_BLEND_LDS_VIEWS
+#define SURF_BLEND_LDS_VIEWS 2
+#endif
+constexpr int VIEW_BYTES = SLOT_GROUPS * 64 * 16;
+template <class P> constexpr int lds_views() {
+  const int n = (160 * 1024 - lds_bytes<P>()) / (WPB * VIEW_BYTES);
+  return n < SURF_BLEND_LDS_VIEWS ? n : SURF_BLEND_LDS_VIEWS;
+}
+struct Stage {
+  float* slot;   // this wavefront's staging slot in global memory
+  char* lds_v;   // ... and in LDS (+ lane * 16)
+  int n_lds;     // views [0, n_lds) are in LDS
+};
 
 struct ViewState {
   float floc[12];
@@ -319,35 +336,45 @@ struct ViewState {
   float ex;  // > 0; mk = 1
   float mk;
 };
-__device__ __forceinline__ void slot_store(float* slot, int v, int lane, const ViewState& s) {
-  f32x4* p = reinterpret_cast<f32x4*>(slot + (int64_t)(v * SLOT_GROUPS) * 256 + lane * 4);
+// (v is wave-uniform: a scalar branch; the two address spaces get their own instructions - a pointer select would make
+//  every access a FLAT one)
+template <class PtrT>
+__device__ __forceinline__ void slot_store_at(PtrT p, const ViewState& s) {
   p[0 * 64] = f32x4{s.floc[0], s.floc[1], s.floc[2], s.floc[3]};
   p[1 * 64] = f32x4{s.floc[4], s.floc[5], s.floc[6], s.floc[7]};
   p[2 * 64] = f32x4{s.floc[8], s.floc[9], s.floc[10], s.floc[11]};
   p[3 * 64] = f32x4{s.rd[0], s.rd[1], s.rd[2], s.rd[3]};
   p[4 * 64] = f32x4{s.rgb[0], s.rgb[1], s.rgb[2], s.mk != 0.f ? s.ex : -s.ex};
 }
-__device__ __forceinline__ void slot_load_floc(const float* slot, int v, int lane, float (&floc)[12]) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(slot + (int64_t)(v * SLOT_GROUPS) * 256 + lane * 4);
+template <class PtrT>
+__device__ __forceinline__ void slot_load_at(PtrT p, ViewState& s) {
+  f32x4 x[5];
+#pragma unroll
+  for (int g = 0; g < 5; ++g) x[g] = p[g * 64];
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
-    const f32x4 x = p[g * 64];
-    floc[4 * g + 0] = x[0]; floc[4 * g + 1] = x[1]; floc[4 * g + 2] = x[2]; floc[4 * g + 3] = x[3];
+    s.floc[4 * g + 0] = x[g][0]; s.floc[4 * g + 1] = x[g][1]; s.floc[4 * g + 2] = x[g][2]; s.floc[4 * g + 3] = x[g][3];
   }
+  s.rd[0] = x[3][0]; s.rd[1] = x[3][1]; s.rd[2] = x[3][2]; s.rd[3] = x[3][3];
+  s.rgb[0] = x[4][0]; s.rgb[1] = x[4][1]; s.rgb[2] = x[4][2];
+  s.mk = x[4][3] > 0.f ? 1.f : 0.f;
+  s.ex = fabsf(x[4][3]);
 }
-__device__ __forceinline__ void slot_load_tail(const float* slot, int v, int lane, ViewState& s) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(slot + (int64_t)(v * SLOT_GROUPS) * 256 + lane * 4);
-  const f32x4 r = p[3 * 64], c = p[4 * 64];
-  s.rd[0] = r[0]; s.rd[1] = r[1]; s.rd[2] = r[2]; s.rd[3] = r[3];
-  s.rgb[0] = c[0]; s.rgb[1] = c[1]; s.rgb[2] = c[2];
-  s.mk = c[3] > 0.f ? 1.f : 0.f;
-  s.ex = fabsf(c[3]);
+typedef __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
+__device__ __forceinline__ void slot_store(const Stage& g, int v, int lane, const ViewState& s) {
+  if (v < g.n_lds) slot_store_at((lds_f32x4_ptr)(g.lds_v + v * VIEW_BYTES), s);
+  else slot_store_at(reinterpret_cast<f32x4*>(g.slot + (int64_t)(v * SLOT_GROUPS) * 256 + lane * 4), s);
+}
+__device__ __forceinline__ void slot_load(const Stage& g, int v, int lane, ViewState& s) {
+  if (v < g.n_lds) slot_load_at((lds_f32x4_ptr)(g.lds_v + v * VIEW_BYTES), s);
+  else slot_load_at(reinterpret_cast<const f32x4*>(g.slot + (int64_t)(v * SLOT_GROUPS) * 256 + lane * 4), s);
 }
 
 template <class P>
 __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArgs a) {
   typedef typename P::Frag Frag;
-  __shared__ __attribute__((aligned(16))) char lds[lds_bytes<P>()];
+  __shared__ __attribute__((aligned(16))) char lds[lds_bytes<P>() + WPB * lds_views<P>() * VIEW_BYTES];
+  static_assert(lds_bytes<P>() % 16 == 0 && lds_bytes<P>() + WPB * lds_views<P>() * VIEW_BYTES <= 160 * 1024, "LDS");
   // ---- the weight image: global -> LDS once per workgroup --------------------------------------------------------
   for (int o = threadIdx.x * 16; o < lds_bytes<P>(); o += WPB * 64 * 16)
     *reinterpret_cast<u32x4*>(lds + o) = *reinterpret_cast<const u32x4*>(a.w + o);
@@ -364,7 +391,10 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
   const int64_t n_waves = (int64_t)gridDim.x * WPB;
   const int64_t n_pts = a.n_dev ? (int64_t)*a.n_dev : a.n;
   const int64_t n_tiles = (n_pts + TILE - 1) / TILE;
-  float* slot = a.scratch + wave_id * slot_floats(NS);
+  Stage slot;
+  slot.slot = a.scratch + wave_id * slot_floats(NS);
+  slot.lds_v = lds + lds_bytes<P>() + (threadIdx.x >> 6) * (lds_views<P>() * VIEW_BYTES) + lane * 16;
+  slot.n_lds = lds_views<P>();
   const float* scal = reinterpret_cast<const float*>(lds + scal_off<P::BB>());
   const float s_abs = scal[0], b_vis = scal[1], b_vis2 = scal[2], b_rgb4 = scal[3];
 
@@ -483,8 +513,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
 #pragma unroll 1
     for (int v = 0; v < NS; ++v) {
       ViewState st;
-      slot_load_floc(slot, v, lane, st.floc);
-      slot_load_tail(slot, v, lane, st);
+      slot_load(slot, v, lane, st);
       const float w = (st.ex - emin) * st.mk;
       wsum += w;
 #pragma unroll
@@ -496,8 +525,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
 #pragma unroll 1
     for (int v = 0; v < NS; ++v) {
       ViewState st;
-      slot_load_floc(slot, v, lane, st.floc);
-      slot_load_tail(slot, v, lane, st);
+      slot_load(slot, v, lane, st);
       const float w = (st.ex - emin) * st.mk * winv;
 #pragma unroll
       for (int ch = 0; ch < 12; ++ch) { const float d = st.floc[ch] - mv[ch]; mv[12 + ch] += w * (d * d); }
@@ -522,8 +550,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
     for (int v = 0; v < NS; ++v) {
       const Ctx c = opaque(c0);
       ViewState st;
-      slot_load_floc(slot, v, lane, st.floc);
-      slot_load_tail(slot, v, lane, st);
+      slot_load(slot, v, lane, st);
       const float wv = (st.ex - emin) * st.mk * winv;
       // base_fc.0 (view part) : 57 -> 64, on top of the view-independent part
       f32x16 a0 = G0a, a1 = G0b;
