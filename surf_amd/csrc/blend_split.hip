@@ -67,6 +67,10 @@ struct FragT { u32x4 p[NP]; };  // B operand of one 16-wide k-step: NP pieces x 
 
 struct BPolBf3 {
   static constexpr int NP = 3, ID = 1, BB = NP * 1024, LANE_BYTES = 16;
+#ifndef SURF_BLEND_REG_VIEWS_BF3
+#define SURF_BLEND_REG_VIEWS_BF3 2
+#endif
+  static constexpr int REG_VIEWS = SURF_BLEND_REG_VIEWS_BF3;  // staged views kept in registers (after the ones in LDS)
   typedef FragT<NP> Frag;
   static __device__ __forceinline__ void set_pair(Frag& f, int pr, float a, float b);
   static __device__ __forceinline__ void zero_pair(Frag& f, int pr);
@@ -95,6 +99,10 @@ struct BPolBf3 {
 
 struct BPolH2 {
   static constexpr int NP = 2, ID = 2, BB = NP * 1024, LANE_BYTES = 16;
+#ifndef SURF_BLEND_REG_VIEWS_H2
+#define SURF_BLEND_REG_VIEWS_H2 3
+#endif
+  static constexpr int REG_VIEWS = SURF_BLEND_REG_VIEWS_H2;
   typedef FragT<NP> Frag;
   static __device__ __forceinline__ void set_pair(Frag& f, int pr, float a, float b);
   static __device__ __forceinline__ void zero_pair(Frag& f, int pr);
@@ -151,6 +159,7 @@ template <int NUSED> __device__ __forceinline__ void BPolH2::mma_lds(f32x16& acc
 // per slot that carries data.  Block = [lane][8 floats] = 2 KB.
 struct BPolF32 {
   static constexpr int NP = 1, ID = 3, BB = 2048, LANE_BYTES = 32;
+  static constexpr int REG_VIEWS = 0;
   struct Frag { float v[8]; };
   static __device__ __forceinline__ void set_pair(Frag& f, int pr, float a, float b) { f.v[2 * pr] = a; f.v[2 * pr + 1] = b; }
   static __device__ __forceinline__ void zero_pair(Frag& f, int pr) { f.v[2 * pr] = 0.f; f.v[2 * pr + 1] = 0.f; }
@@ -339,18 +348,18 @@ struct ViewState {
 // (v is wave-uniform: a scalar branch; the two address spaces get their own instructions - a pointer select would make
 //  every access a FLAT one)
 template <class PtrT>
-__device__ __forceinline__ void slot_store_at(PtrT p, const ViewState& s) {
-  p[0 * 64] = f32x4{s.floc[0], s.floc[1], s.floc[2], s.floc[3]};
-  p[1 * 64] = f32x4{s.floc[4], s.floc[5], s.floc[6], s.floc[7]};
-  p[2 * 64] = f32x4{s.floc[8], s.floc[9], s.floc[10], s.floc[11]};
-  p[3 * 64] = f32x4{s.rd[0], s.rd[1], s.rd[2], s.rd[3]};
-  p[4 * 64] = f32x4{s.rgb[0], s.rgb[1], s.rgb[2], s.mk != 0.f ? s.ex : -s.ex};
+__device__ __forceinline__ void slot_store_at(PtrT p, const ViewState& s, int stride = 64) {
+  p[0 * stride] = f32x4{s.floc[0], s.floc[1], s.floc[2], s.floc[3]};
+  p[1 * stride] = f32x4{s.floc[4], s.floc[5], s.floc[6], s.floc[7]};
+  p[2 * stride] = f32x4{s.floc[8], s.floc[9], s.floc[10], s.floc[11]};
+  p[3 * stride] = f32x4{s.rd[0], s.rd[1], s.rd[2], s.rd[3]};
+  p[4 * stride] = f32x4{s.rgb[0], s.rgb[1], s.rgb[2], s.mk != 0.f ? s.ex : -s.ex};
 }
 template <class PtrT>
-__device__ __forceinline__ void slot_load_at(PtrT p, ViewState& s) {
+__device__ __forceinline__ void slot_load_at(PtrT p, ViewState& s, int stride = 64) {
   f32x4 x[5];
 #pragma unroll
-  for (int g = 0; g < 5; ++g) x[g] = p[g * 64];
+  for (int g = 0; g < 5; ++g) x[g] = p[g * stride];
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     s.floc[4 * g + 0] = x[g][0]; s.floc[4 * g + 1] = x[g][1]; s.floc[4 * g + 2] = x[g][2]; s.floc[4 * g + 3] = x[g][3];
@@ -361,13 +370,24 @@ __device__ __forceinline__ void slot_load_at(PtrT p, ViewState& s) {
   s.ex = fabsf(x[4][3]);
 }
 typedef __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
-__device__ __forceinline__ void slot_store(const Stage& g, int v, int lane, const ViewState& s) {
-  if (v < g.n_lds) slot_store_at((lds_f32x4_ptr)(g.lds_v + v * VIEW_BYTES), s);
-  else slot_store_at(reinterpret_cast<f32x4*>(g.slot + (int64_t)(v * SLOT_GROUPS) * 256 + lane * 4), s);
+// ... and the next REG_VIEWS views in registers (20 per lane and view: what the kernel's 256-register budget has left)
+struct ViewRegs { f32x4 x[5]; };
+template <int NRV> struct RegViews { ViewRegs v0, v1, v2; };  // (named members: an indexed array ends up in private memory)
+template <int NRV>
+__device__ __forceinline__ void slot_store(const Stage& g, int v, int lane, const ViewState& s, RegViews<NRV>& keep) {
+  if (v < g.n_lds) { slot_store_at((lds_f32x4_ptr)(g.lds_v + v * VIEW_BYTES), s); return; }
+  if (NRV > 0 && v == g.n_lds) { slot_store_at(&keep.v0.x[0], s, 1); return; }
+  if (NRV > 1 && v == g.n_lds + 1) { slot_store_at(&keep.v1.x[0], s, 1); return; }
+  if (NRV > 2 && v == g.n_lds + 2) { slot_store_at(&keep.v2.x[0], s, 1); return; }
+  slot_store_at(reinterpret_cast<f32x4*>(g.slot + (int64_t)(v * SLOT_GROUPS) * 256 + lane * 4), s);
 }
-__device__ __forceinline__ void slot_load(const Stage& g, int v, int lane, ViewState& s) {
-  if (v < g.n_lds) slot_load_at((lds_f32x4_ptr)(g.lds_v + v * VIEW_BYTES), s);
-  else slot_load_at(reinterpret_cast<const f32x4*>(g.slot + (int64_t)(v * SLOT_GROUPS) * 256 + lane * 4), s);
+template <int NRV>
+__device__ __forceinline__ void slot_load(const Stage& g, int v, int lane, ViewState& s, const RegViews<NRV>& keep) {
+  if (v < g.n_lds) { slot_load_at((lds_f32x4_ptr)(g.lds_v + v * VIEW_BYTES), s); return; }
+  if (NRV > 0 && v == g.n_lds) { slot_load_at(&keep.v0.x[0], s, 1); return; }
+  if (NRV > 1 && v == g.n_lds + 1) { slot_load_at(&keep.v1.x[0], s, 1); return; }
+  if (NRV > 2 && v == g.n_lds + 2) { slot_load_at(&keep.v2.x[0], s, 1); return; }
+  slot_load_at(reinterpret_cast<const f32x4*>(g.slot + (int64_t)(v * SLOT_GROUPS) * 256 + lane * 4), s);
 }
 
 template <class P>
@@ -420,6 +440,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
     }
     int nvalid = 0;
     float emin = INFINITY;
+    RegViews<P::REG_VIEWS> keep;
     // ------------------------------ pass 1: per view, projections + texel fetches + direction feature ----------------
 #pragma unroll 1
     for (int v = 0; v < NS; ++v) {
@@ -499,7 +520,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       st.floc[11] = 0.f;
       st.ex = expf(s_abs * (st.rd[3] - 1.0f));
       emin = fminf(emin, st.ex);
-      slot_store(slot, v, lane, st);
+      slot_store(slot, v, lane, st, keep);
     }
     if (a.n_valid && active && h == 0) a.n_valid[i] = (uint8_t)nvalid;
 
@@ -513,7 +534,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
 #pragma unroll 1
     for (int v = 0; v < NS; ++v) {
       ViewState st;
-      slot_load(slot, v, lane, st);
+      slot_load(slot, v, lane, st, keep);
       const float w = (st.ex - emin) * st.mk;
       wsum += w;
 #pragma unroll
@@ -525,7 +546,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
 #pragma unroll 1
     for (int v = 0; v < NS; ++v) {
       ViewState st;
-      slot_load(slot, v, lane, st);
+      slot_load(slot, v, lane, st, keep);
       const float w = (st.ex - emin) * st.mk * winv;
 #pragma unroll
       for (int ch = 0; ch < 12; ++ch) { const float d = st.floc[ch] - mv[ch]; mv[12 + ch] += w * (d * d); }
@@ -550,7 +571,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
     for (int v = 0; v < NS; ++v) {
       const Ctx c = opaque(c0);
       ViewState st;
-      slot_load(slot, v, lane, st);
+      slot_load(slot, v, lane, st, keep);
       const float wv = (st.ex - emin) * st.mk * winv;
       // base_fc.0 (view part) : 57 -> 64, on top of the view-independent part
       f32x16 a0 = G0a, a1 = G0b;
