@@ -911,6 +911,7 @@ int64_t scratch_bytes(int64_t n_points) {
 
 }  // namespace
 
+#ifndef SURF_SDF_TU_F16  // (this translation unit: the bf16x3 kernels; sdf_mlp_split_f16.hip: the f16x2 ones)
 #ifdef SURF_SDF_TIMING
 extern "C" int surf_debug_phases(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 8) != hipSuccess) return 100;
@@ -941,6 +942,7 @@ extern "C" int surf_sdf_mlp_bf16x3_dn(const float* pts, const int32_t* idx, int6
   return launch<PolBf3>(pts, nullptr, idx, n_capacity, h_vols, h_tables, h_dims, n_vol, packed, sdf, grad, scratch, stream, d_n);
 }
 
+#else
 extern "C" int64_t surf_sdf_f16_packed_bytes(void) { return stream_bytes<PolH2>() + TAIL_FLOATS * 4; }
 extern "C" int64_t surf_sdf_f16_scratch_bytes(int64_t n_points) { return scratch_bytes<PolH2>(n_points); }
 extern "C" int surf_sdf_pack_weights_f16(const float* const* h_W, const float* const* h_b, unsigned char* out) {
@@ -959,3 +961,4 @@ extern "C" int surf_sdf_mlp_f16x2_dn(const float* pts, const int32_t* idx, int64
   if (!idx || !d_n) return SURF_E_ARG;
   return launch<PolH2>(pts, nullptr, idx, n_capacity, h_vols, h_tables, h_dims, n_vol, packed, sdf, grad, scratch, stream, d_n);
 }
+#endif
