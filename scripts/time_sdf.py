@@ -34,9 +34,10 @@ for grad in (False, True):
     from surf_amd import _lib
     import ctypes
     L = _lib.lib()
-    if hasattr(L, 'surf_debug_phases'):
+    fn = 'surf_debug_phases_f16' if os.environ.get('SURF_PREC') == 'f16x2' else 'surf_debug_phases'
+    if hasattr(L, fn):
         buf = (ctypes.c_ulonglong * 8)()
-        L.surf_debug_phases(buf, 1)
+        getattr(L, fn)(buf, 1)
         v = list(buf); tot = sum(v) or 1
         names = ['gather', 'forward', 'tail', 'backward', 'epilogue', 'stage_wait', 'lds_commit', 'barrier']
         print('  phases (3 runs, wave 0 clocks): ' + ', '.join(f'{n} {x/tot:.3f}' for n, x in zip(names, v)) + f'  total/run/block {tot/3/256:.0f} clk')

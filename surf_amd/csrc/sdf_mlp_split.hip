@@ -50,7 +50,7 @@ struct Ctx {
   int dma_voff;       // lane * 16 + wave * 1024: this wavefront's 1 KB block of every 4 KB DMA piece
   uint32_t dma_lds;   // LDS address of the ring + wave * 1024 (made opaque once per round: see the round loop)
   char* lds;    // the ring
-  char* lds_s;  // this wavefront's softplus' slices + lane * 16
+  char* lds_s;  // this wavefront's exponent slices (the softplus arguments the reverse sweep needs) + lane * 16
 };
 
 // ---- staging ------------------------------------------------------------------------------------------------------------
@@ -58,7 +58,7 @@ struct Ctx {
 // stream lengths are multiples of NS).  While chunk CI is consumed, chunks CI+2 .. CI+NS-1 are in flight by LDS-DMA
 // (buffer_load ... lds, 1 KB per instruction, lane-linear image; chunk CI+NS-1 is issued during chunk CI) and chunk CI+1
 // is retired at the end of chunk CI by a counted vmcnt.  vmcnt retires in issue order, so everything older than that DMA
-// has to be complete too: NS-1 chunks of slack keep the softplus' stores of the chunks before (acknowledged late by L2)
+// has to be complete too: NS-1 chunks of slack keep the exponent-slice stores of the chunks before (acknowledged late by L2)
 // out of that wait.
 template <class P> constexpr int n_dma(int ci) { return (P::CH.ks[ci] * P::NP + 3) / 4; }
 template <class P, int NS, int CI>
@@ -78,7 +78,7 @@ __device__ __forceinline__ void stage_dma(const Ctx& c) {
   for (int k = 0; k < n_dma<P>(CI); ++k) stage_dma_piece<P, NS, CI>(c, k);
 }
 // vector-memory operations a chunk issues by itself, in order: [pre: loads before its DMA] [DMA] [post: stores in fn]
-// which softplus' slice the backward chunk (L, T) loads (layer < 0: none): DEEP: that of the hidden tile computed by the
+// which exponent slice the backward chunk (L, T) loads (layer < 0: none): DEEP: that of the hidden tile computed by the
 // NEXT chunk; otherwise that of its own tile
 constexpr int sprime_layer(bool deep, int L, int T) {
   if (!deep) return (L >= 1 && T < 4) ? L - 1 : -1;
@@ -87,9 +87,9 @@ constexpr int sprime_layer(bool deep, int L, int T) {
   return -1;
 }
 constexpr int sprime_tile(bool deep, int L, int T) { return !deep ? T : ((L >= 1 && T < 3) ? T + 1 : 0); }
-// softplus' slices kept in the workgroup's spare LDS instead of the scratch buffer (P::LDS_SLICES per wavefront, 4 KB each:
+// exponent slices kept in the workgroup's spare LDS instead of the scratch buffer (P::LDS_SLICES per wavefront, 4 KB each:
 // layer 4 tiles first, then layer 3): the CU executes ~90 clocks per vector-memory wave-instruction in this kernel
-// (SQ_INSTS_VMEM / time) and softplus' is a quarter of them; an LDS slice costs eight ds_* instead.
+// (SQ_INSTS_VMEM / time) and the slices are a quarter of them; an LDS slice costs eight ds_* instead.
 template <class P> constexpr int lds_slice(int layer, int tile) {  // index in the wavefront's LDS area or -1
   const int k = (4 - layer) * 4 + tile;
   return (layer <= 4 && layer >= 0 && k < P::LDS_SLICES) ? k : -1;
@@ -101,7 +101,7 @@ template <class P> constexpr int reg_slice(int layer, int tile) {
 }
 template <class P> constexpr bool on_chip(int layer, int tile) { return lds_slice<P>(layer, tile) >= 0 || reg_slice<P>(layer, tile) >= 0; }
 template <class P> struct RegSlices { f32x4 v[P::REG_SLICES > 0 ? P::REG_SLICES : 1][4]; };
-// 16-byte groups of a softplus' slice that are read back: layer 2 has 101 rows, so the second half (k-step 7: rows
+// 16-byte groups of an exponent slice that are read back: layer 2 has 101 rows, so the second half (k-step 7: rows
 // 112..127) of its tile 3 feeds nothing.  Loading it anyway would leave the loads to dead-code elimination, i.e. leave
 // the number of vector-memory operations of that chunk - which stage_barrier's vmcnt counts - to the optimiser.
 constexpr int sprime_groups(int layer, int tile) { return (layer == 2 && tile == 3) ? 2 : 4; }
@@ -383,12 +383,12 @@ __device__ __forceinline__ void fwd_layer(const Ctx& c, f32x16& raw, FragT<P::NP
 }
 
 // ---- backward tiles ----------------------------------------------------------------------------------------------------
-// G (= W^T delta) of hidden tile T is multiplied by softplus' and split under the MFMAs of the tile that follows it.
-// The softplus' slice of a hidden tile is loaded from scratch during the chunk BEFORE the one that computes its G, two
+// G (= W^T delta) of hidden tile T is multiplied by softplus' (formed from the tile's exponent slice) and split under the
+// MFMAs of the tile that follows it.  The exponent slice of a hidden tile is loaded from scratch during the chunk BEFORE the one that computes its G, two
 // chunks before it is used (an HBM round trip is longer than one chunk).
 struct BwdPend {
   f32x16 G;     // finished tile waiting for its conversion
-  f32x4 s[4];   // its softplus' slice
+  f32x4 s[4];   // its exponent slice
   f32x4 sn[4];  // slice of the tile whose G is being computed now
 };
 template <class P, int NG = 4>
@@ -447,7 +447,7 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
       S.d[0] = S.e[0] + 1.0f;
       S.d[1] = S.e[1] + 1.0f;
       slot_pin(S.d);
-    } else if constexpr (kind == K_RCP) {  // h' = 1 / (1 + 2^-u): see sigma_pair
+    } else if constexpr (kind == K_RCP) {  // h' = 1 / (1 + 2^-u)
       slot_pin(S.d);
       S.r[0] = SURF_X_NOSOFTPLUS ? S.d[0] : __builtin_amdgcn_rcpf(S.d[0]);
       S.r[1] = SURF_X_NOSOFTPLUS ? S.d[1] : __builtin_amdgcn_rcpf(S.d[1]);
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
   typedef FragT<P::NP> Frag;
   constexpr int NS = P::nslot(GRAD), NCH = n_chunks<P>(GRAD);
   constexpr int NSL = GRAD ? P::LDS_SLICES : 0;
-  // ONE LDS object (ring + softplus' slices): with a second __shared__ array the compiler's LDS-DMA alias tracking falls
+  // ONE LDS object (ring + exponent slices): with a second __shared__ array the compiler's LDS-DMA alias tracking falls
   // back to `s_waitcnt vmcnt(0)` in front of every ds_read (311 of them, kernel 64 -> 98 ms)
   __shared__ __attribute__((aligned(16))) char lds[NS * slot_bytes<P>() + WPB * NSL * 4096];
   static_assert(NCH % NS == 0 && NCH - N_CHUNKS <= MAX_PAD && NS >= 3, "slot of a chunk = index % ring length");
@@ -911,9 +911,13 @@ int64_t scratch_bytes(int64_t n_points) {
 
 }  // namespace
 
-#ifndef SURF_SDF_TU_F16  // (this translation unit: the bf16x3 kernels; sdf_mlp_split_f16.hip: the f16x2 ones)
 #ifdef SURF_SDF_TIMING
-extern "C" int surf_debug_phases(unsigned long long* out, int reset) {
+#ifdef SURF_SDF_TU_F16
+#define SURF_DEBUG_PHASES surf_debug_phases_f16
+#else
+#define SURF_DEBUG_PHASES surf_debug_phases
+#endif
+extern "C" int SURF_DEBUG_PHASES(unsigned long long* out, int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 8) != hipSuccess) return 100;
   if (reset) {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -922,6 +926,8 @@ extern "C" int surf_debug_phases(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
+
+#ifndef SURF_SDF_TU_F16  // (this translation unit: the bf16x3 kernels; sdf_mlp_split_f16.hip: the f16x2 ones)
 
 extern "C" int64_t surf_sdf_bf16_packed_bytes(void) { return stream_bytes<PolBf3>() + TAIL_FLOATS * 4; }
 extern "C" int64_t surf_sdf_bf16_scratch_bytes(int64_t n_points) { return scratch_bytes<PolBf3>(n_points); }

@@ -57,7 +57,7 @@ constexpr int TAIL_W6P = TAIL_W6H + 128;  // [h][16]
 constexpr int TAIL_B6 = TAIL_W6P + 32;
 constexpr int TAIL_FLOATS = TAIL_B6 + 4;
 
-// per-wave scratch slot (floats): softplus exponent arguments of layers 0..4 (sigma_pair) + feature Jacobian
+// per-wave scratch slot (floats): softplus exponent arguments of layers 0..4 ("exponent slices") + feature Jacobian
 constexpr int SCR_S = 5 * 16 * 64 * 4;
 constexpr int SCR_J = 12 * 64 * 4;
 constexpr int SCR_SLOT = SCR_S + SCR_J;
@@ -107,9 +107,6 @@ __device__ __forceinline__ void slot_pin(uint32_t&) {}
 #ifndef SURF_X_NOSOFTPLUS
 #define SURF_X_NOSOFTPLUS 0
 #endif
-#ifndef SURF_SDF_SGB  // > 0: sched_group_barrier pattern of the k-steps (VALU operations per MFMA)
-#define SURF_SDF_SGB 0
-#endif
 #ifndef SURF_X_NODMA  // no LDS-DMA inside the chunks (the ring keeps whatever the prologue loaded)
 #define SURF_X_NODMA 0
 #endif
@@ -152,11 +149,11 @@ struct PolBf3 {
   static constexpr int occ(bool) { return 1; }  // three-piece activations need the whole register file
   static constexpr int nslot(bool) { return SURF_SDF_NSLOT_BF3; }  // LDS ring length (36 KB slots)
   static constexpr int REG_SLICES = SURF_SDF_REG_SLICES_BF3;
-  static constexpr int LDS_SLICES = SURF_SDF_LDS_SLICES_BF3;       // softplus' slices per wavefront in the spare LDS (3 x 36 + 4 x 3 x 4 KB = 156 KB)
+  static constexpr int LDS_SLICES = SURF_SDF_LDS_SLICES_BF3;       // exponent slices per wavefront in the spare LDS (3 x 36 + 4 x 3 x 4 KB = 156 KB)
 #ifndef SURF_SDF_DEEP_BF3
 #define SURF_SDF_DEEP_BF3 1
 #endif
-  static constexpr bool DEEP = SURF_SDF_DEEP_BF3;   // backward softplus' reads two chunks ahead (registers to spare)
+  static constexpr bool DEEP = SURF_SDF_DEEP_BF3;   // the reverse sweep reads its exponent slices two chunks ahead
   static constexpr bool DEEPJ = true;  // feature Jacobian fetched under the last backward chunk
   static constexpr ChunkTable CH = make_chunks(NP);
   struct Acc { f32x16 v[NA]; };
@@ -287,7 +284,7 @@ struct SdfArgs {
 __device__ __forceinline__ f32x4 bload(rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
-// Cache policy of the softplus' / Jacobian scratch round trip (written once, read once ~40 us later by the same wave):
+// Cache policy of the exponent-slice / Jacobian scratch round trip (written once, read once ~40 us later by the same wave):
 // SURF_X_SCRATCH_NT bit 0: stores non-temporal, bit 1: loads non-temporal (timing experiment of round 3).
 #ifndef SURF_X_SCRATCH_NT
 #define SURF_X_SCRATCH_NT 0
@@ -323,7 +320,7 @@ __device__ __forceinline__ void frag_set_pair(FragT<P::NP>& f, int pair /*0..3*/
 // overflow-free form  h = max(t, 0) + log(1 + exp(-|100 t|)) / 100,  h' = (t >= 0 ? 1 : exp(-|100 t|)) / (1 + exp(-|100 t|)),
 // which equals torch's thresholded softplus to fp32 rounding (the linear branch differs from it by < 2^-33 relative).
 // MODE 0: h only.  MODE 1: sv = h'.  MODE 2: sv = u = 100 log2(e) t, the exponent argument: the reverse sweep forms
-// h' = 1 / (1 + 2^-u) from it (sigma_pair) under ITS MFMAs.  The forward tiles are bound by the issue slots of their
+// h' = 1 / (1 + 2^-u) from it under ITS MFMAs.  The forward tiles are bound by the issue slots of their
 // conversion arithmetic (~42 issue cycles per 32-cycle MFMA with h' formed here, round-3 ISA count), the backward tiles
 // have slots to spare (~22), so the compare / select / reciprocal / multiply of h' move there; the scratch round trip
 // carries u instead of h' (same bytes).
@@ -363,20 +360,10 @@ __device__ __forceinline__ void softplus_pair(f32x2 acc, float acc_scale_inv, f3
     sv = arg;
   }
 }
-// h' = 1 / (1 + 2^-u) of a stored exponent argument u = 100 log2(e) t (softplus_pair MODE 2).  No branch and no overflow
-// case: u << 0 gives 2^-u = inf and 1 / inf = 0, u >> 0 gives 2^-u = 0 and h' = 1; for u < 0 this is e / (1 + e) with
-// e = 2^u divided through by e, i.e. the same value as MODE 1 to fp32 rounding.
-__device__ __forceinline__ f32x2 sigma_pair(f32x2 u) {
-  if (SURF_X_NOSOFTPLUS) return u;
-  f32x2 e;
-  e[0] = __builtin_amdgcn_exp2f(-u[0]);
-  e[1] = __builtin_amdgcn_exp2f(-u[1]);
-  const f32x2 d = e + 1.0f;
-  f32x2 r;
-  r[0] = __builtin_amdgcn_rcpf(d[0]);
-  r[1] = __builtin_amdgcn_rcpf(d[1]);
-  return r;
-}
+// h' = 1 / (1 + 2^-u) of a stored exponent argument u = 100 log2(e) t (softplus_pair MODE 2), formed by the reverse sweep's
+// mini-phases K_EXPN / K_ADD1 / K_RCP.  No branch and no overflow case: u << 0 gives 2^-u = inf and 1 / inf = 0, u >> 0 gives
+// 2^-u = 0 and h' = 1; for u < 0 this is e / (1 + e) with e = 2^u divided through by e, i.e. the same value as MODE 1 to
+// fp32 rounding.
 
 // ---- conversion slots ------------------------------------------------------------------------------------------------------
 // One wavefront per SIMD issues in order, and an MFMA that follows another within its 32 cycles holds the wave's issue until
