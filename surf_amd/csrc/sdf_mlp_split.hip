@@ -243,6 +243,7 @@ struct FwdPlan {
   static constexpr int DEADLINE = (T == 0 && L >= 1) ? (NKS - 1) * P::NM : NG;
   static constexpr GapPlan v = plan_gaps(NKS, P::NM, P::NP, chunk_dma<P, GRAD, CI, n_chunks<P>(GRAD)>(), DEADLINE, prog);
   static_assert(!(T == 0 && L >= 1) || pair_done_gap(v, prog, 3, NG) < (fwd_nl(L) + 6) * P::NM, "hin[6] is multiplied before it is complete");
+  static_assert(plan_ok(v, prog, mini, NG, DEADLINE), "gap plan");
 };
 template <class P, bool GRAD, int L, int T>
 __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>* hin, FragT<P::NP>* hout,
@@ -419,6 +420,7 @@ struct BwdPlan {
   static constexpr MiniProg mini = bwd_prog<P>();
   static constexpr SlotProg prog = CONVERT ? weave(mini, 8, 0) : SlotProg{};
   static constexpr GapPlan v = plan_gaps(NKS, P::NM, P::NP, chunk_dma<P, true, CI, n_chunks<P>(true)>(), NKS * P::NM, prog);
+  static_assert(plan_ok(v, prog, mini, NKS * P::NM, NKS * P::NM), "gap plan");
 };
 template <class P, int L, int T, bool CONVERT>
 __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din, FragT<P::NP>* dout, const BwdPend& prev,

@@ -468,6 +468,27 @@ constexpr GapPlan plan_gaps(int nks, int nm, int np, int n_dma, int deadline, Sl
   pl.per_stream = per;
   return pl;
 }
+// What every plan is checked for at compile time (static_assert in FwdPlan / BwdPlan): each pair's mini-phases 0 .. n-1 appear
+// exactly once and in order in the woven sequence; the slots are dealt out in order (first[] non-decreasing, from 0 to all of
+// them) and all of them before the deadline gap; no gap holds more mini-phases of one stream than the plan reports.
+constexpr bool plan_ok(const GapPlan& pl, const SlotProg& sp, const MiniProg& mp, int ng, int deadline) {
+  if (deadline > ng) deadline = ng;
+  int next[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int s = 0; s < sp.n; ++s) {
+    if (sp.q[s] < 0 || sp.q[s] >= 8 || sp.j[s] != next[sp.q[s]]) return false;
+    ++next[sp.q[s]];
+  }
+  for (int q = 0; q < 8; ++q)
+    if (sp.n > 0 && next[q] != mp.n) return false;
+  if (pl.first[0] != 0 || (ng > 0 && pl.first[ng] != sp.n) || (sp.n > 0 && pl.first[deadline] != sp.n)) return false;
+  for (int g = 0; g < ng; ++g) {
+    if (pl.first[g] > pl.first[g + 1]) return false;
+    int cnt[2] = {0, 0};
+    for (int s = pl.first[g]; s < pl.first[g + 1]; ++s) ++cnt[sp.q[s] & 1];
+    if (cnt[0] > pl.per_stream || cnt[1] > pl.per_stream) return false;
+  }
+  return true;
+}
 // gap in which the last mini-phase of pair q runs
 constexpr int pair_done_gap(const GapPlan& pl, const SlotProg& sp, int q, int ng) {
   int last = 0;
