@@ -593,6 +593,28 @@ def test_blend_split_matches_golden(scene, weights, gpu_scene, golden_render, pr
         assert torch.equal(first, again)
 
 
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1.0), ("f16x2", 4.0), ("f32lds", 1.0)])
+def test_blend_split_view_counts(scene, weights, gpu_scene, precision, tol):
+    """2..7 views (1..6 source views): the split kernels stage the per-view state of a tile in LDS (first two views), registers
+    (the next two / three) and the global slot (the rest) - every count takes a different mix of the three paths - against the
+    fp32-MFMA kernel, which unrolls its views and stages nothing."""
+    from surf_amd import ops
+    d = dev()
+    w16 = ops.blend_pack_weights(weights, d, precision=precision)
+    g = torch.Generator().manual_seed(33)
+    pts = ((torch.rand(20_000, 3, generator=g) * 2 - 1) * 0.7).to(d).contiguous()
+    nv0 = int(scene["intrs"].shape[0])
+    for nv in (2, 3, 4, 5, 6, 7):
+        sel = [i % nv0 for i in range(nv)]                               # views beyond the scene's five repeat earlier ones
+        cams = ops.Cameras(scene["intrs"][sel], scene["c2ws"][sel])
+        feats = [f[sel].contiguous() for f in gpu_scene["feats_t4"]]
+        imgs = gpu_scene["imgs_t4"][sel].contiguous()
+        a, na = ops.blend(pts, feats, imgs, cams, w16)
+        b, nb = ops.blend(pts, feats, imgs, cams, gpu_scene["blend_w"])
+        rel_close(a, b, 0, 3e-6 * tol)
+        assert torch.equal(na, nb) and int(na.max()) == nv - 1
+
+
 def test_finetune_volume_api_round_trip(scene, tmp_path):
     """surf.py:47-78: init_volumes freezes the scene's volumes, a has_vol forward renders from them (identical to the
     build-every-call forward), get_params_vol / load_params_vol round trip through a file into a model constructed with
