@@ -481,7 +481,7 @@ def run_rank_train(args):
             result["voxels_per_stage"] = getattr(model, "last_voxels_per_stage", None)
         print(json.dumps(result))
     if world > 1:
-        torch.distributed.destroy_process_group()
+        D.shutdown()
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -736,7 +736,7 @@ def run_rank(args):
                                               "scenes": n_scenes_total, "rays_per_step": rays_per_step_job},
                 "scenes": recs}))
         if world > 1:
-            torch.distributed.destroy_process_group()
+            D.shutdown()
         return
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region -----------------------
@@ -874,7 +874,7 @@ def run_rank(args):
             result["training_step"] = training_step_timing(args, dev)
         print(json.dumps(result))
     if world > 1:
-        torch.distributed.destroy_process_group()
+        D.shutdown()
 
 
 if __name__ == "__main__":

@@ -225,7 +225,9 @@ __host__ inline int64_t slab_rows(int64_t rows) {
 extern "C" int64_t surf_colgram_workspace_floats(int64_t rows, int M, int N) {
   const int64_t rpb = slab_rows(rows), blocks = (rows + rpb - 1) / rpb;
   int64_t need = blocks * M * (N + 1);
-  if (rows >= CG_MFMA_MIN_ROWS && M <= 128) {
+  // the MFMA plan is also taken for SHORT inputs when precision == 1 (surf_colgram_p), and its partial count
+  // nsplit * ceil(rows / (per * nsplit)) can exceed the VALU slab count there: size for whichever is larger, always
+  if (rows > 0 && M <= 128) {
     const CgPlan p = cg_plan(rows, M);
     const int64_t need2 = (int64_t)p.blocks * p.nsplit * M * (N + 1);
     if (need2 > need) need = need2;

@@ -101,6 +101,23 @@ def broadcast_module_state(module, src=0, buffers_only=False):
         for t in tensors:
             if not torch.is_tensor(t) or t.numel() == 0:
                 continue
-            dist.broadcast(t.data, src=src)
+            d = t.detach()                     # shares the version counter with t (t.data does not)
+            dist.broadcast(d, src=src)
+            # c10d writes through the storage without telling autograd: every weight cache of the package (packed SDF /
+            # blend images, inv_s, agg_mlp host copy, sparse-conv prep, the frozen-volume scene) is keyed on
+            # (parameter._version, data_ptr) and would keep serving the pre-broadcast weights.  A self copy_ is an in-place
+            # op autograd sees: it bumps the shared counter (no value change, any dtype).
+            d.copy_(d)
             n += 1
     return n
+
+
+def shutdown():
+    """Leave the process group in step: barrier, then destroy_process_group().  A rank that simply exits while another is
+    still inside its last collective makes gloo's (and RCCL's) background thread abort the slower one
+    ("terminate called without an active exception").  Every spawned worker and bench.py end with this."""
+    if dist.is_initialized():
+        try:
+            dist.barrier()
+        finally:
+            dist.destroy_process_group()

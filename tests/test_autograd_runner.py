@@ -315,6 +315,9 @@ DDP_WORKER = textwrap.dedent("""
     torch.cuda.synchronize()
     sd = {n: p.detach().double().cpu() for n, p in model.named_parameters() if p.requires_grad}
     print("RESULT " + json.dumps({"sum": {n: float(v.sum()) for n, v in sd.items()}, "abs": {n: float(v.abs().sum()) for n, v in sd.items()}}))
+    if mode == "ddp":
+        dist.barrier()
+        dist.destroy_process_group()
 """) % ROOT
 
 

@@ -168,6 +168,8 @@ DDP_WORKER = FAKE + textwrap.dedent("""
     g_is = float(first.grad.flatten()[0])
     g_fpn = float(next(model.feature_network.parameters()).grad.flatten()[0])
     print("RESULT " + json.dumps({"rank": rank, "before": before, "after": after, "g_is": g_is, "g_fpn": g_fpn, "calls": calls}))
+    dist.barrier()
+    dist.destroy_process_group()
 """)
 
 

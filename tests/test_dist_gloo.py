@@ -21,6 +21,7 @@ WORKER = textwrap.dedent("""
     recs = D.gather_records({"rank": rank, "scenes": scenes, "dt": dt})
     if rank == 0:
         print(json.dumps({"world": world, "tmax": tmax, "recs": recs}))
+    D.shutdown()
 """) % ROOT
 
 
@@ -118,6 +119,7 @@ GRAD_WORKER = textwrap.dedent("""
         print(json.dumps({"buckets": n, "g0": float(params[0].grad.mean()), "g1": params[1].grad.tolist(), "g2": float(params[2].grad.mean())}))
     else:
         assert abs(float(params[2].grad.mean()) - 0.5) < 1e-6
+    D.shutdown()
 """) % ROOT
 
 
@@ -181,13 +183,24 @@ STATE_WORKER = textwrap.dedent("""
     net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.BatchNorm1d(7), torch.nn.Linear(7, 2))
     net(torch.randn(16, 5))                             # moves the BatchNorm running statistics, differently per rank
     before = float(sum(p.detach().abs().sum() for p in net.parameters()) + sum(b.float().abs().sum() for b in net.buffers()))
+    versions = [t._version for t in list(net.parameters()) + list(net.buffers())]
     n_all = D.broadcast_module_state(net, src=0)
+    # every weight cache of the package is keyed on (parameter._version, data_ptr): the broadcast must be visible there
+    versions_bumped = all(t._version > v for t, v in zip(list(net.parameters()) + list(net.buffers()), versions))
     after = float(sum(p.detach().abs().sum() for p in net.parameters()) + sum(b.float().abs().sum() for b in net.buffers()))
     with torch.no_grad():
         net[1].running_mean.add_(float(rank + 1))       # per-rank drift of the buffers during training
     n_buf = D.broadcast_module_state(net, src=0, buffers_only=True)
     rm = float(net[1].running_mean.sum())
-    print("RESULT " + json.dumps({"rank": rank, "before": before, "after": after, "n_all": n_all, "n_buf": n_buf, "rm": rm}))
+    # a cache of the package itself: inv_s read before the broadcast (a warm-up / val forward) must be re-read after it
+    from surf_amd.implicit_surface import SingleVarianceNetwork
+    dev_net = SingleVarianceNetwork(0.1 * (rank + 1))
+    stale = dev_net.inv_s()
+    D.broadcast_module_state(dev_net, src=0)
+    inv_s = dev_net.inv_s()
+    print("RESULT " + json.dumps({"rank": rank, "before": before, "after": after, "n_all": n_all, "n_buf": n_buf, "rm": rm,
+                                  "versions_bumped": versions_bumped, "inv_s": inv_s, "stale": stale}))
+    D.shutdown()
 """) % ROOT
 
 
@@ -211,3 +224,5 @@ def test_broadcast_module_state_makes_replicas_identical(tmp_path):
     assert res[0]["after"] == res[1]["after"] == res[0]["before"]
     assert res[0]["n_all"] == res[1]["n_all"] == 6 + 3 and res[0]["n_buf"] == 3      # 6 parameters + 3 BatchNorm buffers
     assert res[0]["rm"] == res[1]["rm"]
+    assert res[0]["versions_bumped"] and res[1]["versions_bumped"]
+    assert res[0]["stale"] != res[1]["stale"] and res[1]["inv_s"] == res[0]["inv_s"] == res[0]["stale"]

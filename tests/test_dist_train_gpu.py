@@ -80,6 +80,7 @@ WORKER = textwrap.dedent("""
     sd = {n: p.detach().double().cpu() for n, p in model.named_parameters() if p.requires_grad}
     out = {"sum": {n: float(v.sum()) for n, v in sd.items()}, "abs": {n: float(v.abs().sum()) for n, v in sd.items()}}
     print("RESULT " + json.dumps(out))
+    D.shutdown()
 """) % ROOT
 
 

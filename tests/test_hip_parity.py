@@ -1320,6 +1320,35 @@ def test_colgram_matches_matmul(rows, M, N):
     assert float((out_b - ref).abs().max()) <= 2e-2 * float(ref.abs().max()) + 1e-3 * (rows ** 0.5)
 
 
+@pytest.mark.parametrize("rows", [10, 65, 2050, 4095])
+@pytest.mark.parametrize("M", [1, 8, 32, 64, 101])
+@pytest.mark.parametrize("precision", [0, 1])
+def test_colgram_short_inputs_stay_inside_workspace(rows, M, precision):
+    """surf_colgram_p with the bf16 policy takes the matrix-core plan for SHORT inputs too (rows < 4096): its partial count
+    nsplit * ceil(rows / (per * nsplit)) must fit surf_colgram_workspace_floats.  Guard words behind the workspace and behind
+    the output must survive, and the result must be the matmul of the (rounded) operands."""
+    import ctypes
+    from surf_amd import _lib, ops
+    d = dev()
+    N = 33
+    g = torch.Generator().manual_seed(1000 * rows + M)
+    A = torch.randn(rows, M, generator=g).to(d)
+    X = torch.randn(rows, N, generator=g).to(d)
+    L = _lib.lib()
+    need = int(L.surf_colgram_workspace_floats(rows, M, N))
+    GUARD = 4096
+    ws = torch.full((need + GUARD,), 12345.0, dtype=torch.float32, device=d)
+    out = torch.full((M * (N + 1) + GUARD,), 54321.0, dtype=torch.float32, device=d)
+    rc = L.surf_colgram_p(ops._p(A), M, M, ops._p(X), N, N, rows, 1, 0, precision, ops._p(ws), ops._p(out), ops._stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert bool((ws[need:] == 12345.0).all()), "surf_colgram_p wrote past its workspace"
+    assert bool((out[M * (N + 1):] == 54321.0).all())
+    Ar, Xr = (A.to(torch.bfloat16), X.to(torch.bfloat16)) if precision else (A, X)
+    ref = (Ar.double().t() @ torch.cat([Xr.double(), torch.ones(rows, 1, dtype=torch.float64, device=d)], dim=1)).float()
+    rel_close(out[:M * (N + 1)].reshape(M, N + 1), ref, 1e-4, 1e-4 * float(ref.abs().max()))
+
+
 def test_mfc_backward_pieces_match_autograd(scene, gpu_scene, golden_train, golden_fpn):
     """Row f2: the forward-mode tangent of (surface_patch_warp2 -> compute_LNCC2) along the ray (surf_patch_warp_tangent,
     surf_lncc_jvp) against torch.autograd.functional.jvp through the oracle, and surf_crossing_backward against autograd of

@@ -231,3 +231,23 @@ def test_agg_mlp_host_copy_is_cached_per_parameter_version():
         vol.agg_mlp[2].bias.add_(1.0)
     b = vol.agg_host()
     assert b is not a and abs(float(b[48] - a[48]) - 1.0) < 1e-6
+
+
+def test_colgram_workspace_covers_both_launch_plans():
+    """surf_colgram_workspace_floats must cover the matrix-core plan of surf_colgram_p for every row count: with
+    train_precision = bf16 that plan is taken for short inputs too (advisor finding, round 3: rows = 2050, M = 32 wrote 36
+    partials into 33).  The plan is restated here from colgram.hip (cg_plan / slab_rows); no compute call, no GPU."""
+    from surf_amd import _lib
+    L = _lib.lib()
+
+    def mfma_partials(rows, M):
+        nsplit = 4 // ((M + 31) // 32)
+        per = -(-rows // (256 * nsplit))
+        per = max(64, -(-per // 16) * 16)
+        return nsplit * -(-rows // (per * nsplit))
+
+    for rows in list(range(1, 300)) + [2049, 2050, 4095, 4096, 4097, 60864, 243456, 1000003]:
+        for M in (1, 8, 31, 32, 33, 64, 65, 96, 101, 128):
+            for N in (1, 8, 33, 57, 156):
+                need = int(L.surf_colgram_workspace_floats(rows, M, N))
+                assert need >= mfma_partials(rows, M) * M * (N + 1), (rows, M, N)
