@@ -34,5 +34,36 @@ for prec in os.environ.get('SURF_BLEND', 'f32,f32lds,bf16x3,f16x2').split(','):
     flop = n_act * (nv - 1) * 2 * 9928
     if ref is None:
         ref = col
+    if os.environ.get('SURF_PHASES'):         # a -DSURF_BLEND_TIMING build: shader clocks of wavefront 0 of every workgroup, by phase
+        import ctypes
+        from surf_amd import _lib
+        raw = ctypes.CDLL(_lib.LIB_PATH)
+        buf = (ctypes.c_ulonglong * 10)()
+        raw.surf_debug_blend_phases(buf, 1)
+        col, nval = ops.blend(st["pts"], scene.feats_t4, scene.imgs_t4, scene.cams, w, mask=st["vmask"], active_idx=act)
+        torch.cuda.synchronize()
+        raw.surf_debug_blend_phases(buf, 0)
+        tiles_per_wave = (n_act / 32) / (256 * 8)
+        names = ['tile setup', 'pass 1 (4 views)', 'pooling sweeps', 'shared base_fc.0', 'p2 base_fc', 'p2 vis_fc', 'p2 vis_fc2', 'p2 rgb_fc+softmax']
+        tot = sum(buf[:8])
+        for k in range(8):
+            print(f"   phase {k} {names[k]:20s} {buf[k] / 256 / tiles_per_wave:9.0f} clocks per tile  ({100.0 * buf[k] / tot:4.1f} %)")
+        print(f"   total {tot / 256 / tiles_per_wave:9.0f} clocks per tile per wave;  workgroup 0: {buf[8]} s_memtime ticks in {buf[9] / 100.0:.1f} us "
+              f"(s_memrealtime, 100 MHz) = {buf[8] / max(buf[9], 1) * 0.1:.3f} GHz")
+        wg = (ctypes.c_ulonglong * 512)()
+        raw.surf_debug_blend_wg(wg)
+        t0 = min(wg[2 * i] for i in range(256))
+        dur = [(wg[2 * i + 1] - wg[2 * i]) / 100.0 for i in range(256)]
+        start = [(wg[2 * i] - t0) / 100.0 for i in range(256)]
+        print("   workgroup durations (us): min %.0f  median %.0f  max %.0f;  latest start %.0f us" % (min(dur), sorted(dur)[128], max(dur), max(start)))
+        for x in range(8):
+            d = [dur[i] for i in range(x, 256, 8)]
+            print(f"   XCD {x}: min {min(d):.0f}  mean {sum(d) / len(d):.0f}  max {max(d):.0f} us")
+    if os.environ.get('SURF_SAVE'):          # A/B of two library builds: SURF_SAVE=a.pt, then SURF_SAVE=b.pt SURF_CMP=a.pt
+        torch.save({'col': col.cpu(), 'nval': nval.cpu()}, os.environ['SURF_SAVE'] + '.' + prec)
+    if os.environ.get('SURF_CMP'):
+        o = torch.load(os.environ['SURF_CMP'] + '.' + prec)
+        print(f"   vs {os.environ['SURF_CMP']}: max |rgb diff| {float((o['col'] - col.cpu()).abs().max()):.3e}, "
+              f"bitwise equal {bool(torch.equal(o['col'], col.cpu()))}, n_valid equal {bool(torch.equal(o['nval'], nval.cpu()))}")
     print(f"{prec}: {dt*1e3:.2f} ms for {n_act} samples x {nv-1} views, {flop/dt/1e12:.1f} TFLOP/s algorithmic, "
           f"{dt/ (n_act/32) * 1e9 * 256 * 4 / (nv-1):.0f} ns per (tile, view) per SIMD, max |rgb - first| {float((col-ref).abs().max()):.2e}")

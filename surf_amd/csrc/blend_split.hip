@@ -65,8 +65,14 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int NP>
 struct FragT { u32x4 p[NP]; };  // B operand of one 16-wide k-step: NP pieces x 8 x 16 bit
 
+// Matrix-pipe residuals of the exact bf16 split (round 4; see split_tile_mres below): 1 = on (default), 0 = the VALU form
+#ifndef SURF_BLEND_MRES
+#define SURF_BLEND_MRES 1
+#endif
+
 struct BPolBf3 {
   static constexpr int NP = 3, ID = 1, BB = NP * 1024, LANE_BYTES = 16;
+  static constexpr bool MRES = SURF_BLEND_MRES != 0;
 #ifndef SURF_BLEND_REG_VIEWS_BF3
 #define SURF_BLEND_REG_VIEWS_BF3 2
 #endif
@@ -99,6 +105,7 @@ struct BPolBf3 {
 
 struct BPolH2 {
   static constexpr int NP = 2, ID = 2, BB = NP * 1024, LANE_BYTES = 16;
+  static constexpr bool MRES = false;  // one residual level, formed by v_fma_mix-style arithmetic: nothing to gain
 #ifndef SURF_BLEND_REG_VIEWS_H2
 #define SURF_BLEND_REG_VIEWS_H2 3
 #endif
@@ -159,6 +166,7 @@ template <int NUSED> __device__ __forceinline__ void BPolH2::mma_lds(f32x16& acc
 // per slot that carries data.  Block = [lane][8 floats] = 2 KB.
 struct BPolF32 {
   static constexpr int NP = 1, ID = 3, BB = 2048, LANE_BYTES = 32;
+  static constexpr bool MRES = false;
   static constexpr int REG_VIEWS = 0;
   struct Frag { float v[8]; };
   static __device__ __forceinline__ void set_pair(Frag& f, int pr, float a, float b) { f.v[2 * pr] = a; f.v[2 * pr + 1] = b; }
@@ -172,6 +180,19 @@ struct BPolF32 {
     for (int i = 0; i < NUSED; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(i < 4 ? a0[i] : a1[i - 4], b.v[i], acc, 0, 0, 0);
   }
 };
+
+#ifdef SURF_BLEND_TIMING  // debug builds only (scripts/build_variant.sh): per-phase shader-clock totals of wavefront 0 of every workgroup
+__device__ unsigned long long g_bwg[256][2];  // s_memrealtime at the start / end of every workgroup's wavefront 0
+__device__ unsigned long long g_bphase[10];  // [8], [9]: s_memtime / s_memrealtime (100 MHz) span of workgroup 0's wavefront 0
+#define SURF_BT(k)                                                \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    tacc[k] += now_ - tprev;                                      \
+    tprev = now_;                                                 \
+  } while (0)
+#else
+#define SURF_BT(k)
+#endif
 
 struct BlendArgs {
   const float* pts;
@@ -235,9 +256,34 @@ __device__ __forceinline__ void elu_frags(const f32x16& acc, typename P::Frag* f
   for (int r = 0; r < N; r += 2) P::set_pair(f[r >> 3], (r & 7) >> 1, elu_t(acc[r]), elu_t(acc[r + 1]));
 }
 
+// ---- the residuals of the exact bf16 split on the matrix pipe (bf16x3, round 4) ------------------------------------------
+// The kernel is VALU-issue bound (SQ counters, profiles/r04_blend_sq_bf16x3_before.txt: VALU issue 77 % of SIMD time, matrix
+// pipe 33 %), and a third of its VALU instructions were the operand split a = p0 + p1 + p2: per PAIR of values three
+// v_cvt_pk_bf16_f32 plus, for each of the two residual levels, two expands (shift / and) and two subtracts = 11 instructions.
+// A residual r = a - p0 of a whole activation tile is an accumulator update with a constant A operand,
+//       R (32 rows x 32 samples) = A_tile - sum_s I_s * P0_s ,
+// where P0_s is the packed first piece AS the B fragment of its own k-step s (which it is about to be anyway) and I_s has a
+// single -1 per row: row rho of the tile = k-slot (g, i') of step s with rho = (i' & 3) + 8 (2 s + (i' >> 2)) + 4 g, the same
+// register <-> feature map `hk` that makes an accumulator tile the next layer's B operand.  One v_mfma_f32_32x32x16_bf16 per
+// k-step and level (12 issue cycles) replaces 16 VALU instructions (~70 issue cycles) of every lane; the products -1 x p0 and
+// the sum a - p0 are exact (Sterbenz), and scripts/microbench/mfma_residual.hip shows the pipe returns them bit-identical to
+// the VALU subtraction for 2 M values (zeros, bf16 ties, both exponent extremes; not inf: 0 x inf would poison a column -
+// activations here are ELU outputs of O(1)).  So the kernel's results do not change by a single bit.
+__device__ __forceinline__ u32x4 ident_frag(int lane, int s) {
+  const int i = lane & 31, g = lane >> 5;
+  u32x4 f = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int ip = 0; ip < 8; ++ip) {
+    const int rho = (ip & 3) + 8 * (2 * s + (ip >> 2)) + 4 * g;
+    if (rho == i) f[ip >> 1] |= (ip & 1) ? 0xBF800000u : 0x0000BF80u;  // bf16(-1.0)
+  }
+  return f;
+}
+
 struct Ctx {
   const char* lds;
   int lane16, h64;
+  u32x4 I0, I1;  // (bf16x3) A operands of the matrix-pipe residual, k-steps 0 and 1 of a 32-row tile: see split_tile_mres
 };
 // A copy of the context whose LDS offsets the optimiser cannot see through.  The LDS image is read-only inside the tile
 // loop, so without this every ds_read of a weight fragment / bias row is a loop invariant AND common to all (unrolled)
@@ -247,6 +293,67 @@ __device__ __forceinline__ Ctx opaque(const Ctx& c) {
   Ctx o = c;
   asm volatile("" : "+v"(o.lane16), "+v"(o.h64));
   return o;
+}
+
+// first N values of r (the rest of r must be finite: zeros) -> NF = ceil(N / 8) fragments, exact three-way split, residuals on
+// the matrix pipe
+template <class P, int N, int NF>
+__device__ __forceinline__ void split_tile_mres(const Ctx& c, f32x16 r, typename P::Frag* f) {
+  static_assert(NF == (N + 7) / 8 && NF <= 2 && P::NP == 3, "one 32-row tile");
+#pragma unroll
+  for (int lvl = 0; lvl < 3; ++lvl) {
+#pragma unroll
+    for (int s = 0; s < NF; ++s)
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        const int i0 = 8 * s + 2 * pr;
+        if (i0 < N) {
+          bf16x2 v;
+          v[0] = (__bf16)r[i0];
+          v[1] = (__bf16)(i0 + 1 < N ? r[i0 + 1] : 0.0f);
+          f[s].p[lvl][pr] = __builtin_bit_cast(uint32_t, v);
+        } else {
+          f[s].p[lvl][pr] = 0u;
+        }
+      }
+    if (lvl == 2) break;
+    r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.I0), __builtin_bit_cast(bf16x8, f[0].p[lvl]), r, 0, 0, 0);
+    if (NF > 1)
+      r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, c.I1), __builtin_bit_cast(bf16x8, f[1].p[lvl]), r, 0, 0, 0);
+  }
+}
+// N values -> fragments (policy's way)
+template <class P, int N, int NF>
+__device__ __forceinline__ void make_frags(const Ctx& c, const float* v, typename P::Frag* f) {
+  if constexpr (P::MRES && N >= 3) {
+    constexpr int N0 = N > 16 ? 16 : N;  // tile by tile (two k-steps each)
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = i < N0 ? v[i] : 0.0f;
+    split_tile_mres<P, N0, (N0 + 7) / 8>(c, r, f);
+    if constexpr (N > 16) {
+      constexpr int N1 = N - 16;
+      static_assert(N1 <= 16, "at most two tiles");
+      f32x16 r1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) r1[i] = i < N1 ? v[16 + i] : 0.0f;
+      split_tile_mres<P, N1, (N1 + 7) / 8>(c, r1, f + 2);
+    }
+  } else {
+    frags_from<P, N, NF>(v, f);
+  }
+}
+// ELU of the first N registers of an accumulator tile -> fragments
+template <class P, int N>
+__device__ __forceinline__ void elu_make_frags(const Ctx& c, const f32x16& acc, typename P::Frag* f) {
+  if constexpr (P::MRES) {
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = i < N ? elu_t(acc[i]) : 0.0f;
+    split_tile_mres<P, N, (N + 7) / 8>(c, r, f);
+  } else {
+    elu_frags<P, N>(acc, f);
+  }
 }
 
 template <class P>
@@ -406,6 +513,8 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
   c0.lds = lds;
   c0.lane16 = lane * 16;
   c0.h64 = h * 64;
+  c0.I0 = ident_frag(lane, 0);
+  c0.I1 = ident_frag(lane, 1);
   const int NS = a.nv - 1;
   const int64_t wave_id = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6);
   const int64_t n_waves = (int64_t)gridDim.x * WPB;
@@ -425,7 +534,12 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
   const int HB = h ? a.hw[6] : a.hw[2], WB = h ? a.hw[7] : a.hw[3];
   const float scA = h ? 0.25f : 1.0f, scB = h ? 0.125f : 0.5f;
 
+#ifdef SURF_BLEND_TIMING
+  unsigned long long tprev = __builtin_readcyclecounter(), tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_begin = tprev, rt_begin = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
+    SURF_BT(0);
     const int64_t slot_i = tile * TILE + j;
     const int64_t sc = slot_i < n_pts ? slot_i : n_pts - 1;
     const int64_t i = a.idx ? (int64_t)a.idx[sc] : sc;
@@ -491,7 +605,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
         frags_from<P, 2, 1>(bin, &fb);
         f32x16 acc1 = bias_row<P>(c, B_RD0);
         mma_layer<P, L_RD0, 0, 1>(c, acc1, &fb);
-        elu_frags<P, 8>(acc1, &f8);
+        elu_make_frags<P, 8>(c, acc1, &f8);
         f32x16 acc2 = bias_row<P>(c, B_RD2);
         mma_layer<P, L_RD2, 0, 1>(c, acc2, &f8);
         // rows of half 1 beyond its 8 channels carry zero weights and zero bias: elu(0) = 0
@@ -523,6 +637,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       slot_store(slot, v, lane, st, keep);
     }
     if (a.n_valid && active && h == 0) a.n_valid[i] = (uint8_t)nvalid;
+    SURF_BT(1);
 
     // ------------------------------ pooling weights, weighted mean / variance (:76-86) ----------------------
     // w_v = (ex_v - min_v ex) mk_v / (sum + 1e-8); mean = sum_v w_v f_v; var = sum_v w_v (f_v - mean)^2: two sweeps
@@ -551,6 +666,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
 #pragma unroll
       for (int ch = 0; ch < 12; ++ch) { const float d = st.floc[ch] - mv[ch]; mv[12 + ch] += w * (d * d); }
     }
+    SURF_BT(2);
     // view-independent part of base_fc.0: [mean(12) | var(12)] -> 64 (two tiles), initialised with the bias
     f32x16 G0a, G0b;
     {
@@ -558,7 +674,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       G0a = bias_row<P>(c, B_B0_T0);
       G0b = bias_row<P>(c, B_B0_T1);
       Frag fm[3];
-      frags_from<P, 24, 3>(mv, fm);
+      make_frags<P, 24, 3>(c, mv, fm);
       mma_layer<P, L_B0S, 0, 3>(c, G0a, fm);
       mma_layer<P, L_B0S, 1, 3>(c, G0b, fm);
     }
@@ -567,6 +683,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
     // Written for short live ranges (two wavefronts per SIMD = 256 registers): every activation tile is converted to
     // B fragments pair by pair as it leaves the accumulator and consumed by the next layer's k-steps at once.
     float Mx = -INFINITY, Zs = 0.f, o_r = 0.f, o_g = 0.f, o_b = 0.f;
+    SURF_BT(3);
 #pragma unroll 1
     for (int v = 0; v < NS; ++v) {
       const Ctx c = opaque(c0);
@@ -577,7 +694,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       f32x16 a0 = G0a, a1 = G0b;
       {
         Frag fl[2];
-        frags_from<P, 12, 2>(st.floc, fl);
+        make_frags<P, 12, 2>(c, st.floc, fl);
         mma_layer<P, L_B0V, 0, 2>(c, a0, fl);
         mma_layer<P, L_B0V, 1, 2>(c, a1, fl);
       }
@@ -585,17 +702,18 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       f32x16 ax2 = bias_row<P>(c, B_B2);
       {
         Frag hf[2];
-        elu_frags<P, 16>(a0, hf);
+        elu_make_frags<P, 16>(c, a0, hf);
         mma_blk<P, L_B2, 0, 0>(c, ax2, hf[0]);
         mma_blk<P, L_B2, 1, 0>(c, ax2, hf[1]);
         SURF_PHASE();
-        elu_frags<P, 16>(a1, hf);
+        elu_make_frags<P, 16>(c, a1, hf);
         mma_blk<P, L_B2, 2, 0>(c, ax2, hf[0]);
         mma_blk<P, L_B2, 3, 0>(c, ax2, hf[1]);
         SURF_PHASE();
       }
       float x[16];
       elu_rows<16>(ax2, x);
+      SURF_BT(4);
       // vis_fc: 32 -> 32 (ELU) -> 33 (ELU)
       float vis;
       {
@@ -604,7 +722,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
         for (int r = 0; r < 16; ++r) at[r] = 0.f;
         {
           Frag xf[2];
-          frags_from<P, 16, 2>(x, xf);
+          make_frags<P, 16, 2>(c, x, xf);
           mma_layer<P, L_V0, 0, 2>(c, at, xf);
         }
         const f32x16 bt = bias_row<P>(c, B_V0);
@@ -618,7 +736,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
 #pragma unroll
           for (int r = 0; r < 16; ++r) vraw = fmaf(dvis[r], t16[r], vraw);
           Frag tf[2];
-          frags_from<P, 16, 2>(t16, tf);
+          make_frags<P, 16, 2>(c, t16, tf);
           mma_layer<P, L_V2, 0, 2>(c, ar, tf);
         }
         vraw += __shfl_xor(vraw, 32);
@@ -629,8 +747,9 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       // vis_fc2: 32 -> 32 (ELU) -> 1 (sigmoid).  Its input x vis and the x part of rgb_fc's input share ONE operand
       // split: a Linear commutes with the per-sample scale, W (x vis) + b = vis (W x) + b, so the matrix product runs on
       // the fragments of x itself and the scale is applied to the accumulator (16 FMAs instead of a second split).
+      SURF_BT(5);
       Frag rf[3];
-      frags_from<P, 16, 2>(x, rf);
+      make_frags<P, 16, 2>(c, x, rf);
       float vis2;
       {
         f32x16 aw;
@@ -645,19 +764,20 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
         v2 += __shfl_xor(v2, 32);
         vis2 = sigm(v2 + b_vis2) * st.mk;
       }
+      SURF_BT(6);
       // rgb_fc: [x(32), vis, ray_diff(4)] = 37 -> 16 (ELU) -> 8 (ELU) -> 1
       float rr;
       {
         f32x16 a16 = bias_row<P>(c, B_R0);
         {
           const float extra[3] = {h ? st.rd[0] : vis2, h ? st.rd[2] : st.rd[1], h ? 0.f : st.rd[3]};
-          frags_from<P, 3, 1>(extra, rf + 2);
+          make_frags<P, 3, 1>(c, extra, rf + 2);
           mma_layer<P, L_R0, 0, 3>(c, a16, rf);
         }
         f32x16 a8 = bias_row<P>(c, B_R2);
         {
           Frag f8;
-          elu_frags<P, 8>(a16, &f8);
+          elu_make_frags<P, 8>(c, a16, &f8);
           mma_layer<P, L_R2, 0, 1>(c, a8, &f8);
         }
         const f32x16 drgb4 = dot_row<P>(c, D_RGB4);
@@ -676,6 +796,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       o_g = o_g * scl + e * st.rgb[1];
       o_b = o_b * scl + e * st.rgb[2];
       Mx = Mn;
+      SURF_BT(7);
     }
     if (active && h == 0) {
       a.color[i * 3 + 0] = o_r / Zs;
@@ -683,6 +804,18 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       a.color[i * 3 + 2] = o_b / Zs;
     }
   }
+#ifdef SURF_BLEND_TIMING
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 8; ++k) atomicAdd(&g_bphase[k], tacc[k]);
+  if (threadIdx.x == 0 && blockIdx.x < 256) {
+    g_bwg[blockIdx.x][0] = rt_begin;
+    g_bwg[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    g_bphase[8] = __builtin_readcyclecounter() - t_begin;
+    g_bphase[9] = __builtin_amdgcn_s_memrealtime() - rt_begin;
+  }
+#endif
 }
 
 int grid_blocks(int64_t n) {
@@ -840,6 +973,20 @@ int launch(const BlendArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef SURF_BLEND_TIMING
+extern "C" int surf_debug_blend_wg(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwg), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : 100;
+}
+extern "C" int surf_debug_blend_phases(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bphase), sizeof(unsigned long long) * 10) != hipSuccess) return 100;
+  if (reset) {
+    unsigned long long z[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bphase), z, sizeof(z)) != hipSuccess) return 100;
+  }
+  return 0;
+}
+#endif
 
 extern "C" int64_t surf_blend_split_packed_bytes(int precision) {
   if (precision == BPolBf3::ID) return image_bytes<BPolBf3::BB>();
