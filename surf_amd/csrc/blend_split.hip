@@ -391,31 +391,64 @@ __device__ __forceinline__ void mma_layer(const Ctx& c, f32x16& acc, const typen
   SURF_PHASE();
 }
 
-// Bilinear fetch of a texel4 map with zero padding, branch-free: out-of-range taps read a clamped texel with
-// weight 0, so all four 16-byte loads of a fetch (and of every fetch of a view) can be in flight together.
-struct Tap4 {
-  f32x4 v[4];
+// Bilinear fetch of a texel4 map with zero padding (grid_sample, align_corners=False), branch-free: out-of-range taps read a
+// clamped texel with weight 0, so all four 16-byte loads of a fetch (and of every fetch of a view) can be in flight together.
+// Round 4: the kernel is VALU-issue bound and the fetch was ~75 instructions a map (per CORNER: range test, clamp, 64-bit
+// address, weight select).  Now per AXIS two clamped indices and two weights that are zero outside (TapGeom, shared by the maps
+// of one resolution: the image and the finest feature level), 32-bit texel indices and one v_lshl_add_u64 per load.
+// a / c for a divisor with its correctly rounded reciprocal rc = RN(1 / c) at hand: q = RN(a rc), r = a - q c (exact, one FMA),
+// RN(q + r rc) is the correctly rounded quotient (Markstein); checked against IEEE division for 1.3e8 random numerators over
+// every divisor (W - 1) / 2 of the pyramids in use.  Three instructions instead of the ten of v_div_scale .. v_div_fixup.
+__device__ __forceinline__ float div_const(float a, float c, float rc) {
+  const float q = a * rc;
+  const float r = fmaf(-q, c, a);
+  return fmaf(r, rc, q);
+}
+struct TapGeom {
+  int idx[4];   // texel index (y * W + x) of (y0,x0), (y0,x1), (y1,x0), (y1,x1) = grid_sample's nw, ne, sw, se
   float w[4];
 };
-__device__ __forceinline__ void tap_issue(Tap4& t, const float* __restrict__ map, int H, int W, float x, float y) {
-  const float fx = floorf(x), fy = floorf(y);
-  const float tx = x - fx, ty = y - fy;
-  const int x0 = (int)fx, y0 = (int)fy;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {  // order (y0,x0), (y0,x1), (y1,x0), (y1,x1) = grid_sample's nw, ne, sw, se
-    const int dx = k & 1, dy = k >> 1;
-    const int xi = x0 + dx, yi = y0 + dy;
-    const bool ok = (xi >= 0) & (xi < W) & (yi >= 0) & (yi < H);
-    const int xc = min(max(xi, 0), W - 1), yc = min(max(yi, 0), H - 1);
-    t.v[k] = *reinterpret_cast<const f32x4*>(map + ((int64_t)yc * W + xc) * 4);
-    t.w[k] = ok ? (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) : 0.0f;
-  }
+__device__ __forceinline__ void axis_taps(float g, int n, int& i0, int& i1, float& w0, float& w1) {
+  const float f = floorf(g);
+  const float t = g - f;
+  const int i = (int)f;
+  i0 = min(max(i, 0), n - 1);
+  i1 = min(max(i + 1, 0), n - 1);
+  w0 = (unsigned)i < (unsigned)n ? 1.0f - t : 0.0f;
+  w1 = (unsigned)(i + 1) < (unsigned)n ? t : 0.0f;
 }
-__device__ __forceinline__ f32x4 tap_finish(const Tap4& t) {
+__device__ __forceinline__ TapGeom tap_geom(int H, int W, float x, float y) {
+  int x0, x1, y0, y1;
+  float wx0, wx1, wy0, wy1;
+  axis_taps(x, W, x0, x1, wx0, wx1);
+  axis_taps(y, H, y0, y1, wy0, wy1);
+  TapGeom g;
+  const int r0 = y0 * W, r1 = y1 * W;
+  g.idx[0] = r0 + x0; g.idx[1] = r0 + x1; g.idx[2] = r1 + x0; g.idx[3] = r1 + x1;
+  g.w[0] = wx0 * wy0; g.w[1] = wx1 * wy0; g.w[2] = wx0 * wy1; g.w[3] = wx1 * wy1;
+  return g;
+}
+struct Tap4 {
+  f32x4 v[4];
+};
+__device__ __forceinline__ void tap_issue(Tap4& t, const float* __restrict__ map, const TapGeom& g) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) t.v[k] = *reinterpret_cast<const f32x4*>(map + (int64_t)g.idx[k] * 4);
+}
+__device__ __forceinline__ f32x4 tap_finish(const Tap4& t, const TapGeom& g) {
+#ifdef SURF_BX_NOFMA
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < 4; ++k) acc += t.v[k] * t.w[k];
+  for (int k = 0; k < 4; ++k) acc += t.v[k] * g.w[k];
   return acc;
+#else
+  f32x4 acc = t.v[0] * g.w[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) acc[ch] = fmaf(t.v[k][ch], g.w[k], acc[ch]);
+  return acc;
+#endif
 }
 
 template <class P> constexpr int lds_bytes() { return image_bytes<P::BB>(); }
@@ -533,6 +566,8 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
   const int HA = h ? a.hw[4] : a.hw[0], WA = h ? a.hw[5] : a.hw[1];
   const int HB = h ? a.hw[6] : a.hw[2], WB = h ? a.hw[7] : a.hw[3];
   const float scA = h ? 0.25f : 1.0f, scB = h ? 0.125f : 0.5f;
+  const float cWA = (float)(WA - 1) / 2.0f, cHA = (float)(HA - 1) / 2.0f, cWB = (float)(WB - 1) / 2.0f, cHB = (float)(HB - 1) / 2.0f;
+  const float rWA = 1.0f / cWA, rHA = 1.0f / cHA, rWB = 1.0f / cWB, rHB = 1.0f / cHB;
 
 #ifdef SURF_BLEND_TIMING
   unsigned long long tprev = __builtin_readcyclecounter(), tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -561,15 +596,31 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       const Ctx c = opaque(c0);
       const int cam = v + 1;
       ViewState st;
-      // ray_diff (projector.py:485-498)
+      // ray_diff (projector.py:485-498).  The direction to the source camera keeps the reference's arithmetic (correctly rounded
+      // sqrt and divisions): its dot product with the reference direction goes through exp(|s| (dot - 1)) - min over views, a
+      // difference of nearly equal numbers wherever the views see the point under similar angles, and 1-ulp changes of the
+      // direction moved single colours by 1e-4.  The DIFFERENCE direction below only feeds the direction MLP (continuous,
+      // well conditioned): v_sqrt / v_rcp (1 ulp each) instead of a correctly rounded sqrt and three divisions (~45 instructions)
       float bx = a.cpos[cam][0] - px, by = a.cpos[cam][1] - py, bz = a.cpos[cam][2] - pz;
-      const float nn = sqrtf(bx * bx + by * by + bz * bz) + 1e-6f;
-      bx /= nn; by /= nn; bz /= nn;
+      {
+        const float nn = sqrtf(bx * bx + by * by + bz * bz) + 1e-6f;
+        bx /= nn; by /= nn; bz /= nn;
+      }
       const float ddx = ax - bx, ddy = ay - by, ddz = az - bz;
-      const float dn = fmaxf(sqrtf(ddx * ddx + ddy * ddy + ddz * ddz), 1e-6f);
-      st.rd[0] = ddx / dn; st.rd[1] = ddy / dn; st.rd[2] = ddz / dn;
+#ifdef SURF_BX_EXACT_RD
+      {
+        const float dn = fmaxf(sqrtf(ddx * ddx + ddy * ddy + ddz * ddz), 1e-6f);
+        st.rd[0] = ddx / dn; st.rd[1] = ddy / dn; st.rd[2] = ddz / dn;
+      }
+#else
+      {
+        const float inv = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(ddx * ddx + ddy * ddy + ddz * ddz), 1e-6f));
+        st.rd[0] = ddx * inv; st.rd[1] = ddy * inv; st.rd[2] = ddz * inv;
+      }
+#endif
       st.rd[3] = ax * bx + ay * by + az * bz;
-      // projection (projector.py:527-539); level l uses intrinsics rows 0,1 x 0.5^l = exact scaling of u,v
+      // projection (projector.py:527-539); level l uses intrinsics rows 0,1 x 0.5^l = exact scaling of u,v.  u0, v0 decide the
+      // view mask (comparisons): separate multiplies / adds and correctly rounded divisions, as the reference
       const float* M = a.w2c[cam];
       const float X = M[0] * px + M[1] * py + M[2] * pz + M[3];
       const float Y = M[4] * px + M[5] * py + M[6] * pz + M[7];
@@ -581,21 +632,27 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       const float u0 = qx / qz, v0 = qy / qz;
       bool ok = qz > 0.f;
       Tap4 qA, qB, qC;
+      TapGeom gA, gB;
       {
+        // normalise / un-normalise (grid_sample's rule).  The quotient u / ((W - 1) / 2) has to be the reference's to the bit:
+        // the detour through [-1, 1] magnifies one ulp of it to W / 2 ulps of the texel coordinate (2e-5 texels at W = 800,
+        // 1e-4 in single colours on a noisy image) - div_const gives the correctly rounded quotient in three instructions
         const float u = u0 * scA, vv = v0 * scA;
         ok = ok && (u >= 0.f) && (u < (float)WA) && (vv >= 0.f) && (vv < (float)HA);
-        const float nx = u / ((float)(WA - 1) / 2.0f) - 1.0f, ny = vv / ((float)(HA - 1) / 2.0f) - 1.0f;
-        const float gx = ((nx + 1.0f) * (float)WA - 1.0f) / 2.0f, gy = ((ny + 1.0f) * (float)HA - 1.0f) / 2.0f;
-        tap_issue(qA, mapA + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
+        const float nx = div_const(u, cWA, rWA) - 1.0f, ny = div_const(vv, cHA, rHA) - 1.0f;
+        const float gx = ((nx + 1.0f) * (float)WA - 1.0f) * 0.5f, gy = ((ny + 1.0f) * (float)HA - 1.0f) * 0.5f;
+        gA = tap_geom(HA, WA, gx, gy);
+        tap_issue(qA, mapA + (int64_t)cam * HA * WA * 4, gA);
         // half 1 re-reads its level-A taps instead of the image (same addresses: L1 hits), result unused
-        tap_issue(qC, (h == 0 ? a.imgs : mapA) + (int64_t)cam * HA * WA * 4, HA, WA, gx, gy);
+        tap_issue(qC, (h == 0 ? a.imgs : mapA) + (int64_t)cam * HA * WA * 4, gA);
       }
       {
         const float u = u0 * scB, vv = v0 * scB;
         ok = ok && (u >= 0.f) && (u < (float)WB) && (vv >= 0.f) && (vv < (float)HB);
-        const float nx = u / ((float)(WB - 1) / 2.0f) - 1.0f, ny = vv / ((float)(HB - 1) / 2.0f) - 1.0f;
-        const float gx = ((nx + 1.0f) * (float)WB - 1.0f) / 2.0f, gy = ((ny + 1.0f) * (float)HB - 1.0f) / 2.0f;
-        tap_issue(qB, mapB + (int64_t)cam * HB * WB * 4, HB, WB, gx, gy);
+        const float nx = div_const(u, cWB, rWB) - 1.0f, ny = div_const(vv, cHB, rHB) - 1.0f;
+        const float gx = ((nx + 1.0f) * (float)WB - 1.0f) * 0.5f, gy = ((ny + 1.0f) * (float)HB - 1.0f) * 0.5f;
+        gB = tap_geom(HB, WB, gx, gy);
+        tap_issue(qB, mapB + (int64_t)cam * HB * WB * 4, gB);
       }
       // direction feature ELU(L(ELU(L(ray_diff))))  4 -> 16 -> 19  (blending_network.py:72-74), under the fetches
       float d12[12];
@@ -611,8 +668,8 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
         // rows of half 1 beyond its 8 channels carry zero weights and zero bias: elu(0) = 0
         elu_rows<12>(acc2, d12);
       }
-      const f32x4 tA = tap_finish(qA), tB = tap_finish(qB);
-      f32x4 tC = tap_finish(qC);
+      const f32x4 tA = tap_finish(qA, gA), tB = tap_finish(qB, gB);
+      f32x4 tC = tap_finish(qC, gA);
       if (h != 0) tC = f32x4{0.f, 0.f, 0.f, 0.f};
       ok = ok && (__shfl_xor((int)ok, 32) != 0);  // AND over all four levels
       st.mk = ok ? 1.f : 0.f;
