@@ -385,9 +385,11 @@ def run_rank_train(args):
         dev = torch.device("cpu")
         D.init_from_env("gloo")
     else:
+        if args.one_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        D.init_from_env("nccl", dev)
+        D.init_from_env(args.backend, dev)
     if args.fail_rank == rank:
         sys.exit(3)
 
@@ -479,6 +481,7 @@ def run_rank_train(args):
         }
         if not dry:
             result["voxels_per_stage"] = getattr(model, "last_voxels_per_stage", None)
+        result["collective_backend"] = (args.backend + (" (all ranks on cuda:0)" if args.one_gpu else "")) if world > 1 else None
         print(json.dumps(result))
     if world > 1:
         D.shutdown()
@@ -577,7 +580,15 @@ def parse_args(argv):
     ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16"],
                     help="training-backward policy (model conf key train_precision): bf16 = weight-gradient reductions on bf16 operands")
     ap.add_argument("--fail-rank", type=int, default=-1, help="(tests) this rank exits 3 before the first barrier")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of a multi-rank run: nccl (= RCCL, the measured configuration) or gloo (tests: "
+                         "device tensors through gloo, so that N ranks can share ONE GPU with --one-gpu)")
+    ap.add_argument("--one-gpu", action="store_true",
+                    help="(tests) every rank uses cuda:0 - the real kernels, the record gather, the device-tensor MAX reduction and "
+                         "DDP's bucket hooks of an N-rank run on a one-GPU box; needs --backend gloo (RCCL wants one device per rank)")
     args = ap.parse_args(argv)
+    if args.one_gpu and args.backend != "gloo" and args.gpus > 1:
+        ap.error("--one-gpu needs --backend gloo")
     wl = WORKLOADS[args.workload]
     for k in ("height", "width", "views", "n_samples"):
         if getattr(args, k) is None:
@@ -622,9 +633,11 @@ def run_rank(args):
         dev = torch.device("cpu")
         D.init_from_env("gloo")
     else:
+        if args.one_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        D.init_from_env("nccl", dev)          # RCCL; only the barrier, the MAX of the elapsed time and the record gather
+        D.init_from_env(args.backend, dev)    # RCCL; only the barrier, the MAX of the elapsed time and the record gather
     if torch.distributed.is_initialized():
         assert torch.distributed.get_world_size() == world == args.gpus
     if args.fail_rank == rank:
@@ -872,6 +885,7 @@ def run_rank(args):
             result["volume_build"] = volume_build_timing(args, dev)
         if world == 1 and args.train_step and args.workload == "dtu":
             result["training_step"] = training_step_timing(args, dev)
+        result["collective_backend"] = (args.backend + (" (all ranks on cuda:0)" if args.one_gpu else "")) if world > 1 else None
         print(json.dumps(result))
     if world > 1:
         D.shutdown()

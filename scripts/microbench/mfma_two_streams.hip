@@ -40,11 +40,20 @@ __device__ __forceinline__ void valu_block(const f32x16& acc, Frags& f) {
     f.p[0][pr >> 2][pr & 3] = p0; f.p[1][pr >> 2][pr & 3] = p1; f.p[2][pr >> 2][pr & 3] = p2;
   }
 }
+template <int NOP = 0>
 __device__ __forceinline__ void mfma_block(f32x16& acc, const Frags& f, const u32x4& w) {
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-#define MF(pc) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, f.p[pc][s]), acc, 0, 0, 0)
-    MF(2); MF(2); MF(1); MF(1); MF(0); MF(0);
+    // NOP > 0: the wavefront steps back from the issue port for NOP cycles after every MFMA (s_nop is not a VALU instruction), so
+    // that its NEXT MFMA does not sit at the port waiting for the matrix pipe while the other wavefront has VALU work
+#define MF(pc)                                                                                                                              \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, f.p[pc][s]), acc, 0, 0, 0); \
+  if (NOP >= 8) __builtin_amdgcn_sched_barrier(0);                                                                                          \
+  if (NOP >= 8) asm volatile("s_nop 7");                                                                                                  \
+  if (NOP >= 16) asm volatile("s_nop 7");                                                                                                 \
+  if (NOP >= 24) asm volatile("s_nop 7");                                                                                                 \
+  if (NOP >= 8) __builtin_amdgcn_sched_barrier(0);
+    MF(2) MF(2) MF(1) MF(1) MF(0) MF(0)
 #undef MF
   }
 }
@@ -92,7 +101,10 @@ __global__ __launch_bounds__(256 * WAVES, 1) void k(float* out, int iters) {
       if (NV == 1) __builtin_amdgcn_s_setprio(0);
       if (NV == 2) __builtin_amdgcn_s_setprio(3);
       for (int r = 0; r < 16; ++r) acc[0][r] = 0.01f * r;
-      mfma_block(acc[0], fr[0], w);
+      if (NV == 8) mfma_block<8>(acc[0], fr[0], w);
+      else if (NV == 16) mfma_block<16>(acc[0], fr[0], w);
+      else if (NV == 24) mfma_block<24>(acc[0], fr[0], w);
+      else mfma_block(acc[0], fr[0], w);
       __builtin_amdgcn_sched_barrier(0);
     }
   } else if (NV == 0) {
@@ -159,6 +171,10 @@ int main() {
   run<1, 2, 0>(out, "A  two waves / SIMD, one chain each");
   run<1, 2, 1>(out, "A  two waves / SIMD, VALU phase at s_setprio 3");
   run<1, 2, 2>(out, "A  two waves / SIMD, MFMA phase at s_setprio 3");
+  run<1, 2, 8>(out, "A  two waves / SIMD, s_nop 8 cycles after every MFMA");
+  run<1, 2, 16>(out, "A  two waves / SIMD, s_nop 16 cycles after every MFMA");
+  run<1, 2, 24>(out, "A  two waves / SIMD, s_nop 24 cycles after every MFMA");
+  run<1, 3, 16>(out, "A3 three waves / SIMD, s_nop 16 cycles after every MFMA");
   run<1, 3, 0>(out, "A3 three waves / SIMD, one chain each");
   run<1, 4, 0>(out, "A4 four waves / SIMD, one chain each");
   run<2, 1, 8>(out, "B  one wave / SIMD, two chains, 1 MFMA : 8 VALU");

@@ -1089,19 +1089,33 @@ def table_from_coords(coords, D):
     return table
 
 
-DOWN_RULES = {"dilate": 0, "floor": 1}     # SURF_DOWN_DILATE / SURF_DOWN_FLOOR
+# SURF_DOWN_DILATE / SURF_DOWN_FLOOR; "pad0" is the dilate kernel on coordinates stored + 1 with a fixed site range (below)
+DOWN_RULES = {"dilate": 0, "floor": 1, "pad0": 0}
+_pad0_ranges = {}
 
 
-def down_sites(coords, D, rule="dilate"):
+def down_sites(coords, D, rule="dilate", q_max=None):
     """Output sites of a k3/s2 sparse conv on the (D//2+1)^3 lattice: (coords2 (M,3) int32, table2, D2).
-    rule: "dilate" (torchsparse-2.1 spconv-style, default) or "floor" (unique(floor(c/2))): SURVEY App. C."""
+    rule: "dilate" (torchsparse-2.1 spdownsample, default) or "floor" (unique(floor(c/2))): SURVEY App. C.
+    "pad0": the spconv-style map with no padding (window 2q + {0,1,2}^3).  With every level's coordinates
+    STORED + 1 (SparseCostRegNet.forward) that window is the centred one of the stored coordinates - 2 (q + 1) + {-1,0,1} =
+    (2q + {0,1,2}) + 1 - so the same kernels serve; what differs is which even sites are outputs: all stored q in
+    [1, q_max] with an input in the window (q_max = the true output lattice size (D_true - 3) // 2 + 1), instead of the even
+    sites inside the inputs' bounding box."""
     _chk(coords, torch.int32, "coords")
     dev = coords.device
     D2 = D // 2 + 1
     if coords.shape[0] == 0:
         return (torch.empty(0, 3, dtype=torch.int32, device=dev), torch.full((D2, D2, D2), -1, dtype=torch.int32, device=dev), D2)
-    bbox = torch.empty(6, dtype=torch.int32, device=dev)          # stays on the device: no host round trip
-    _lib.check(_lib.lib().surf_coords_bbox(_p(coords), coords.shape[0], _p(bbox), _stream()), "surf_coords_bbox")
+    if rule == "pad0":
+        assert q_max is not None and q_max + 1 <= D2, (q_max, D2)
+        key = (int(q_max), dev)
+        if key not in _pad0_ranges:                                 # even sites 2 .. 2 q_max of the stored fine lattice
+            _pad0_ranges[key] = torch.tensor([2, 2, 2, 2 * q_max, 2 * q_max, 2 * q_max], dtype=torch.int32, device=dev)
+        bbox = _pad0_ranges[key]
+    else:
+        bbox = torch.empty(6, dtype=torch.int32, device=dev)          # stays on the device: no host round trip
+        _lib.check(_lib.lib().surf_coords_bbox(_p(coords), coords.shape[0], _p(bbox), _stream()), "surf_coords_bbox")
     marks = torch.zeros(D2 * D2 * D2, dtype=torch.uint8, device=dev)
     _lib.check(_lib.lib().surf_mark_down_sites(_p(coords), coords.shape[0], int(D), _p(bbox), _p(marks), DOWN_RULES[rule],
                                                _stream()), "surf_mark_down_sites")

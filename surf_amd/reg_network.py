@@ -99,18 +99,29 @@ class SparseCostRegNet(nn.Module):
 
     def forward(self, feats, coords, D, table=None, tape=None):
         """feats (N, d_in) fp32, coords (N,3) int32 on the D lattice -> (out (N,8), mid (N,8))  (reg_network.py:69-88)"""
+        q1 = q2 = q3 = None
+        if self.down_rule == "pad0":
+            # uncentred stride-2 window 2q + {0,1,2}^3 (ops.down_sites): every level's coordinates are stored + 1, which turns
+            # it into the centred window the kernels walk; the true lattices shrink as (D - 3) // 2 + 1
+            coords = (coords + 1).contiguous()
+            q1 = (D - 3) // 2 + 1
+            q2 = (q1 - 3) // 2 + 1
+            q3 = (q2 - 3) // 2 + 1
+            if min(q1, q2, q3) < 1:
+                raise ValueError(f"reg_network.down_rule = pad0 needs a lattice of at least 15^3 sites, got {D}^3")
+            D, table = D + 1, None
         t0 = table if table is not None else ops.table_from_coords(coords, D)
         s0 = (t0, coords)
         c0 = self._conv(self.conv0, feats, s0, s0, ops.SUBM, tape=tape)
-        cd1, t1, D1 = ops.down_sites(coords, D, self.down_rule)
+        cd1, t1, D1 = ops.down_sites(coords, D, self.down_rule, q1)
         s1 = (t1, cd1)
         x = self._conv(self.conv1, c0, s0, s1, ops.DOWN, tape=tape)
         c2 = self._conv(self.conv2, x, s1, s1, ops.SUBM, tape=tape)
-        cd2, t2, D2 = ops.down_sites(cd1, D1, self.down_rule)
+        cd2, t2, D2 = ops.down_sites(cd1, D1, self.down_rule, q2)
         s2 = (t2, cd2)
         x = self._conv(self.conv3, c2, s1, s2, ops.DOWN, tape=tape)
         c4 = self._conv(self.conv4, x, s2, s2, ops.SUBM, tape=tape)
-        cd3, t3, D3 = ops.down_sites(cd2, D2, self.down_rule)
+        cd3, t3, D3 = ops.down_sites(cd2, D2, self.down_rule, q3)
         s3 = (t3, cd3)
         x = self._conv(self.conv5, c4, s2, s3, ops.DOWN, tape=tape)
         x = self._conv(self.conv6, x, s3, s3, ops.SUBM, tape=tape)

@@ -56,6 +56,12 @@ def golden_perturb():
 
 
 @pytest.fixture(scope="session")
+def golden_validate():
+    """ImplicitSurface.validate's image outputs from the reference itself (tests/golden/make_golden.py)."""
+    return load_npz("validate.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_grid():
     return load_npz("sdf_grid.npz")
 

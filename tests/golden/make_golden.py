@@ -17,6 +17,8 @@ Fixtures
   render.npz     lookup_sparse_volume, SDFNetworkSparse.{sdf,gradient}, lookup_feature,
                  BlendingNetwork, ImplicitSurface.render (perturb=0) outputs        (rows a8-a14)
   sdf_grid.npz   extract_geometry lattice values at resolution 24                   (row a16)
+  validate.npz   ImplicitSurface.validate's image outputs (img_fine, normal_img, sdf_depth, render_depth) on the 7 x 8
+                 ray lattice, 256-ray chunks as the reference renders them            (row a16)
 """
 import os
 import sys
@@ -285,6 +287,15 @@ def main():
     npz("render_perturb.npz", t_rand=t_rand, mid_z_vals=outs["mid_z_vals"].detach(), color_fine=outs["color_fine"].detach(),
         render_depth=outs["render_depth"].detach(), weights=outs["weights"].detach())
     isurf.perturb = 0.0
+
+    # ---------------- a16 validate(): the image outputs the runner saves (implicit_surface.py:359-402, runner.py:222-229) ----
+    # mesh extraction off (PyMCubes is absent; the lattice is pinned by sdf_grid.npz): what is pinned here is the assembly -
+    # x 256 clip, normals rotated into the reference camera x 128 + 128, depth maps - on top of the chunked render
+    val = isurf.validate(scene["rays_o"], scene["rays_d"], near, far, mvol, vols_r, tabs_r, masks_r, scene["imgs"], feats_r,
+                         feats_r, intrs, c2ws, torch.tensor([-0.8] * 3), torch.tensor([0.8] * 3), (7, 8), 1.0, None,
+                         extract_geometry=False)
+    npz("validate.npz", color_fine=val["color_fine"], img_fine=val["img_fine"], normal_img=val["normal_img"],
+        sdf_depth=val["sdf_depth"], render_depth=val["render_depth"])
 
     # ---------------- a16 SDF lattice ----------------
     bmin, bmax = torch.tensor([-0.7, -0.6, -0.65]), torch.tensor([0.7, 0.75, 0.6])

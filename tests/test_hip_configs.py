@@ -92,3 +92,53 @@ def test_bench_train_workload_line_on_one_gpu():
     assert any(n.startswith("spconv_wgrad<") for n in names)
     top = r["roofline"]
     assert top is not None and top["bound"] in ("hbm", "valu") and 0 < top["frac"]
+
+
+def _bench(args, timeout=900):
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout, cwd=root)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+SMALL = ["--steps", "2", "--warmup", "1", "--height", "48", "--width", "64", "--base-dim", "16", "--cpu-seconds", "0", "--build", "0",
+         "--train-step", "0", "--mesh-grid", "0", "--also", ""]
+
+
+def test_bench_scene_dealing_on_one_gpu():
+    """BASELINE configs[2] (15 scans scene-parallel) at reduced size: `bench.py --gpus 1 --scenes 3` deals three different synthetic
+    scenes (seeds 0..2) to the one rank, renders each with the real kernels inside the timed region and reports one record per scene."""
+    r = _bench(["--gpus", "1", "--scenes", "3"] + SMALL)
+    assert r["n_gpus"] == 1 and r["config"]["scenes"] == 3 and r["config"]["rays_per_step"] == 3 * 48 * 64
+    recs = r["scenes"]
+    assert [x["scene"] for x in recs] == [0, 1, 2] and all(x["rank"] == 0 and x["ms_per_render"] > 0 for x in recs)
+    assert abs(r["value"] - 3 * 48 * 64 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    assert sum(x["ms_per_render"] for x in recs) <= r["ms_per_step"] * 1.05
+
+
+def test_bench_two_ranks_share_the_gpu_render():
+    """The N > 1 path of the inference bench with its REAL kernels: two fresh ranks started by bench.py's own launcher, both on
+    cuda:0, process group gloo (RCCL wants one device per rank; the collectives here are only the barrier, the MAX of the elapsed
+    time on a device tensor and the record gather).  Five scenes dealt 3 + 2; rank 0 relays one line."""
+    r = _bench(["--gpus", "2", "--scenes", "5", "--backend", "gloo", "--one-gpu"] + SMALL)
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["collective_backend"].startswith("gloo")
+    recs = r["scenes"]
+    assert [x["scene"] for x in recs] == [0, 1, 2, 3, 4] and [x["rank"] for x in recs] == [0, 1, 0, 1, 0]
+    assert abs(r["value"] - 5 * 48 * 64 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+
+
+def test_bench_two_ranks_share_the_gpu_train():
+    """BASELINE configs[3]'s N > 1 leg with its real kernels: two ranks on cuda:0, DistributedDataParallel over gloo (bucket hooks,
+    the broadcast at wrap time, the gradient all-reduce timing) - what RCCL serves on an 8-GPU node."""
+    r = _bench(["--workload", "train", "--gpus", "2", "--backend", "gloo", "--one-gpu", "--steps", "2", "--warmup", "1", "--height", "96",
+                "--width", "128", "--base-dim", "16", "--rays", "128"])
+    assert r["n_gpus"] == 2 and r["config"]["parallelism"] == "ddp2" and r["config"]["rays_per_rank_step"] == 128
+    assert r["gradient_allreduce_ms"] > 0 and r["loss"] == r["loss"] and r["collective_backend"].startswith("gloo")
+    assert abs(r["value"] - 2 * 128 * r["steps_per_s"]) < 1e-6 * r["value"]

@@ -193,6 +193,33 @@ def test_render_matches_golden(scene, weights, gpu_scene, golden_render):
         rel_close(eik[0] / (eik[1] + 1e-5), g["gradient_error"], 1e-3, 1e-5)
 
 
+def test_validate_images_match_golden(scene, weights, gpu_scene, golden_validate):
+    """ImplicitSurface.validate (implicit_surface.py:359-402): img_fine (x 256, clip), normal_img (sum w grad inside_sphere rotated
+    into the reference camera, x 128 + 128, clip), sdf_depth, render_depth against the reference's own validate() on the 7 x 8
+    ray lattice - through the HIP kernels, chunked as the runner would (chunk = 20 rays: ragged last chunk)."""
+    from surf_amd import conf
+    from surf_amd.implicit_surface import ImplicitSurface, SceneVolumes
+    from tests.golden.make_golden import MODEL_CONF
+    d = dev()
+    model = ImplicitSurface(conf.from_dict(MODEL_CONF["implicit_surface"]))
+    model.load_state_dict({k[len("implicit_surface."):]: v for k, v in weights.items() if k.startswith("implicit_surface.")})
+    model = model.to(d).eval()
+    sc = SceneVolumes.from_device_layouts(gpu_scene["mvol"], gpu_scene["sv"].vols, gpu_scene["sv"].tables, gpu_scene["feats_t4"],
+                                          gpu_scene["imgs_t4"], gpu_scene["cams"])
+    R = scene["rays_o"].shape[0]
+    near, far = scene["near"].repeat(R, 1).to(d), scene["far"].repeat(R, 1).to(d)
+    g = golden_validate
+    for chunk in (65536, 20):
+        out = model.validate(scene["rays_o"].to(d), scene["rays_d"].to(d), near, far, sc, torch.tensor([-0.8] * 3), torch.tensor([0.8] * 3),
+                             (7, 8), 1.0, None, extract_geometry=False, chunk=chunk)
+        rel_close(out["color_fine"], g["color_fine"], 1e-3, 2e-5)
+        rel_close(torch.from_numpy(out["img_fine"]), g["img_fine"], 1e-3, 256 * 2e-5)
+        rel_close(torch.from_numpy(out["normal_img"]), g["normal_img"], 1e-3, 128 * 1e-4)
+        rel_close(torch.from_numpy(out["sdf_depth"]), g["sdf_depth"], 1e-3, 2e-5)
+        rel_close(torch.from_numpy(out["render_depth"]), g["render_depth"], 1e-3, 2e-5)
+        assert out["img_fine"].shape == (7, 8, 3) and out["normal_img"].shape == (7, 8, 3)
+
+
 def test_render_with_perturb_matches_golden(scene, weights, gpu_scene, golden_perturb):
     """render.perturb = 1 (every shipped conf): the kernels, fed the reference's four torch.rand([R, 1]) - 0.5 draws,
     against the reference's own outputs under the same seed."""
@@ -277,11 +304,11 @@ def test_compact_large_and_edge_cases():
         assert torch.equal(idx.cpu().long(), flags.nonzero().view(-1))
 
 
-@pytest.mark.parametrize("rule", ["dilate", "floor"])
+@pytest.mark.parametrize("rule", ["dilate", "floor", "pad0"])
 def test_sparse_unet_matches_oracle(golden_pipe, rule):
     """Row a5 (parity unpinned vs torchsparse): the HIP sparse U-Net against the oracle's restatement, on the
-    stage-1 and stage-2 voxel sets of the pipeline fixture with seeded weights and non-trivial BN statistics, for both
-    candidate stride-2 output-site rules (reg_network.down_rule)."""
+    stage-1 and stage-2 voxel sets of the pipeline fixture with seeded weights and non-trivial BN statistics, for the three
+    candidate stride-2 output-site rules (reg_network.down_rule: torchsparse's spdownsample, floor, spconv-style without padding)."""
     from surf_amd import conf
     from surf_amd.reg_network import SparseCostRegNetList
     from surf_amd.ops import down_sites as ops_down
@@ -305,8 +332,12 @@ def test_sparse_unet_matches_oracle(golden_pipe, rule):
         feats = golden_pipe[f"s{s}_reg_in"].contiguous()
         out_ref, mid_ref = O.sparse_unet(sd, feats, coords.long(), D, s, rule=rule)
         cd_ref, D1 = O.down_coords(coords.long(), D, rule)
-        cd, _, D1g = ops_down(coords.to(d).contiguous(), D, rule)
-        assert D1g == D1 and torch.equal(cd.cpu().long(), cd_ref)
+        if rule == "pad0":            # (the kernels see every level's coordinates stored + 1: ops.down_sites)
+            cd, _, _ = ops_down((coords + 1).to(d).contiguous(), D + 1, rule, q_max=D1)
+            assert torch.equal(cd.cpu().long() - 1, cd_ref)
+        else:
+            cd, _, D1g = ops_down(coords.to(d).contiguous(), D, rule)
+            assert D1g == D1 and torch.equal(cd.cpu().long(), cd_ref)
         out, mid = net(feats.to(d), coords.to(d).contiguous(), D, s)
         rel_close(mid, mid_ref, 1e-3, 1e-4)
         rel_close(out, out_ref, 1e-3, 1e-4)
@@ -444,9 +475,10 @@ def test_surf_forward_end_to_end_vs_oracle(scene):
     rr = O.render(sd, scene["rays_o"], scene["rays_d"], near, far, mvol.cpu(), [v[:, 1:].cpu() for v in volumes[::-1]], tabs,
                   [(tb >= 0).float() for tb in tabs], feats_got[::-1], scene["imgs"], scene["intrs"], scene["c2ws"],
                   cfg["implicit_surface"]["render"]["n_samples"], [1.0, 0.4, 0.1, 0.01], 256, 1.0)
-    rel_close(out["color_fine"], rr["color_fine"], 1e-3, 1e-3 * float(rr["color_fine"].abs().max()))
-    rel_close(torch.from_numpy(out["render_depth"]).reshape(-1), rr["render_depth"], 1e-3, 1e-3)
-    rel_close(torch.from_numpy(out["sdf_depth"]).reshape(-1), rr["sdf_depth"].reshape(-1), 1e-3, 1e-3)
+    # (teacher-forced on the model's own pyramid: the same kernels and the same bar as test_render_matches_golden)
+    rel_close(out["color_fine"], rr["color_fine"], 1e-3, 2e-5)
+    rel_close(torch.from_numpy(out["render_depth"]).reshape(-1), rr["render_depth"], 1e-3, 2e-5)
+    rel_close(torch.from_numpy(out["sdf_depth"]).reshape(-1), rr["sdf_depth"].reshape(-1), 1e-3, 2e-5)
 
 
 @pytest.mark.parametrize("precision,tol", [("bf16x3", 1.0), ("f16x2", 4.0)])

@@ -137,6 +137,24 @@ def test_a8_a14_render(scene, weights, golden_fpn, golden_pipe, golden_render):
         assert float(g["mid_inside_sphere"].sum()) >= 5
 
 
+def test_a16_validate_images(scene, weights, golden_fpn, golden_pipe, golden_validate):
+    """implicit_surface.py:359-402: the image assembly of validate() - img_fine x 256 clip, normal_img = rot . sum w grad
+    inside_sphere x 128 + 128, the two depth maps - against the reference's own validate() on the 7 x 8 ray lattice."""
+    vols, tabs, masks, mvol = pipeline_views(golden_pipe)
+    feats = [golden_fpn[f"out{i}"] for i in range(4)][::-1]
+    R = scene["rays_o"].shape[0]
+    near, far = scene["near"].repeat(R, 1), scene["far"].repeat(R, 1)
+    out = O.render(weights, scene["rays_o"], scene["rays_d"], near, far, mvol, vols, tabs, masks, feats, scene["imgs"],
+                   scene["intrs"], scene["c2ws"], CFG["n_samples"], CFG["sample_ranges"], CFG["n_depth"], 1.0)
+    img, nimg = O.validate_images(out, scene["c2ws"], (7, 8))
+    g = golden_validate
+    close(torch.from_numpy(img), g["img_fine"], atol=256 * 2e-5, rtol=1e-4)
+    close(torch.from_numpy(nimg), g["normal_img"], atol=128 * 1e-4, rtol=1e-3)
+    close(out["sdf_depth"].reshape(7, 8), g["sdf_depth"], atol=5e-5, rtol=1e-4)
+    close(out["render_depth"].reshape(7, 8), g["render_depth"], atol=5e-5, rtol=1e-4)
+    assert float(g["normal_img"].min()) < 100 and float(g["normal_img"].max()) > 156    # the normals carry signal on this lattice
+
+
 def test_a8_render_with_perturb(scene, weights, golden_fpn, golden_pipe, golden_perturb):
     """render.perturb = 1 (what every shipped conf sets): the reference's output under torch.manual_seed(4321), replayed
     with the same four torch.rand([R, 1]) - 0.5 jitters."""

@@ -57,3 +57,59 @@ def test_unet_runs_on_a_ragged_voxel_set():
     out, mid = O.sparse_unet(sd, torch.randn(coords.shape[0], 16, generator=g), coords, D, 1)
     assert out.shape == (coords.shape[0], 8) and mid.shape == (coords.shape[0], 8)
     assert torch.isfinite(out).all() and float(mid.abs().max()) > 0
+
+
+def test_pad0_rule_equals_unpadded_strided_dense_conv_and_up_is_its_adjoint():
+    """rule 'pad0' (torchsparse >= 2.1 builds strided maps spconv-style, out = (in + 2 pad - k) / stride, and
+    the reference passes no padding): on a full lattice the down conv IS F.conv3d(stride 2, padding 0) - output lattice
+    (D - 3) // 2 + 1, window 2q + {0,1,2}^3 - and the transposed conv inheriting the map is its adjoint; on a ragged set every
+    output site has an input in its window and every input inside the covered range reaches an output."""
+    g = torch.Generator().manual_seed(3)
+    for D in (8, 9):
+        cin, cout = 4, 8
+        coords = O.init_coords(D).long()
+        feat = torch.randn(D ** 3, cin, generator=g)
+        kernel = torch.randn(27, cin, cout, generator=g) * 0.1
+        out, oc, D2 = O.spconv_down(feat, coords, D, kernel, "pad0")
+        assert D2 == (D - 3) // 2 + 1 and oc.shape[0] == D2 ** 3
+        dense = feat.view(D, D, D, cin).permute(3, 0, 1, 2)[None]
+        ref = F.conv3d(dense, _dense_weight(kernel), padding=0, stride=2)[0]
+        assert ref.shape[1:] == (D2, D2, D2)
+        assert torch.allclose(out, ref[:, oc[:, 0], oc[:, 1], oc[:, 2]].t(), atol=1e-5)
+        y = torch.randn(oc.shape[0], cout, generator=g)
+        up = O.spconv_up(y, oc, coords, D, kernel.transpose(1, 2).contiguous(), "pad0")
+        assert torch.allclose((out * y).sum(), (feat * up).sum(), rtol=1e-4)
+    D = 17
+    coords = O.init_coords(D).long()
+    coords = coords[torch.rand(coords.shape[0], generator=g) < 0.05]
+    oc, D2 = O.down_coords(coords, D, "pad0")
+    assert D2 == 8 and bool(((oc >= 0) & (oc < D2)).all())
+    table = O._build_table(coords, D)
+    hit = torch.zeros(oc.shape[0], dtype=torch.bool)
+    for o in O.KOFFS:
+        hit |= O._lookup(table, oc * 2 + torch.tensor(o) + 1, D) >= 0
+    assert bool(hit.all())
+    t2 = O._build_table(oc, D2)
+    inside = ((coords <= 2 * (D2 - 1) + 2).all(dim=1))
+    reached = torch.zeros(coords.shape[0], dtype=torch.bool)
+    for o in O.KOFFS:
+        c = coords - (torch.tensor(o) + 1)
+        ok = ((c % 2) == 0).all(dim=1)
+        reached |= ok & (O._lookup(t2, torch.div(c, 2, rounding_mode="floor"), D2) >= 0)
+    assert bool(reached[inside].all())
+
+
+def test_unet_runs_with_every_down_rule():
+    g = torch.Generator().manual_seed(4)
+    D = 20
+    coords = O.init_coords(D).long()
+    coords = coords[torch.rand(coords.shape[0], generator=g) < 0.3]
+    from surf_amd import conf
+    from surf_amd.reg_network import SparseCostRegNetList
+    torch.manual_seed(0)
+    net = SparseCostRegNetList(conf.from_dict({"d_in": [8, 16], "d_out": [8, 8], "d_base": [8, 8]})).eval()
+    sd = {"reg_network." + k: v.detach() for k, v in net.state_dict().items()}
+    x = torch.randn(coords.shape[0], 16, generator=g)
+    outs = {rule: O.sparse_unet(sd, x, coords, D, 1, rule=rule)[0] for rule in ("dilate", "floor", "pad0")}
+    assert all(o.shape == (coords.shape[0], 8) and torch.isfinite(o).all() for o in outs.values())
+    assert float((outs["pad0"] - outs["dilate"]).abs().max()) > 1e-3        # the rules are different networks
