@@ -224,6 +224,39 @@ def volume_build_timing(args, dev):
     return res
 
 
+def scene_timing(args, dev, mesh_resolution=512):
+    """BASELINE configs[1] as ONE number: a whole scene through surf_amd.surf.SuRF.forward("val") - FPN, 4-stage volume build,
+    the full-resolution render of the reference view, the mesh_resolution^3 SDF lattice and marching cubes (surf.py:133-163,
+    implicit_surface.py:337-402) - wall clock around the call, inputs resident in HBM, outputs delivered as the runner reads them
+    (images / depth maps on the host, mesh arrays on the host).  Same synthetic scene and sphere logit as volume_build_timing."""
+    from surf_amd import conf, synthetic
+    from surf_amd.surf import SuRF
+    H, W, nv = args.height, args.width, args.views
+    torch.manual_seed(0)
+    mc = surf_conf(args.base_dim)
+    mc["implicit_surface"]["render"]["n_samples"] = [int(x) for x in args.n_samples.split(",")]
+    model = SuRF(conf.from_dict(mc)).eval().to(dev)
+    model.logit_override = synthetic.sphere_logit
+    intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
+    rays_o, rays_d = synthetic.pixel_rays(intrs[0], c2ws[0], H, W, 1, dev)
+    ipts = {"imgs": synthetic.procedural_images(nv, H, W, 0, dev), "intrs": intrs.to(dev), "c2ws": c2ws.to(dev),
+            "near_fars": near_fars.to(dev), "near": near_fars[0, 0].reshape(1, 1).to(dev), "far": near_fars[0, 1].reshape(1, 1).to(dev),
+            "rays_o": rays_o, "rays_d": rays_d, "bound_min": torch.tensor([-1.0] * 3), "bound_max": torch.tensor([1.0] * 3),
+            "hw": (H, W), "mesh_resolution": mesh_resolution}
+    ms = []
+    for it in range(2):                      # first pass warms allocator and code objects
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = model("val", ipts, 1.0)
+        torch.cuda.synchronize()
+        ms.append((time.perf_counter() - t0) * 1e3)
+    return {"scene_ms": ms[-1], "first_call_ms": ms[0], "rays": int(rays_o.shape[0]), "mesh_resolution": mesh_resolution,
+            "vertices": int(len(out["vertices"])), "triangles": int(len(out["triangles"])),
+            "what": "SuRF.forward('val'): FPN + 4-stage volume build + full-resolution render of the reference view + "
+                    f"{mesh_resolution}^3 SDF lattice + marching cubes, host wall clock incl. the device-to-host copies of the outputs"}
+
+
 def training_step_setup(dev, H=576, W=800, nv=5, base_dim=88, rays=512, device_jitter=True, scene_seed=0, precision="fp32"):
     """A volume-building SuRF in train mode on the synthetic scene + the inputs / loss targets of one training step
     (runner.py:150-166).  Weights are random-init, so the analytic sphere logit replaces the U-Net's matching logit in the
@@ -420,8 +453,12 @@ def run_rank_train(args):
         opt.step()
         return loss
 
+    if not dry:
+        ops.count_pairs = True              # (site, offset) pair counts of the sparse-conv backward: warm-up only, cached
     for _ in range(args.warmup):
         loss = step()
+    if not dry:
+        ops.count_pairs = False
     sync()
     D.barrier()
     sync()
@@ -876,13 +913,16 @@ def run_rank(args):
             rps, n_done, dt, err = cpu_baseline(model, cpu_scene, sc0["rays_o"].cpu()[idx], sc0["rays_d"].cpu()[idx],
                                                 sc0["near"].cpu()[idx], sc0["far"].cpu()[idx], n_samples, args.cpu_seconds,
                                                 out, idx)
-            result["cpu_baseline"] = {"value": rps, "unit": "rays/s", "cores": CPU_THREADS, "kind": "port",
+            result["cpu_baseline"] = {"value": rps, "unit": "rays/s", "cores": CPU_THREADS, "threads": CPU_THREADS,
+                                      "host_cores": os.cpu_count(), "kind": "port",
                                       "sample": f"{n_done} rays (every {R // n_sub}th pixel ray, 256-ray chunks) of the same "
                                                 f"scene in {dt:.1f} s, torch CPU fp32",
                                       "max_abs_rgb_diff_vs_gpu": err}
         if world == 1 and args.build and args.workload == "dtu":
             sc0["cpu"] = None
             result["volume_build"] = volume_build_timing(args, dev)
+            if args.mesh_grid > 0:
+                result["scene"] = scene_timing(args, dev, args.mesh_grid)
         if world == 1 and args.train_step and args.workload == "dtu":
             result["training_step"] = training_step_timing(args, dev)
         result["collective_backend"] = (args.backend + (" (all ranks on cuda:0)" if args.one_gpu else "")) if world > 1 else None

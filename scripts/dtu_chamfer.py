@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""The second half of BASELINE.json's metric - "DTU scan24 Chamfer vs ref" - as ONE command:
+
+    python scripts/dtu_chamfer.py --conf confs/surf.conf --ckpt ckpt.pth --data_dir <DTU> --eval_dir <DTU eval data> --scan 24
+
+loader (surf_amd.datasets, the val_dataset block of the HOCON conf)  ->  SuRF(conf.model).load_state_dict(ckpt["model"])
+-> model("val", inputs)                                     (runner.py:213-229: FPN, 4-stage volumes, render, SDF lattice, marching cubes)
+-> [clean_mesh with the item's masks, --clean_mesh]         (runner.py:233-234, utils/clean_mesh.py:110-130)
+-> mesh_io.export_mesh(<out>/meshes/final/scan<N>.ply, scale_mat)   (runner.py:236-240; the file name evaluation/dtu_eval.py reads)
+-> evaluation.dtu_eval.evaluate_scan                        (evaluation/dtu_eval.py:31-190)
+-> one JSON line: {"scan", "d2s", "s2d", "chamfer", "reference_chamfer", "delta", ...}.
+
+Needs external data (a DTU tree, the DTU evaluation files ObsMask/ + Points/stl/, a checkpoint): nothing in the test-suite's
+default path calls it with real data; tests/test_end_to_end_dtu.py runs it on a synthetic scene written in DTU's file formats.
+Measurement harness, not a training / serving control plane: no logging framework, no resume logic, one scan per call.
+
+--down_rule {dilate,floor,pad0}: which stride-2 site rule of torchsparse the checkpoint's sparse U-Net was trained under
+(row a5 is parity-unpinned: torchsparse is not available to the build; with three rules behind one switch the authors'
+checkpoint picks its own - the right rule is the one that reproduces the published Chamfer, README.md:87-106).
+--reference_chamfer X: the reference's own number for this scan (or the published mean 1.05); "delta" = ours - X is then the
+quantity north_star bounds by 0.01."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--conf", required=True, help="HOCON conf with `model` and `val_dataset` blocks (the reference's confs/*.conf)")
+    ap.add_argument("--ckpt", default=None, help="checkpoint saved by runner.py (`model` key) - omitted: seeded random weights")
+    ap.add_argument("--data_dir", default=None, help="overrides val_dataset.data_dir")
+    ap.add_argument("--eval_dir", required=True, help="DTU evaluation data: ObsMask/ObsMask<N>_10.mat, ObsMask/Plane<N>.mat, Points/stl/stl<NNN>_total.ply")
+    ap.add_argument("--scan", type=int, default=24)
+    ap.add_argument("--ref_view", type=int, default=None, help="overrides val_dataset.ref_view")
+    ap.add_argument("--out_dir", default="./outputs")
+    ap.add_argument("--down_rule", default=None, choices=["dilate", "floor", "pad0"], help="model.reg_network.down_rule")
+    ap.add_argument("--sdf_precision", default=None, choices=["f32", "bf16x3", "f16x2"])
+    ap.add_argument("--mesh_resolution", type=int, default=512)
+    ap.add_argument("--clean_mesh", action="store_true", help="runner.py --clean_mesh: drop faces outside the dilated masks / frusta")
+    ap.add_argument("--downsample_density", type=float, default=0.2)
+    ap.add_argument("--patch_size", type=float, default=60)
+    ap.add_argument("--max_dist", type=float, default=20)
+    ap.add_argument("--shuffle_seed", type=int, default=0, help="seed of the thinning shuffle of the evaluator (the reference's is unseeded)")
+    ap.add_argument("--reference_chamfer", type=float, default=None)
+    ap.add_argument("--logit_override", default=None, choices=["sphere"],
+                    help="(tests) replace the U-Nets' matching logits by a sphere-concentrated field, as an untrained model needs")
+    ap.add_argument("--device", default="cuda:0")
+    return ap.parse_args(argv)
+
+
+def run(args):
+    from surf_amd import conf as C
+    from surf_amd import mesh_io, synthetic
+    from surf_amd.datasets import get_loader
+    from surf_amd.evaluation import clean_mesh as CM
+    from surf_amd.evaluation import dtu_eval
+    from surf_amd.surf import SuRF
+
+    dev = torch.device(args.device)
+    cfg = C.parse_file(args.conf)
+    dconf = cfg["val_dataset"]
+    if args.data_dir is not None:
+        dconf["data_dir"] = args.data_dir
+    dconf["scene"] = [f"scan{args.scan}"]
+    if args.ref_view is not None:
+        dconf["ref_view"] = [args.ref_view]
+    mconf = cfg["model"]
+    if args.down_rule is not None:
+        mconf["reg_network"]["down_rule"] = args.down_rule
+    if args.sdf_precision is not None:
+        mconf["implicit_surface"]["render"]["sdf_precision"] = args.sdf_precision
+
+    t0 = time.perf_counter()
+    loader, _, dataset = get_loader(dconf, "val", False, num_workers=0)
+    if len(dataset) < 1:
+        raise SystemExit(f"dtu_chamfer: no validation item for scan{args.scan} under {dconf['data_dir']}")
+    item = next(iter(loader))
+    inputs = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in item.items()}              # runner.py's tocuda
+    inputs["mesh_resolution"] = args.mesh_resolution
+
+    torch.manual_seed(0)
+    model = SuRF(mconf)
+    missing = unexpected = None
+    if args.ckpt is not None:
+        ckpt = torch.load(args.ckpt, map_location="cpu")
+        res = model.load_state_dict(ckpt["model"] if "model" in ckpt else ckpt, strict=True)        # runner.py:79
+        missing, unexpected = list(res.missing_keys), list(res.unexpected_keys)
+    model = model.to(dev).eval()
+    if args.logit_override == "sphere":
+        model.logit_override = synthetic.sphere_logit
+    t_load = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = model("val", inputs, cos_anneal_ratio=1.0)                                          # runner.py:216
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    t_val = time.perf_counter() - t0
+    v, t = np.asarray(out["vertices"]), np.asarray(out["triangles"])
+    if len(t) == 0:
+        raise SystemExit("dtu_chamfer: the SDF lattice has no zero crossing inside the bounding box (empty mesh)")
+    if args.clean_mesh:
+        v, t = CM.clean_mesh(v, t, item["masks"], item["intrs"], item["c2ws"], device=dev.type)
+    mesh_path = os.path.join(args.out_dir, "meshes", "final", f"scan{args.scan}.ply")
+    os.makedirs(os.path.dirname(mesh_path), exist_ok=True)
+    mesh_io.export_mesh(mesh_path, v, t, item["scale_mat"])                                       # runner.py:236-240
+
+    t0 = time.perf_counter()
+    d2s, s2d, overall = dtu_eval.evaluate_scan(mesh_path, args.eval_dir, args.scan, patch_size=args.patch_size, max_dist=args.max_dist,
+                                               downsample_density=args.downsample_density,
+                                               rng=np.random.default_rng(args.shuffle_seed))
+    t_eval = time.perf_counter() - t0
+    rec = {"scan": args.scan, "d2s": d2s, "s2d": s2d, "chamfer": overall, "reference_chamfer": args.reference_chamfer,
+           "delta": None if args.reference_chamfer is None else overall - args.reference_chamfer,
+           "mesh": mesh_path, "vertices": int(len(v)), "triangles": int(len(t)), "mesh_resolution": args.mesh_resolution,
+           "views": int(item["imgs"].shape[0]), "render_hw": [int(x) for x in out["img_fine"].shape[:2]],
+           "down_rule": model.reg_network.nets[0].down_rule, "sdf_precision": model.implicit_surface.sdf_precision,
+           "checkpoint": args.ckpt, "missing_keys": missing, "unexpected_keys": unexpected, "cleaned": bool(args.clean_mesh),
+           "seconds": {"load": t_load, "val_forward": t_val, "evaluate": t_eval}}
+    with open(os.path.join(args.out_dir, f"chamfer_scan{args.scan}.json"), "w") as f:
+        json.dump(rec, f)
+    return rec
+
+
+def main(argv=None):
+    print(json.dumps(run(parse_args(argv))))
+
+
+if __name__ == "__main__":
+    main()

@@ -56,6 +56,7 @@ class _Render(torch.autograd.Function):
         ctx.feat_layout = cfg.get("feat_layout", "t4")
         keys = RENDER_KEYS + (("pseudo_sdf",) if "pseudo_sdf" in out else ())
         ctx.keys = keys
+        ctx.precision = ops.colgram_precision          # the policy this forward ran under is the one its backward runs under
         cfg["holder"].update({k: v for k, v in out.items() if k not in keys})
         cfg["holder"]["_keys"] = keys
         return tuple(out[k] for k in keys)
@@ -72,9 +73,10 @@ class _Render(torch.autograd.Function):
         want_feats = ctx.n_feats > 0 and any(ctx.needs_input_grad[first_feat:])
         gfeats = [torch.zeros_like(f) for f in scene.feats_t4] if want_feats else None
         patches = (g["ref_gray_val"], g["sampled_gray_val"])
-        dvols = isurf.backward_render(g["color_fine"], g["render_depth"], _scalar(g["gradient_error"]), g["sparse_sdf"], None,
-                                      gfeats_t4=gfeats, g_smooth_error=_scalar(g["smooth_error"]), g_pseudo_sdf=g.get("pseudo_sdf"),
-                                      g_patches=None if patches == (None, None) else patches, ctx=rec, sink=sink)
+        with ops.precision_scope(ctx.precision):
+            dvols = isurf.backward_render(g["color_fine"], g["render_depth"], _scalar(g["gradient_error"]), g["sparse_sdf"], None,
+                                          gfeats_t4=gfeats, g_smooth_error=_scalar(g["smooth_error"]), g_pseudo_sdf=g.get("pseudo_sdf"),
+                                          g_patches=None if patches == (None, None) else patches, ctx=rec, sink=sink)
         ctx.rec = None
         rows = []
         for dv, w in zip(dvols, ctx.row_widths):                   # (N_s, 7) -> the input's own width ([logit | 7] rows: logit 0)
@@ -95,6 +97,7 @@ class _Build(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         outputs, volumes, tables, mvol, features, cams, tape = model.run_build(mode, ipts, record=True)
         ctx.model, ctx.tape, ctx.params = model, tape, params
+        ctx.precision = ops.colgram_precision
         n = model.num_stage
         ctx.n = n
         holder.update(tables=tables, mvol=mvol, cams=cams)
@@ -109,7 +112,8 @@ class _Build(torch.autograd.Function):
         g_rows, g_feats, g_dep, g_src = g[:n], g[n:2 * n], g[2 * n:3 * n], g[3 * n:4 * n]
         sink = GradSink()
         gfeats = [torch.zeros_like(f) if gf is None else gf.contiguous().clone() for f, gf in zip(tape["feats"], g_feats)]
-        model.backward_volumes(list(g_rows[::-1]), {s: (g_dep[s], g_src[s]) for s in range(n)}, tape=tape, gfeats=gfeats, sink=sink)
+        with ops.precision_scope(ctx.precision):
+            model.backward_volumes(list(g_rows[::-1]), {s: (g_dep[s], g_src[s]) for s in range(n)}, tape=tape, gfeats=gfeats, sink=sink)
         ctx.tape = None
         return (None, None, None, None) + tuple(sink.get(p) for p in ctx.params)
 

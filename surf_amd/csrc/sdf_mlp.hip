@@ -29,9 +29,6 @@
 #ifndef SURF_SDF_PRIO
 #define SURF_SDF_PRIO 0
 #endif
-#ifndef SURF_SDF_V2
-#define SURF_SDF_V2 1   // 1 = tile-major schedule (sdf_mlp_kernel2), 0 = first schedule (sdf_mlp_kernel)
-#endif
 #ifndef SURF_SDF_NOWEIGHTS
 #define SURF_SDF_NOWEIGHTS 0
 #endif
@@ -44,7 +41,7 @@
 
 namespace {
 
-constexpr int HID = 128, NFEAT = 28, NE = 27, H2 = 101;
+constexpr int HID = 128, NE = 27, H2 = 101;
 constexpr int TILE = 32;  // samples per wavefront pass
 
 // ---- packed weight buffer (floats) --------------------------------------------------------------
@@ -85,9 +82,6 @@ struct SdfArgs {
   float* grad;
   float* scratch;
 };
-
-__device__ __forceinline__ int hid_k(int tt, int r, int h) { return 32 * tt + (r & 3) + 8 * (r >> 2) + 4 * h; }
-
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 // 16-byte buffer load / store: wave-uniform descriptor + per-lane byte offset + compile-time byte offset.
@@ -144,18 +138,6 @@ __device__ __forceinline__ void mma_seg(f32x16 (&acc)[NT], const float* b, rsrc_
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-
-__device__ __forceinline__ void load_bias(f32x16 (&acc)[4], rsrc_t wr, int l, int h64) {
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 v = bload(wr, h64, (BIAS_OFF + (l * 4 + t) * 32) * 4 + g * 16);
-      acc[t][4 * g + 0] = v[0]; acc[t][4 * g + 1] = v[1]; acc[t][4 * g + 2] = v[2]; acc[t][4 * g + 3] = v[3];
-    }
-  }
-}
-
 // nn.Softplus(beta=100, threshold=20) and its derivative from the pre-activation.
 // Raw v_exp_f32 / v_log_f32 / v_rcp_f32 (1 ulp): 1 + e >= 1 is never denormal, and an e that underflows to 0
 // gives h = 0, s = 0, the fp32 limits.  Absolute error of h <= 2e-8, of s <= 3e-7.
@@ -189,24 +171,6 @@ __device__ __forceinline__ void activate(const f32x16 (&acc)[4], float (&h)[64],
         s[i] = sv;
       }
       if (STORE && !SURF_SDF_NOSCRATCH) bstore(sr, svoff, off + (t * 4 + g) * 1024, s);
-    }
-  }
-}
-
-// delta[k] = softplus'(t_l)[k] * G[k], softplus' read back from scratch (all 16 loads in flight at once)
-__device__ __forceinline__ void make_delta(const f32x16 (&G)[4], float (&delta)[64], rsrc_t sr, int svoff, int off) {
-  f32x4 s[16];
-#pragma unroll
-  for (int tg = 0; tg < 16; ++tg) {
-    if (SURF_SDF_NOSCRATCH) s[tg] = f32x4{0.5f, 0.5f, 0.5f, 0.5f};  // timing-only diagnostic build
-    else s[tg] = bload(sr, svoff, off + tg * 1024);
-  }
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) delta[16 * t + 4 * g + i] = s[t * 4 + g][i] * G[t][4 * g + i];
     }
   }
 }
@@ -318,201 +282,9 @@ __device__ __forceinline__ void posenc_half(int h, float x, float y, float z, fl
   e[14] = e[15] = 0.f;
 }
 
-template <bool GRAD>
 #ifndef SURF_SDF_OCC
 #define SURF_SDF_OCC 2  // wavefronts per SIMD the register budget is sized for
 #endif
-__global__ __launch_bounds__(WPB * 64, SURF_SDF_OCC) void sdf_mlp_kernel(SdfArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int wave_in_block = threadIdx.x >> 6;
-  const int j = lane & 31, h = lane >> 5;
-  const int64_t wave_id = (int64_t)blockIdx.x * WPB + wave_in_block;
-  const int64_t n_waves = (int64_t)gridDim.x * WPB;
-  const int64_t n_tiles = (a.n + TILE - 1) / TILE;
-  // wave-uniform descriptors; every per-lane part lives in the 32-bit offsets
-  const rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, PACKED_FLOATS * 4, 0x00020000);
-  const rsrc_t sr = __builtin_amdgcn_make_buffer_rsrc((void*)a.scratch, 0, GRAD ? 0x7fffffff : 0, 0x00020000);
-  const int lane16 = lane * 16;                                  // weights: [..][lane] x 16 B
-  const int h64 = h * 64;                                        // bias rows: [h][16] floats
-  const int svoff = (int)(wave_id * (SCR_SLOT * 4)) + lane * 16;  // this wave's scratch slot
-
-#if SURF_SDF_STAGGER
-  // The two wavefronts that share a SIMD (w and w + 4 of an 8-wave workgroup) run the same program and fall into
-  // lockstep: their MFMA phases collide and their VALU / memory phases leave the matrix pipe idle.  Delay the
-  // second half once.
-  if (WPB == 8 && wave_in_block >= 4) {
-    for (int k = 0; k < SURF_SDF_STAGGER; ++k) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
-  for (int64_t tile = wave_id; tile < n_tiles; tile += n_waves) {
-    const int64_t slot = tile * TILE + j;
-    const int64_t sc = slot < a.n ? slot : a.n - 1;
-    const int64_t i = a.idx ? (int64_t)a.idx[sc] : sc;  // point index (inputs gathered / outputs scattered)
-    const bool active = (slot < a.n) && (!a.mask || a.mask[i] != 0);
-    if (__ballot(active) == 0ull) continue;
-    const float px = a.pts[i * 3 + 0], py = a.pts[i * 3 + 1], pz = a.pts[i * 3 + 2];
-
-    float phi[16];
-    float e[16];
-    {
-      float J[14][3];
-      gather_features<GRAD>(a, h, px, py, pz, phi, J);
-      if (GRAD) {
-        // spill the feature Jacobian: 42 floats -> 11 x 16 B
-#pragma unroll
-        for (int g = 0; g < 11; ++g) {
-          f32x4 v;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int idx = 4 * g + q;
-            v[q] = idx < 42 ? J[idx / 3][idx % 3] : 0.f;
-          }
-          bstore(sr, svoff, SCR_S * 4 + g * 1024, v);
-        }
-      }
-      float je_unused[14];
-      posenc_half(h, px, py, pz, e, je_unused, false);
-    }
-
-    // ------------------------------------------------ forward ------------------------------------------
-    constexpr int SEG = 16 * 4 * 1024;  // bytes of the 16 hidden k-groups x 4 tiles
-    float hbuf[64];
-    f32x16 acc[4];
-    // layer 0: e(27) -> 128
-    load_bias(acc, wr, 0, h64);
-    mma_seg<4, 4>(acc, e, wr, lane16, fwd_off(0) * 4);
-    activate<GRAD>(acc, hbuf, sr, svoff, 0 * 16384);
-    // layer 1: [h0 | phi] -> 128
-    load_bias(acc, wr, 1, h64);
-    mma_seg<16, 4>(acc, hbuf, wr, lane16, fwd_off(1) * 4);
-    mma_seg<4, 4>(acc, phi, wr, lane16, fwd_off(1) * 4 + SEG);
-    activate<GRAD>(acc, hbuf, sr, svoff, 1 * 16384);
-    // layer 2: [h1 | phi] -> 101 (rows >= 101 are zero-padded)
-    load_bias(acc, wr, 2, h64);
-    mma_seg<16, 4>(acc, hbuf, wr, lane16, fwd_off(2) * 4);
-    mma_seg<4, 4>(acc, phi, wr, lane16, fwd_off(2) * 4 + SEG);
-    activate<GRAD>(acc, hbuf, sr, svoff, 2 * 16384);
-    // layer 3 (skip): [[h2 | e]/sqrt2 | phi] -> 128, 1/sqrt2 folded into the packed weights
-    load_bias(acc, wr, 3, h64);
-    mma_seg<16, 4>(acc, hbuf, wr, lane16, fwd_off(3) * 4);
-    mma_seg<4, 4>(acc, e, wr, lane16, fwd_off(3) * 4 + SEG);
-    mma_seg<4, 4>(acc, phi, wr, lane16, fwd_off(3) * 4 + SEG + 4 * 4 * 1024);
-    activate<GRAD>(acc, hbuf, sr, svoff, 3 * 16384);
-    // layer 4
-    load_bias(acc, wr, 4, h64);
-    mma_seg<16, 4>(acc, hbuf, wr, lane16, fwd_off(4) * 4);
-    mma_seg<4, 4>(acc, phi, wr, lane16, fwd_off(4) * 4 + SEG);
-    activate<GRAD>(acc, hbuf, sr, svoff, 4 * 16384);
-    // layer 5
-    load_bias(acc, wr, 5, h64);
-    mma_seg<16, 4>(acc, hbuf, wr, lane16, fwd_off(5) * 4);
-    mma_seg<4, 4>(acc, phi, wr, lane16, fwd_off(5) * 4 + SEG);
-
-    // layer 6, row 0 only (the 128 appearance outputs are unused downstream): y0 = w6 . [h5 | phi] + b6
-    float delta[64];
-    float y0 = 0.f;
-    const int h256 = h * 256;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 w = bload(wr, h256, W6H_OFF * 4 + (t * 4 + g) * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float hv, sv;
-          softplus100(acc[t][4 * g + q], hv, sv);
-          y0 = fmaf(w[q], hv, y0);
-          delta[16 * t + 4 * g + q] = sv * w[q];  // delta5 = softplus'(t5) * W6[0, :128]
-        }
-      }
-    }
-    f32x16 accP;  // running sum over layers of d y0 / d phi, starts at W6[0, 128:156]
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 w = bload(wr, h64, W6P_OFF * 4 + g * 16);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        y0 = fmaf(w[q], phi[4 * g + q], y0);
-        accP[4 * g + q] = w[q];
-      }
-    }
-    y0 += __shfl_xor(y0, 32);
-    y0 += a.packed[B6_OFF];
-    if (active && h == 0) a.sdf[i] = y0;
-    if (!GRAD) continue;
-
-    // ------------------------------------------------ reverse sweep ---------------------------------------
-    f32x16 accE;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) accE[r] = 0.f;
-    const f32x16 zero16 = accE;
-    // layers 5, 4: G = W^T delta -> [H0..H3 | P]
-#pragma unroll
-    for (int l = 5; l >= 4; --l) {
-      f32x16 G[5] = {zero16, zero16, zero16, zero16, accP};
-      mma_seg<16, 5>(G, delta, wr, lane16, bwd_off(l) * 4);
-      accP = G[4];
-      f32x16 Gh[4] = {G[0], G[1], G[2], G[3]};
-      make_delta(Gh, delta, sr, svoff, (l - 1) * 16384);
-    }
-    // layer 3: [H0..H3 (h2, /sqrt2) | E (/sqrt2) | P]
-    {
-      f32x16 G[6] = {zero16, zero16, zero16, zero16, accE, accP};
-      mma_seg<16, 6>(G, delta, wr, lane16, bwd_off(3) * 4);
-      accE = G[4];
-      accP = G[5];
-      f32x16 Gh[4] = {G[0], G[1], G[2], G[3]};
-      make_delta(Gh, delta, sr, svoff, 2 * 16384);
-    }
-    // layers 2, 1
-#pragma unroll
-    for (int l = 2; l >= 1; --l) {
-      f32x16 G[5] = {zero16, zero16, zero16, zero16, accP};
-      mma_seg<16, 5>(G, delta, wr, lane16, bwd_off(l) * 4);
-      accP = G[4];
-      f32x16 Gh[4] = {G[0], G[1], G[2], G[3]};
-      make_delta(Gh, delta, sr, svoff, (l - 1) * 16384);
-    }
-    // layer 0: E only
-    {
-      f32x16 G[1] = {accE};
-      mma_seg<16, 1>(G, delta, wr, lane16, bwd_off(0) * 4);
-      accE = G[0];
-    }
-    // grad = J_e^T G_e + J_phi^T G_phi; each half holds its own 14 (13) channels of both
-    float g3[3] = {0.f, 0.f, 0.f};
-    {
-      float e2[16], je[14];
-      posenc_half(h, px, py, pz, e2, je, true);
-#pragma unroll
-      for (int s = 0; s < 14; ++s) {
-        // channel 14 h + s differentiates w.r.t. coordinate (14 h + s) % 3
-        const int c0 = s % 3, c1 = (14 + s) % 3;
-        const float v = accE[s] * je[s];
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) g3[ax] += ((h ? c1 : c0) == ax) ? v : 0.f;
-      }
-      float Jf[44];
-#pragma unroll
-      for (int g = 0; g < 11; ++g) {
-        f32x4 v = bload(sr, svoff, SCR_S * 4 + g * 1024);
-        Jf[4 * g + 0] = v[0]; Jf[4 * g + 1] = v[1]; Jf[4 * g + 2] = v[2]; Jf[4 * g + 3] = v[3];
-      }
-#pragma unroll
-      for (int c = 0; c < 14; ++c) {
-#pragma unroll
-        for (int ax = 0; ax < 3; ++ax) g3[ax] = fmaf(accP[c], Jf[3 * c + ax], g3[ax]);
-      }
-    }
-#pragma unroll
-    for (int ax = 0; ax < 3; ++ax) g3[ax] += __shfl_xor(g3[ax], 32);
-    if (active && h == 0) {
-      a.grad[i * 3 + 0] = g3[0];
-      a.grad[i * 3 + 1] = g3[1];
-      a.grad[i * 3 + 2] = g3[2];
-    }
-  }
-}
 
 // =================================================================================================================
 // v2 schedule: output-tile-major layers.  Each 32-row output tile runs its whole k-loop alone (a dependent MFMA
@@ -580,17 +352,6 @@ __device__ __forceinline__ void stream_mma(WRing& ring, f32x16& acc, const float
     __builtin_amdgcn_sched_barrier(0);
   }
 }
-
-__device__ __forceinline__ f32x16 bias_tile(rsrc_t wr, int l, int t, int h64) {
-  f32x16 acc;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    f32x4 v = bload(wr, h64, (BIAS_OFF + (l * 4 + t) * 32) * 4 + g * 16);
-    acc[4 * g + 0] = v[0]; acc[4 * g + 1] = v[1]; acc[4 * g + 2] = v[2]; acc[4 * g + 3] = v[3];
-  }
-  return acc;
-}
-
 struct SdfCtx {
   rsrc_t wr, sr;
   int lane16, h64, h256, svoff;
@@ -982,16 +743,9 @@ extern "C" int surf_sdf_mlp(const float* pts, const uint8_t* mask, const int32_t
     if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
   }
   dim3 grid(grid_blocks(n)), block(WPB * 64);
-#if SURF_SDF_V2
   if (grad)
     hipLaunchKernelGGL(sdf_mlp_kernel2<true>, grid, block, 0, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL(sdf_mlp_kernel2<false>, grid, block, 0, (hipStream_t)stream, a);
-#else
-  if (grad)
-    hipLaunchKernelGGL(sdf_mlp_kernel<true>, grid, block, 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(sdf_mlp_kernel<false>, grid, block, 0, (hipStream_t)stream, a);
-#endif
   return surf_check_launch();
 }

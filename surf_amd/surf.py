@@ -111,14 +111,23 @@ class SuRF(nn.Module):
         if getattr(self, "_train_tape", None) is not None:       # volume-building model: the colour path's share of d FPN maps
             self._train_tape["gfeats"] = [torch.zeros_like(f) for f in self._train_tape["feats"]]      # coarse -> fine
             gfeats = self._train_tape["gfeats"][::-1]
-        dvols = self.implicit_surface.backward_render(g_color, g_depth, g_gradient_error, g_sparse_sdf, g_ncc, gfeats_t4=gfeats,
-                                                      g_smooth_error=g_smooth_error, g_pseudo_sdf=g_pseudo_sdf)
+        with ops.precision_scope(getattr(self, "_fwd_precision", None)):
+            dvols = self.implicit_surface.backward_render(g_color, g_depth, g_gradient_error, g_sparse_sdf, g_ncc, gfeats_t4=gfeats,
+                                                          g_smooth_error=g_smooth_error, g_pseudo_sdf=g_pseudo_sdf)
         if self.has_vol:
             for p, g in zip(self.volumes, dvols[::-1]):          # volumes are kept coarse -> fine
                 accumulate(p, g)
         return dvols
 
     def backward_volumes(self, row_grads_f2c, g_depths=None, tape=None, gfeats=None, sink=None):
+        """See _backward_volumes.  With the module's own tape (tape=None) it runs under the training-precision policy that forward
+        was recorded with (a graph node passes its tape AND sets its own scope: surf_amd.autograd._Build)."""
+        if tape is not None:
+            return self._backward_volumes(row_grads_f2c, g_depths, tape, gfeats, sink)
+        with ops.precision_scope(getattr(self, "_fwd_precision", None)):
+            return self._backward_volumes(row_grads_f2c, g_depths, tape, gfeats, sink)
+
+    def _backward_volumes(self, row_grads_f2c, g_depths=None, tape=None, gfeats=None, sink=None):
         """Backward of the volume build + FPN of the last `forward("train", ..., record=True)` (surf.py:80-131 under
         loss.backward()): row_grads_f2c = d loss / d the stages' feature rows, fine -> coarse, (N_s, 7) (what
         ImplicitSurface.backward_render returns) or (N_s, 8) = [logit | 7 features] rows, None = no gradient; g_depths =
@@ -314,6 +323,7 @@ class SuRF(nn.Module):
         instead keeps the tapes on the module for `SuRF.backward` / `SuRF.backward_volumes` and returns plain tensors."""
         if mode != "val":
             ops.set_train_precision(self.train_precision)
+            self._fwd_precision = ops.colgram_precision          # what the explicit backward entry points below run under
         if self._wants_graph(mode, record):
             from . import autograd
             return autograd.differentiable_forward(self, mode, ipts, cos_anneal_ratio, step)

@@ -51,7 +51,12 @@ def test_sparse_conv_backward_identities_full_size(full_train, stage):
         dy = torch.randn(e["raw"].shape, device="cuda", generator=g)
         dx, dW = ops.spconv_backward(e["x"], e["in_site"][0], e["in_site"][1], e["out_site"][0], e["out_site"][1], e["mode"], e["w"], dy)
         ref = _dot(dy, e["raw"])                       # raw = conv(x; W) of the forward
-        _close(_dot(dx, e["x"]), ref)
+        # <dx, x> is a sum of millions of signed terms that cancels to ~1e-5 of their total magnitude; the wide layers' dx comes
+        # from the matrix-core kernel (fp32 accumulation of up to 27 x 64 products in another order: 5e-6 absolute per element
+        # against the per-voxel kernel, scripts/dbg_spconv_dgrad.py), so the identity is held to 2e-8 of the UN-cancelled sum
+        slack = 2e-8 * float((dx.double().abs() * e["x"].double().abs()).sum())
+        got = _dot(dx, e["x"])
+        assert abs(got - ref) <= 2e-3 * max(abs(got), abs(ref), 1e-12) + slack, (got, ref, slack)
         _close(_dot(dW, e["w"]), ref)
     assert len(seen) >= 8
 

@@ -120,3 +120,24 @@ def test_dtu_files_to_chamfer(tmp_path):
     assert 0.85 * delta < d2s < delta + 0.1, d2s
     assert 0.85 * delta < s2d < delta + density, s2d
     assert abs(overall - 0.5 * (d2s + s2d)) < 1e-9
+
+    # ---- the same chain as ONE command: scripts/dtu_chamfer.py (conf + data_dir + eval_dir + scan -> one JSON record) ----
+    import json
+    import sys
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root_dir, "scripts"))
+    import dtu_chamfer
+    conf_path = tmp_path / "surf_synth.conf"
+    conf_path.write_text(json.dumps({"model": mcfg, "val_dataset": {k: dconf[k] for k in dconf}}, indent=1))    # (JSON is a HOCON subset)
+    rec = dtu_chamfer.run(dtu_chamfer.parse_args([
+        "--conf", str(conf_path), "--eval_dir", str(ev), "--scan", "24", "--ref_view", "1", "--out_dir", str(tmp_path / "exp2"),
+        "--mesh_resolution", "128", "--downsample_density", str(density), "--logit_override", "sphere", "--reference_chamfer", str(overall)]))
+    assert rec["scan"] == 24 and rec["down_rule"] == "dilate" and rec["views"] == 3 and rec["triangles"] == len(t)
+    # same seeded weights, same files, same evaluator seed: the command reproduces the chain above
+    assert abs(rec["chamfer"] - overall) < 1e-6 and abs(rec["delta"]) < 1e-6, (rec["chamfer"], overall)
+    assert os.path.exists(rec["mesh"]) and json.load(open(tmp_path / "exp2" / "chamfer_scan24.json"))["chamfer"] == rec["chamfer"]
+    # ... and with another stride-2 site rule it is a different network (row a5: three candidates behind one switch)
+    rec0 = dtu_chamfer.run(dtu_chamfer.parse_args([
+        "--conf", str(conf_path), "--eval_dir", str(ev), "--scan", "24", "--ref_view", "1", "--out_dir", str(tmp_path / "exp3"),
+        "--mesh_resolution", "64", "--downsample_density", str(density), "--logit_override", "sphere", "--down_rule", "pad0"]))
+    assert rec0["down_rule"] == "pad0" and np.isfinite(rec0["chamfer"])

@@ -251,3 +251,25 @@ def test_colgram_workspace_covers_both_launch_plans():
             for N in (1, 8, 33, 57, 156):
                 need = int(L.surf_colgram_workspace_floats(rows, M, N))
                 assert need >= mfma_partials(rows, M) * M * (N + 1), (rows, M, N)
+
+
+def test_precision_scope_restores_the_process_wide_policy():
+    """A backward runs under the training-precision policy its forward was recorded with (advisor finding, round 3: the
+    policy was a process global read at backward time, so model B's forward between A's forward and A's loss.backward()
+    changed A's weight-gradient arithmetic)."""
+    from surf_amd import ops
+    ops.set_train_precision("fp32")
+    with ops.precision_scope(1):
+        assert ops.colgram_precision == 1
+        with ops.precision_scope(None):         # no recorded policy: leave whatever is set
+            assert ops.colgram_precision == 1
+        with ops.precision_scope(0):
+            assert ops.colgram_precision == 0
+        assert ops.colgram_precision == 1
+    assert ops.colgram_precision == 0
+    try:
+        with ops.precision_scope(1):
+            raise KeyError("x")
+    except KeyError:
+        pass
+    assert ops.colgram_precision == 0
