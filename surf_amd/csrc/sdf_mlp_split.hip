@@ -573,43 +573,14 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
   c.tprev = __builtin_readcyclecounter();
   for (int k = 0; k < 8; ++k) c.tacc[k] = 0;
 #endif
-  // The index -> point -> table -> rows chain at the head of a tile is four dependent memory round trips with nothing of the
-  // tile's own to overlap (15.6 K of a tile's 122 K clocks, round 3).  Round 4: the first two links of the NEXT round are walked
-  // under the current one - its index is requested at the top of the round, its point once that index has landed (behind the
-  // current tile's row loads) - at the price of four registers carried through the sweeps.  Both requests are issued OUTSIDE the
-  // chunk code, before the round's first LDS-DMA: the counted s_waitcnt vmcnt(N) of the chunks count operations issued AFTER
-  // their DMA, older loads can only be complete by then.
-#ifndef SURF_SDF_PREFETCH
-#define SURF_SDF_PREFETCH 1
-#endif
-  int64_t i_nx = 0;
-  float p_nx[3] = {0.f, 0.f, 0.f};
-  bool m_nx = true;
-  if (SURF_SDF_PREFETCH && blockIdx.x < n_rounds) {
-    const int64_t slot0 = ((int64_t)blockIdx.x * WPB + c.wave) * TILE + (c.lane & 31);
-    const int64_t sc = slot0 < n_pts ? slot0 : n_pts - 1;
-    i_nx = a.idx ? (int64_t)a.idx[sc] : sc;
-    m_nx = !a.mask || a.mask[i_nx] != 0;
-    p_nx[0] = a.pts[i_nx * 3 + 0]; p_nx[1] = a.pts[i_nx * 3 + 1]; p_nx[2] = a.pts[i_nx * 3 + 2];
-  }
   for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
     asm volatile("" : "+s"(c.dma_lds));  // not loop-invariant: the DMA addresses of a round are formed where they are used
     const int64_t tile = round * WPB + c.wave;
     const int64_t slot0 = tile * TILE + (c.lane & 31);
     const int64_t sc = slot0 < n_pts ? slot0 : n_pts - 1;
-#if SURF_SDF_PREFETCH
-    const int64_t i = i_nx;
-    const bool active = (slot0 < n_pts) && m_nx;
-    const float px = p_nx[0], py = p_nx[1], pz = p_nx[2];
-    // the next round's index: requested now, it lands while this tile's table and row loads are in flight
-    const int64_t slot_n = ((round + gridDim.x) * WPB + c.wave) * TILE + (c.lane & 31);
-    const int64_t sc_n = slot_n < n_pts ? slot_n : n_pts - 1;
-    i_nx = a.idx ? (int64_t)a.idx[sc_n] : sc_n;
-#else
     const int64_t i = a.idx ? (int64_t)a.idx[sc] : sc;
     const bool active = (slot0 < n_pts) && (!a.mask || a.mask[i] != 0);
     const float px = a.pts[i * 3 + 0], py = a.pts[i * 3 + 1], pz = a.pts[i * 3 + 2];
-#endif
 
     Frag ef[2], pf[2];
     float y0 = 0.f;
@@ -630,11 +601,6 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
       } else {
         gather_features<GRAD>(a, c, px, py, pz, phi, posenc);
       }
-#if SURF_SDF_PREFETCH
-      // ... and the next round's point (its index has landed: it was requested before this tile's table lookups)
-      m_nx = !a.mask || a.mask[i_nx] != 0;
-      p_nx[0] = a.pts[i_nx * 3 + 0]; p_nx[1] = a.pts[i_nx * 3 + 1]; p_nx[2] = a.pts[i_nx * 3 + 2];
-#endif
       f32x4 w6p[4];  // feature part of the last layer (all four loads first: the statements are emitted in source order)
 #pragma unroll
       for (int g = 0; g < 4; ++g) w6p[g] = bload(c.tr, c.h * 64, TAIL_W6P * 4 + g * 16);
