@@ -220,6 +220,39 @@ def test_validate_images_match_golden(scene, weights, gpu_scene, golden_validate
         assert out["img_fine"].shape == (7, 8, 3) and out["normal_img"].shape == (7, 8, 3)
 
 
+def test_all_masked_out_chunk_in_val_mode(scene, weights, gpu_scene):
+    """implicit_surface.py:88-89: a chunk without a single masked-in sample sends its first ten points through the networks in
+    the reference - in val as in train.  Their compositing weights are zero (alpha is multiplied by the unchanged voxel mask), so
+    every output validate() consumes (colour, depths, the weighted normal) is what it is without the rule; surf_amd applies the rule
+    in training forwards only (where sparse_sdf / the graph need it) and skips the ten evaluations in inference.  Pinned here: on
+    rays that look AWAY from the volume the consumed outputs equal the oracle's, which applies the rule as the reference does; the
+    outputs nothing reads in val - valid_mask / gradient_error / the ten sdf values of ray 0 - are the documented difference."""
+    from surf_amd import conf
+    from surf_amd.implicit_surface import ImplicitSurface, SceneVolumes
+    from tests.golden.make_golden import MODEL_CONF
+    d = dev()
+    model = ImplicitSurface(conf.from_dict(MODEL_CONF["implicit_surface"]))
+    model.load_state_dict({k[len("implicit_surface."):]: v for k, v in weights.items() if k.startswith("implicit_surface.")})
+    model = model.to(d).eval()
+    sc = SceneVolumes.from_device_layouts(gpu_scene["mvol"], gpu_scene["sv"].vols, gpu_scene["sv"].tables, gpu_scene["feats_t4"],
+                                          gpu_scene["imgs_t4"], gpu_scene["cams"])
+    R = 24
+    rays_o = scene["rays_o"][:R].contiguous()
+    rays_d = (-scene["rays_d"][:R]).contiguous()                      # away from the origin: no sample inside the volume
+    near, far = scene["near"].repeat(R, 1), scene["far"].repeat(R, 1)
+    out = model.render_scene(rays_o.to(d), rays_d.to(d), near.to(d), far.to(d), sc, 1.0)
+    torch.cuda.synchronize()
+    c = gpu_scene["cpu"]
+    ref = O.render(weights, rays_o, rays_d, near, far, c["mvol"], c["vols"], c["tabs"], c["masks"], c["feats"], scene["imgs"],
+                   scene["intrs"], scene["c2ws"], CFG["n_samples"], CFG["sample_ranges"], CFG["n_depth"], 1.0)
+    assert float(ref["weights"].abs().max()) == 0.0 and int(out["valid_mask"].sum()) == 0
+    for k in ("color_fine", "render_depth", "sdf_depth", "normal"):
+        rel_close(out[k], ref[k].reshape(out[k].shape), 0, 1e-6)
+    assert float(out["weights"].abs().max()) == 0.0
+    # the rule's footprint in the reference (oracle): ten real SDF values on ray 0, everything else the 100 placeholder
+    assert int((ref["sdf"].reshape(-1) != 100).sum()) == 10 and bool((out["sdf"].cpu().reshape(-1) == 100).all())
+
+
 def test_render_with_perturb_matches_golden(scene, weights, gpu_scene, golden_perturb):
     """render.perturb = 1 (every shipped conf): the kernels, fed the reference's four torch.rand([R, 1]) - 0.5 draws,
     against the reference's own outputs under the same seed."""
