@@ -873,15 +873,17 @@ def test_sparse_unet_train_mode_batch_statistics(golden_pipe):
     rel_close(mid_e, mid_eref, 1e-3, 1e-4)
 
 
-def test_sparse_unet_backward_matches_autograd(golden_pipe):
+@pytest.mark.parametrize("rule", ["dilate", "floor", "pad0"])
+def test_sparse_unet_backward_matches_autograd(golden_pipe, rule):
     """SparseCostRegNet.backward (train-mode BatchNorm backward + sparse-convolution backward kernels) against torch
     autograd through the oracle's sparse_unet(training=True): every kernel, BatchNorm weight / bias, out_lin and the
-    input features, for upstream gradients on both outputs (out, mid)."""
+    input features, for upstream gradients on both outputs (out, mid); for each stride-2 site rule (pad0: the tape holds the
+    coordinates stored + 1, the backward walks the same lattices)."""
     from surf_amd import conf
     from surf_amd.reg_network import SparseCostRegNetList
     d = dev()
     torch.manual_seed(9)
-    net = SparseCostRegNetList(conf.from_dict({"d_in": [8, 16, 16, 16], "d_out": [8] * 4, "d_base": [8] * 4}))
+    net = SparseCostRegNetList(conf.from_dict({"d_in": [8, 16, 16, 16], "d_out": [8] * 4, "d_base": [8] * 4, "down_rule": rule}))
     s, D = 1, 16
     with torch.no_grad():      # non-trivial BatchNorm affine so that dgamma / dbeta are exercised away from (1, 0)
         for name, p_ in net.named_parameters():
@@ -896,7 +898,7 @@ def test_sparse_unet_backward_matches_autograd(golden_pipe):
     d_out = torch.randn(feats.shape[0], 8, generator=g)
     d_mid = torch.randn(feats.shape[0], 8, generator=g)
     f_ref = feats.clone().requires_grad_(True)
-    out_ref, mid_ref = O.sparse_unet(sd, f_ref, coords.long(), D, s, training=True)
+    out_ref, mid_ref = O.sparse_unet(sd, f_ref, coords.long(), D, s, rule=rule, training=True)
     ((out_ref * d_out).sum() + (mid_ref * d_mid).sum()).backward()
 
     net = net.to(d).train()
