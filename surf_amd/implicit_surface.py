@@ -483,7 +483,7 @@ class ImplicitSurface(nn.Module):
                  extract_geometry=True, mesh_resolution=512, threshold=0.0, chunk=1 << 19):
         """implicit_surface.py:359-402.  The reference's 256-ray chunks exist to bound autograd memory; here rays are
         independent, so `chunk` is only a scratch-size knob (default 2^19 rays: a 576 x 800 image in one launch of every kernel -
-        eight 65,536-ray chunks cost 31 ms more per image in launch tails and small launches; ~60 B of scratch per sample).  With render.perturb > 0 the jitters are drawn in the
+        eight 65,536-ray chunks cost 6 ms more per image in launch tails and small launches; ~60 B of scratch per sample).  With render.perturb > 0 the jitters are drawn in the
         reference's order (per 256-ray block, stages inner: draw_jitter), so a seeded run reproduces the reference's
         sample positions whatever `chunk` is."""
         outputs = {}
