@@ -47,8 +47,9 @@ struct Ctx {
 #endif
   rsrc_t wr, sr, sl, tr;  // packed stream, scratch (stores / loads), fp32 tail
   int lane, lane16, h, svoff, wave;
+  int wave1024;       // wave * 1024 (scalar)
   int dma_voff;       // lane * 16 + wave * 1024: this wavefront's 1 KB block of every 4 KB DMA piece
-  uint32_t dma_lds;   // LDS address of the ring + wave * 1024 (made opaque once per round: see the round loop)
+  uint32_t dma_lds;   // LDS address of the ring (+ wave * 1024 in the piece-major assignment; made opaque once per round)
   char* lds;    // the ring
   char* lds_s;  // this wavefront's exponent slices (the softplus arguments the reverse sweep needs) + lane * 16
 };
@@ -61,21 +62,40 @@ struct Ctx {
 // has to be complete too: NS-1 chunks of slack keep the exponent-slice stores of the chunks before (acknowledged late by L2)
 // out of that wait.
 template <class P> constexpr int n_dma(int ci) { return (P::CH.ks[ci] * P::NP + 3) / 4; }
-template <class P, int NS, int CI>
-__device__ __forceinline__ void stage_dma_piece(const Ctx& c, int k) {  // blocks wave + 4 k of chunk CI
+#ifndef SURF_SDF_DMA_WAVEMAJOR
+#define SURF_SDF_DMA_WAVEMAJOR 1
+#endif
+template <class P, int NS, int CI, int k>
+__device__ __forceinline__ void stage_dma_piece(const Ctx& c) {
   constexpr int OFF = P::CH.off[CI];
   // blocks past the end of a chunk read into the next one / out of range (= 0) and land in the unused tail of the slot.
+#if SURF_SDF_DMA_WAVEMAJOR
+  // Round 4: wave-major assignment - of the 4 ND one-KB blocks of chunk CI (ND = n_dma pieces a wavefront issues) wavefront w
+  // moves blocks w ND .. w ND + ND - 1 instead of 4 k + w: consecutive pieces of a wavefront are then 1 KB apart on BOTH sides
+  // (stream and LDS image are unchanged: block b still lands at slot + 1024 b), so four of them share one M0 / one scalar
+  // offset and differ in the instruction's 12-bit immediate (0, 1024, 2048, 3072).  Two SALU instructions per four DMAs
+  // instead of eight (an SALU instruction costs ~7 issue cycles between MFMAs, microbench/mfma_issue_model.hip); the wave's
+  // share w ND 1024 is a scalar product with a compile-time ND (a handful of distinct values per kernel).
+  constexpr int ND = n_dma<P>(CI);
+  const uint32_t wshare = (uint32_t)c.wave1024 * (uint32_t)ND;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(
+      c.wr, (__attribute__((address_space(3))) void*)(uintptr_t)(c.dma_lds + wshare + ((CI % NS) * slot_bytes<P>() + (k >> 2) * 4096)), 16,
+      c.lane16, (int)wshare + (OFF + (k >> 2) * 4096), (k & 3) * 1024, 0);
+#else
   // The wave's share of the address sits in the offset VGPR / the per-round LDS base, so that the scalar offset is a
   // compile-time constant: with `wave` inside it the ~330 distinct offsets of a round were loop-invariant SGPR values that
   // the compiler hoisted out of the round loop and spilled to VGPR lanes (v_readlane + 5 wait states in front of every DMA).
   __builtin_amdgcn_raw_ptr_buffer_load_lds(
       c.wr, (__attribute__((address_space(3))) void*)(uintptr_t)(c.dma_lds + ((CI % NS) * slot_bytes<P>() + k * 4096)), 16, c.dma_voff,
       OFF + k * 4096, 0, 0);
+#endif
 }
-template <class P, int NS, int CI>
+template <class P, int NS, int CI, int K = 0>
 __device__ __forceinline__ void stage_dma(const Ctx& c) {
-#pragma unroll
-  for (int k = 0; k < n_dma<P>(CI); ++k) stage_dma_piece<P, NS, CI>(c, k);
+  if constexpr (K < n_dma<P>(CI)) {
+    stage_dma_piece<P, NS, CI, K>(c);
+    stage_dma<P, NS, CI, K + 1>(c);
+  }
 }
 // vector-memory operations a chunk issues by itself, in order: [pre: loads before its DMA] [DMA] [post: stores in fn]
 // which exponent slice the backward chunk (L, T) loads (layer < 0: none): DEEP: that of the hidden tile computed by the
@@ -188,7 +208,7 @@ __device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F slot) {
       static_for<0, ND>([&](auto kc) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
         if constexpr (PL::v.dma_gap[k] == g)
-          if (!SURF_X_NODMA) stage_dma_piece<P, NS, NXT>(c, k);
+          if (!SURF_X_NODMA) stage_dma_piece<P, NS, NXT, k>(c);
       });
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -551,8 +571,9 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
   c.lane16 = c.lane * 16;
   c.lds = lds;
   c.lds_s = lds + NS * slot_bytes<P>() + c.wave * (NSL * 4096) + c.lane16;
+  c.wave1024 = c.wave * 1024;
   c.dma_voff = c.lane16 + c.wave * 1024;
-  c.dma_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds + c.wave * 1024;
+  c.dma_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds + (SURF_SDF_DMA_WAVEMAJOR ? 0 : c.wave * 1024);
   c.wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.packed, 0, stream_bytes<P>(), 0x00020000);
   c.tr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.packed + stream_bytes<P>()), 0, TAIL_FLOATS * 4, 0x00020000);
   c.sr = __builtin_amdgcn_make_buffer_rsrc((void*)a.scratch, 0, (GRAD && !(SURF_X_NOSCRATCH & 1)) ? 0x7fffffff : 0, 0x00020000);
@@ -575,6 +596,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
 #endif
   for (int64_t round = blockIdx.x; round < n_rounds; round += gridDim.x) {
     asm volatile("" : "+s"(c.dma_lds));  // not loop-invariant: the DMA addresses of a round are formed where they are used
+    asm volatile("" : "+s"(c.wave1024));  // (likewise the wave's share of the scalar offsets)
     const int64_t tile = round * WPB + c.wave;
     const int64_t slot0 = tile * TILE + (c.lane & 31);
     const int64_t sc = slot0 < n_pts ? slot0 : n_pts - 1;
