@@ -198,7 +198,13 @@ __device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F slot) {
         // An MFMA is a pure value to the compiler: instruction selection is free to linearise it anywhere between its
         // operands and its use (it sank whole k-steps below their gaps' scheduling barriers, with the A pieces spilled to
         // scratch memory meanwhile).  Passing the accumulator through an empty volatile statement ties it to this gap.
-        if (SURF_SDF_PINS & 2) asm volatile("" : "+v"(acc.v[m & (P::NA - 1)]));
+        // (round 4: the statement only READS the accumulator.  As an in-out operand it made the hazard recogniser treat the
+        // statement as a VALU write of the MFMA's srcC and put an s_nop in front of the next MFMA - 616 of the gradient kernel's
+        // ~1,000 s_nop, 3.4 issue cycles each; as an input it still keeps the MFMA from sinking below this gap, and source-order
+        // selection keeps the next one from rising above it: same interleave, no spills, -0.7 K s_nop.  SURF_SDF_PINS & 4: the
+        // in-out form)
+        if (SURF_SDF_PINS & 4) asm volatile("" : "+v"(acc.v[m & (P::NA - 1)]));
+        else if (SURF_SDF_PINS & 2) asm volatile("" ::"v"(acc.v[m & (P::NA - 1)]));
       } else if (m == 0) {
         acc.v[0][ks % 16] += __builtin_bit_cast(float, b.p[0][0]) + __builtin_bit_cast(float, a_q[ks % (PF + 1)][0][0]);
       }
