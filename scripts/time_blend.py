@@ -39,30 +39,20 @@ for prec in os.environ.get('SURF_BLEND', 'f32,f32lds,bf16x3,f16x2').split(','):
         from surf_amd import _lib
         raw = ctypes.CDLL(_lib.LIB_PATH)
         buf = (ctypes.c_ulonglong * 10)()
-        woven = os.environ.get('SURF_PHASES') == 'weave'          # the woven bf16x3 kernel keeps its own counters (blend_weave.hip)
-        ph = raw.surf_debug_weave_phases if woven else raw.surf_debug_blend_phases
+        ph = raw.surf_debug_blend_phases
         ph(buf, 1)
-        rbuf = (ctypes.c_ulonglong * 20)()
-        if woven:
-            raw.surf_debug_weave_regions(rbuf, 1)
         col, nval = ops.blend(st["pts"], scene.feats_t4, scene.imgs_t4, scene.cams, w, mask=st["vmask"], active_idx=act)
         torch.cuda.synchronize()
         ph(buf, 0)
-        tiles_per_wave = (n_act / 32) / (256 * (4 if woven else 8))
-        names = ['tile setup', 'pass 1 (4 views)', 'pooling sweeps', 'shared base_fc.0', 'pass 2 view pairs (woven)', 'pass 2 odd view', '-', '-'] if woven else ['tile setup', 'pass 1 (4 views)', 'pooling sweeps', 'shared base_fc.0', 'p2 base_fc', 'p2 vis_fc', 'p2 vis_fc2', 'p2 rgb_fc+softmax']
+        tiles_per_wave = (n_act / 32) / (256 * 8)
+        names = ['tile setup', 'pass 1 (4 views)', 'pooling sweeps', 'shared base_fc.0', 'p2 base_fc', 'p2 vis_fc', 'p2 vis_fc2', 'p2 rgb_fc+softmax']
         tot = sum(buf[:8])
         for k in range(8):
             print(f"   phase {k} {names[k]:20s} {buf[k] / 256 / tiles_per_wave:9.0f} clocks per tile  ({100.0 * buf[k] / tot:4.1f} %)")
         print(f"   total {tot / 256 / tiles_per_wave:9.0f} clocks per tile per wave;  workgroup 0: {buf[8]} s_memtime ticks in {buf[9] / 100.0:.1f} us "
               f"(s_memrealtime, 100 MHz) = {buf[8] / max(buf[9], 1) * 0.1:.3f} GHz")
-        if woven:
-            raw.surf_debug_weave_regions(rbuf, 0)
-            rn = ['-|E1', 'MF1|E1', 'MF1|E2a', 'MF2a|E2a', 'MF2a|E2b', 'MF2b|E2b', 'MF2b|E3', 'MF3|E3', 'MF3|E4', 'MF4|E4', 'MF4|E5', 'MF5|E5',
-                  'MF5|E6', 'MF6|E6', 'MF6|E7', 'MF7|E7', 'MF7|E8', '-|E8', 'view loads', '-']
-            pairs = tiles_per_wave * 2
-            print("   pair-loop regions (clocks per pair of views): " + "  ".join(f"{rn[k]} {rbuf[k] / 256 / pairs:.0f}" for k in range(19)))
         wg = (ctypes.c_ulonglong * 512)()
-        (raw.surf_debug_weave_wg if woven else raw.surf_debug_blend_wg)(wg)
+        raw.surf_debug_blend_wg(wg)
         t0 = min(wg[2 * i] for i in range(256))
         dur = [(wg[2 * i + 1] - wg[2 * i]) / 100.0 for i in range(256)]
         start = [(wg[2 * i] - t0) / 100.0 for i in range(256)]

@@ -65,10 +65,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int NP>
 struct FragT { u32x4 p[NP]; };  // B operand of one 16-wide k-step: NP pieces x 8 x 16 bit
 
-// bf16x3: the woven kernel (blend_weave.hip; 1 = default) or the two-wavefronts-per-SIMD kernel of rounds 2-3 (0)
-#ifndef SURF_BLEND_WEAVE
-#define SURF_BLEND_WEAVE 1
-#endif
 // Matrix-pipe residuals of the exact bf16 split (round 4; see split_tile_mres below): 1 = on (default), 0 = the VALU form
 #ifndef SURF_BLEND_MRES
 #define SURF_BLEND_MRES 1
@@ -187,7 +183,6 @@ struct BPolF32 {
 
 #ifdef SURF_BLEND_TIMING  // debug builds only (scripts/build_variant.sh): per-phase shader-clock totals of wavefront 0 of every workgroup
 __device__ unsigned long long g_bwg[256][2];  // s_memrealtime at the start / end of every workgroup's wavefront 0
-__device__ unsigned long long g_bregion[20];  // woven kernel: clocks per region of the pair loop
 __device__ unsigned long long g_bphase[10];  // [8], [9]: s_memtime / s_memrealtime (100 MHz) span of workgroup 0's wavefront 0
 #define SURF_BT(k)                                                \
   do {                                                            \
@@ -195,15 +190,8 @@ __device__ unsigned long long g_bphase[10];  // [8], [9]: s_memtime / s_memrealt
     tacc[k] += now_ - tprev;                                      \
     tprev = now_;                                                 \
   } while (0)
-#define SURF_RT(k)                                                \
-  do {                                                            \
-    const unsigned long long now_ = __builtin_readcyclecounter(); \
-    racc[k] += now_ - tprev;                                      \
-    tprev = now_;                                                 \
-  } while (0)
 #else
 #define SURF_BT(k)
-#define SURF_RT(k)
 #endif
 
 struct BlendArgs {
@@ -932,604 +920,6 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
 #endif
 }
 
-#ifdef SURF_BLEND_WEAVE_TU
-// =====================================================================================================================
-// K10c (round 4): the bf16x3 kernel with pass 2 WOVEN - one wavefront per SIMD carrying two source views at once.
-//
-// What the counters said about the kernel above (profiles/r04_blend_sq_bf16x3_before.txt, phase clocks of a
-// -DSURF_BLEND_TIMING build, scripts/microbench/mfma_two_streams.hip): its SIMD time is 4 V + 32 M cycles per (tile, view) -
-// V VALU instructions, M MFMAs - i.e. the VALU blocks (ELU + operand split of a tile) and the MFMA blocks (one layer) of its
-// two wavefronts per SIMD do NOT overlap: a wavefront whose next instruction is an MFMA behind a busy matrix pipe holds the
-// SIMD's VALU issue port, whichever wavefront the waiting VALU work belongs to (two waves, one chain each: 459 ns per tile in
-// the microbenchmark against 465 = no overlap at all; s_setprio: 443).  What does overlap is VALU work that stands BETWEEN
-// two MFMAs of the same wavefront in program order (the SDF kernel's rule: a gap costs max(32, 12 + 4 n) cycles for n VALU
-// instructions).  A view's chain has no such work of its own - every ELU needs the layer before it - so this kernel runs the
-// chains of TWO source views in one wavefront, half a layer apart: while view A's layer-k MFMAs are issued, the gaps between
-// them carry view B's ELU + first-piece conversion for layer k, then B's MFMAs carry A's ELU for layer k + 1, and so on
-// (17 regions per pair of views).  The residual levels of the exact split are MFMAs of the owning stream (split_tile_mres'
-// identity trick) with their two conversion passes in the gaps of that stream's own product MFMAs: per stream and layer
-//      E-phase   ELU of 16 values + v_cvt_pk first pieces                (VALU, in the OTHER stream's gaps)
-//      MF-phase  R1 R1 | 3 x P(., p0) with the p1 conversions | R2 R2 | 2 x P(., p1) with the p2 conversions | P(., p2)
-// One wavefront per SIMD (512 registers: two streams' accumulators, fragments and the layer's A pieces), workgroups of 4
-// wavefronts, all four staged views of a tile in LDS (4 waves x 4 views x 5 KB behind the 80 KB weight image); products are
-// accumulated first-piece-first here (the kernel above: smallest-first) - same six terms, fp32 accumulate.
-// Compiled as its own translation unit (blend_weave.hip) with -mllvm -pre-RA-sched=source: one scheduling barrier per gap and
-// the accumulator pinned in its gap, as in sdf_mlp_split.hip.
-constexpr int WPB2 = 4;
-constexpr int LDS_VIEWS2 = 4;
-
-template <int I> struct IC { static constexpr int value = I; };
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for_range(F&& f) {
-  if constexpr (I < N) {
-    f(IC<I>{});
-    static_for_range<I + 1, N>(f);
-  }
-}
-
-enum { S_NONE = -1, S1 = 0, S2A, S2B, S3, S4, S5, S6, S7, S8, N_STAGE };
-enum { INIT_KEEP = 0, INIT_ZERO, INIT_BIAS, INIT_G0A, INIT_G0B };
-struct Op {
-  int kind;        // 0: residual MFMA r -= I_idn x f[s].p[lvl];  1: product acc += W[blk].piece x  x  f[s].p[y]
-  int s, idn, lvl; // residual
-  int blk, x, y, acc, init;  // product (init != INIT_KEEP: first product into this accumulator, C operand = init source)
-  int clvl, cs, cbeg, cend;  // after the MFMA: pairs [cbeg, cend) of fragment cs.. (flattened q: fragment cs + q / 4, pair q % 4) <- cvt(r), level clvl
-};
-struct Blk { int L, ks, t; };
-struct OpList {
-  int n, nblk, bias;  // bias: accumulator-init row to load (or -1)
-  Blk blk[4];
-  Op op[32];
-};
-constexpr Op op_res(int s, int idn, int lvl) { return Op{0, s, idn, lvl, 0, 0, 0, 0, 0, 0, 0, 0, 0}; }
-constexpr Op op_prod(int blk, int s, int x, int y, int acc, int init) { return Op{1, s, 0, 0, blk, x, y, acc, init, 0, 0, 0, 0}; }
-// standard stage: fragments [0, nf) are split now (npair real pairs), product p uses block p with fragment fs[p] into accumulator accs[p]
-constexpr OpList ops_std(int nf, int npair, int nprod, const Blk* blk, const int* fs, const int* accs, const int* inits, int bias) {
-  OpList o{};
-  o.nblk = nprod;
-  o.bias = bias;
-  for (int p = 0; p < nprod; ++p) o.blk[p] = blk[p];
-  int n = 0;
-  bool seen[3] = {false, false, false};
-  for (int s = 0; s < nf; ++s) o.op[n++] = op_res(s, s, 0);
-  {
-    const int m = 3 * nprod - 1;
-    int k = 0;
-    for (int p = 0; p < nprod; ++p)
-      for (int x = 2; x >= 0; --x, ++k) {
-        Op q = op_prod(p, fs[p], x, 0, accs[p], seen[accs[p]] ? INIT_KEEP : inits[accs[p]]);
-        seen[accs[p]] = true;
-        if (k >= 1) { q.clvl = 1; q.cs = 0; q.cbeg = (k - 1) * npair / m; q.cend = k * npair / m; }
-        o.op[n++] = q;
-      }
-  }
-  for (int s = 0; s < nf; ++s) o.op[n++] = op_res(s, s, 1);
-  {
-    const int m = 2 * nprod - 1;
-    int k = 0;
-    for (int p = 0; p < nprod; ++p)
-      for (int x = 1; x >= 0; --x, ++k) {
-        Op q = op_prod(p, fs[p], x, 1, accs[p], INIT_KEEP);
-        if (k >= 1) { q.clvl = 2; q.cs = 0; q.cbeg = (k - 1) * npair / m; q.cend = k * npair / m; }
-        o.op[n++] = q;
-      }
-  }
-  for (int p = 0; p < nprod; ++p) o.op[n++] = op_prod(p, fs[p], 0, 2, accs[p], INIT_KEEP);
-  o.n = n;
-  return o;
-}
-constexpr OpList ops_of(int stage) {
-  if (stage == S1) {  // base_fc.0, view part: f (12) -> 64 on top of the shared part
-    const Blk b[4] = {{L_B0V, 0, 0}, {L_B0V, 1, 0}, {L_B0V, 0, 1}, {L_B0V, 1, 1}};
-    const int fs[4] = {0, 1, 0, 1}, accs[4] = {0, 0, 1, 1}, inits[3] = {INIT_G0A, INIT_G0B, INIT_KEEP};
-    return ops_std(2, 6, 4, b, fs, accs, inits, -1);
-  }
-  if (stage == S2A || stage == S2B) {  // base_fc.2: 64 -> 32, two k-steps per input tile
-    const int k0 = stage == S2A ? 0 : 2;
-    const Blk b[2] = {{L_B2, k0, 0}, {L_B2, k0 + 1, 0}};
-    const int fs[2] = {0, 1}, accs[2] = {2, 2}, inits[3] = {INIT_KEEP, INIT_KEEP, stage == S2A ? INIT_BIAS : INIT_KEEP};
-    return ops_std(2, 8, 2, b, fs, accs, inits, stage == S2A ? B_B2 : -1);
-  }
-  if (stage == S3 || stage == S5) {  // vis_fc.0 / vis_fc2.0: 32 -> 32, bias and per-sample scale applied afterwards
-    const int L = stage == S3 ? L_V0 : L_W0;
-    const Blk b[2] = {{L, 0, 0}, {L, 1, 0}};
-    const int fs[2] = {0, 1}, accs[2] = {0, 0}, inits[3] = {INIT_ZERO, INIT_KEEP, INIT_KEEP};
-    return ops_std(2, 8, 2, b, fs, accs, inits, -1);
-  }
-  if (stage == S4) {  // vis_fc.2 rows 0..31
-    const Blk b[2] = {{L_V2, 0, 0}, {L_V2, 1, 0}};
-    const int fs[2] = {0, 1}, accs[2] = {1, 1}, inits[3] = {INIT_KEEP, INIT_BIAS, INIT_KEEP};
-    return ops_std(2, 8, 2, b, fs, accs, inits, B_V2);
-  }
-  if (stage == S7) {  // rgb_fc.2: 16 -> 8
-    const Blk b[1] = {{L_R2, 0, 0}};
-    const int fs[1] = {0}, accs[1] = {0}, inits[3] = {INIT_BIAS, INIT_KEEP, INIT_KEEP};
-    return ops_std(1, 4, 1, b, fs, accs, inits, B_R2);
-  }
-  if (stage == S6) {  // rgb_fc.0: [x (fragments 0, 1: complete since S5) | vis2, ray_diff (fragment 2: split now)] -> 16
-    OpList o{};
-    o.nblk = 3;
-    o.bias = B_R0;
-    o.blk[0] = Blk{L_R0, 0, 0}; o.blk[1] = Blk{L_R0, 1, 0}; o.blk[2] = Blk{L_R0, 2, 0};
-    int n = 0;
-    o.op[n++] = op_res(2, 0, 0);
-    const int xs[6] = {2, 1, 0, 1, 0, 0}, ys[6] = {0, 0, 0, 1, 1, 2};
-    for (int k = 0; k < 6; ++k) {
-      Op q = op_prod(0, 0, xs[k], ys[k], 1, k == 0 ? INIT_BIAS : INIT_KEEP);
-      if (k == 2) { q.clvl = 1; q.cs = 2; q.cbeg = 0; q.cend = 2; }
-      o.op[n++] = q;
-    }
-    o.op[n++] = op_res(2, 0, 1);
-    for (int k = 0; k < 6; ++k) {
-      Op q = op_prod(1, 1, xs[k], ys[k], 1, INIT_KEEP);
-      if (k == 2) { q.clvl = 2; q.cs = 2; q.cbeg = 0; q.cend = 2; }
-      o.op[n++] = q;
-    }
-    for (int k = 0; k < 6; ++k) o.op[n++] = op_prod(2, 2, xs[k], ys[k], 1, INIT_KEEP);
-    o.n = n;
-    return o;
-  }
-  return OpList{};
-}
-// chunks of the E-phases (see e_chunk)
-constexpr int n_chunks(int stage) {
-  return stage == S1 ? 7 : stage == S4 ? 18 : stage == S6 ? 19 : stage == S7 ? 8 : stage == S8 ? 3 : stage == S_NONE ? 0 : 16;
-}
-
-struct Stream {  // one source view on its way through pass 2
-  ViewState st;
-  float wv;
-  FragT<3> f[3];
-  f32x16 acc0, acc1, acc2;
-  f32x16 r;  // the tile being split: values, then first, then second residuals
-  float x[16];
-  float vraw, vis, v2, vis2, rr;
-};
-struct TileState {  // per tile, shared by its views
-  f32x16 G0a, G0b;
-  float emin, winv;
-  float Mx, Zs, o_r, o_g, o_b;
-  float b_vis, b_vis2, b_rgb4;
-  int h;
-};
-struct Rows { f32x16 a, b; };
-template <int K> __device__ __forceinline__ f32x16& acc_of(Stream& s) {
-  if constexpr (K == 0) return s.acc0;
-  else if constexpr (K == 1) return s.acc1;
-  else return s.acc2;
-}
-__device__ __forceinline__ uint32_t cvt2(float a, float b) {
-  bf16x2 v;
-  v[0] = (__bf16)a;
-  v[1] = (__bf16)b;
-  return __builtin_bit_cast(uint32_t, v);
-}
-#define SURF_PIN(v) asm volatile("" : "+v"(v))
-// v + (v of the lane 32 away): v_permlane32_swap exchanges the upper half of one copy with the lower half of the other - VALU only.
-// (__shfl_xor(v, 32) is a ds_bpermute: an LDS round trip and an s_waitcnt that one wavefront per SIMD sits out in full)
-__device__ __forceinline__ float add_other_half(float v) {
-  const uint32_t u = __builtin_bit_cast(uint32_t, v);
-  const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  return __builtin_bit_cast(float, (uint32_t)sw[0]) + __builtin_bit_cast(float, (uint32_t)sw[1]);
-}
-
-// ---- MF-phase ----------------------------------------------------------------------------------------------------------
-template <int SM>
-__device__ __forceinline__ void mf_prefetch(const Ctx& c, u32x4 (&A)[4][3], f32x16& bias) {
-  if constexpr (SM != S_NONE) {
-    constexpr OpList OL = ops_of(SM);
-#pragma unroll
-    for (int b = 0; b < OL.nblk; ++b) {
-      const int off = (blk_off(OL.blk[b].L) + OL.blk[b].ks * NT[OL.blk[b].L] + OL.blk[b].t) * BPolBf3::BB;
-#pragma unroll
-      for (int p = 0; p < 3; ++p) A[b][p] = *reinterpret_cast<const u32x4*>(c.lds + off + c.lane16 + p * 1024);
-    }
-    if constexpr (OL.bias >= 0) bias = bias_row<BPolBf3>(c, OL.bias);
-  }
-}
-template <int SM, int J>
-__device__ __forceinline__ void mf_slot(const Ctx& c, Stream& s, const u32x4 (&A)[4][3], const f32x16& bias, const TileState& T) {
-  constexpr Op op = ops_of(SM).op[J];
-  if constexpr (op.kind == 0) {
-    s.r = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, op.idn ? c.I1 : c.I0),
-                                                  __builtin_bit_cast(bf16x8, s.f[op.s].p[op.lvl]), s.r, 0, 0, 0);
-    SURF_PIN(s.r);
-  } else {
-    f32x16& acc = acc_of<op.acc>(s);
-    const bf16x8 wa = __builtin_bit_cast(bf16x8, A[op.blk][op.x]), fb = __builtin_bit_cast(bf16x8, s.f[op.s].p[op.y]);
-    if constexpr (op.init == INIT_KEEP) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, fb, acc, 0, 0, 0);
-    else if constexpr (op.init == INIT_BIAS) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, fb, bias, 0, 0, 0);
-    else if constexpr (op.init == INIT_G0A) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, fb, T.G0a, 0, 0, 0);
-    else if constexpr (op.init == INIT_G0B) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, fb, T.G0b, 0, 0, 0);
-    else {
-      const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, fb, z, 0, 0, 0);
-    }
-    SURF_PIN(acc);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  if constexpr (op.cend > op.cbeg) {
-#pragma unroll
-    for (int q = op.cbeg; q < op.cend; ++q) s.f[op.cs + q / 4].p[op.clvl][q % 4] = cvt2(s.r[2 * q], s.r[2 * q + 1]);
-  }
-}
-
-// ---- E-phase -----------------------------------------------------------------------------------------------------------
-template <int SE>
-__device__ __forceinline__ void e_prefetch(const Ctx& c, Rows& rows) {
-  if constexpr (SE == S4) { rows.a = bias_row<BPolBf3>(c, B_V0); rows.b = dot_row<BPolBf3>(c, D_VIS); }
-  if constexpr (SE == S6) { rows.a = bias_row<BPolBf3>(c, B_W0); rows.b = dot_row<BPolBf3>(c, D_VIS2); }
-  if constexpr (SE == S8) { rows.a = dot_row<BPolBf3>(c, D_RGB4); }
-}
-// value I of the tile being split + (odd I) the first piece of its pair
-template <int I>
-__device__ __forceinline__ void put_val(Stream& s, float v) {
-  s.r[I] = v;
-  if constexpr (I & 1) s.f[I / 8].p[0][(I % 8) / 2] = cvt2(s.r[I - 1], s.r[I]);
-}
-template <int SE, int I>
-__device__ __forceinline__ void e_chunk(Stream& s, const Rows& rows, TileState& T) {
-  if constexpr (SE == S1) {  // the view's local features: 12 values (the last one zero)
-    if constexpr (I == 0) s.wv = (s.st.ex - T.emin) * s.st.mk * T.winv;
-    if constexpr (I < 6) { put_val<2 * I>(s, s.st.floc[2 * I]); put_val<2 * I + 1>(s, s.st.floc[2 * I + 1]); }
-    if constexpr (I == 6) {
-#pragma unroll
-      for (int lvl = 0; lvl < 3; ++lvl) { s.f[1].p[lvl][2] = 0u; s.f[1].p[lvl][3] = 0u; }
-    }
-  } else if constexpr (SE == S2A) {
-    put_val<I>(s, elu_t(s.acc0[I]));
-  } else if constexpr (SE == S2B) {
-    put_val<I>(s, elu_t(s.acc1[I]));
-  } else if constexpr (SE == S3) {
-    s.x[I] = elu_t(s.acc2[I]);
-    put_val<I>(s, s.x[I]);
-  } else if constexpr (SE == S4) {  // vis_fc: t = ELU(wv * (W x) + b); row 32 of vis_fc.2 as a per-lane dot
-    if constexpr (I < 16) {
-      const float t = elu_t(fmaf(s.acc0[I], s.wv, rows.a[I]));
-      s.vraw = I == 0 ? rows.b[I] * t : fmaf(rows.b[I], t, s.vraw);
-      put_val<I>(s, t);
-    }
-    if constexpr (I == 16) s.vraw = add_other_half(s.vraw);
-    if constexpr (I == 17) s.vis = sigm(elu_x(s.vraw + T.b_vis)) * s.st.mk;
-  } else if constexpr (SE == S5) {
-    s.x[I] += elu_t(s.acc1[I]);
-    put_val<I>(s, s.x[I]);
-  } else if constexpr (SE == S6) {  // vis_fc2 on vis * (W x) + b -> vis2; then the three extra inputs of rgb_fc
-    if constexpr (I < 16) {
-      const float e = elu_t(fmaf(s.acc0[I], s.vis, rows.a[I]));
-      s.v2 = I == 0 ? rows.b[I] * e : fmaf(rows.b[I], e, s.v2);
-    }
-    if constexpr (I == 16) s.v2 = add_other_half(s.v2);
-    if constexpr (I == 17) s.vis2 = sigm(s.v2 + T.b_vis2) * s.st.mk;
-    if constexpr (I == 18) {
-      const int h = T.h;
-      s.r[0] = h ? s.st.rd[0] : s.vis2; s.r[1] = h ? s.st.rd[2] : s.st.rd[1]; s.r[2] = h ? 0.f : s.st.rd[3]; s.r[3] = 0.f;
-      s.f[2].p[0][0] = cvt2(s.r[0], s.r[1]);
-      s.f[2].p[0][1] = cvt2(s.r[2], 0.f);
-#pragma unroll
-      for (int lvl = 0; lvl < 3; ++lvl) { s.f[2].p[lvl][2] = 0u; s.f[2].p[lvl][3] = 0u; }
-    }
-  } else if constexpr (SE == S7) {
-    put_val<I>(s, elu_t(s.acc1[I]));
-  } else if constexpr (SE == S8) {  // rgb_fc.4 as a dot, masked online softmax over the views (:104-116)
-    if constexpr (I == 0) {
-      float rr = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) rr = fmaf(rows.a[r], elu_t(s.acc0[r]), rr);
-      s.rr = rr;
-    }
-    if constexpr (I == 1) {
-      s.rr = add_other_half(s.rr);
-      s.rr += T.b_rgb4;
-      if (s.st.mk == 0.f) s.rr = -1e9f;
-    }
-    if constexpr (I == 2) {
-      const float Mn = fmaxf(T.Mx, s.rr);
-      const float scl = expf(T.Mx - Mn);  // exp(-inf) = 0 on the first view
-      const float e = expf(s.rr - Mn);
-      T.Zs = T.Zs * scl + e;
-      T.o_r = T.o_r * scl + e * s.st.rgb[0];
-      T.o_g = T.o_g * scl + e * s.st.rgb[1];
-      T.o_b = T.o_b * scl + e * s.st.rgb[2];
-      T.Mx = Mn;
-    }
-  }
-}
-
-// What a region reads from the LDS image: the A pieces of its MF stage, the accumulator-init row, the bias / dot rows of its
-// E stage.  With one wavefront per SIMD nothing hides an LDS round trip at the head of a region (17 regions a pair of views),
-// so every region issues the reads of the NEXT one before its own first MFMA and the two buffers alternate.
-struct RegionBuf {
-  u32x4 A[4][3];
-  f32x16 bias;
-  Rows rows;
-};
-// one region: the MF-phase of stage SM of stream m with the E-phase of stage SE of stream e dealt out over its MFMA gaps;
-// (SMn, SEn) = the stages of the region after it
-template <int SM, int SE, int SMn, int SEn>
-__device__ __forceinline__ void weave(const Ctx& c0, Stream& m, Stream& e, TileState& T, const RegionBuf&, RegionBuf&) {
-  // (the LDS reads of a region are issued at its head: reading the NEXT region's one region ahead - two alternating buffers,
-  // 192 registers - measured no gain and is what the cross-tile prefetch of pass 1 needs the registers for)
-  const Ctx c = opaque(c0);
-  constexpr int NM = SM == S_NONE ? 0 : ops_of(SM).n;
-  constexpr int NE = n_chunks(SE);
-  RegionBuf cur;
-  mf_prefetch<SM>(c, cur.A, cur.bias);
-  e_prefetch<SE>(c, cur.rows);
-  if constexpr (NM == 0) {
-    static_for_range<0, NE>([&](auto I) { e_chunk<SE, decltype(I)::value>(e, cur.rows, T); });
-  } else {
-    static_for_range<0, NM>([&](auto J) {
-      constexpr int j = decltype(J)::value;
-      mf_slot<SM, j>(c, m, cur.A, cur.bias, T);
-      static_for_range<j * NE / NM, (j + 1) * NE / NM>([&](auto I) { e_chunk<SE, decltype(I)::value>(e, cur.rows, T); });
-      __builtin_amdgcn_sched_barrier(0);
-    });
-  }
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-__global__ __launch_bounds__(WPB2 * 64, 1) void blend_weave_kernel(BlendArgs a) {
-  typedef BPolBf3 P;
-  typedef P::Frag Frag;
-  __shared__ __attribute__((aligned(16))) char lds[lds_bytes<P>() + WPB2 * LDS_VIEWS2 * VIEW_BYTES];
-  static_assert(lds_bytes<P>() + WPB2 * LDS_VIEWS2 * VIEW_BYTES <= 160 * 1024, "LDS");
-  for (int o = threadIdx.x * 16; o < lds_bytes<P>(); o += WPB2 * 64 * 16)
-    *reinterpret_cast<u32x4*>(lds + o) = *reinterpret_cast<const u32x4*>(a.w + o);
-  __syncthreads();
-
-  Ctx c0;
-  const int lane = threadIdx.x & 63;
-  const int j = lane & 31, h = lane >> 5;
-  c0.lds = lds;
-  c0.lane16 = lane * 16;
-  c0.h64 = h * 64;
-  c0.I0 = ident_frag(lane, 0);
-  c0.I1 = ident_frag(lane, 1);
-  const int NS = a.nv - 1;
-  const int64_t wave_id = (int64_t)blockIdx.x * WPB2 + (threadIdx.x >> 6);
-  const int64_t n_waves = (int64_t)gridDim.x * WPB2;
-  const int64_t n_pts = a.n_dev ? (int64_t)*a.n_dev : a.n;
-  const int64_t n_tiles = (n_pts + TILE - 1) / TILE;
-  Stage slot;
-  slot.slot = a.scratch + wave_id * slot_floats(NS);
-  slot.lds_v = lds + lds_bytes<P>() + (threadIdx.x >> 6) * (LDS_VIEWS2 * VIEW_BYTES) + lane * 16;
-  slot.n_lds = LDS_VIEWS2;
-  const float* scal = reinterpret_cast<const float*>(lds + scal_off<P::BB>());
-  const float s_abs = scal[0];
-  TileState T;
-  T.b_vis = scal[1]; T.b_vis2 = scal[2]; T.b_rgb4 = scal[3];
-  T.h = h;
-  const Geo geo = make_geo(a, h);
-  RegViews<0> keep;
-  // The four wavefronts of a workgroup would run in lockstep (same work per tile, no barrier in the loop) and hit pass 1 - whose
-  // gathers are bound by the CU's L1 fill rate, ~4 K clocks a tile - all at once, with nothing to overlap them: start them a
-  // quarter of a tile apart so that one wavefront's fetches run under the other three's MFMAs.
-#ifndef SURF_WEAVE_STAGGER
-#define SURF_WEAVE_STAGGER 2
-#endif
-  for (int k = 0; k < SURF_WEAVE_STAGGER * (int)(threadIdx.x >> 6); ++k) __builtin_amdgcn_s_sleep(100);
-#ifdef SURF_BLEND_TIMING
-  unsigned long long tprev = __builtin_readcyclecounter(), tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long racc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const unsigned long long t_begin = tprev, rt_begin = __builtin_amdgcn_s_memrealtime();
-#endif
-
-  // ---- cross-tile software pipeline (round 4, second version) -----------------------------------------------------------
-  // Pass 1 of tile t + 1 runs UNDER pass 2 of tile t: at the start of the pair iteration over views (v, v + 1) of tile t - right
-  // after their staged state has been read out of slots v, v + 1 - the texel fetches of views (v, v + 1) of tile t + 1 are issued;
-  // at the end of the iteration they are turned into local features and stored into the same two slots.  The gathers' time in
-  // the CU's memory pipeline (~1.75 K clocks per view and tile, scripts/microbench/gather_b128.hip) and their ~3 K clocks of
-  // latency then overlap with the 13 K clocks of the woven regions instead of standing in front of them.
-  struct TileCtx {
-    int64_t i;
-    bool active;
-    float px, py, pz, ax, ay, az;
-    int nvalid;
-    float emin;
-  };
-  auto load_tile = [&](int64_t tile) __attribute__((always_inline)) {
-    TileCtx t;
-    const int64_t slot_i = tile * TILE + j;
-    const int64_t sc = slot_i < n_pts ? slot_i : n_pts - 1;
-    t.i = a.idx ? (int64_t)a.idx[sc] : sc;
-    t.active = (slot_i < n_pts) && (!a.mask || a.mask[t.i] != 0);
-    t.px = a.pts[t.i * 3 + 0]; t.py = a.pts[t.i * 3 + 1]; t.pz = a.pts[t.i * 3 + 2];
-    t.ax = a.cpos[0][0] - t.px; t.ay = a.cpos[0][1] - t.py; t.az = a.cpos[0][2] - t.pz;
-    const float nn = sqrtf(t.ax * t.ax + t.ay * t.ay + t.az * t.az) + 1e-6f;
-    t.ax /= nn; t.ay /= nn; t.az /= nn;
-    t.nvalid = 0;
-    t.emin = INFINITY;
-    return t;
-  };
-  auto finish_view = [&](TileCtx& t, int v, ViewState& st, const Fetch& q) __attribute__((always_inline)) {
-    const Ctx c = opaque(c0);
-    t.nvalid += pass1_finish<P>(c, geo, s_abs, st, q) ? 1 : 0;
-    t.emin = fminf(t.emin, st.ex);
-    slot_store(slot, v, lane, st, keep);
-  };
-  int64_t tile = wave_id;
-  if (tile >= n_tiles) return;
-  TileCtx cur = load_tile(tile);
-  {  // prologue: pass 1 of this wavefront's first tile, on its own
-    ViewState st0, st1;
-    Fetch q0, q1;
-#pragma unroll 1
-    for (int v = 0; v < NS; v += 2) {
-      pass1_issue(a, geo, v + 1, cur.px, cur.py, cur.pz, cur.ax, cur.ay, cur.az, st0, q0);
-      if (v + 1 < NS) pass1_issue(a, geo, v + 2, cur.px, cur.py, cur.pz, cur.ax, cur.ay, cur.az, st1, q1);
-      finish_view(cur, v, st0, q0);
-      if (v + 1 < NS) finish_view(cur, v + 1, st1, q1);
-    }
-  }
-  for (;;) {
-    SURF_BT(0);
-    const int64_t next_tile = tile + n_waves;
-    const bool has_next = next_tile < n_tiles;
-    TileCtx nxt = load_tile(has_next ? next_tile : tile);
-    const int64_t i = cur.i;
-    const bool active = cur.active;
-    const int nvalid = cur.nvalid;
-    const float emin = cur.emin;
-    if (a.n_valid && active && h == 0) a.n_valid[i] = (uint8_t)nvalid;
-    SURF_BT(1);
-
-    // ------------------------------ pooling weights, weighted mean / variance (:76-86) ----------------------
-    float wsum = 0.f;
-    float mv[24];
-#pragma unroll
-    for (int ch = 0; ch < 24; ++ch) mv[ch] = 0.f;
-#pragma unroll 1
-    for (int v = 0; v < NS; ++v) {
-      ViewState st;
-      slot_load(slot, v, lane, st, keep);
-      const float w = (st.ex - emin) * st.mk;
-      wsum += w;
-#pragma unroll
-      for (int ch = 0; ch < 12; ++ch) mv[ch] += st.floc[ch] * w;
-    }
-    const float winv = 1.0f / (wsum + 1e-8f);
-#pragma unroll
-    for (int ch = 0; ch < 12; ++ch) mv[ch] *= winv;
-#pragma unroll 1
-    for (int v = 0; v < NS; ++v) {
-      ViewState st;
-      slot_load(slot, v, lane, st, keep);
-      const float w = (st.ex - emin) * st.mk * winv;
-#pragma unroll
-      for (int ch = 0; ch < 12; ++ch) { const float d = st.floc[ch] - mv[ch]; mv[12 + ch] += w * (d * d); }
-    }
-    SURF_BT(2);
-    {
-      const Ctx c = opaque(c0);
-      T.G0a = bias_row<P>(c, B_B0_T0);
-      T.G0b = bias_row<P>(c, B_B0_T1);
-      Frag fm[3];
-      make_frags<P, 24, 3>(c, mv, fm);
-      mma_layer<P, L_B0S, 0, 3>(c, T.G0a, fm);
-      mma_layer<P, L_B0S, 1, 3>(c, T.G0b, fm);
-    }
-    T.emin = emin; T.winv = winv;
-    T.Mx = -INFINITY; T.Zs = 0.f; T.o_r = 0.f; T.o_g = 0.f; T.o_b = 0.f;
-
-    SURF_BT(3);
-    // ------------------------------ pass 2: two views at a time, woven (:88-116) ----------------------------------------
-    int v = 0;
-    RegionBuf R0, R1;
-    Stream SA, SB;  // (declared per tile: nothing of them is live through pass 1)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { SA.r[r] = 0.f; SB.r[r] = 0.f; }  // rows of the split tile beyond a stage's values are carried, never read
-#pragma unroll 1
-    for (; v + 1 < NS; v += 2) {
-      slot_load(slot, v, lane, SA.st, keep);
-      slot_load(slot, v + 1, lane, SB.st, keep);
-      ViewState nst0, nst1;                    // views (v, v + 1) of the NEXT tile: fetched now, finished after the regions
-      Fetch nq0, nq1;
-      if (has_next) {
-        pass1_issue(a, geo, v + 1, nxt.px, nxt.py, nxt.pz, nxt.ax, nxt.ay, nxt.az, nst0, nq0);
-        pass1_issue(a, geo, v + 2, nxt.px, nxt.py, nxt.pz, nxt.ax, nxt.ay, nxt.az, nst1, nq1);
-      }
-      SURF_RT(18);
-      weave<S_NONE, S1, S1, S1>(c0, SB, SA, T, R0, R1);
-      SURF_RT(0);
-      weave<S1, S1, S1, S2A>(c0, SA, SB, T, R1, R0);
-      SURF_RT(1);
-      weave<S1, S2A, S2A, S2A>(c0, SB, SA, T, R0, R1);
-      SURF_RT(2);
-      weave<S2A, S2A, S2A, S2B>(c0, SA, SB, T, R1, R0);
-      SURF_RT(3);
-      weave<S2A, S2B, S2B, S2B>(c0, SB, SA, T, R0, R1);
-      SURF_RT(4);
-      weave<S2B, S2B, S2B, S3>(c0, SA, SB, T, R1, R0);
-      SURF_RT(5);
-      weave<S2B, S3, S3, S3>(c0, SB, SA, T, R0, R1);
-      SURF_RT(6);
-      weave<S3, S3, S3, S4>(c0, SA, SB, T, R1, R0);
-      SURF_RT(7);
-      weave<S3, S4, S4, S4>(c0, SB, SA, T, R0, R1);
-      SURF_RT(8);
-      weave<S4, S4, S4, S5>(c0, SA, SB, T, R1, R0);
-      SURF_RT(9);
-      weave<S4, S5, S5, S5>(c0, SB, SA, T, R0, R1);
-      SURF_RT(10);
-      weave<S5, S5, S5, S6>(c0, SA, SB, T, R1, R0);
-      SURF_RT(11);
-      weave<S5, S6, S6, S6>(c0, SB, SA, T, R0, R1);
-      SURF_RT(12);
-      weave<S6, S6, S6, S7>(c0, SA, SB, T, R1, R0);
-      SURF_RT(13);
-      weave<S6, S7, S7, S7>(c0, SB, SA, T, R0, R1);
-      SURF_RT(14);
-      weave<S7, S7, S7, S8>(c0, SA, SB, T, R1, R0);
-      SURF_RT(15);
-      weave<S7, S8, S_NONE, S8>(c0, SB, SA, T, R0, R1);
-      SURF_RT(16);
-      weave<S_NONE, S8, S_NONE, S_NONE>(c0, SA, SB, T, R1, R0);
-      SURF_RT(17);
-      if (has_next) {
-        finish_view(nxt, v, nst0, nq0);
-        finish_view(nxt, v + 1, nst1, nq1);
-      }
-      SURF_RT(19);
-      SURF_BT(4);
-    }
-    if (v < NS) {  // an odd view left: its chain alone (nothing to weave it with)
-      slot_load(slot, v, lane, SA.st, keep);
-      ViewState nst0;
-      Fetch nq0;
-      if (has_next) pass1_issue(a, geo, v + 1, nxt.px, nxt.py, nxt.pz, nxt.ax, nxt.ay, nxt.az, nst0, nq0);
-      weave<S_NONE, S1, S1, S_NONE>(c0, SB, SA, T, R0, R1);
-      weave<S1, S_NONE, S_NONE, S2A>(c0, SA, SB, T, R1, R0);
-      weave<S_NONE, S2A, S2A, S_NONE>(c0, SB, SA, T, R0, R1);
-      weave<S2A, S_NONE, S_NONE, S2B>(c0, SA, SB, T, R1, R0);
-      weave<S_NONE, S2B, S2B, S_NONE>(c0, SB, SA, T, R0, R1);
-      weave<S2B, S_NONE, S_NONE, S3>(c0, SA, SB, T, R1, R0);
-      weave<S_NONE, S3, S3, S_NONE>(c0, SB, SA, T, R0, R1);
-      weave<S3, S_NONE, S_NONE, S4>(c0, SA, SB, T, R1, R0);
-      weave<S_NONE, S4, S4, S_NONE>(c0, SB, SA, T, R0, R1);
-      weave<S4, S_NONE, S_NONE, S5>(c0, SA, SB, T, R1, R0);
-      weave<S_NONE, S5, S5, S_NONE>(c0, SB, SA, T, R0, R1);
-      weave<S5, S_NONE, S_NONE, S6>(c0, SA, SB, T, R1, R0);
-      weave<S_NONE, S6, S6, S_NONE>(c0, SB, SA, T, R0, R1);
-      weave<S6, S_NONE, S_NONE, S7>(c0, SA, SB, T, R1, R0);
-      weave<S_NONE, S7, S7, S_NONE>(c0, SB, SA, T, R0, R1);
-      weave<S7, S_NONE, S_NONE, S8>(c0, SA, SB, T, R1, R0);
-      weave<S_NONE, S8, S_NONE, S_NONE>(c0, SB, SA, T, R0, R1);
-      if (has_next) finish_view(nxt, v, nst0, nq0);
-      SURF_BT(5);
-    }
-    if (active && h == 0) {
-      a.color[i * 3 + 0] = T.o_r / T.Zs;
-      a.color[i * 3 + 1] = T.o_g / T.Zs;
-      a.color[i * 3 + 2] = T.o_b / T.Zs;
-    }
-    if (!has_next) break;
-    cur = nxt;
-    tile = next_tile;
-  }
-#ifdef SURF_BLEND_TIMING
-  if (threadIdx.x == 0) {
-    for (int k = 0; k < 20; ++k) { atomicAdd(&g_bregion[k], racc[k]); tacc[4] += racc[k]; }
-    for (int k = 0; k < 8; ++k) atomicAdd(&g_bphase[k], tacc[k]);
-  }
-  if (threadIdx.x == 0 && blockIdx.x < 256) {
-    g_bwg[blockIdx.x][0] = rt_begin;
-    g_bwg[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
-  }
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    g_bphase[8] = __builtin_readcyclecounter() - t_begin;
-    g_bphase[9] = __builtin_amdgcn_s_memrealtime() - rt_begin;
-  }
-#endif
-}
-
-int grid_blocks_weave(int64_t n) {
-  const int64_t tiles = (n + TILE - 1) / TILE;
-  const int64_t blocks = (tiles + WPB2 - 1) / WPB2;
-  return (int)(blocks < 256 ? blocks : 256);
-}
-#endif  // SURF_BLEND_WEAVE_TU
-
 int grid_blocks(int64_t n) {
   const int64_t tiles = (n + TILE - 1) / TILE;
   const int64_t blocks = (tiles + WPB - 1) / WPB;
@@ -1677,40 +1067,6 @@ int pack_weights(const float* raw, unsigned char* out) {
   return 0;
 }
 
-#ifdef SURF_BLEND_WEAVE_TU
-}  // namespace
-// the woven bf16x3 kernel's launch, called from blend_split.hip's translation unit (BlendArgs has the same layout in both)
-#ifdef SURF_BLEND_TIMING
-extern "C" int surf_debug_weave_wg(unsigned long long* out) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwg), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : 100;
-}
-extern "C" int surf_debug_weave_regions(unsigned long long* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bregion), sizeof(unsigned long long) * 20) != hipSuccess) return 100;
-  if (reset) {
-    unsigned long long z[20] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bregion), z, sizeof(z)) != hipSuccess) return 100;
-  }
-  return 0;
-}
-extern "C" int surf_debug_weave_phases(unsigned long long* out, int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bphase), sizeof(unsigned long long) * 10) != hipSuccess) return 100;
-  if (reset) {
-    unsigned long long z[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bphase), z, sizeof(z)) != hipSuccess) return 100;
-  }
-  return 0;
-}
-#endif
-int surf_blend_weave_launch(const void* args, void* stream) {
-  const BlendArgs& a = *reinterpret_cast<const BlendArgs*>(args);
-  dim3 grid(grid_blocks_weave(a.n)), block(WPB2 * 64);
-  hipLaunchKernelGGL(blend_weave_kernel, grid, block, 0, (hipStream_t)stream, a);
-  return surf_check_launch();
-}
-#else
-}  // namespace
-int surf_blend_weave_launch(const void* args, void* stream);  // blend_weave.hip
-namespace {
 template <class P>
 int launch(const BlendArgs& a, hipStream_t st) {
   dim3 grid(grid_blocks(a.n)), block(WPB * 64);
@@ -1780,9 +1136,6 @@ static int blend_split_impl(const float* pts, const uint8_t* mask, const int32_t
       for (int cc = 0; cc < 4; ++cc) a.w2c[v][r * 4 + cc] = h_w2c[s * 16 + r * 4 + cc];
     for (int r = 0; r < 3; ++r) a.cpos[v][r] = h_c2w[s * 16 + r * 4 + 3];
   }
-#if SURF_BLEND_WEAVE
-  if (precision == BPolBf3::ID) return surf_blend_weave_launch(&a, stream);
-#endif
   if (precision == BPolBf3::ID) return launch<BPolBf3>(a, (hipStream_t)stream);
   if (precision == BPolH2::ID) return launch<BPolH2>(a, (hipStream_t)stream);
   return launch<BPolF32>(a, (hipStream_t)stream);
@@ -1806,4 +1159,3 @@ extern "C" int surf_blend_split_dn(const float* pts, const int32_t* idx, int64_t
   return blend_split_impl(pts, nullptr, idx, n_capacity, d_n, h_feats, h_hw, n_level, imgs, nv, h_intrs, h_w2c, h_c2w, blend_w,
                           precision, color, n_valid, scratch, stream);
 }
-#endif  // SURF_BLEND_WEAVE_TU

@@ -20,17 +20,12 @@ for s in "${SRCS[@]}"; do
   stale=0
   for hdr in "${HERE}"/*.h "${HERE}/../../include/surf_hip.h"; do [[ "$hdr" -nt "$o" ]] && stale=1; done
   [[ "$(basename "$s")" == sdf_mlp_split_f16.hip && "${HERE}/sdf_mlp_split.hip" -nt "$o" ]] && stale=1
-  [[ "$(basename "$s")" == blend_weave.hip && "${HERE}/blend_split.hip" -nt "$o" ]] && stale=1
   if [[ ! -f "$o" || "$s" -nt "$o" || $stale == 1 ]]; then
     per_file=()
     # blend_split.hip is VALU-issue bound with two wavefronts per SIMD: without packed fp32 VALU instructions (v_pk_add / mul /
     # fma_f32 cost more than two plain ones beside MFMAs, MI355X_MICROARCH.md) it runs 3.6 % faster (41.2 -> 39.7 ms, same box);
     # the SDF kernel measured +0.8 % slower without them and keeps them.
     case "$(basename "$s")" in blend_split.hip) per_file=(-Xclang -target-feature -Xclang -packed-fp32-ops);; esac
-    # blend_weave.hip (= blend_split.hip's woven bf16x3 kernel as its own translation unit) deals the VALU work of one source
-    # view out between the MFMAs of another by hand, one scheduling barrier per gap: source-order instruction selection, as for
-    # the split SDF kernels below.
-    case "$(basename "$s")" in blend_weave.hip) per_file=(-Xclang -target-feature -Xclang -packed-fp32-ops -mllvm -pre-RA-sched=source);; esac
     # sdf_mlp_split.hip places its conversion arithmetic between the MFMAs by hand (one scheduling barrier per MFMA gap): the
     # instruction selector has to emit the statements in source order for the barriers to find them in their gaps.
     # No SLP vectoriser there either: it would pack that arithmetic into v_pk_*_f32, which beside an MFMA cost ~15 cycles more
