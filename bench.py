@@ -372,6 +372,11 @@ def train_kernel_rooflines(per_kernel):
             ci, co = (int(v) for v in name[name.index("<") + 1:-1].split(","))
             pairs, sites = sum(r[1]["pairs"] for r in rows), sum(r[1]["sites"] for r in rows)
             b = pairs * 4.0 * ci + sites * (108.0 + 4.0 * co)
+            if sites > 0 and not pairs > 0:       # pair counting was off (--warmup 0): no algorithmic byte count, no fraction
+                e.update(bound="hbm", achieved=None, pairs_per_step=None, sites_per_step=sites,
+                         note="pairs not counted (needs >= 1 warm-up step): achieved GB/s not reported")
+                out.append(e)
+                continue
             e.update(bound="hbm", achieved=b / (ms * 1e-3) / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", pairs_per_step=pairs,
                      sites_per_step=sites, algorithmic_bytes_per_step=b)
         else:
@@ -387,7 +392,7 @@ def train_kernel_rooflines(per_kernel):
             elif name == "blend_bwd":
                 f = 2 * 2 * 20e3
                 e.update(bound="valu", achieved=units * f / (ms * 1e-3) / 1e12, peak=VALU_FP32_PEAK, unit="TFLOP/s", flop_per_unit=f)
-        if "achieved" in e:
+        if e.get("achieved") is not None:
             e["frac"] = e["achieved"] / e["peak"]
         out.append(e)
     return out
@@ -454,11 +459,11 @@ def run_rank_train(args):
         return loss
 
     if not dry:
-        ops.count_pairs = True              # (site, offset) pair counts of the sparse-conv backward: warm-up only, cached
+        ops.set_count_pairs(True)           # (site, offset) pair counts of the sparse-conv backward: warm-up only, cached
     for _ in range(args.warmup):
         loss = step()
     if not dry:
-        ops.count_pairs = False
+        ops.set_count_pairs(False)
     sync()
     D.barrier()
     sync()

@@ -65,7 +65,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int NP>
 struct FragT { u32x4 p[NP]; };  // B operand of one 16-wide k-step: NP pieces x 8 x 16 bit
 
-// Matrix-pipe residuals of the exact bf16 split (round 4; see split_tile_mres below): 1 = on (default), 0 = the VALU form
+// Matrix-pipe residuals of the exact bf16 split (round 4; see split_tile_mres below): 1 = on (default), 0 = the VALU form.
+// Precondition of the matrix-pipe form: FINITE activations.  The residual multiplies a sample's whole B column by the identity
+// operand, so one inf / NaN activation turns all 32 rows of that sample's column into NaN (the VALU form confines it to the
+// one value).  Finite inputs and weights give finite activations (ELU / sigmoid / softmax layers); nothing upstream of this
+// kernel produces a non-finite feature.
 #ifndef SURF_BLEND_MRES
 #define SURF_BLEND_MRES 1
 #endif
@@ -1127,6 +1131,9 @@ static int blend_split_impl(const float* pts, const uint8_t* mask, const int32_t
     a.feats[l] = h_feats[l];
     a.hw[2 * l] = h_hw[2 * l];
     a.hw[2 * l + 1] = h_hw[2 * l + 1];
+    // pass 1 normalises texel coordinates by the reciprocal of (W - 1) / 2 (div_const): a one-texel-wide or -high pyramid
+    // level makes that infinite and the taps NaN (IEEE division gave inf and a zero weight instead).  No shipped conf has one.
+    if (h_hw[2 * l] < 2 || h_hw[2 * l + 1] < 2) return SURF_E_LIMIT;
   }
   for (int v = 0; v < SURF_MAX_VIEWS; ++v) {
     const int s = v < nv ? v : 0;

@@ -181,6 +181,7 @@ class ImplicitSurface(nn.Module):
         self.sample_ranges = [float(r) for r in confs.get_list("render.sample_ranges")]
         self.n_depth = confs.get_int("render.n_depth")
         self.perturb = confs.get_float("render.perturb")
+        self.val_chunk = confs.get_int("render.val_chunk", 1 << 19)     # rays per launch of validate (ours; see val_chunk_rays)
         self.sdf_network = SDFNetworkSparse(**dict(confs["sdf_network"]))
         self.color_network = BlendingNetwork(**dict(confs["color_network"]))
         self.deviation_network = SingleVarianceNetwork(**dict(confs["variance_network"]))
@@ -480,10 +481,14 @@ class ImplicitSurface(nn.Module):
         return vertices, triangles
 
     def validate(self, rays_o, rays_d, near, far, scene, bound_min, bound_max, hw, cos_anneal_ratio=1.0, step=None,
-                 extract_geometry=True, mesh_resolution=512, threshold=0.0, chunk=1 << 19):
+                 extract_geometry=True, mesh_resolution=512, threshold=0.0, chunk=None):
         """implicit_surface.py:359-402.  The reference's 256-ray chunks exist to bound autograd memory; here rays are
-        independent, so `chunk` is only a scratch-size knob (default 2^19 rays: a 576 x 800 image in one launch of every kernel -
-        eight 65,536-ray chunks cost 6 ms more per image in launch tails and small launches; ~60 B of scratch per sample).  With render.perturb > 0 the jitters are drawn in the
+        independent, so `chunk` is only a scratch-size knob: default `render.val_chunk` (conf key of ours, 2^19 rays: a 576 x 800
+        image in one launch of every kernel - eight 65,536-ray chunks cost 6 ms more per image in launch tails and small
+        launches), capped so that a chunk's per-sample buffers (~128 B per sample: points, masks, SDF + gradient, colours, the
+        gradient kernel's scratch) take at most half of the device memory that is free right now - ranks that share a device
+        (`--one-gpu`, scene-parallel runs on fewer GPUs than ranks) then shrink their chunks instead of running out of memory.
+        With render.perturb > 0 the jitters are drawn in the
         reference's order (per 256-ray block, stages inner: draw_jitter), so a seeded run reproduces the reference's
         sample positions whatever `chunk` is."""
         outputs = {}
@@ -493,6 +498,7 @@ class ImplicitSurface(nn.Module):
         height, width = int(hw[0]), int(hw[1])
         cols, nrms, sdeps, rdeps = [], [], [], []
         jitter = self.draw_jitter(rays_o.shape[0], ref_chunk=256) if self.perturb > 0 else None
+        chunk = self.val_chunk_rays(rays_o.device) if chunk is None else int(chunk)
         for s in range(0, rays_o.shape[0], chunk):
             o = self.render_scene(rays_o[s:s + chunk], rays_d[s:s + chunk], near[s:s + chunk], far[s:s + chunk], scene,
                                   cos_anneal_ratio, per_sample=False, jitter=None if jitter is None else jitter[s:s + chunk])
@@ -510,6 +516,16 @@ class ImplicitSurface(nn.Module):
         outputs["sdf_depth"] = torch.cat(sdeps).cpu().numpy().reshape([height, width])
         outputs["render_depth"] = torch.cat(rdeps).cpu().numpy().reshape([height, width])
         return outputs
+
+    def val_chunk_rays(self, device):
+        """Rays per launch of `validate`: render.val_chunk (default 2^19), at most what half of the free device memory holds."""
+        chunk = self.val_chunk
+        if torch.device(device).type == "cuda":
+            free, _ = torch.cuda.mem_get_info(device)
+            per_ray = 128 * sum(self.n_samples) + 256
+            fit = (free // 2) // per_ray
+            chunk = int(max(256, min(chunk, (fit // 256) * 256)))
+        return chunk
 
     def pseudo_sdf(self, pseudo_pts, scene):
         """implicit_surface.py:425-434: the SDF at the dataset's pseudo surface points (zero where no level is occupied), the

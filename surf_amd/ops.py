@@ -1110,13 +1110,16 @@ def table_from_coords(coords, D):
 
 # SURF_DOWN_DILATE / SURF_DOWN_FLOOR; "pad0" is the dilate kernel on coordinates stored + 1 with a fixed site range (below)
 DOWN_RULES = {"dilate": 0, "floor": 1, "pad0": 0}
+# The rule a conf without `reg_network.down_rule` gets (round 5): the reference pins torchsparse 2.1.0 (requirements.txt:205) and
+# passes no padding (reg_network.py:9-13); that version's strided map is the spconv-style one = "pad0".
+DEFAULT_DOWN_RULE = "pad0"
 _pad0_ranges = {}
 
 
-def down_sites(coords, D, rule="dilate", q_max=None):
+def down_sites(coords, D, rule=DEFAULT_DOWN_RULE, q_max=None):
     """Output sites of a k3/s2 sparse conv on the (D//2+1)^3 lattice: (coords2 (M,3) int32, table2, D2).
-    rule: "dilate" (torchsparse-2.1 spdownsample, default) or "floor" (unique(floor(c/2))): SURVEY App. C.
-    "pad0": the spconv-style map with no padding (window 2q + {0,1,2}^3).  With every level's coordinates
+    rule: "dilate" (torchsparse's spdownsample for kernel != stride) or "floor" (unique(floor(c/2))): SURVEY App. C.
+    "pad0" (the default): the spconv-style map with no padding (window 2q + {0,1,2}^3).  With every level's coordinates
     STORED + 1 (SparseCostRegNet.forward) that window is the centred one of the stored coordinates - 2 (q + 1) + {-1,0,1} =
     (2q + {0,1,2}) + 1 - so the same kernels serve; what differs is which even sites are outputs: all stored q in
     [1, q_max] with an input in the window (q_max = the true output lattice size (D_true - 3) // 2 + 1), instead of the even
@@ -1187,22 +1190,40 @@ def spconv(x, in_table, out_coords, mode, weight, bn_scale=None, bn_shift=None, 
     return out
 
 
-count_pairs = False     # bench.py: count the (site, offset) pairs of every sparse-conv backward during its warm-up steps
+count_pairs = False     # bench.py (set_count_pairs): count the (site, offset) pairs of every sparse-conv backward during its warm-up steps
 _pair_counts = {}
 
 
-def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight, dy):
-    """Backward of y = spconv(x, in_table, out_coords, mode, weight) (no BN / ReLU / skip).  Returns (dx (n_in, Cin),
-    dW (27, Cin, Cout)).  dx is a sparse convolution of dy over the OUTPUT lattice (`out_table` indexes out_coords):
-    submanifold with mirrored offsets, down <-> up, kernel slices transposed."""
-    _chk(dy, torch.float32, "dy")
-    cin, cout = int(weight.shape[1]), int(weight.shape[2])
-    wt = weight.transpose(1, 2).contiguous()                        # (27, Cout, Cin)
+def set_count_pairs(on):
+    """Switch the pair counting of spconv_backward on / off.  The counts are cached per (mode, lattice, rows in, rows out) for
+    ONE scene: switching it on forgets what an earlier scene left (two scenes whose sizes coincide must not share a count)."""
+    global count_pairs
+    if on:
+        _pair_counts.clear()
+    count_pairs = bool(on)
+
+
+def dgrad_weights(weight, mode, use_mfma=True):
+    """Kernel of the input-gradient convolution of a sparse convolution with `weight` (27, Cin, Cout): slices transposed
+    (27, Cout, Cin), offsets mirrored for the submanifold mode; + its split-bf16 operand image for surf_spconv_mfma (None when
+    use_mfma is off or a channel count is below 16)."""
+    wt = weight.transpose(1, 2).contiguous()
     if mode == SUBM:
         wt = wt.flip(0).contiguous()
-    # the wide layers' input gradient runs on the matrix cores like their forward (surf_spconv_mfma: both channel counts >= 16;
-    # spconv_pack_weights returns None otherwise): the per-voxel kernel sat at 0.02-0.18 of HBM there (round 3)
-    wt_packed = spconv_pack_weights(wt)
+    return wt, (spconv_pack_weights(wt) if use_mfma else None)
+
+
+def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight, dy, use_mfma=True, dgrad=None):
+    """Backward of y = spconv(x, in_table, out_coords, mode, weight) (no BN / ReLU / skip).  Returns (dx (n_in, Cin),
+    dW (27, Cin, Cout)).  dx is a sparse convolution of dy over the OUTPUT lattice (`out_table` indexes out_coords):
+    submanifold with mirrored offsets, down <-> up, kernel slices transposed.
+    use_mfma: the wide layers' input gradient on the matrix cores like their forward (surf_spconv_mfma, bf16x3: both channel
+    counts >= 16; the per-voxel kernel sat at 0.02-0.18 of HBM there, round 3); False: every layer on the fp32 per-voxel kernel
+    (SparseCostRegNet.use_mfma).  dgrad: a cached dgrad_weights(weight, mode, use_mfma) (SparseCostRegNet keeps one per block
+    and parameter version)."""
+    _chk(dy, torch.float32, "dy")
+    cin, cout = int(weight.shape[1]), int(weight.shape[2])
+    wt, wt_packed = dgrad if dgrad is not None else dgrad_weights(weight, mode, use_mfma)
     pairs = 0
     key = (int(mode), int(in_table.shape[0]), int(x.shape[0]), int(out_coords.shape[0]))
     if count_pairs and key not in _pair_counts and out_coords.shape[0] > 0 and x.shape[0] > 0:

@@ -58,9 +58,18 @@ class _Block(nn.Module):
             self._bn_dirty = False
         return self._wprep[1], self._bprep[1], self._bprep[2], self._wprep[2]
 
+    def prepared_dgrad(self, mode, use_mfma=True):
+        """ops.dgrad_weights of this block's kernel (transposed / mirrored slices + their split-bf16 image), cached per
+        parameter version: one re-layout per optimiser step instead of one per backward call."""
+        conv = self.net[0]
+        key = (conv.kernel._version, conv.kernel.data_ptr(), int(mode), bool(use_mfma))
+        if getattr(self, "_tprep", None) is None or self._tprep[0] != key:
+            self._tprep = (key, ops.dgrad_weights(conv.kernel.detach().float().contiguous(), mode, use_mfma))
+        return self._tprep[1]
+
 
 class SparseCostRegNet(nn.Module):
-    def __init__(self, d_in, d_out=8, d_base=8, down_rule="dilate"):
+    def __init__(self, d_in, d_out=8, d_base=8, down_rule=ops.DEFAULT_DOWN_RULE):
         super().__init__()
         if down_rule not in ops.DOWN_RULES:
             raise ValueError(f"reg_network.down_rule must be one of {sorted(ops.DOWN_RULES)}, got {down_rule!r}")
@@ -104,11 +113,11 @@ class SparseCostRegNet(nn.Module):
             # uncentred stride-2 window 2q + {0,1,2}^3 (ops.down_sites): every level's coordinates are stored + 1, which turns
             # it into the centred window the kernels walk; the true lattices shrink as (D - 3) // 2 + 1
             coords = (coords + 1).contiguous()
-            q1 = (D - 3) // 2 + 1
-            q2 = (q1 - 3) // 2 + 1
-            q3 = (q2 - 3) // 2 + 1
-            if min(q1, q2, q3) < 1:
-                raise ValueError(f"reg_network.down_rule = pad0 needs a lattice of at least 15^3 sites, got {D}^3")
+            # (lattices below 15^3 run out of sites before the third level: those levels are EMPTY, as in the oracle's
+            # down_coords - nothing flows through their blocks, the transposed convolutions above them add zeros)
+            q1 = max((D - 3) // 2 + 1, 0)
+            q2 = max((q1 - 3) // 2 + 1, 0)
+            q3 = max((q2 - 3) // 2 + 1, 0)
             D, table = D + 1, None
         t0 = table if table is not None else ops.table_from_coords(coords, D)
         s0 = (t0, coords)
@@ -171,7 +180,8 @@ class SparseCostRegNet(nn.Module):
             acc(bn.weight, dgamma)
             acc(bn.bias, dbeta)
             dx, dW = ops.spconv_backward(e["x"], e["in_site"][0], e["in_site"][1], e["out_site"][0], e["out_site"][1], e["mode"],
-                                         e["w"], draw)
+                                         e["w"], draw, use_mfma=self.use_mfma,
+                                         dgrad=e["blk"].prepared_dgrad(e["mode"], self.use_mfma))
             acc(e["blk"].net[0].kernel, dW)
             add(e["x"], dx)
         return grads.pop(id(feats))
@@ -183,7 +193,7 @@ class SparseCostRegNetList(nn.Module):
         d_in, d_out, d_base = confs.get_list("d_in"), confs.get_list("d_out"), confs.get_list("d_base")
         self.num_stages = len(d_in)
         # optional key (ours): which stride-2 output-site rule of torchsparse the checkpoint was trained with
-        rule = confs.get_string("down_rule", "dilate")
+        rule = confs.get_string("down_rule", ops.DEFAULT_DOWN_RULE)
         self.nets = nn.ModuleList([SparseCostRegNet(d_in[i], d_out[i], d_base[i], rule) for i in range(self.num_stages)])
 
     def forward(self, feats, coords, D, stage_idx, table=None, tape=None):

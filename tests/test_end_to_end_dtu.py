@@ -132,12 +132,12 @@ def test_dtu_files_to_chamfer(tmp_path):
     rec = dtu_chamfer.run(dtu_chamfer.parse_args([
         "--conf", str(conf_path), "--eval_dir", str(ev), "--scan", "24", "--ref_view", "1", "--out_dir", str(tmp_path / "exp2"),
         "--mesh_resolution", "128", "--downsample_density", str(density), "--logit_override", "sphere", "--reference_chamfer", str(overall)]))
-    assert rec["scan"] == 24 and rec["down_rule"] == "dilate" and rec["views"] == 3 and rec["triangles"] == len(t)
+    assert rec["scan"] == 24 and rec["down_rule"] == "pad0" and rec["views"] == 3 and rec["triangles"] == len(t)
     # same seeded weights, same files, same evaluator seed: the command reproduces the chain above
     assert abs(rec["chamfer"] - overall) < 1e-6 and abs(rec["delta"]) < 1e-6, (rec["chamfer"], overall)
     assert os.path.exists(rec["mesh"]) and json.load(open(tmp_path / "exp2" / "chamfer_scan24.json"))["chamfer"] == rec["chamfer"]
     # ... and with another stride-2 site rule it is a different network (row a5: three candidates behind one switch)
     rec0 = dtu_chamfer.run(dtu_chamfer.parse_args([
         "--conf", str(conf_path), "--eval_dir", str(ev), "--scan", "24", "--ref_view", "1", "--out_dir", str(tmp_path / "exp3"),
-        "--mesh_resolution", "64", "--downsample_density", str(density), "--logit_override", "sphere", "--down_rule", "pad0"]))
-    assert rec0["down_rule"] == "pad0" and np.isfinite(rec0["chamfer"])
+        "--mesh_resolution", "64", "--downsample_density", str(density), "--logit_override", "sphere", "--down_rule", "dilate"]))
+    assert rec0["down_rule"] == "dilate" and np.isfinite(rec0["chamfer"])

@@ -1487,7 +1487,7 @@ def test_spconv_backward_matches_autograd(cin, cout):
     D = 14
     occ = torch.rand(D, D, D, generator=g) < 0.3
     coords = occ.nonzero().to(torch.int32).contiguous()
-    cd_ref, D2 = O.down_coords(coords.long(), D)
+    cd_ref, D2 = O.down_coords(coords.long(), D, "dilate")   # (centred window on the raw coordinates: the kernels' own form)
     cd = cd_ref.to(torch.int32).contiguous()
     tf, tc = ops.table_from_coords(coords.to(d), D), ops.table_from_coords(cd.to(d), D2)
     w = (torch.randn(27, cin, cout, generator=g) / (27 * cin) ** 0.5)
@@ -1500,10 +1500,10 @@ def test_spconv_backward_matches_autograd(cin, cout):
             y = O.spconv_subm(xr, coords.long(), D, wr)
             args = (tf, coords.to(d), tf, coords.to(d))
         elif mode == ops.DOWN:
-            y = O.spconv_down(xr, coords.long(), D, wr)[0]
+            y = O.spconv_down(xr, coords.long(), D, wr, "dilate")[0]
             args = (tf, coords.to(d), tc, cd.to(d))
         else:
-            y = O.spconv_up(xr, cd.long(), coords.long(), D, wr)
+            y = O.spconv_up(xr, cd.long(), coords.long(), D, wr, "dilate")
             args = (tc, cd.to(d), tf, coords.to(d))
         (y * dy).sum().backward()
         dx, dW = ops.spconv_backward(x.to(d), args[0], args[1], args[2], args[3], mode, w.to(d), dy.to(d))

@@ -32,15 +32,15 @@ def test_down_equals_strided_dense_conv_and_up_is_its_adjoint():
     coords = O.init_coords(D).long()
     feat = torch.randn(D ** 3, cin, generator=g)
     kernel = torch.randn(27, cin, cout, generator=g) * 0.1
-    out, oc, D2 = O.spconv_down(feat, coords, D, kernel)
-    # output sites are the even positions inside the bounding box: 0,2,4,6 per axis
+    out, oc, D2 = O.spconv_down(feat, coords, D, kernel, "dilate")
+    # (rule 'dilate') output sites are the even positions inside the bounding box: 0,2,4,6 per axis
     assert D2 == D // 2 + 1 and oc.shape[0] == 4 ** 3
     dense = feat.view(D, D, D, cin).permute(3, 0, 1, 2)[None]
     ref = F.conv3d(dense, _dense_weight(kernel), padding=1, stride=2)[0]        # (cout,4,4,4), centred on even sites
     assert torch.allclose(out, ref[:, oc[:, 0], oc[:, 1], oc[:, 2]].t(), atol=1e-5)
     # <down(x), y> == <x, up(y)> with the transposed kernel
     y = torch.randn(oc.shape[0], cout, generator=g)
-    up = O.spconv_up(y, oc, coords, D, kernel.transpose(1, 2).contiguous())
+    up = O.spconv_up(y, oc, coords, D, kernel.transpose(1, 2).contiguous(), "dilate")
     assert torch.allclose((out * y).sum(), (feat * up).sum(), rtol=1e-4)
 
 
