@@ -1603,3 +1603,29 @@ def test_inference_render_keeps_the_active_count_on_the_device(scene, weights, g
     assert torch.equal(col_a, col_b) and torch.equal(nv_a, nv_b)
     for k in ("color_fine", "render_depth", "sdf_depth"):
         assert torch.equal(out0[k], out1[k]), k
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 64), (64, 64), (64, 32), (16, 16)])
+def test_spconv_dgrad_mfma_matches_per_voxel_kernel(cin, cout):
+    """the wide layers' input gradient on the matrix cores (surf_spconv_mfma, bf16x3 = fp32-equivalent operands)
+    against the fp32 per-voxel kernel (SparseCostRegNet.use_mfma = False reaches it through spconv_backward's `use_mfma`),
+    ELEMENT by element, for the three modes - not only through the adjoint identity."""
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(7 * cin + cout)
+    D = 20
+    occ = torch.rand(D, D, D, generator=g) < 0.25
+    coords = occ.nonzero().to(torch.int32).contiguous()
+    cd, tc, D2 = ops.down_sites(coords.to(d), D, "dilate")
+    tf = ops.table_from_coords(coords.to(d), D)
+    w = (torch.randn(27, cin, cout, generator=g) / (27 * cin) ** 0.5).to(d)
+    for mode, n_in, n_out, args in ((ops.SUBM, coords.shape[0], coords.shape[0], (tf, coords.to(d), tf, coords.to(d))),
+                                    (ops.DOWN, coords.shape[0], cd.shape[0], (tf, coords.to(d), tc, cd)),
+                                    (ops.UP, cd.shape[0], coords.shape[0], (tc, cd, tf, coords.to(d)))):
+        x = torch.randn(n_in, cin, generator=g).to(d)
+        dy = torch.randn(n_out, cout, generator=g).to(d)
+        dx_m, dW_m = ops.spconv_backward(x, *args, mode, w, dy, use_mfma=True)
+        dx_v, dW_v = ops.spconv_backward(x, *args, mode, w, dy, use_mfma=False)
+        assert ops.dgrad_weights(w, mode, True)[1] is not None and ops.dgrad_weights(w, mode, False)[1] is None
+        rel_close(dx_m, dx_v, 2e-6, 2e-6 * float(dx_v.abs().max()))
+        assert torch.equal(dW_m, dW_v)                 # (the kernel gradient does not depend on the switch)
