@@ -100,9 +100,10 @@ __device__ __forceinline__ void stage_dma(const Ctx& c) {
 // vector-memory operations a chunk issues by itself, in order: [pre: loads before its DMA] [DMA] [post: stores in fn]
 // which exponent slice the backward chunk (L, T) loads (layer < 0: none): DEEP: that of the hidden tile computed by the
 // NEXT chunk; otherwise that of its own tile
-constexpr int sprime_layer(bool deep, int L, int T) {
+constexpr int sprime_layer(bool deep, int L, int T, bool r0 = false) {
   if (!deep) return (L >= 1 && T < 4) ? L - 1 : -1;
   if (L >= 1 && T < 3) return L - 1;                // (L, T + 1)
+  if (r0 && L == 2 && T == BWD_NT[L] - 1) return -1;  // (R0: slice (0, 0) exists only after the recompute chunk that follows)
   if (L >= 2 && T == BWD_NT[L] - 1) return L - 2;   // last tile of the layer -> (L - 1, 0)
   return -1;
 }
@@ -119,20 +120,27 @@ template <class P> constexpr int reg_slice(int layer, int tile) {
   const int k = (4 - layer) * 4 + tile - P::LDS_SLICES;
   return (layer <= 4 && layer >= 0 && k >= 0 && k < P::REG_SLICES) ? k : -1;
 }
-template <class P> constexpr bool on_chip(int layer, int tile) { return lds_slice<P>(layer, tile) >= 0 || reg_slice<P>(layer, tile) >= 0; }
-template <class P> struct RegSlices { f32x4 v[P::REG_SLICES > 0 ? P::REG_SLICES : 1][4]; };
+// (R0: layer 0's slices are neither kept nor stored: the reverse sweep recomputes them into RegSlices::r0)
+template <class P> constexpr bool on_chip(int layer, int tile) {
+  return lds_slice<P>(layer, tile) >= 0 || reg_slice<P>(layer, tile) >= 0 || (P::R0 && layer == 0);
+}
+template <class P> struct RegSlices {
+  f32x4 v[P::REG_SLICES > 0 ? P::REG_SLICES : 1][4];
+  f32x16 r0[P::R0 ? 4 : 1];  // the recomputed accumulators of layer 0 (their registers are those of slices that are dead by then)
+};
 // 16-byte groups of an exponent slice that are read back: layer 2 has 101 rows, so the second half (k-step 7: rows
 // 112..127) of its tile 3 feeds nothing.  Loading it anyway would leave the loads to dead-code elimination, i.e. leave
 // the number of vector-memory operations of that chunk - which stage_barrier's vmcnt counts - to the optimiser.
 constexpr int sprime_groups(int layer, int tile) { return (layer == 2 && tile == 3) ? 2 : 4; }
 template <class P> constexpr int vm_pre(int ci) {
   if (ci < N_FWD_CHUNKS) return (ci / 4 == 5 && ci % 4 > 0) ? 4 : 0;  // W6 slices
-  if (ci >= N_CHUNKS) return 0;                                        // padding chunk
-  int l = 5, t = ci - N_FWD_CHUNKS;
+  if (ci >= P::CH.n) return 0;                                         // padding chunk
+  if (P::R0 && ci == r0_chunk()) return 0;                             // recompute chunk: MFMAs only
+  int l = 5, t = ci - N_FWD_CHUNKS - ((P::R0 && ci > r0_chunk()) ? 1 : 0);
   while (t >= BWD_NT[l]) { t -= BWD_NT[l]; --l; }
   if (l == 0) return P::DEEPJ ? 12 : 0;  // feature Jacobian for the epilogue
-  if (sprime_layer(P::DEEP, l, t) < 0 || on_chip<P>(sprime_layer(P::DEEP, l, t), sprime_tile(P::DEEP, l, t))) return 0;
-  return sprime_groups(sprime_layer(P::DEEP, l, t), sprime_tile(P::DEEP, l, t));
+  if (sprime_layer(P::DEEP, l, t, P::R0) < 0 || on_chip<P>(sprime_layer(P::DEEP, l, t, P::R0), sprime_tile(P::DEEP, l, t))) return 0;
+  return sprime_groups(sprime_layer(P::DEEP, l, t, P::R0), sprime_tile(P::DEEP, l, t));
 }
 template <class P, bool GRAD> constexpr int vm_post(int ci) {
   if (!GRAD || ci >= N_FWD_CHUNKS) return 0;
@@ -165,17 +173,22 @@ __device__ __forceinline__ void stage_barrier() {
 // One chunk: NKS k-steps of P::NM MFMAs read from its LDS slot; B fragments come from bsel(ks).  After MFMA m of k-step ks
 // (gap g = ks * NM + m) come, pinned by a scheduling barrier: the LDS read of piece m of the next k-step's A fragment, the
 // conversion slots the plan PL puts there (slot(s), in order) and the DMA pieces it puts there.
-template <class P, bool GRAD, int CI, int NCH, class PL, class BSel, class F>
-__device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F slot) {
+// NACC > 1 (the R0 chunk): k-steps [a NKS / NACC, (a + 1) NKS / NACC) accumulate into tile a.
+template <class P, bool GRAD, int CI, int NCH, class PL, int NACC, class BSel, class F>
+__device__ __forceinline__ void run_chunk_n(const Ctx& c, BSel bsel, F slot, f32x16 (&result)[NACC]) {
   constexpr int NKS = P::CH.ks[CI];
   constexpr int NP = P::NP, NM = P::NM;
   constexpr int NS = P::nslot(GRAD);
+  constexpr int KPA = NKS > 0 ? NKS / NACC : 1;
+  static_assert(NKS % NACC == 0, "k-steps per accumulator");
   const char* rd = c.lds + (CI % NS) * slot_bytes<P>() + c.lane16;
-  typename P::Acc acc;
+  typename P::Acc accs[NACC];
 #pragma unroll
-  for (int q = 0; q < P::NA; ++q)
+  for (int a = 0; a < NACC; ++a)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc.v[q][r] = 0.f;
+    for (int q = 0; q < P::NA; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accs[a].v[q][r] = 0.f;
   constexpr int PF = P::PF;  // A fragments are read PF k-steps ahead of their MFMAs
   static_assert(PF == 1, "the gap plan places the reads of k-step ks + 1 behind the MFMAs of k-step ks");
   u32x4 a_q[PF + 1][NP];
@@ -193,6 +206,7 @@ __device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F slot) {
     const FragT<NP>& b = bsel(ks);
     static_for<0, NM>([&](auto mc) __attribute__((always_inline)) {
       constexpr int m = decltype(mc)::value, g = ks * NM + m;
+      typename P::Acc& acc = accs[ks / KPA];
       if (!SURF_X_NOMMA) {
         P::mma_one(acc, a_q[SURF_X_NOLDS ? 0 : ks % (PF + 1)], b, m);
         // An MFMA is a pure value to the compiler: instruction selection is free to linearise it anywhere between its
@@ -222,7 +236,14 @@ __device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F slot) {
   SURF_T(CI < N_FWD_CHUNKS ? 1 : 3);
   stage_barrier<P, GRAD, CI, NCH>();
   SURF_T(7);
-  return P::finish(acc);
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) result[a] = P::finish(accs[a]);
+}
+template <class P, bool GRAD, int CI, int NCH, class PL, class BSel, class F>
+__device__ __forceinline__ f32x16 run_chunk(const Ctx& c, BSel bsel, F slot) {
+  f32x16 r[1];
+  run_chunk_n<P, GRAD, CI, NCH, PL, 1>(c, bsel, slot, r);
+  return r[0];
 }
 template <class P, bool GRAD, int CI, int NCH> constexpr int chunk_dma() { return n_dma<P>((CI + P::nslot(GRAD) - 1) % NCH); }
 
@@ -372,7 +393,8 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
         for (int k = 0; k < P::NP; ++k) f.p[k][(el & 7) >> 1] = S.pc[k];
         if (GRAD && !LAST && (el & 3) == 2) {
           constexpr int ls = lds_slice<P>(s_layer, dst_tile), rs = reg_slice<P>(s_layer, dst_tile);
-          if constexpr (rs >= 0) keep.v[rs][el >> 2] = sbuf[q >> 1 & 1];
+          if constexpr (P::R0 && s_layer == 0) {}  // recomputed by the reverse sweep
+          else if constexpr (rs >= 0) keep.v[rs][el >> 2] = sbuf[q >> 1 & 1];
           else if constexpr (ls >= 0) *reinterpret_cast<f32x4*>(c.lds_s + ls * 4096 + (el >> 2) * 1024) = sbuf[q >> 1 & 1];
           else bstore(c.sr, c.svoff, s_layer * 16384 + (dst_tile * 4 + (el >> 2)) * 1024, sbuf[q >> 1 & 1]);
         }
@@ -423,7 +445,10 @@ __device__ __forceinline__ void load_sprime(const Ctx& c, int layer, int tile, f
   const int ls = lds_slice<P>(layer, tile), rs = reg_slice<P>(layer, tile);
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    if (rs >= 0) dst[g] = keep.v[rs][g];
+    if (P::R0 && layer == 0) {
+      const f32x16& t = keep.r0[P::R0 ? tile : 0];
+      dst[g] = f32x4{t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]};
+    } else if (rs >= 0) dst[g] = keep.v[rs][g];
     else if (ls >= 0) dst[g] = *reinterpret_cast<const f32x4*>(c.lds_s + ls * 4096 + g * 1024);
     else dst[g] = bload_scratch(c.sl, c.svoff, layer * 16384 + (tile * 4 + g) * 1024);
   }
@@ -442,7 +467,7 @@ constexpr MiniProg bwd_prog() {
 }
 template <class P, int L, int T, bool CONVERT>
 struct BwdPlan {
-  static constexpr int CI = bwd_chunk(L, T), NKS = P::CH.ks[CI];
+  static constexpr int CI = bwd_chunk(L, T, P::R0), NKS = P::CH.ks[CI];
   static constexpr MiniProg mini = bwd_prog<P>();
   static constexpr SlotProg prog = CONVERT ? weave(mini, 8, 0) : SlotProg{};
   static constexpr GapPlan v = plan_gaps(NKS, P::NM, P::NP, chunk_dma<P, true, CI, n_chunks<P>(true)>(), NKS * P::NM, prog);
@@ -453,8 +478,8 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
                                            f32x4 (&s_load)[4], const RegSlices<P>& keep) {
   typedef FragT<P::NP> Frag;
   typedef BwdPlan<P, L, T, CONVERT> PL;
-  constexpr int CI = bwd_chunk(L, T);
-  constexpr int SL = sprime_layer(P::DEEP, L, T);
+  constexpr int CI = bwd_chunk(L, T, P::R0);
+  constexpr int SL = sprime_layer(P::DEEP, L, T, P::R0);
   constexpr int NG = SL >= 0 ? sprime_groups(SL, sprime_tile(P::DEEP, L, T)) : 0;
   static_assert((SL >= 0 && on_chip<P>(SL, sprime_tile(P::DEEP, L, T)) ? 0 : NG) + ((L == 0 && P::DEEPJ) ? 12 : 0) == vm_pre<P>(CI),
                 "vmcnt bookkeeping");
@@ -547,6 +572,24 @@ __device__ __forceinline__ void bwd_layer(const Ctx& c, const FragT<P::NP>* din,
   }
 }
 
+// R0: the recompute chunk (sdf_split_common.h, make_chunks): layer 0's four pre-activation tiles = W0 [e | 1] again, from the
+// positional-encoding fragments the forward sweep used, in the same k-step and product order (the same bits).  MFMAs only:
+// nothing is converted under it (the tile before it accumulates into accP), and the accumulators ARE the exponent arguments.
+template <class P, int CI>
+struct R0Plan {
+  static constexpr GapPlan v = plan_gaps(R0_KS, P::NM, P::NP, chunk_dma<P, true, CI, n_chunks<P>(true)>(), R0_KS * P::NM, SlotProg{});
+};
+template <class P>
+__device__ __forceinline__ void recompute_layer0(const Ctx& c, const FragT<P::NP> (&ef)[2], RegSlices<P>& keep) {
+  if constexpr (P::R0) {
+    constexpr int CI = r0_chunk();
+    static_assert(P::CH.ks[CI] == R0_KS && P::CH.off[CI] == P::CH.off[fwd_chunk(0, 0)] && fwd_ne(0) == 2 && fwd_nl(0) == 2, "R0 chunk");
+    run_chunk_n<P, true, CI, n_chunks<P>(true), R0Plan<P, CI>, 4>(
+        c, [&](int ks) __attribute__((always_inline)) -> const FragT<P::NP>& { return ef[ks & 1]; }, [&](auto) __attribute__((always_inline)) {},
+        keep.r0);
+  }
+}
+
 // empty chunks at the end of the gradient stream (n_chunks): their only content is the DMA issue and the barrier
 template <class P, int CI>
 struct PadPlan {
@@ -569,7 +612,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
   // ONE LDS object (ring + exponent slices): with a second __shared__ array the compiler's LDS-DMA alias tracking falls
   // back to `s_waitcnt vmcnt(0)` in front of every ds_read (311 of them, kernel 64 -> 98 ms)
   __shared__ __attribute__((aligned(16))) char lds[NS * slot_bytes<P>() + WPB * NSL * 4096];
-  static_assert(NCH % NS == 0 && NCH - N_CHUNKS <= MAX_PAD && NS >= 3, "slot of a chunk = index % ring length");
+  static_assert(NCH % NS == 0 && (!GRAD || NCH - P::CH.n <= MAX_PAD) && NS >= 3, "slot of a chunk = index % ring length");
   Ctx c;
   c.lane = threadIdx.x & 63;
   c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -702,6 +745,10 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
       bwd_layer<P, 4>(c, hA, dA, accE, accP, pend, keep);
       bwd_layer<P, 3>(c, dA, hA, accE, accP, pend, keep);
       bwd_layer<P, 2>(c, hA, dA, accE, accP, pend, keep);
+      if constexpr (P::R0) {
+        recompute_layer0<P>(c, ef, keep);
+        load_sprime<P>(c, 0, 0, pend.sn, keep);  // slice of hidden tile (1, 0): what reverse layer 2's last chunk fetches otherwise
+      }
       bwd_layer<P, 1>(c, dA, hA, accE, accP, pend, keep);
       f32x4 Jq[12];  // feature Jacobian: DEEP fetches it under the last chunk
       if (P::DEEPJ) {
@@ -712,7 +759,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
         f32x4 unused[4];
         accE += bwd_tile<P, 0, 0, false>(c, hA, dA, pend, unused, keep);
       }
-      pad_chunks<P, N_CHUNKS>(c, hA);
+      pad_chunks<P, P::CH.n>(c, hA);
       SURF_T(3);
       float g3[3] = {0.f, 0.f, 0.f};
       {

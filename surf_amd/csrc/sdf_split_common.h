@@ -31,26 +31,40 @@ constexpr int N_BWD_CHUNKS = n_bwd_chunks();
 constexpr int N_CHUNKS = N_FWD_CHUNKS + N_BWD_CHUNKS;
 
 constexpr int MAX_PAD = 4;  // empty chunks that round the gradient stream up to a multiple of the ring length
+// Round 5, "R0": the reverse sweep RECOMPUTES layer 0's pre-activations (= its softplus exponent arguments) instead of reading
+// them back from the scratch slot: one extra chunk of 8 k-steps between the reverse layers 2 and 1 whose LDS image is the four
+// forward chunks of layer 0 - they are contiguous at the start of the packed stream, so the chunk is only a second table entry
+// with offset 0 (no packer change) - multiplied by the positional-encoding fragments (kept live) into four accumulators.
+// 48 MFMAs per tile (+1.9 %) for 16 of the 40 KB a wavefront moves through its scratch slot per tile.
+constexpr int R0_KS = 8;
 struct ChunkTable {
-  int off[N_CHUNKS + MAX_PAD + 1];  // byte offset into the packed stream
-  int ks[N_CHUNKS + MAX_PAD + 1];
+  int off[N_CHUNKS + 1 + MAX_PAD + 1];  // byte offset into the packed stream
+  int ks[N_CHUNKS + 1 + MAX_PAD + 1];
+  int n;      // chunks of the gradient stream (N_CHUNKS, + 1 with R0)
+  int total;  // bytes of the packed stream
 };
-constexpr ChunkTable make_chunks(int np) {  // one k-step = np pieces x 64 lanes x 16 B
+constexpr ChunkTable make_chunks(int np, bool r0) {  // one k-step = np pieces x 64 lanes x 16 B
   ChunkTable c{};
   int n = 0, o = 0;
   for (int l = 0; l < 6; ++l)
     for (int t = 0; t < 4; ++t) { c.off[n] = o; c.ks[n] = fwd_ks(l); o += fwd_ks(l) * np * 1024; ++n; }
-  for (int l = 5; l >= 0; --l)
+  for (int l = 5; l >= 0; --l) {
+    if (r0 && l == 1) { c.off[n] = 0; c.ks[n] = R0_KS; ++n; }
     for (int t = 0; t < BWD_NT[l]; ++t) { c.off[n] = o; c.ks[n] = bwd_ks(l); o += bwd_ks(l) * np * 1024; ++n; }
-  for (; n <= N_CHUNKS + MAX_PAD; ++n) { c.off[n] = o; c.ks[n] = 0; }
+  }
+  c.n = n;
+  c.total = o;
+  for (; n <= N_CHUNKS + 1 + MAX_PAD; ++n) { c.off[n] = o; c.ks[n] = 0; }
   return c;
 }
+static_assert(fwd_ks(0) * 4 == R0_KS, "the recompute chunk is the four forward chunks of layer 0");
 constexpr int fwd_chunk(int l, int t) { return l * 4 + t; }
-constexpr int bwd_chunk(int l, int t) {
+constexpr int bwd_chunk(int l, int t, bool r0 = false) {
   int n = N_FWD_CHUNKS;
   for (int i = 5; i > l; --i) n += BWD_NT[i];
-  return n + t;
+  return n + t + ((r0 && l <= 1) ? 1 : 0);
 }
+constexpr int r0_chunk() { return bwd_chunk(1, 0, false); }  // (its index when present: in front of reverse layer 1)
 // fp32 tail of the packed buffer (floats): W6[0] in lane order, b6
 constexpr int TAIL_W6H = 0;               // [h][64]
 constexpr int TAIL_W6P = TAIL_W6H + 128;  // [h][16]
@@ -155,7 +169,11 @@ struct PolBf3 {
 #endif
   static constexpr bool DEEP = SURF_SDF_DEEP_BF3;   // the reverse sweep reads its exponent slices two chunks ahead
   static constexpr bool DEEPJ = true;  // feature Jacobian fetched under the last backward chunk
-  static constexpr ChunkTable CH = make_chunks(NP);
+#ifndef SURF_SDF_R0_BF3
+#define SURF_SDF_R0_BF3 1
+#endif
+  static constexpr bool R0 = SURF_SDF_R0_BF3;  // layer 0's exponent arguments recomputed by the reverse sweep (see make_chunks)
+  static constexpr ChunkTable CH = make_chunks(NP, R0);
   struct Acc { f32x16 v[NA]; };
   static __device__ __forceinline__ uint32_t pack2(float a, float b) {
     bf16x2 v;
@@ -214,7 +232,8 @@ struct PolH2 {
   static constexpr int REG_SLICES = SURF_SDF_REG_SLICES_H2;
   static constexpr int LDS_SLICES = SURF_SDF_LDS_SLICES_H2;        // 3 x 24 + 4 x 5 x 4 KB = 152 KB (gradient kernel: one workgroup per CU)  // 24 KB slots; two workgroups per CU forward-only
   static constexpr bool DEEP = true, DEEPJ = true;
-  static constexpr ChunkTable CH = make_chunks(NP);
+  static constexpr bool R0 = false;  // all 20 slices already stay on the CU
+  static constexpr ChunkTable CH = make_chunks(NP, R0);
   struct Acc { f32x16 v[NA]; };
   static __device__ __forceinline__ void split(float a, float b, uint32_t (&p)[NP]) {
     const f32x2 v = {a, b};
@@ -257,13 +276,13 @@ struct PolH2 {
 template <class P> struct Scales { static constexpr float W = 1.0f, D = 1.0f; };
 template <> struct Scales<PolH2> { static constexpr float W = 256.0f, D = 256.0f; };
 
-template <class P> constexpr int stream_bytes() { return P::CH.off[N_CHUNKS]; }
+template <class P> constexpr int stream_bytes() { return P::CH.total; }
 template <class P> constexpr int slot_bytes() { return MAX_KS * P::NP * 1024; }
 template <class P> constexpr int max_blocks(bool grad) { return 256 * P::occ(grad); }
 // chunks per round: the gradient stream is padded with empty chunks to a multiple of the ring length, so that the slot of
 // a chunk (index % ring length) continues across rounds
 template <class P> constexpr int n_chunks(bool grad) {
-  return grad ? (N_CHUNKS + P::nslot(true) - 1) / P::nslot(true) * P::nslot(true) : N_FWD_CHUNKS;
+  return grad ? (P::CH.n + P::nslot(true) - 1) / P::nslot(true) * P::nslot(true) : N_FWD_CHUNKS;
 }
 
 struct SdfArgs {
