@@ -621,6 +621,13 @@ def parse_args(argv):
     ap.add_argument("--rays", type=int, default=512, help="--workload train: rays per rank and step (confs/surf.conf: 512)")
     ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16"],
                     help="training-backward policy (model conf key train_precision): bf16 = weight-gradient reductions on bf16 operands")
+    ap.add_argument("--split", default="scenes", choices=["scenes", "rays"],
+                    help="how N ranks share the work: scenes (default: one scene per rank, weak scaling) or rays (SURVEY 8e's "
+                         "single-scene split: ONE scene on N GPUs, rank r renders rays [r R / N, (r + 1) R / N) and an x-range of the "
+                         "mesh lattice, rank 0 stitches; strong scaling)")
+    ap.add_argument("--check-split", action="store_true",
+                    help="(--split rays) rank 0 also renders the whole image and the whole lattice alone and reports whether the "
+                         "stitched results are bit-equal")
     ap.add_argument("--fail-rank", type=int, default=-1, help="(tests) this rank exits 3 before the first barrier")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend of a multi-rank run: nccl (= RCCL, the measured configuration) or gloo (tests: "
@@ -663,9 +670,118 @@ class DryScene:
         self.seed, self.R = seed, R
 
 
+def run_rank_split(args):
+    """--split rays: ONE scene on N GPUs (north_star's 1 / 2 / 4 / 8-GPU numbers for one image).  Every rank holds the
+    same scene (the 19.5 ms volume build is replicated, not split: implicit_surface.py:367-370's rays and :338-351's lattice are
+    what shard), renders its contiguous share of the R pixel rays inside the timed region and sends it to rank 0, which stitches
+    the image: one all_gather of (R / N, 3) colours per step - the only data-path collective, RCCL over xGMI.  value = R x steps /
+    max-over-ranks time: the throughput of ONE image, strong scaling.  After the timed region the mesh lattice is split the same
+    way (x-ranges, lattice-mode kernel) and gathered; --check-split compares both with rank 0's own single-rank results."""
+    from surf_amd import dist as D
+    from surf_amd import ops, synthetic
+    from surf_amd.implicit_surface import ImplicitSurface
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if args.one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    D.init_from_env(args.backend, dev)
+    if args.fail_rank == rank:
+        sys.exit(3)
+    n_samples = [int(x) for x in args.n_samples.split(",")]
+    H, W, nv = args.height, args.width, args.views
+    R = H * W
+    torch.manual_seed(0)
+    model = ImplicitSurface(model_conf(n_samples, args.sdf_precision, args.blend_precision)).to(dev)
+    intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
+    imgs = synthetic.procedural_images(nv, H, W, 0, dev)
+    feats = synthetic.feature_pyramid(nv, H, W, 0, dev)
+    vols, tabs, mvol = synthetic.sphere_pyramid(args.base_dim, dev, seed=0)
+    sc = model.scene(mvol, vols[::-1], tabs[::-1], None, feats, imgs, intrs.to(dev), c2ws.to(dev))
+    rays_o, rays_d = synthetic.pixel_rays(intrs[0], c2ws[0], H, W, 1, dev)
+    near = near_fars[0, 0].reshape(1, 1).repeat(R, 1).to(dev)
+    far = near_fars[0, 1].reshape(1, 1).repeat(R, 1).to(dev)
+    r0, r1 = rank * R // world, (rank + 1) * R // world
+
+    def render(a, b):
+        outs = [model.render_scene(rays_o[s:min(s + RAY_CHUNK, b)], rays_d[s:min(s + RAY_CHUNK, b)], near[s:min(s + RAY_CHUNK, b)],
+                                   far[s:min(s + RAY_CHUNK, b)], sc, 1.0, per_sample=False)["color_fine"] for s in range(a, b, RAY_CHUNK)]
+        return outs[0] if len(outs) == 1 else torch.cat(outs)
+
+    def step():
+        return D.gather_rows(render(r0, r1))           # rank 0: the stitched (R, 3) image
+
+    for _ in range(args.warmup):
+        image = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        image = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    # the rank's own share of the time: render alone (HIP events) vs render + gather
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    render(r0, r1)
+    b.record()
+    torch.cuda.synchronize()
+    render_ms = D.max_over_ranks(a.elapsed_time(b), dev)
+
+    # ---- the mesh lattice, split by x-range (after the timed region) ----
+    lattice = None
+    res = args.mesh_grid
+    if res > 0:
+        sdf_w, _ = model.packed_weights(dev)
+        axes = [torch.linspace(-1.0, 1.0, res).to(dev) for _ in range(3)]
+        x0, x1 = rank * res // world, (rank + 1) * res // world
+        u = torch.empty(res, res, res, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        D.barrier()
+        t1 = time.perf_counter()
+        if x1 > x0:
+            ops.sdf_lattice(axes, sc.sv, sdf_w, u, x0, x1 - x0, sign=-1.0)
+        torch.cuda.synchronize()
+        lat_ms = D.max_over_ranks((time.perf_counter() - t1) * 1e3, dev)
+        t2 = time.perf_counter()
+        u_all = D.gather_rows(u[x0:x1])
+        torch.cuda.synchronize()
+        gather_ms = D.max_over_ranks((time.perf_counter() - t2) * 1e3, dev)
+        lattice = {"resolution": res, "sdf_ms": lat_ms, "gather_ms": gather_ms}
+    check = None
+    if args.check_split and rank == 0:
+        whole = render(0, R)
+        check = {"image_bit_equal": bool(torch.equal(whole, image))}
+        if res > 0:
+            u1 = torch.empty_like(u)
+            ops.sdf_lattice(axes, sc.sv, sdf_w, u1, 0, res, sign=-1.0)
+            check["lattice_bit_equal"] = bool(torch.equal(u1, u_all))
+    if rank == 0:
+        print(json.dumps({
+            "metric": WORKLOADS[args.workload]["metric"], "value": R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": {"f32": "f32", "bf16x3": "f32 (operands split exactly into 3 bf16 pieces, fp32 accumulate)",
+                      "f16x2": "f32 accumulate, 22-bit operands (2 fp16 pieces)"}[args.sdf_precision],
+            "data": "synthetic",
+            "config": {"workload": f"ONE {H}x{W} image ({nv} views, samples {n_samples}) split over {world} GPU(s) by ray range; "
+                                   f"colours gathered on rank 0 inside the timed region", "rays_per_step": R, "split": "rays",
+                       "rays_per_rank": [(k + 1) * R // world - k * R // world for k in range(world)]},
+            "split": {"render_ms_max_over_ranks": render_ms, "step_ms": elapsed / args.steps * 1e3, "lattice": lattice, "check": check},
+            "roofline": None, "cpu_baseline": None,
+            "collective_backend": (args.backend + (" (all ranks on cuda:0)" if args.one_gpu else "")) if world > 1 else None}))
+    if world > 1:
+        D.shutdown()
+
+
 def run_rank(args):
     if args.workload == "train":
         return run_rank_train(args)
+    if args.split == "rays":
+        return run_rank_split(args)
     from surf_amd import dist as D
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 30
+#define SURF_ABI_VERSION 31
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -127,6 +127,17 @@ int surf_sdf_mlp_bf16x3_dn(const float* pts, const int32_t* idx, int64_t n_capac
 int surf_sdf_mlp_f16x2_dn(const float* pts, const int32_t* idx, int64_t n_capacity, const int32_t* d_n, const float* const* h_vols,
                           const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* sdf,
                           float* grad, void* scratch, void* stream);
+
+/* The SDF on a lattice WITHOUT point tensors (extract_geometry, models/modules/implicit_surface.py:337-351, replaces its
+ * meshgrid + cat of points): out[(ix ny + iy) nz + iz] = sign * sdf(ax[ix], ay[iy], az[iz]) by the forward-only split kernels;
+ * ax / ay / az: device arrays of nx / ny / nz coordinates (torch.linspace's values, :338-340), sign = -1 gives marching cubes'
+ * input u directly (:350).  nx ny nz < 2^31 per call (the caller walks slabs of x). */
+int surf_sdf_lattice_bf16x3(const float* ax, const float* ay, const float* az, int nx, int ny, int nz, const float* const* h_vols,
+                            const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* out,
+                            float sign, void* stream);
+int surf_sdf_lattice_f16x2(const float* ax, const float* ay, const float* az, int nx, int ny, int nz, const float* const* h_vols,
+                           const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* out,
+                           float sign, void* stream);
 
 /*
  * Second-order term of the SDF network (training): grad (n,3) (optional) and smooth (n,3) = H.1, the row sums of the

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
 # must equal SURF_ABI_VERSION of include/surf_hip.h (tests/test_host_modules.py compares the two texts); lib() refuses a
 # library built from another header
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -37,6 +37,8 @@ SIGNATURES = {
     "surf_sdf_pack_weights_bf16": (c_int, [c_ptr, c_ptr, c_ptr]),
     "surf_sdf_mlp_bf16x3": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_sdf_mlp_bf16x3_dn": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_sdf_lattice_bf16x3": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_float, c_ptr]),
+    "surf_sdf_lattice_f16x2": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_float, c_ptr]),
     "surf_sdf_mlp_f16x2_dn": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_blend_split_dn": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int,
                                     c_ptr, c_ptr, c_ptr, c_ptr]),

@@ -52,7 +52,31 @@ struct Ctx {
   uint32_t dma_lds;   // LDS address of the ring (+ wave * 1024 in the piece-major assignment; made opaque once per round)
   char* lds;    // the ring
   char* lds_s;  // this wavefront's exponent slices (the softplus arguments the reverse sweep needs) + lane * 16
+  u32x4 I0, I1;  // (P::MRES) A operands of the matrix-pipe residuals, k-steps 0 / 1 of a tile: -1 where lane row = the tile row of k-slot
 };
+// A[i][8 g + ip] of k-step s (lane: row i = lane & 31, k group g = lane >> 5) = -1 iff row i is the accumulator row of register
+// 8 s + ip in lane half g: (ip & 3) + 8 (2 s + (ip >> 2)) + 4 g - the row <-> k-slot permutation every packed fragment uses.
+__device__ __forceinline__ u32x4 minus_identity_frag(int lane, int s) {
+  const int i = lane & 31, g = lane >> 5;
+  u32x4 f = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int ip = 0; ip < 8; ++ip) {
+    const int rho = (ip & 3) + 8 * (2 * s + (ip >> 2)) + 4 * g;
+    if (rho == i) f[ip >> 1] |= (ip & 1) ? 0xBF800000u : 0x0000BF80u;  // bf16(-1.0)
+  }
+  return f;
+}
+// one residual MFMA: vt -= (the fragment's piece, as the B operand of its own k-step)
+template <class P>
+__device__ __forceinline__ void mres_step(const Ctx& c, f32x16& vt, const u32x4& piece, int s2) {
+  if constexpr (P::MRES) {
+    __builtin_amdgcn_sched_barrier(0);  // what precedes it in the gap runs in the product MFMA's shadow, what follows in its own
+    const u32x4 I = s2 ? c.I1 : c.I0;
+    vt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, I), __builtin_bit_cast(bf16x8, piece), vt, 0, 0, 0);
+    asm volatile("" ::"v"(vt));  // tie the MFMA to this place (see run_chunk)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
 
 // ---- staging ------------------------------------------------------------------------------------------------------------
 // The chunk stream is cyclic over rounds and lives in a ring of NS = P::nslot LDS slots (chunk CI in slot CI % NS; the
@@ -272,10 +296,10 @@ constexpr MiniProg fwd_prog() {
       mini_add(mp, K_RCP, 0, 16);
       mini_add(mp, K_SEL, 0, 16);
       mini_add(mp, K_SIG, 0, 16);
-      mini_add_split(mp, P::NP, P::FUSED_SUB);
+      mini_add_split(mp, P::NP, P::FUSED_SUB, P::MRES);
     }
   } else {
-    mini_add_split(mp, P::NP, P::FUSED_SUB);
+    mini_add_split(mp, P::NP, P::FUSED_SUB, P::MRES);
   }
   return mp;
 }
@@ -284,7 +308,8 @@ struct FwdPlan {
   static constexpr int CI = fwd_chunk(L, T), NKS = P::CH.ks[CI], NG = NKS * P::NM;
   static constexpr bool LAST = (L == 5 && T > 0), CONV = !(L == 0 && T == 0);
   static constexpr MiniProg mini = fwd_prog<P, GRAD, LAST>();
-  static constexpr SlotProg prog = CONV ? weave(mini, 8, (GRAD && !LAST) ? 8 : 0) : SlotProg{};
+  static constexpr bool SPLITS = !LAST || GRAD;  // (forward-only layer 5: h feeds lin6's row 0 and nothing is split)
+  static constexpr SlotProg prog = CONV ? weave(mini, 8, (GRAD && !LAST) ? 8 : 0, (P::MRES && SPLITS) ? P::NP : 0) : SlotProg{};
   // T == 0 (L >= 1) converts tile 3 of the layer below into hin[6] (pairs 0..3) and hin[7], which this very chunk multiplies
   // in its last two k-steps (layer 3, 101 inputs: hin[6] in the last one, hin[7] not at all)
   static constexpr int DEADLINE = (T == 0 && L >= 1) ? (NKS - 1) * P::NM : NG;
@@ -315,11 +340,14 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
   }
   f32x4 sbuf[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};  // exponent arguments of pairs (4k, 4k + 1) / (4k + 2, 4k + 3)
   MiniState<P::NP> st[2] = {};
+  // (P::MRES) the tile the matrix pipe forms the residuals of: starts as the pre-activations, a pair's activations replace them in
+  // its K_PACK slot (its last use of them is before that), so that the tile costs no registers beside the accumulators it was
+  f32x16 vt = prev;
   auto slot = [&](auto sc) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value;
-    constexpr int q = PL::prog.q[s], j = PL::prog.j[s], kind = PL::mini.kind[j], i = PL::mini.arg[j], el = 2 * q;
+    constexpr int q = PL::prog.q[s] < 0 ? 0 : PL::prog.q[s], kind = PL::prog.kind[s], i = PL::prog.arg[s], el = 2 * q;
     MiniState<P::NP>& S = st[q & 1];
-    const f32x2 t2 = {prev[el], prev[el + 1]};
+    const f32x2 t2 = P::MRES ? f32x2{vt[el], vt[el + 1]} : f32x2{prev[el], prev[el + 1]};
     const f32x2 w2 = {LAST ? w6[el >> 2][el & 3] : 0.f, LAST ? w6[(el + 1) >> 2][(el + 1) & 3] : 0.f};
     if constexpr (kind == K_ARG) {
       S.u[0] = t2[0] * (144.269504088896341f * inv_w);  // 100 log2(e) t   (element by element: no packed fp32 beside MFMAs)
@@ -387,10 +415,17 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
       slot_pin(S.val);
       S.pc[i] = SURF_X_NOSPLIT ? __builtin_bit_cast(uint32_t, S.val[i & 1]) : P::pack(S.val);
       slot_pin(S.pc[i]);
-      if (i == P::NP - 1) {
-        Frag& f = dst[2 * dst_tile + (el >> 3)];
+      if (P::MRES) {  // piece 0 into its fragment, the value into the tile whose residuals the matrix pipe forms
+        dst[2 * dst_tile + (el >> 3)].p[0][(el & 7) >> 1] = S.pc[0];
+        vt[el] = S.val[0];
+        vt[el + 1] = S.val[1];
+      }
+      if (i == P::NP - 1 || P::MRES) {
+        if (!P::MRES) {
+          Frag& f = dst[2 * dst_tile + (el >> 3)];
 #pragma unroll
-        for (int k = 0; k < P::NP; ++k) f.p[k][(el & 7) >> 1] = S.pc[k];
+          for (int k = 0; k < P::NP; ++k) f.p[k][(el & 7) >> 1] = S.pc[k];
+        }
         if (GRAD && !LAST && (el & 3) == 2) {
           constexpr int ls = lds_slice<P>(s_layer, dst_tile), rs = reg_slice<P>(s_layer, dst_tile);
           if constexpr (P::R0 && s_layer == 0) {}  // recomputed by the reverse sweep
@@ -399,6 +434,11 @@ __device__ __forceinline__ void fwd_tile(const Ctx& c, f32x16& raw, FragT<P::NP>
           else bstore(c.sr, c.svoff, s_layer * 16384 + (dst_tile * 4 + (el >> 2)) * 1024, sbuf[q >> 1 & 1]);
         }
       }
+    } else if constexpr (kind == K_MRES) {
+      mres_step<P>(c, vt, dst[2 * dst_tile + (i & 1)].p[i >> 1], i & 1);
+    } else if constexpr (kind == K_PACKT) {
+      const f32x2 r2 = {vt[el], vt[el + 1]};
+      dst[2 * dst_tile + (el >> 3)].p[i][(el & 7) >> 1] = P::pack(r2);
     } else if constexpr (kind == K_EXPAND) {
       slot_pin(S.pc[i]);
       S.x = SURF_X_NOSPLIT ? S.val : P::expand(S.pc[i]);
@@ -462,14 +502,14 @@ constexpr MiniProg bwd_prog() {
   mini_add(mp, K_ADD1, 0, 8);
   mini_add(mp, K_RCP, 0, 16);
   mini_add(mp, K_MULG, 0, 8 + (Scales<P>::W != 1.0f ? 8 : 0));
-  mini_add_split(mp, P::NP, P::FUSED_SUB);
+  mini_add_split(mp, P::NP, P::FUSED_SUB, P::MRES);
   return mp;
 }
 template <class P, int L, int T, bool CONVERT>
 struct BwdPlan {
   static constexpr int CI = bwd_chunk(L, T, P::R0), NKS = P::CH.ks[CI];
   static constexpr MiniProg mini = bwd_prog<P>();
-  static constexpr SlotProg prog = CONVERT ? weave(mini, 8, 0) : SlotProg{};
+  static constexpr SlotProg prog = CONVERT ? weave(mini, 8, 0, P::MRES ? P::NP : 0) : SlotProg{};
   static constexpr GapPlan v = plan_gaps(NKS, P::NM, P::NP, chunk_dma<P, true, CI, n_chunks<P>(true)>(), NKS * P::NM, prog);
   static_assert(plan_ok(v, prog, mini, NKS * P::NM, NKS * P::NM), "gap plan");
 };
@@ -485,10 +525,11 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
                 "vmcnt bookkeeping");
   if (SL >= 0) load_sprime<P, NG>(c, SL, sprime_tile(P::DEEP, L, T), s_load, keep);
   MiniState<P::NP> st[2] = {};
+  f32x16 vt = prev.G;  // (P::MRES) G, pair by pair replaced by the deltas (K_PACK), then their residuals
   auto slot = [&](auto sc) __attribute__((always_inline)) {
     constexpr int s = decltype(sc)::value;
     constexpr float inv_w = 1.0f / Scales<P>::W;  // G arrives x W_SCALE x D_SCALE, deltas are kept x D_SCALE
-    constexpr int q = PL::prog.q[s], j = PL::prog.j[s], kind = PL::mini.kind[j], i = PL::mini.arg[j], el = 2 * q;
+    constexpr int q = PL::prog.q[s] < 0 ? 0 : PL::prog.q[s], kind = PL::prog.kind[s], i = PL::prog.arg[s], el = 2 * q;
     MiniState<P::NP>& S = st[q & 1];
     if constexpr (kind == K_EXPN) {
       const f32x2 u = {prev.s[el >> 2][el & 3], prev.s[(el + 1) >> 2][(el + 1) & 3]};  // exponent arguments (forward K_ARG)
@@ -507,8 +548,8 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
       slot_pin(S.r);
     } else if constexpr (kind == K_MULG) {
       slot_pin(S.r);
-      S.val[0] = S.r[0] * prev.G[el];
-      S.val[1] = S.r[1] * prev.G[el + 1];
+      S.val[0] = S.r[0] * (P::MRES ? vt[el] : prev.G[el]);
+      S.val[1] = S.r[1] * (P::MRES ? vt[el + 1] : prev.G[el + 1]);
       if (inv_w != 1.0f) {
         S.val[0] *= inv_w;
         S.val[1] *= inv_w;
@@ -518,11 +559,20 @@ __device__ __forceinline__ f32x16 bwd_tile(const Ctx& c, const FragT<P::NP>* din
       slot_pin(S.val);
       S.pc[i] = SURF_X_NOSPLIT ? __builtin_bit_cast(uint32_t, S.val[i & 1]) : P::pack(S.val);
       slot_pin(S.pc[i]);
-      if (i == P::NP - 1) {
+      if (P::MRES) {
+        dout[2 * (T - 1) + (el >> 3)].p[0][(el & 7) >> 1] = S.pc[0];
+        vt[el] = S.val[0];
+        vt[el + 1] = S.val[1];
+      } else if (i == P::NP - 1) {
         Frag& f = dout[2 * (T - 1) + (el >> 3)];
 #pragma unroll
         for (int k = 0; k < P::NP; ++k) f.p[k][(el & 7) >> 1] = S.pc[k];
       }
+    } else if constexpr (kind == K_MRES) {
+      mres_step<P>(c, vt, dout[2 * (T - 1) + (i & 1)].p[i >> 1], i & 1);
+    } else if constexpr (kind == K_PACKT) {
+      const f32x2 r2 = {vt[el], vt[el + 1]};
+      dout[2 * (T - 1) + (el >> 3)].p[i][(el & 7) >> 1] = P::pack(r2);
     } else if constexpr (kind == K_EXPAND) {
       slot_pin(S.pc[i]);
       S.x = SURF_X_NOSPLIT ? S.val : P::expand(S.pc[i]);
@@ -620,6 +670,10 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
   c.lane16 = c.lane * 16;
   c.lds = lds;
   c.lds_s = lds + NS * slot_bytes<P>() + c.wave * (NSL * 4096) + c.lane16;
+  if (P::MRES) {
+    c.I0 = minus_identity_frag(c.lane, 0);
+    c.I1 = minus_identity_frag(c.lane, 1);
+  }
   c.wave1024 = c.wave * 1024;
   c.dma_voff = c.lane16 + c.wave * 1024;
   c.dma_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds + (SURF_SDF_DMA_WAVEMAJOR ? 0 : c.wave * 1024);
@@ -651,7 +705,15 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
     const int64_t sc = slot0 < n_pts ? slot0 : n_pts - 1;
     const int64_t i = a.idx ? (int64_t)a.idx[sc] : sc;
     const bool active = (slot0 < n_pts) && (!a.mask || a.mask[i] != 0);
-    const float px = a.pts[i * 3 + 0], py = a.pts[i * 3 + 1], pz = a.pts[i * 3 + 2];
+    float px, py, pz;
+    if (a.pts) {
+      px = a.pts[i * 3 + 0]; py = a.pts[i * 3 + 1]; pz = a.pts[i * 3 + 2];
+    } else {  // lattice mode: the point from its linear index (n < 2^31, checked at launch)
+      const uint32_t ii = (uint32_t)i, yz = ii / (uint32_t)a.lat_nz;
+      px = a.lat_axes[0][yz / (uint32_t)a.lat_ny];
+      py = a.lat_axes[1][yz % (uint32_t)a.lat_ny];
+      pz = a.lat_axes[2][ii % (uint32_t)a.lat_nz];
+    }
 
     Frag ef[2], pf[2];
     float y0 = 0.f;
@@ -723,7 +785,7 @@ __global__ __launch_bounds__(WPB * 64, P::occ(GRAD)) void sdf_mlp_split_kernel(S
       y0 += __shfl_xor(y0, 32);
       y0 += b6[0];
     }
-    if (active && c.h == 0) a.sdf[i] = y0;
+    if (active && c.h == 0) a.sdf[i] = GRAD ? y0 : y0 * a.out_sign;
     SURF_T(2);
     if (GRAD) {
       // ---------------------------------------------- reverse sweep ----------------------------------------------
@@ -911,7 +973,7 @@ int pack_weights(const float* const* h_W, const float* const* h_b, unsigned char
   // ---- backward: G_in = W_l^T delta_l
   for (int l = 0; l < 6; ++l)
     for (int t = 0; t < BWD_NT[l]; ++t) {
-      const int ci = bwd_chunk(l, t);
+      const int ci = bwd_chunk(l, t, P::R0);
       const int hid_in = (l == 3) ? H2 : HID;
       for (int ks = 0; ks < bwd_ks(l); ++ks)
         for (int lane = 0; lane < 64; ++lane)
@@ -954,17 +1016,24 @@ int pack_weights(const float* const* h_W, const float* const* h_b, unsigned char
   return 0;
 }
 
+struct Lattice { const float* ax[3]; int ny, nz; float sign; };
 template <class P>
 int launch(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n, const float* const* h_vols,
            const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* sdf, float* grad,
-           void* scratch, void* stream, const int32_t* d_n) {
-  if (!pts || !h_vols || !h_tables || !h_dims || !packed || !sdf) return SURF_E_ARG;
+           void* scratch, void* stream, const int32_t* d_n, const Lattice* lat = nullptr) {
+  if ((!pts && !lat) || !h_vols || !h_tables || !h_dims || !packed || !sdf) return SURF_E_ARG;
   if (n <= 0 || n_vol <= 0) return SURF_E_ARG;
   if (n_vol > SURF_MAX_STAGES) return SURF_E_LIMIT;
   if (grad && !scratch) return SURF_E_ARG;
   SdfArgs a;
   a.pts = pts; a.mask = mask; a.idx = idx; a.n = n; a.n_dev = d_n; a.packed = (const unsigned char*)packed; a.sdf = sdf; a.grad = grad;
   a.scratch = (float*)scratch;
+  a.lat_axes[0] = a.lat_axes[1] = a.lat_axes[2] = nullptr; a.lat_ny = a.lat_nz = 1; a.out_sign = 1.0f;
+  if (lat) {
+    if (grad || mask || idx || d_n || n >= (int64_t)1 << 31 || lat->ny < 1 || lat->nz < 1 || !lat->ax[0] || !lat->ax[1] || !lat->ax[2]) return SURF_E_ARG;
+    for (int k = 0; k < 3; ++k) a.lat_axes[k] = lat->ax[k];
+    a.lat_ny = lat->ny; a.lat_nz = lat->nz; a.out_sign = lat->sign;
+  }
   for (int s = 0; s < SURF_MAX_STAGES; ++s) {
     a.vols[s] = s < n_vol ? h_vols[s] : h_vols[0];
     a.tables[s] = s < n_vol ? h_tables[s] : h_tables[0];  // absent levels: a valid address for gather_features' unconditional loads
@@ -978,6 +1047,17 @@ int launch(const float* pts, const uint8_t* mask, const int32_t* idx, int64_t n,
   else
     hipLaunchKernelGGL((sdf_mlp_split_kernel<P, false>), grid, block, 0, (hipStream_t)stream, a);
   return surf_check_launch();
+}
+
+// extract_geometry's lattice (implicit_surface.py:337-351) without point tensors: nx x ny x nz values out[(ix ny + iy) nz + iz]
+// = sign * sdf(ax[ix], ay[iy], az[iz]) by the forward-only kernel
+template <class P>
+int launch_lattice(const float* ax, const float* ay, const float* az, int nx, int ny, int nz, const float* const* h_vols,
+                   const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* out, float sign, void* stream) {
+  if (nx < 1 || ny < 1 || nz < 1) return SURF_E_ARG;
+  const Lattice lat = {{ax, ay, az}, ny, nz, sign};
+  return launch<P>(nullptr, nullptr, nullptr, (int64_t)nx * ny * nz, h_vols, h_tables, h_dims, n_vol, packed, out, nullptr, nullptr, stream,
+                   nullptr, &lat);
 }
 
 template <class P>
@@ -1025,7 +1105,18 @@ extern "C" int surf_sdf_mlp_bf16x3_dn(const float* pts, const int32_t* idx, int6
   return launch<PolBf3>(pts, nullptr, idx, n_capacity, h_vols, h_tables, h_dims, n_vol, packed, sdf, grad, scratch, stream, d_n);
 }
 
+extern "C" int surf_sdf_lattice_bf16x3(const float* ax, const float* ay, const float* az, int nx, int ny, int nz, const float* const* h_vols,
+                                       const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* out,
+                                       float sign, void* stream) {
+  return launch_lattice<PolBf3>(ax, ay, az, nx, ny, nz, h_vols, h_tables, h_dims, n_vol, packed, out, sign, stream);
+}
+
 #else
+extern "C" int surf_sdf_lattice_f16x2(const float* ax, const float* ay, const float* az, int nx, int ny, int nz, const float* const* h_vols,
+                                      const int32_t* const* h_tables, const int* h_dims, int n_vol, const void* packed, float* out,
+                                      float sign, void* stream) {
+  return launch_lattice<PolH2>(ax, ay, az, nx, ny, nz, h_vols, h_tables, h_dims, n_vol, packed, out, sign, stream);
+}
 extern "C" int64_t surf_sdf_f16_packed_bytes(void) { return stream_bytes<PolH2>() + TAIL_FLOATS * 4; }
 extern "C" int64_t surf_sdf_f16_scratch_bytes(int64_t n_points) { return scratch_bytes<PolH2>(n_points); }
 extern "C" int surf_sdf_pack_weights_f16(const float* const* h_W, const float* const* h_b, unsigned char* out) {

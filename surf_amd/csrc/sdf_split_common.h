@@ -150,8 +150,10 @@ __device__ __forceinline__ void slot_pin(uint32_t&) {}
 // refuses such a build): 13 of the 20 slices never leave the CU.
 // f16x2: 15 (504 registers): all 20 stay on the CU and only the feature Jacobian still makes the round trip.
 // Measured (round 3, half image, same box): bf16x3 61.5 -> 58.6 ms with 10, f16x2 42.9 -> 37.7 ms with 15.
+// (round 5, with R0: 9 - the positional-encoding fragments stay live through the reverse sweep, 24 registers; layers 4, 3, 2 on the
+// CU, layer 1 through the scratch slot, layer 0 recomputed)
 #ifndef SURF_SDF_REG_SLICES_BF3
-#define SURF_SDF_REG_SLICES_BF3 10
+#define SURF_SDF_REG_SLICES_BF3 9
 #endif
 #ifndef SURF_SDF_REG_SLICES_H2
 #define SURF_SDF_REG_SLICES_H2 15
@@ -159,7 +161,10 @@ __device__ __forceinline__ void slot_pin(uint32_t&) {}
 
 struct PolBf3 {
   // NA: accumulator chains (two independent ones measured no faster); PF: k-steps of LDS read-ahead (2, 3: no faster)
-  static constexpr int NP = 3, NA = 1, PF = 1;
+#ifndef SURF_SDF_NA_BF3
+#define SURF_SDF_NA_BF3 1
+#endif
+  static constexpr int NP = 3, NA = SURF_SDF_NA_BF3, PF = 1;
   static constexpr int occ(bool) { return 1; }  // three-piece activations need the whole register file
   static constexpr int nslot(bool) { return SURF_SDF_NSLOT_BF3; }  // LDS ring length (36 KB slots)
   static constexpr int REG_SLICES = SURF_SDF_REG_SLICES_BF3;
@@ -194,6 +199,13 @@ struct PolBf3 {
     return x;
   }
   static constexpr bool FUSED_SUB = false;  // (no fp32 instruction reads a bf16 half in place)
+  // Residuals of the split on the matrix pipe (K_MRES / K_PACKT), round 5 - measured and OFF: -35 % plain VALU instructions per tile
+  // (7,993 -> 5,216) for +6.8 % MFMAs (2,538 -> 2,710), bit-identical results, and the gradient kernel got SLOWER, 114.4 -> 116.2 ms
+  // same-box (forward-only 52.7 -> 53.9): the sweeps are not bound by the number of VALU instructions in their gaps (DESIGN K9b).
+#ifndef SURF_SDF_MRES_BF3
+#define SURF_SDF_MRES_BF3 0
+#endif
+  static constexpr bool MRES = SURF_SDF_MRES_BF3;
   // The network runs in units of the softplus exponent: pre-activations u = 100 log2(e) t, activations z = y 100 / ln 2
   // = max(u, 0) + log2(1 + 2^-|u|).  Because 100 log2(e) x ln(2) / 100 = 1, every hidden matrix is UNCHANGED (u' = W z + c b):
   // the packer scales only the biases and the input (positional-encoding / feature) columns by c = 100 log2 e and row 0 of
@@ -251,6 +263,7 @@ struct PolH2 {
   // v - (the two halves of p as floats), one v_fma_mix_f32 per element (an fp32 FMA that reads an fp16 half directly: no
   // conversion instruction): fma(half, -1, v) is exact in the half and rounds once, like the subtraction it replaces.
   static constexpr bool FUSED_SUB = true;
+  static constexpr bool MRES = false;  // one residual, one v_fma_mix per element: nothing to move
   static constexpr bool PRESCALED = false;
   static __device__ __forceinline__ f32x2 sub_piece(f32x2 v, uint32_t p) {
     f32x2 r;
@@ -298,6 +311,11 @@ struct SdfArgs {
   float* sdf;
   float* grad;
   float* scratch;
+  // lattice mode (pts == nullptr, forward only; surf_sdf_lattice_*): point i = (ax[i / (ny nz)], ay[(i / nz) % ny], az[i % nz]) from
+  // the three axis arrays - no point tensor is written or read - and sdf[i] = out_sign * value (extract_geometry's u = -sdf)
+  const float* lat_axes[3];
+  int lat_ny, lat_nz;
+  float out_sign;
 };
 
 __device__ __forceinline__ f32x4 bload(rsrc_t r, int voff, int soff) {
@@ -403,14 +421,23 @@ enum MiniKind : int {
   K_Y0, K_RCP, K_SEL, K_SIG,                  // layer 5: y0 += w6 h | 1 / d | (t >= 0 ? 1 : e) | h' w6
   K_EXPN, K_MULG,                             // reverse sweep: e = 2^-u | delta = G / d
   K_PACK, K_EXPAND, K_SUB,                    // operand split: piece i = pack(v) | its exact value | v -= that
-  K_SUBP                                      // ... or both in one where an fp32 instruction reads the packed halves (f16x2)
+  K_SUBP,                                     // ... or both in one where an fp32 instruction reads the packed halves (f16x2)
+  // Matrix-pipe residuals (round 5, P::MRES): the tile's values stay an accumulator tile `vt`; after piece i of ALL pairs is packed,
+  // vt -= (piece i) as two MFMAs with a constant "minus identity" A operand (one per 16-row k-step of the tile; bit-identical to
+  // the VALU subtraction, scripts/microbench/mfma_residual.hip); piece i + 1 of every pair is then packed from vt.
+  K_MRES,                                     // arg = 2 lvl + s: vt = mfma(-I_s, piece lvl of fragment s, vt)
+  K_PACKT                                     // arg = lvl: piece lvl of pair q = pack(vt[2q], vt[2q + 1])
 };
 constexpr int MAX_MINI = 24, MAX_SLOTS = 8 * MAX_MINI;
 struct MiniProg { int n; int kind[MAX_MINI]; int arg[MAX_MINI]; int cost[MAX_MINI]; };
 constexpr void mini_add(MiniProg& mp, int kind, int arg, int cost) {
   mp.kind[mp.n] = kind; mp.arg[mp.n] = arg; mp.cost[mp.n] = cost; ++mp.n;
 }
-constexpr void mini_add_split(MiniProg& mp, int np, bool fused_sub) {
+constexpr void mini_add_split(MiniProg& mp, int np, bool fused_sub, bool mres = false) {
+  if (mres) {  // per pair only piece 0 (and the value into the tile); weave() appends the tile-wide tail
+    mini_add(mp, K_PACK, 0, 4);
+    return;
+  }
   for (int i = 0; i < np; ++i) {
     mini_add(mp, K_PACK, i, 4);
     if (i + 1 < np && fused_sub) mini_add(mp, K_SUBP, i, 8);
@@ -418,8 +445,11 @@ constexpr void mini_add_split(MiniProg& mp, int np, bool fused_sub) {
   }
 }
 // the woven sequence of a tile's `pairs` pairs: slot s = mini-phase j[s] of pair q[s] (stream q & 1)
-struct SlotProg { int n; int q[MAX_SLOTS]; int j[MAX_SLOTS]; int cost[MAX_SLOTS]; };
-constexpr SlotProg weave(MiniProg mp, int pairs, int store_cost) {
+// (kind / arg of a slot; q = -1: a tile-wide slot; j: position in the pair's own sequence, the tail's pieces continuing it)
+struct SlotProg { int n; int q[MAX_SLOTS]; int j[MAX_SLOTS]; int cost[MAX_SLOTS]; int kind[MAX_SLOTS]; int arg[MAX_SLOTS]; int per_pair; };
+// mres_np > 0: the per-pair programs end with piece 0 (K_PACK 0); the tail is, for every further piece lvl = 1 .. mres_np - 1:
+// K_MRES (lvl - 1, s = 0), K_MRES (lvl - 1, s = 1), then K_PACKT lvl of pairs 0 .. pairs - 1.
+constexpr SlotProg weave(MiniProg mp, int pairs, int store_cost, int mres_np = 0) {
   SlotProg sp{};
   const int per = (pairs / 2) * mp.n, lag = mp.n | 1;  // stream B starts `lag` half-steps after stream A
   int ia = 0, ib = 0;
@@ -428,8 +458,21 @@ constexpr SlotProg weave(MiniProg mp, int pairs, int store_cost) {
     const int i = take_a ? ia++ : ib++;
     const int q = 2 * (i / mp.n) + (take_a ? 0 : 1), j = i % mp.n;
     sp.q[sp.n] = q; sp.j[sp.n] = j;
+    sp.kind[sp.n] = mp.kind[j]; sp.arg[sp.n] = mp.arg[j];
     sp.cost[sp.n] = mp.cost[j] + ((j == mp.n - 1 && (q & 1)) ? store_cost : 0);
     ++sp.n;
+  }
+  sp.per_pair = mp.n;
+  for (int lvl = 1; lvl < mres_np; ++lvl) {
+    for (int s2 = 0; s2 < 2; ++s2) {
+      sp.q[sp.n] = -1; sp.j[sp.n] = 0; sp.kind[sp.n] = K_MRES; sp.arg[sp.n] = 2 * (lvl - 1) + s2; sp.cost[sp.n] = 0;
+      ++sp.n;
+    }
+    for (int q = 0; q < pairs; ++q) {
+      sp.q[sp.n] = q; sp.j[sp.n] = mp.n + lvl - 1; sp.kind[sp.n] = K_PACKT; sp.arg[sp.n] = lvl; sp.cost[sp.n] = 4;
+      ++sp.n;
+    }
+    sp.per_pair = mp.n + lvl;
   }
   return sp;
 }
@@ -463,8 +506,35 @@ constexpr GapPlan plan_gaps(int nks, int nm, int np, int n_dma, int deadline, Sl
   for (bool done = sp.n == 0; !done;) {  // fewest mini-phases of one stream per gap first, then the smallest budget
     for (cap = 24; cap <= 32 + 8 * per && !done; cap += 4) {
       int g = 0, used = fixed[0], cnt[2] = {0, 0};
-      bool ok = true;
+      int mres_gap = -1;
+      bool ok = true, after_mres = false;
       for (int s = 0; s < sp.n && ok; ++s) {
+        if (sp.kind[s] == K_MRES) {
+          // a residual MFMA: at most one per gap (the second of a level depends on the first), behind what the gap already
+          // holds; whatever follows it in the gap runs in ITS 32 cycles: a fresh budget
+          if (mres_gap == g) {
+            if (g + 1 >= deadline) { ok = false; break; }
+            ++g; used = fixed[g]; cnt[0] = cnt[1] = 0;
+          }
+          at[s] = g;
+          mres_gap = g;
+          used = 0; cnt[0] = cnt[1] = 0;
+          after_mres = true;
+          continue;
+        }
+        if (sp.kind[s] == K_PACKT) {
+          // reads the residual tile: not in the gap of the MFMA that writes it (its result is 32+ cycles away)
+          if (after_mres && mres_gap == g) {
+            if (g + 1 >= deadline) { ok = false; break; }
+            ++g; used = fixed[g]; cnt[0] = cnt[1] = 0;
+          }
+          after_mres = false;
+          while (used + sp.cost[s] > cap && g + 1 < deadline) { ++g; used = fixed[g]; cnt[0] = cnt[1] = 0; }
+          if (used + sp.cost[s] > cap) ok = false;
+          at[s] = g;
+          used += sp.cost[s];
+          continue;
+        }
         const int st = sp.q[s] & 1;
         while ((used + sp.cost[s] > cap || cnt[st] >= per) && g + 1 < deadline) { ++g; used = fixed[g]; cnt[0] = cnt[1] = 0; }
         if (used + sp.cost[s] > cap || cnt[st] >= per) ok = false;
@@ -490,21 +560,39 @@ constexpr GapPlan plan_gaps(int nks, int nm, int np, int n_dma, int deadline, Sl
 // What every plan is checked for at compile time (static_assert in FwdPlan / BwdPlan): each pair's mini-phases 0 .. n-1 appear
 // exactly once and in order in the woven sequence; the slots are dealt out in order (first[] non-decreasing, from 0 to all of
 // them) and all of them before the deadline gap; no gap holds more mini-phases of one stream than the plan reports.
+// With matrix-pipe residuals (K_MRES / K_PACKT slots) also: the residual MFMAs of level lvl come after piece lvl of every pair
+// and before piece lvl + 1 of any, s = 0 before s = 1 and in different gaps, and no piece is packed in the gap of the MFMA that
+// forms its residual.
 constexpr bool plan_ok(const GapPlan& pl, const SlotProg& sp, const MiniProg& mp, int ng, int deadline) {
   if (deadline > ng) deadline = ng;
   int next[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int mres_seen = 0;  // residual MFMAs so far: 2 lvl + s is the next one expected
   for (int s = 0; s < sp.n; ++s) {
+    if (sp.kind[s] == K_MRES) {
+      if (sp.arg[s] != mres_seen) return false;
+      for (int q = 0; q < 8; ++q)  // piece lvl of every pair is packed, none of the next one
+        if (next[q] != mp.n + sp.arg[s] / 2) return false;
+      ++mres_seen;
+      continue;
+    }
     if (sp.q[s] < 0 || sp.q[s] >= 8 || sp.j[s] != next[sp.q[s]]) return false;
+    if (sp.kind[s] == K_PACKT && (sp.j[s] != mp.n + sp.arg[s] - 1 || mres_seen != 2 * sp.arg[s])) return false;
     ++next[sp.q[s]];
   }
   for (int q = 0; q < 8; ++q)
-    if (sp.n > 0 && next[q] != mp.n) return false;
+    if (sp.n > 0 && next[q] != sp.per_pair) return false;
   if (pl.first[0] != 0 || (ng > 0 && pl.first[ng] != sp.n) || (sp.n > 0 && pl.first[deadline] != sp.n)) return false;
   for (int g = 0; g < ng; ++g) {
     if (pl.first[g] > pl.first[g + 1]) return false;
-    int cnt[2] = {0, 0};
-    for (int s = pl.first[g]; s < pl.first[g + 1]; ++s) ++cnt[sp.q[s] & 1];
-    if (cnt[0] > pl.per_stream || cnt[1] > pl.per_stream) return false;
+    int cnt[2] = {0, 0}, n_mres = 0;
+    bool mres_here = false;
+    for (int s = pl.first[g]; s < pl.first[g + 1]; ++s) {
+      if (sp.kind[s] == K_MRES) { ++n_mres; mres_here = true; cnt[0] = cnt[1] = 0; continue; }
+      if (sp.kind[s] == K_PACKT) { if (mres_here) return false; continue; }
+      ++cnt[sp.q[s] & 1];
+      if (cnt[0] > pl.per_stream || cnt[1] > pl.per_stream) return false;
+    }
+    if (n_mres > 1) return false;
   }
   return true;
 }

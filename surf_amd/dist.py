@@ -55,6 +55,29 @@ def gather_records(record, dst=0):
     return out
 
 
+def gather_rows(t, dst=0):
+    """Concatenate every rank's rows (dim 0, possibly different counts per rank) on `dst`, in rank order; None elsewhere.
+    The data-path collective of the single-scene split (bench.py --split rays: rank r renders rays [r R / N, (r + 1) R / N) of ONE
+    image, the image is stitched on rank 0).  RCCL: one padded all_gather of device tensors over xGMI; gloo (tests): through
+    host copies (gloo has no device all_gather)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    world, rank = dist.get_world_size(), dist.get_rank()
+    backend = dist.get_backend()
+    counts = [None] * world
+    dist.all_gather_object(counts, int(t.shape[0]))
+    m = max(counts)
+    src = t if backend == "nccl" else t.cpu()
+    if src.shape[0] < m:
+        pad = torch.zeros((m - src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        src = torch.cat([src, pad])
+    parts = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(parts, src.contiguous())
+    if rank != dst:
+        return None
+    return torch.cat([p[:c] for p, c in zip(parts, counts)]).to(t.device)
+
+
 def all_reduce_gradients(params, bucket_bytes=25 << 20):
     """Average `.grad` over the ranks (what DistributedDataParallel does under loss.backward(), runner.py:102,163): the
     gradients are flattened into buckets of at most `bucket_bytes` (DDP's default 25 MB: the ~1.4 M parameters of SuRF, 5.6 MB,

@@ -443,26 +443,34 @@ class ImplicitSurface(nn.Module):
         return self.render_scene(rays_o, rays_d, near, far, scene, cos_anneal_ratio)
 
     def sdf_grid(self, scene, bound_min, bound_max, resolution):
-        """The lattice of extract_geometry (:337-351): u[x,y,z] = -sdf, evaluated by the forward-only kernel."""
+        """The lattice of extract_geometry (:337-351): u[x,y,z] = -sdf, evaluated by the forward-only kernel.  With the split
+        kernels (the defaults) the kernel forms every point from its lattice index and the three axis arrays (torch.linspace's
+        values, :338-340) and writes -sdf straight into `u`, marching cubes' input: no point tensor (1.6 GB written and re-read at
+        512^3 before round 5), no negated copy.  sdf_precision = f32 (the fp32-MFMA kernel) still takes point tensors."""
         dev = scene.device
         sdf_w, _ = self.packed_weights(dev)
         bmin = bound_min.detach().to("cpu", torch.float32)
         bmax = bound_max.detach().to("cpu", torch.float32)
         axes = [torch.linspace(float(bmin[a]), float(bmax[a]), resolution).to(dev) for a in range(3)]
         u = torch.empty(resolution, resolution, resolution, dtype=torch.float32, device=dev)
-        slab = max(1, (1 << 24) // (resolution * resolution))      # ~16M points per launch
+        lattice_mode = self.sdf_precision != "f32"
+        per_launch = (1 << 31) - 1 if lattice_mode else (1 << 24)           # points per launch
+        slab = max(1, per_launch // (resolution * resolution))
         for x0 in range(0, resolution, slab):
-            xs = axes[0][x0:x0 + slab]
-            xx, yy, zz = torch.meshgrid(xs, axes[1], axes[2], indexing="ij")
-            pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1).contiguous()
+            nx = min(slab, resolution - x0)
             if self.kernel_events is not None:
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-            sdf, _ = ops.sdf_mlp(pts, scene.sv, sdf_w, want_grad=False)
+            if lattice_mode:
+                ops.sdf_lattice(axes, scene.sv, sdf_w, u, x0, nx, sign=-1.0)
+            else:
+                xx, yy, zz = torch.meshgrid(axes[0][x0:x0 + nx], axes[1], axes[2], indexing="ij")
+                pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], dim=-1).contiguous()
+                sdf, _ = ops.sdf_mlp(pts, scene.sv, sdf_w, want_grad=False)
+                u[x0:x0 + nx] = -sdf.view(nx, resolution, resolution)
             if self.kernel_events is not None:
                 b.record()
                 self.kernel_events.append(("sdf_grid", a, b))
-            u[x0:x0 + slab] = -sdf.view(len(xs), resolution, resolution)
         return u
 
     def extract_geometry(self, volumes, sparse_idxes, bound_min, bound_max, resolution, threshold, scene=None):
@@ -492,9 +500,6 @@ class ImplicitSurface(nn.Module):
         reference's order (per 256-ray block, stages inner: draw_jitter), so a seeded run reproduces the reference's
         sample positions whatever `chunk` is."""
         outputs = {}
-        if extract_geometry:
-            v, t = self.extract_geometry(None, None, bound_min, bound_max, mesh_resolution, threshold, scene=scene)
-            outputs["vertices"], outputs["triangles"] = v, t
         height, width = int(hw[0]), int(hw[1])
         cols, nrms, sdeps, rdeps = [], [], [], []
         jitter = self.draw_jitter(rays_o.shape[0], ref_chunk=256) if self.perturb > 0 else None
@@ -506,16 +511,49 @@ class ImplicitSurface(nn.Module):
             nrms.append(o["normal_val"])
             sdeps.append(o["sdf_depth"])
             rdeps.append(o["render_depth"])
-        color_fine = torch.cat(cols).cpu()
+        # Round 5: the four image outputs leave the device as ONE pinned buffer on a side stream while the lattice kernels of
+        # extract_geometry run (the reference's order - geometry first, then one .cpu() per output, :363-399 - serialises 15 MB
+        # of pageable copies behind 270 ms of kernels); the host waits for the copy once, after the mesh is there.
+        dev_imgs = torch.cat([torch.cat(cols), torch.cat(nrms), torch.cat(sdeps).reshape(-1, 1), torch.cat(rdeps).reshape(-1, 1)], dim=1)
+        host_imgs, copied = self._to_host_async(dev_imgs)
+        if extract_geometry:
+            v, t = self.extract_geometry(None, None, bound_min, bound_max, mesh_resolution, threshold, scene=scene)
+            outputs["vertices"], outputs["triangles"] = v, t
+        if copied is not None:
+            copied.synchronize()
+        host_imgs = host_imgs.clone()                        # (the pinned staging buffer is reused by the next call)
+        color_fine = host_imgs[:, 0:3].contiguous()
         outputs["color_fine"] = color_fine
         outputs["img_fine"] = (color_fine.numpy().reshape([height, width, 3]) * 256).clip(0, 255)
-        normal_img = torch.cat(nrms).cpu().numpy()
+        normal_img = host_imgs[:, 3:6].numpy()
         rot = scene.cams.rot_ref
         outputs["normal_img"] = (np.matmul(rot[None, :, :], normal_img[:, :, None]).reshape([height, width, 3]) * 128
                                  + 128).clip(0, 255)
-        outputs["sdf_depth"] = torch.cat(sdeps).cpu().numpy().reshape([height, width])
-        outputs["render_depth"] = torch.cat(rdeps).cpu().numpy().reshape([height, width])
+        outputs["sdf_depth"] = host_imgs[:, 6].numpy().reshape([height, width]).copy()
+        outputs["render_depth"] = host_imgs[:, 7].numpy().reshape([height, width]).copy()
         return outputs
+
+    def _to_host_async(self, t):
+        """Device tensor -> (pinned host tensor, event) copied on a side stream that waits for the work queued so far; the caller
+        synchronises on the event before reading.  CPU tensors pass through (event None)."""
+        if not t.is_cuda:
+            return t, None
+        key = (tuple(t.shape), t.dtype)
+        buf = getattr(self, "_pinned", {}).get(key)
+        if buf is None:
+            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._pinned = {key: buf}                         # one staging buffer (the last image size)
+        if getattr(self, "_copy_stream", None) is None or self._copy_stream.device != t.device:
+            self._copy_stream = torch.cuda.Stream(device=t.device)
+        ready = torch.cuda.Event()
+        ready.record()
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(ready)
+            buf.copy_(t, non_blocking=True)
+            t.record_stream(self._copy_stream)
+            done = torch.cuda.Event()
+            done.record(self._copy_stream)
+        return buf, done
 
     def val_chunk_rays(self, device):
         """Rays per launch of `validate`: render.val_chunk (default 2^19), at most what half of the free device memory holds."""

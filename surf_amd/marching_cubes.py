@@ -19,4 +19,7 @@ def marching_cubes(u, threshold=0.0):
         u = torch.from_numpy(np.ascontiguousarray(np.asarray(u, dtype=np.float32))).cuda()
     u = u.float().contiguous()
     v, t = ops.marching_cubes(u, float(threshold))
-    return v.cpu().numpy(), t.cpu().numpy().astype(np.int64)
+    # one device-to-host copy for both arrays (int64 triangle indices formed on the device: same bytes as float64 vertices)
+    both = torch.cat([v.reshape(-1).view(torch.int64), t.reshape(-1).to(torch.int64)]).cpu()
+    nv = v.numel()
+    return both[:nv].view(torch.float64).numpy().reshape(-1, 3), both[nv:].numpy().reshape(-1, 3)

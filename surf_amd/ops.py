@@ -383,6 +383,24 @@ def sdf_mlp(pts, volumes, packed, mask=None, want_grad=True, compact_active=True
     return sdf, grad
 
 
+def sdf_lattice(axes, volumes, packed, out, x0, nx, sign=-1.0):
+    """out[x0:x0+nx] (a slab of the (X, Y, Z) lattice tensor `out`) = sign * sdf on the lattice axes[0][x0:x0+nx] x axes[1] x
+    axes[2], by the forward-only split kernel in lattice mode (no point tensor: implicit_surface.py:337-351's meshgrid / cat
+    is the kernel's index arithmetic).  Split precisions only."""
+    precision = sdf_packed_precision(packed)
+    if precision == "f32":
+        raise ValueError("sdf_lattice: bf16x3 / f16x2 weights only (the fp32-MFMA kernel takes point tensors)")
+    for ax in axes:
+        _chk(ax, torch.float32, "lattice axis")
+    _chk(out, torch.float32, "lattice values")
+    ny, nz = int(axes[1].shape[0]), int(axes[2].shape[0])
+    assert tuple(out.shape) == (int(axes[0].shape[0]), ny, nz) and 0 <= x0 and x0 + nx <= out.shape[0]
+    name = f"surf_sdf_lattice_{precision}"
+    rc = getattr(_lib.lib(), name)(_p(axes[0][x0:]), _p(axes[1]), _p(axes[2]), int(nx), ny, nz, volumes._vp, volumes._tp, volumes._dp,
+                                   volumes.n, _p(packed), _p(out[x0:]), ctypes.c_float(sign), _stream())
+    _lib.check(rc, name)
+
+
 def sdf_smooth_pack_weights_host(layers):
     """[(W_l, b_l)] effective matrices -> fp32 image of the SDF network for surf_sdf_smooth (both orientations of every matrix)."""
     sdf_pack_weights_host(layers)  # shape validation only

@@ -45,8 +45,46 @@ def test_two_rank_gloo_sharding_and_timing(tmp_path):
     assert res["tmax"] >= max(r["dt"] for r in res["recs"]) - 1e-9 and res["tmax"] >= 0.09
 
 
+GATHER_WORKER = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, %r)
+    import torch
+    from surf_amd import dist as D
+    rank, local_rank, world = D.init_from_env(backend="gloo")
+    R = 11                                              # an image of 11 rays split 5 + 6 (bench.py --split rays: r R / N .. (r + 1) R / N)
+    r0, r1 = rank * R // world, (rank + 1) * R // world
+    mine = torch.arange(R * 3, dtype=torch.float32).reshape(R, 3)[r0:r1] * 0.5
+    whole = D.gather_rows(mine)
+    if rank == 0:
+        print(json.dumps({"rows": whole.shape[0], "equal": bool(torch.equal(whole, torch.arange(R * 3, dtype=torch.float32).reshape(R, 3) * 0.5))}))
+    else:
+        assert whole is None
+    D.shutdown()
+""") % ROOT
+
+
+def test_two_rank_gloo_gather_rows_stitches_uneven_shares(tmp_path):
+    """The single-scene split's data-path collective (surf_amd.dist.gather_rows) over gloo, world_size 2, uneven row counts."""
+    script = tmp_path / "gather_worker.py"
+    script.write_text(GATHER_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    import json
+    assert json.loads(outs[0][0].strip().splitlines()[-1]) == {"rows": 11, "equal": True}
+
+
 def test_single_process_helpers():
     from surf_amd import dist as D
+    import torch
+    t = torch.arange(6.0).reshape(2, 3)
+    assert D.gather_rows(t) is t
     assert D.shard_scenes(15, 3, 8) == [3, 11]
     assert D.max_over_ranks(1.5) == 1.5
     assert D.gather_records({"a": 1}) == [{"a": 1}]

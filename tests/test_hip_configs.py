@@ -142,3 +142,20 @@ def test_bench_two_ranks_share_the_gpu_train():
     assert r["n_gpus"] == 2 and r["config"]["parallelism"] == "ddp2" and r["config"]["rays_per_rank_step"] == 128
     assert r["gradient_allreduce_ms"] > 0 and r["loss"] == r["loss"] and r["collective_backend"].startswith("gloo")
     assert abs(r["value"] - 2 * 128 * r["steps_per_s"]) < 1e-6 * r["value"]
+
+
+def test_bench_single_scene_split_over_two_ranks_is_bit_equal():
+    """SURVEY 8e's single-scene split: `bench.py --split rays --gpus 2` - ONE image on two ranks (both on cuda:0,
+    gloo), rank r renders its half of the pixel rays and its x-range of the mesh lattice, rank 0 stitches.  Rays and lattice points
+    are independent, so the stitched image and the stitched `u` lattice must be BIT-equal to rank 0's own single-rank results."""
+    r = _bench(["--split", "rays", "--check-split", "--gpus", "2", "--backend", "gloo", "--one-gpu", "--steps", "2", "--warmup", "1",
+                "--height", "48", "--width", "64", "--base-dim", "16", "--mesh-grid", "48"])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["config"]["split"] == "rays"
+    assert r["config"]["rays_per_rank"] == [1536, 1536] and r["config"]["rays_per_step"] == 48 * 64
+    assert abs(r["value"] - 48 * 64 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+    assert r["split"]["check"] == {"image_bit_equal": True, "lattice_bit_equal": True}
+    assert r["split"]["lattice"]["resolution"] == 48 and r["split"]["lattice"]["sdf_ms"] > 0
+    # ... and N = 1 through the same code path
+    r1 = _bench(["--split", "rays", "--check-split", "--gpus", "1", "--steps", "1", "--warmup", "1", "--height", "48", "--width", "64",
+                 "--base-dim", "16", "--mesh-grid", "32"])
+    assert r1["n_gpus"] == 1 and r1["split"]["check"]["image_bit_equal"] and r1["split"]["check"]["lattice_bit_equal"]
