@@ -407,9 +407,12 @@ int surf_spconv(const float* in, int cin, const int32_t* in_table, int D_in, con
  */
 int64_t surf_spconv_packed_bytes(int cin, int cout);
 int surf_spconv_pack_weights(const float* weight, int cin, int cout, void* packed, void* stream);
+/* bf16_operands != 0 (training under train_precision = bf16, BASELINE configs[3]): both operands rounded to bf16 - the first
+ * piece of the same image, the first piece of the gathered rows - one product per k-step with fp32 accumulation instead of
+ * the six of the exact split. */
 int surf_spconv_mfma(const float* in, int cin, const int32_t* in_table, int D_in, const int32_t* out_coords, int64_t n_out,
                      int mode, const void* packed, int cout, const float* bn_scale, const float* bn_shift,
-                     const float* skip, float* out, void* stream);
+                     const float* skip, float* out, int bf16_operands, void* stream);
 
 /*
  * BatchNorm with BATCH statistics over the voxel rows x (n, C) (train mode of spnn.BatchNorm, reg_network.py:14-15,28-29;

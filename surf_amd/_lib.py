@@ -108,7 +108,7 @@ SIGNATURES = {
     "surf_spconv_wgrad": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr]),
     "surf_spconv_packed_bytes": (c_i64, [c_int, c_int]),
     "surf_spconv_pack_weights": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr]),
-    "surf_spconv_mfma": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_spconv_mfma": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
     "surf_coords_bbox": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
     "surf_mark_down_sites": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_int, c_ptr]),
     "surf_sites_from_keys": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr]),

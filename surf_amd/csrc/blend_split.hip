@@ -74,9 +74,15 @@ struct FragT { u32x4 p[NP]; };  // B operand of one 16-wide k-step: NP pieces x 
 #define SURF_BLEND_MRES 1
 #endif
 
+// ... per call site of make_frags / elu_make_frags (bit k of the mask = site k in source order; default: every site).  Round 5's
+// A/B of "residual MFMAs only at the wide layers' sites" (the ones with >= 16 values a tile): see DESIGN K10b.
+#ifndef SURF_BLEND_MRES_MASK
+#define SURF_BLEND_MRES_MASK 0x3ff
+#endif
 struct BPolBf3 {
   static constexpr int NP = 3, ID = 1, BB = NP * 1024, LANE_BYTES = 16;
   static constexpr bool MRES = SURF_BLEND_MRES != 0;
+  static constexpr bool mres_at(int site) { return MRES && ((SURF_BLEND_MRES_MASK >> site) & 1); }
 #ifndef SURF_BLEND_REG_VIEWS_BF3
 #define SURF_BLEND_REG_VIEWS_BF3 2
 #endif
@@ -110,6 +116,7 @@ struct BPolBf3 {
 struct BPolH2 {
   static constexpr int NP = 2, ID = 2, BB = NP * 1024, LANE_BYTES = 16;
   static constexpr bool MRES = false;  // one residual level, formed by v_fma_mix-style arithmetic: nothing to gain
+  static constexpr bool mres_at(int) { return false; }
 #ifndef SURF_BLEND_REG_VIEWS_H2
 #define SURF_BLEND_REG_VIEWS_H2 3
 #endif
@@ -171,6 +178,7 @@ template <int NUSED> __device__ __forceinline__ void BPolH2::mma_lds(f32x16& acc
 struct BPolF32 {
   static constexpr int NP = 1, ID = 3, BB = 2048, LANE_BYTES = 32;
   static constexpr bool MRES = false;
+  static constexpr bool mres_at(int) { return false; }
   static constexpr int REG_VIEWS = 0;
   struct Frag { float v[8]; };
   static __device__ __forceinline__ void set_pair(Frag& f, int pr, float a, float b) { f.v[2 * pr] = a; f.v[2 * pr + 1] = b; }
@@ -327,9 +335,9 @@ __device__ __forceinline__ void split_tile_mres(const Ctx& c, f32x16 r, typename
   }
 }
 // N values -> fragments (policy's way)
-template <class P, int N, int NF>
+template <class P, int N, int NF, int SITE>
 __device__ __forceinline__ void make_frags(const Ctx& c, const float* v, typename P::Frag* f) {
-  if constexpr (P::MRES && N >= 3) {
+  if constexpr (P::mres_at(SITE) && N >= 3) {
     constexpr int N0 = N > 16 ? 16 : N;  // tile by tile (two k-steps each)
     f32x16 r;
 #pragma unroll
@@ -348,9 +356,9 @@ __device__ __forceinline__ void make_frags(const Ctx& c, const float* v, typenam
   }
 }
 // ELU of the first N registers of an accumulator tile -> fragments
-template <class P, int N>
+template <class P, int N, int SITE>
 __device__ __forceinline__ void elu_make_frags(const Ctx& c, const f32x16& acc, typename P::Frag* f) {
-  if constexpr (P::MRES) {
+  if constexpr (P::mres_at(SITE)) {
     f32x16 r;
 #pragma unroll
     for (int i = 0; i < 16; ++i) r[i] = i < N ? elu_t(acc[i]) : 0.0f;
@@ -648,7 +656,7 @@ __device__ __forceinline__ bool pass1_finish(const Ctx& c, const Geo& geo, float
     frags_from<P, 2, 1>(bin, &fb);
     f32x16 acc1 = bias_row<P>(c, B_RD0);
     mma_layer<P, L_RD0, 0, 1>(c, acc1, &fb);
-    elu_make_frags<P, 8>(c, acc1, &f8);
+    elu_make_frags<P, 8, 0>(c, acc1, &f8);
     f32x16 acc2 = bias_row<P>(c, B_RD2);
     mma_layer<P, L_RD2, 0, 1>(c, acc2, &f8);
     // rows of half 1 beyond its 8 channels carry zero weights and zero bias: elu(0) = 0
@@ -780,7 +788,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       G0a = bias_row<P>(c, B_B0_T0);
       G0b = bias_row<P>(c, B_B0_T1);
       Frag fm[3];
-      make_frags<P, 24, 3>(c, mv, fm);
+      make_frags<P, 24, 3, 1>(c, mv, fm);
       mma_layer<P, L_B0S, 0, 3>(c, G0a, fm);
       mma_layer<P, L_B0S, 1, 3>(c, G0b, fm);
     }
@@ -800,7 +808,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       f32x16 a0 = G0a, a1 = G0b;
       {
         Frag fl[2];
-        make_frags<P, 12, 2>(c, st.floc, fl);
+        make_frags<P, 12, 2, 2>(c, st.floc, fl);
         mma_layer<P, L_B0V, 0, 2>(c, a0, fl);
         mma_layer<P, L_B0V, 1, 2>(c, a1, fl);
       }
@@ -808,11 +816,11 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       f32x16 ax2 = bias_row<P>(c, B_B2);
       {
         Frag hf[2];
-        elu_make_frags<P, 16>(c, a0, hf);
+        elu_make_frags<P, 16, 3>(c, a0, hf);
         mma_blk<P, L_B2, 0, 0>(c, ax2, hf[0]);
         mma_blk<P, L_B2, 1, 0>(c, ax2, hf[1]);
         SURF_PHASE();
-        elu_make_frags<P, 16>(c, a1, hf);
+        elu_make_frags<P, 16, 4>(c, a1, hf);
         mma_blk<P, L_B2, 2, 0>(c, ax2, hf[0]);
         mma_blk<P, L_B2, 3, 0>(c, ax2, hf[1]);
         SURF_PHASE();
@@ -828,7 +836,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
         for (int r = 0; r < 16; ++r) at[r] = 0.f;
         {
           Frag xf[2];
-          make_frags<P, 16, 2>(c, x, xf);
+          make_frags<P, 16, 2, 5>(c, x, xf);
           mma_layer<P, L_V0, 0, 2>(c, at, xf);
         }
         const f32x16 bt = bias_row<P>(c, B_V0);
@@ -842,7 +850,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
 #pragma unroll
           for (int r = 0; r < 16; ++r) vraw = fmaf(dvis[r], t16[r], vraw);
           Frag tf[2];
-          make_frags<P, 16, 2>(c, t16, tf);
+          make_frags<P, 16, 2, 6>(c, t16, tf);
           mma_layer<P, L_V2, 0, 2>(c, ar, tf);
         }
         vraw += __shfl_xor(vraw, 32);
@@ -855,7 +863,7 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
       // the fragments of x itself and the scale is applied to the accumulator (16 FMAs instead of a second split).
       SURF_BT(5);
       Frag rf[3];
-      make_frags<P, 16, 2>(c, x, rf);
+      make_frags<P, 16, 2, 7>(c, x, rf);
       float vis2;
       {
         f32x16 aw;
@@ -877,13 +885,13 @@ __global__ __launch_bounds__(WPB * 64, WPB / 4) void blend_split_kernel(BlendArg
         f32x16 a16 = bias_row<P>(c, B_R0);
         {
           const float extra[3] = {h ? st.rd[0] : vis2, h ? st.rd[2] : st.rd[1], h ? 0.f : st.rd[3]};
-          make_frags<P, 3, 1>(c, extra, rf + 2);
+          make_frags<P, 3, 1, 8>(c, extra, rf + 2);
           mma_layer<P, L_R0, 0, 3>(c, a16, rf);
         }
         f32x16 a8 = bias_row<P>(c, B_R2);
         {
           Frag f8;
-          elu_make_frags<P, 8>(c, a16, &f8);
+          elu_make_frags<P, 8, 9>(c, a16, &f8);
           mma_layer<P, L_R2, 0, 1>(c, a8, &f8);
         }
         const f32x16 drgb4 = dot_row<P>(c, D_RGB4);

@@ -76,7 +76,11 @@ __global__ __launch_bounds__(256) void spconv_pack_kernel(const float* __restric
   for (int q = 0; q < 3; ++q) out[base + q * 64] = p[q];
 }
 
-template <int CIN, int COUT>
+// NPROD = 6: the exact three-way split, fp32-equivalent (inference, and training under train_precision = fp32).
+// NPROD = 1: BASELINE configs[3]'s bf16 policy (train_precision = bf16) - both operands rounded to bf16 (the first piece of the
+// same weight image, the first piece of the gathered rows), ONE product per k-step, fp32 accumulation: what autocast(bf16) gives a
+// convolution.  Used for the wide layers' forward and input gradients of a training step only.
+template <int CIN, int COUT, int NPROD>
 __global__ __launch_bounds__(256) void spconv_mfma_kernel(SpArgs a) {
   typedef Shape<CIN, COUT> S;
   constexpr int KS = S::KS, MT = S::MT, FRAGS = S::FRAGS;
@@ -137,22 +141,31 @@ __global__ __launch_bounds__(256) void spconv_mfma_kernel(SpArgs a) {
         u32x4 b[3];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          uint32_t q[3];
-          split3(xv[ks][j >> 1][2 * (j & 1)], xv[ks][j >> 1][2 * (j & 1) + 1], q);
-          b[0][j] = q[0]; b[1][j] = q[1]; b[2][j] = q[2];
+          if constexpr (NPROD == 1) {
+            b[0][j] = pack2(xv[ks][j >> 1][2 * (j & 1)], xv[ks][j >> 1][2 * (j & 1) + 1]);
+          } else {
+            uint32_t q[3];
+            split3(xv[ks][j >> 1][2 * (j & 1)], xv[ks][j >> 1][2 * (j & 1) + 1], q);
+            b[0][j] = q[0]; b[1][j] = q[1]; b[2][j] = q[2];
+          }
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
           const u32x4* __restrict__ wf = wl + (ks * MT + m) * 3 * 64;
-          const u32x4 a0 = wf[0], a1 = wf[64], a2 = wf[128];
 #define SURF_MF(x, y) \
   acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), acc[m], 0, 0, 0)
-          SURF_MF(a2, b[0]);  // smallest terms first
-          SURF_MF(a0, b[2]);
-          SURF_MF(a1, b[1]);
-          SURF_MF(a1, b[0]);
-          SURF_MF(a0, b[1]);
-          SURF_MF(a0, b[0]);
+          if constexpr (NPROD == 1) {
+            const u32x4 a0 = wf[0];
+            SURF_MF(a0, b[0]);
+          } else {
+            const u32x4 a0 = wf[0], a1 = wf[64], a2 = wf[128];
+            SURF_MF(a2, b[0]);  // smallest terms first
+            SURF_MF(a0, b[2]);
+            SURF_MF(a1, b[1]);
+            SURF_MF(a1, b[0]);
+            SURF_MF(a0, b[1]);
+            SURF_MF(a0, b[0]);
+          }
 #undef SURF_MF
         }
       }
@@ -212,7 +225,7 @@ extern "C" int surf_spconv_pack_weights(const float* weight, int cin, int cout, 
 
 extern "C" int surf_spconv_mfma(const float* in, int cin, const int32_t* in_table, int D_in, const int32_t* out_coords,
                                 int64_t n_out, int mode, const void* packed, int cout, const float* bn_scale,
-                                const float* bn_shift, const float* skip, float* out, void* stream) {
+                                const float* bn_shift, const float* skip, float* out, int bf16_operands, void* stream) {
   if (!in || !in_table || !out_coords || !packed || !out || n_out <= 0 || D_in < 1) return SURF_E_ARG;
   if (mode < 0 || mode > 2 || ((bn_scale == nullptr) != (bn_shift == nullptr))) return SURF_E_ARG;
   SpArgs a;
@@ -222,7 +235,10 @@ extern "C" int surf_spconv_mfma(const float* in, int cin, const int32_t* in_tabl
   if (blocks > 0x7fffffff) return SURF_E_LIMIT;
 #define X(CI, CO)                                                                                                  \
   if (cin == CI && cout == CO) {                                                                                   \
-    hipLaunchKernelGGL((spconv_mfma_kernel<CI, CO>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a); \
+    if (bf16_operands)                                                                                             \
+      hipLaunchKernelGGL((spconv_mfma_kernel<CI, CO, 1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a); \
+    else                                                                                                           \
+      hipLaunchKernelGGL((spconv_mfma_kernel<CI, CO, 6>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a); \
     return surf_check_launch();                                                                                    \
   }
   SPM_CASES(X)

@@ -299,43 +299,48 @@ __device__ __forceinline__ void up2_src(int i, int Dp, int& i0, int& i1, float& 
   l1 = src - (float)i0;
 }
 
-// VEC voxels along z per thread (VEC = 4 when D % 4 == 0: 16-byte stores; 704^3 is 1.4 GB of logits + 1.4 GB of table)
-template <int VEC>
+// VEC voxels along z per vector (VEC = 4 when D % 4 == 0: 16-byte stores; 704^3 is 1.4 GB of logits + 1.4 GB of table), NV vectors
+// per thread at a stride of the workgroup (round 5: 4 - fewer, longer workgroups for the 2.8 GB of stores)
+template <int VEC, int NV>
 __global__ __launch_bounds__(256) void dense_init_kernel(const float* __restrict__ prev, int D, float* __restrict__ dense,
                                                          int32_t* __restrict__ table) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)D * D * D;
-  const int64_t i0 = t * VEC;
-  if (i0 >= total) return;
-  // one 32-bit decomposition per thread (64-bit div / mod per voxel cost more than the whole upsample)
-  const unsigned zc = (unsigned)D / VEC, tu = (unsigned)t;
-  const int zb = (int)(tu % zc) * VEC, y = (int)((tu / zc) % (unsigned)D), x = (int)(tu / (zc * (unsigned)D));
-  float out[VEC];
+  const int64_t t0 = (int64_t)blockIdx.x * (256 * NV) + threadIdx.x;
+  // one 32-bit decomposition per vector (64-bit div / mod per voxel cost more than the whole upsample)
+  const unsigned zc = (unsigned)D / VEC;
 #pragma unroll
-  for (int q = 0; q < VEC; ++q) {
-    float v = 0.f;
-    if (prev) {
-      const int Dp = D / 2;
-      const int z = zb + q;
-      int x0, x1, y0, y1, z0, z1;
-      float lx, ly, lz;
-      up2_src(x, Dp, x0, x1, lx);
-      up2_src(y, Dp, y0, y1, ly);
-      up2_src(z, Dp, z0, z1, lz);
-      const float hx = 1.0f - lx, hy = 1.0f - ly, hz = 1.0f - lz;
-      auto P = [&](int xi, int yi, int zi) { return prev[((int64_t)xi * Dp + yi) * Dp + zi]; };
-      // ATen upsample_trilinear3d: w_d (w_h (w_w a + w_w b) + ...) with d = our x, h = y, w = z
-      v = hx * (hy * (hz * P(x0, y0, z0) + lz * P(x0, y0, z1)) + ly * (hz * P(x0, y1, z0) + lz * P(x0, y1, z1))) +
-          lx * (hy * (hz * P(x1, y0, z0) + lz * P(x1, y0, z1)) + ly * (hz * P(x1, y1, z0) + lz * P(x1, y1, z1)));
+  for (int k = 0; k < NV; ++k) {
+    const int64_t t = t0 + 256 * k, i0 = t * VEC;
+    if (i0 >= total) return;
+    const unsigned tu = (unsigned)t;
+    const int zb = (int)(tu % zc) * VEC, y = (int)((tu / zc) % (unsigned)D), x = (int)(tu / (zc * (unsigned)D));
+    float out[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      float v = 0.f;
+      if (prev) {
+        const int Dp = D / 2;
+        const int z = zb + q;
+        int x0, x1, y0, y1, z0, z1;
+        float lx, ly, lz;
+        up2_src(x, Dp, x0, x1, lx);
+        up2_src(y, Dp, y0, y1, ly);
+        up2_src(z, Dp, z0, z1, lz);
+        const float hx = 1.0f - lx, hy = 1.0f - ly, hz = 1.0f - lz;
+        auto P = [&](int xi, int yi, int zi) { return prev[((int64_t)xi * Dp + yi) * Dp + zi]; };
+        // ATen upsample_trilinear3d: w_d (w_h (w_w a + w_w b) + ...) with d = our x, h = y, w = z
+        v = hx * (hy * (hz * P(x0, y0, z0) + lz * P(x0, y0, z1)) + ly * (hz * P(x0, y1, z0) + lz * P(x0, y1, z1))) +
+            lx * (hy * (hz * P(x1, y0, z0) + lz * P(x1, y0, z1)) + ly * (hz * P(x1, y1, z0) + lz * P(x1, y1, z1)));
+      }
+      out[q] = v;
     }
-    out[q] = v;
-  }
-  if (VEC == 4) {
-    *reinterpret_cast<f32x4*>(dense + i0) = f32x4{out[0], out[1 % VEC], out[2 % VEC], out[3 % VEC]};
-    *reinterpret_cast<int4*>(table + i0) = int4{-1, -1, -1, -1};
-  } else {
-    dense[i0] = out[0];
-    table[i0] = -1;
+    if (VEC == 4) {
+      *reinterpret_cast<f32x4*>(dense + i0) = f32x4{out[0], out[1 % VEC], out[2 % VEC], out[3 % VEC]};
+      *reinterpret_cast<int4*>(table + i0) = int4{-1, -1, -1, -1};
+    } else {
+      dense[i0] = out[0];
+      table[i0] = -1;
+    }
   }
 }
 
@@ -365,42 +370,61 @@ __global__ __launch_bounds__(256) void dense_rows_bwd_kernel(const int32_t* __re
 
 // VEC voxels along z per thread (VEC = 4: 16-byte loads of the mostly-zero dense gradient first, the table only where something
 // is non-zero - the 704^3 sweep is otherwise 2.8 GB of traffic and 1.4 M workgroups).
-template <int VEC>
+// Round 5: NV vectors per thread, all loaded before the first is looked at (a thread that loads one 16-byte vector and returns
+// made the 704^3 sweep 1.4 M workgroups of a few hundred cycles each: 0.58 TB/s, bound by the workgroup dispatch rate).
+template <int VEC, int NV>
 __global__ __launch_bounds__(256) void dense_init_bwd_kernel(const float* __restrict__ g_dense, const int32_t* __restrict__ table,
                                                              int D, float* __restrict__ g_prev) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)D * D * D;
-  const int64_t i0 = t * VEC;
-  if (i0 >= total) return;
-  float gv[VEC];
-  if (VEC == 4) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(g_dense + i0);
-    gv[0] = v[0]; gv[1 % VEC] = v[1]; gv[2 % VEC] = v[2]; gv[3 % VEC] = v[3];
-    if (v[0] == 0.f && v[1] == 0.f && v[2] == 0.f && v[3] == 0.f) return;
-  } else {
-    gv[0] = g_dense[i0];
-    if (gv[0] == 0.f) return;
-  }
-  const int Dp = D / 2;
-  const unsigned zc = (unsigned)D / VEC, tu = (unsigned)t;
-  const int zb = (int)(tu % zc) * VEC, y = (int)((tu / zc) % (unsigned)D), x = (int)(tu / (zc * (unsigned)D));
+  const int64_t t0 = (int64_t)blockIdx.x * (256 * NV) + threadIdx.x;
+  float gv[NV][VEC];
+  bool any = false;
 #pragma unroll
-  for (int q = 0; q < VEC; ++q) {
-    const int64_t i = i0 + q;
-    const float g = gv[q];
-    if (g == 0.f || table[i] >= 0) continue;
-    const int z = zb + q;
-    int x0, x1, y0, y1, z0, z1;
-    float lx, ly, lz;
-    up2_src(x, Dp, x0, x1, lx);
-    up2_src(y, Dp, y0, y1, ly);
-    up2_src(z, Dp, z0, z1, lz);
-    const float hx = 1.0f - lx, hy = 1.0f - ly, hz = 1.0f - lz;
-    auto A = [&](int xi, int yi, int zi, float wgt) {
-      if (wgt != 0.f) atomicAdd(g_prev + ((int64_t)xi * Dp + yi) * Dp + zi, g * wgt);
-    };
-    A(x0, y0, z0, hx * hy * hz); A(x0, y0, z1, hx * hy * lz); A(x0, y1, z0, hx * ly * hz); A(x0, y1, z1, hx * ly * lz);
-    A(x1, y0, z0, lx * hy * hz); A(x1, y0, z1, lx * hy * lz); A(x1, y1, z0, lx * ly * hz); A(x1, y1, z1, lx * ly * lz);
+  for (int k = 0; k < NV; ++k) {
+    const int64_t i0 = (t0 + 256 * k) * VEC;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) gv[k][q] = 0.f;
+    if (i0 >= total) continue;
+    if (VEC == 4) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(g_dense + i0);
+      gv[k][0] = v[0]; gv[k][1 % VEC] = v[1]; gv[k][2 % VEC] = v[2]; gv[k][3 % VEC] = v[3];
+    } else {
+      gv[k][0] = g_dense[i0];
+    }
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) any = any || gv[k][q] != 0.f;
+  }
+  if (!any) return;
+  const int Dp = D / 2;
+  const unsigned zc = (unsigned)D / VEC;
+#pragma unroll 1
+  for (int k = 0; k < NV; ++k) {
+    const int64_t t = t0 + 256 * k, i0 = t * VEC;
+    if (i0 >= total) break;
+    bool nz = false;
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) nz = nz || gv[k][q] != 0.f;
+    if (!nz) continue;
+    const unsigned tu = (unsigned)t;
+    const int zb = (int)(tu % zc) * VEC, y = (int)((tu / zc) % (unsigned)D), x = (int)(tu / (zc * (unsigned)D));
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      const int64_t i = i0 + q;
+      const float g = gv[k][q];
+      if (g == 0.f || table[i] >= 0) continue;
+      const int z = zb + q;
+      int x0, x1, y0, y1, z0, z1;
+      float lx, ly, lz;
+      up2_src(x, Dp, x0, x1, lx);
+      up2_src(y, Dp, y0, y1, ly);
+      up2_src(z, Dp, z0, z1, lz);
+      const float hx = 1.0f - lx, hy = 1.0f - ly, hz = 1.0f - lz;
+      auto A = [&](int xi, int yi, int zi, float wgt) {
+        if (wgt != 0.f) atomicAdd(g_prev + ((int64_t)xi * Dp + yi) * Dp + zi, g * wgt);
+      };
+      A(x0, y0, z0, hx * hy * hz); A(x0, y0, z1, hx * hy * lz); A(x0, y1, z0, hx * ly * hz); A(x0, y1, z1, hx * ly * lz);
+      A(x1, y0, z0, lx * hy * hz); A(x1, y0, z1, lx * hy * lz); A(x1, y1, z0, lx * ly * hz); A(x1, y1, z1, lx * ly * lz);
+    }
   }
 }
 
@@ -450,6 +474,44 @@ __device__ __forceinline__ void bilinear_texel4_scatter_coop(float* __restrict__
   }
 }
 
+// Round 5: the texel adds of ONE view go through an LDS hash first.  A workgroup is 256 voxels in lattice order; at the stages
+// where the kernel spends its time their projections fall on top of each other (a 352^3 voxel is 0.3 texels of pyramid level 2,
+// a 704^3 voxel 0.07 texels of level 3), so that the 2 x 256 x levels memory-side requests a view costs above (one per tap row,
+// the rate that bounds the kernel) are a few dozen DISTINCT texels: the taps are summed in LDS (ds_add_f32) under the key
+// (level, y, x) and every distinct texel is flushed once, its four channels by four adjacent lanes (one 16-byte request).
+// A tap that finds no slot within CVH_PROBES probes (a table fuller than it ever is at the shipped sizes) goes to memory itself.
+constexpr int CVH = 2048, CVH_LOG = 11, CVH_PROBES = 24;
+constexpr unsigned CVH_EMPTY = 0xffffffffu;
+__device__ __forceinline__ void cv_hash_add(unsigned* hkey, float* hval, float* __restrict__ map, int H, int W, int level, float x, float y,
+                                            const float g[4]) {
+  const float fx = floorf(x), fy = floorf(y);
+  const float tx = x - fx, ty = y - fy;
+  const int x0 = (int)fx, y0 = (int)fy;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
+    const float w = ((t & 1) ? tx : 1.0f - tx) * ((t >> 1) ? ty : 1.0f - ty);
+    if (!((xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)) || w == 0.f) continue;
+    const unsigned key = ((unsigned)level << 22) | ((unsigned)yi << 11) | (unsigned)xi;   // H, W <= 2048 (checked at launch)
+    unsigned sl = (key * 2654435761u) >> (32 - CVH_LOG);
+    int slot = -1;
+#pragma unroll 1
+    for (int probe = 0; probe < CVH_PROBES; ++probe) {
+      unsigned cur = hkey[sl];
+      if (cur == CVH_EMPTY) { cur = atomicCAS(&hkey[sl], CVH_EMPTY, key); if (cur == CVH_EMPTY) cur = key; }
+      if (cur == key) { slot = (int)sl; break; }
+      sl = (sl + 1) & (CVH - 1);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float v = w * g[c];
+      if (v == 0.f) continue;
+      if (slot >= 0) atomicAdd(&hval[slot * 4 + c], v);
+      else atomicAdd(map + ((int64_t)yi * W + xi) * 4 + c, v);
+    }
+  }
+}
+
 // K2 backward for the kept voxels (coords of the stage's rows): recomputes the warp and the view softmax, then
 //   d wf_v = g_mean + 2 g_var (wf_v - mean);  d f_v = d wf_v w_v + W1^T d h_v;  d w_v = d wf_v . f_v;
 //   d logit_v = w_v (d w_v - sum_u w_u d w_u)  (views outside the frustum have a constant logit);
@@ -476,7 +538,12 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(CostVolBwdArgs a) {
   // maps measured 30 % slower - the kernel is bound by the locality of its gathers and atomics, not by same-line contention)
   const int64_t i_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i_ < a.n;
-  const int64_t i = live ? i_ : a.n - 1;        // every lane runs the whole body (the scatter below is quad-cooperative)
+  const int64_t i = live ? i_ : a.n - 1;        // every lane runs the whole body (the flush below is cooperative)
+  __shared__ unsigned hkey[CVH];
+  __shared__ float hval[CVH * 4];
+  for (int e = threadIdx.x; e < CVH; e += 256) hkey[e] = CVH_EMPTY;
+  for (int e = threadIdx.x; e < CVH * 4; e += 256) hval[e] = 0.f;
+  __syncthreads();
   float gacc[49];
 #pragma unroll
   for (int k = 0; k < 49; ++k) gacc[k] = 0.f;
@@ -569,10 +636,33 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(CostVolBwdArgs a) {
           }
         }
         const bool act = live && !(df[0] == 0.f && df[1] == 0.f && df[2] == 0.f && df[3] == 0.f);   // views outside the frustum: 0
+#ifdef SURF_CV_DIRECT   // (A/B: round 4's direct octet-cooperative atomics)
         for (int l = a.stage; l < 4; ++l) {
           const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
           bilinear_texel4_scatter_coop(a.gfeats[l] + (int64_t)v * H * W * 4, H, W, unnorm_act(nxv[v], W), unnorm_act(nyv[v], H), df, act);
         }
+#else
+        if (act)
+          for (int l = a.stage; l < 4; ++l) {
+            const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
+            cv_hash_add(hkey, hval, a.gfeats[l] + (int64_t)v * H * W * 4, H, W, l, unnorm_act(nxv[v], W), unnorm_act(nyv[v], H), df);
+          }
+        __syncthreads();
+        // flush this view's distinct texels (lanes 4 s .. 4 s + 3 = the channels of slot s: 16 contiguous bytes per request) and
+        // empty the table for the next view (the four lanes of a slot read its key in the same instruction, before lane 0's store)
+        for (int e = threadIdx.x; e < CVH * 4; e += 256) {
+          const unsigned key = hkey[e >> 2];
+          if (key != CVH_EMPTY) {
+            const int l = (int)(key >> 22), yi = (int)((key >> 11) & 2047u), xi = (int)(key & 2047u);
+            const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
+            const float val = hval[e];
+            if (val != 0.f) atomicAdd(a.gfeats[l] + (int64_t)v * H * W * 4 + ((int64_t)yi * W + xi) * 4 + (e & 3), val);
+            hval[e] = 0.f;
+            if ((e & 3) == 0) hkey[e >> 2] = CVH_EMPTY;
+          }
+        }
+        __syncthreads();
+#endif
       }
     }
   }
@@ -686,9 +776,9 @@ extern "C" int surf_densify(const int32_t* coords, const float* rows, int row_st
   if (prev && (D & 1)) return SURF_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (D % 4 == 0)
-    hipLaunchKernelGGL(dense_init_kernel<4>, grid1d((int64_t)D * D * D / 4, 256), dim3(256), 0, st, prev, D, dense, table);
+    hipLaunchKernelGGL((dense_init_kernel<4, 4>), grid1d((int64_t)D * D * D / 4, 256 * 4), dim3(256), 0, st, prev, D, dense, table);
   else
-    hipLaunchKernelGGL(dense_init_kernel<1>, grid1d((int64_t)D * D * D, 256), dim3(256), 0, st, prev, D, dense, table);
+    hipLaunchKernelGGL((dense_init_kernel<1, 4>), grid1d((int64_t)D * D * D, 256 * 4), dim3(256), 0, st, prev, D, dense, table);
   hipLaunchKernelGGL(dense_scatter_kernel, grid1d(n, 256), dim3(256), 0, st, coords, rows, row_stride, n, D, dense, table);
   return surf_check_launch();
 }
@@ -703,9 +793,9 @@ extern "C" int surf_densify_backward(const int32_t* coords, int64_t n, int D, co
   {
     const int64_t total = (int64_t)D * D * D;
     if (D % 4 == 0)
-      hipLaunchKernelGGL(dense_init_bwd_kernel<4>, grid1d(total / 4, 256), dim3(256), 0, st, g_dense, table, D, g_prev);
+      hipLaunchKernelGGL((dense_init_bwd_kernel<4, 8>), grid1d(total / 4, 256 * 8), dim3(256), 0, st, g_dense, table, D, g_prev);
     else
-      hipLaunchKernelGGL(dense_init_bwd_kernel<1>, grid1d(total, 256), dim3(256), 0, st, g_dense, table, D, g_prev);
+      hipLaunchKernelGGL((dense_init_bwd_kernel<1, 8>), grid1d(total, 256 * 8), dim3(256), 0, st, g_dense, table, D, g_prev);
   }
   return surf_check_launch();
 }
@@ -732,6 +822,7 @@ extern "C" int surf_costvol_backward(const int32_t* coords, const float* g, int6
     a.gfeats[l] = h_gfeats[l];
     a.hw[2 * l] = h_hw[2 * l];
     a.hw[2 * l + 1] = h_hw[2 * l + 1];
+    if (h_hw[2 * l] > 2048 || h_hw[2 * l + 1] > 2048) return SURF_E_LIMIT;   // 11-bit texel coordinates in the LDS hash keys
   }
   fill_views(a.vs, nv, h_intrs, h_w2c);
   for (int k = 0; k < 32; ++k) a.w1[k] = h_agg[k];

@@ -515,7 +515,10 @@ def set_train_precision(name):
     every backward reduction fp32-equivalent.  "bf16": the operands of the weight-gradient reductions dW = adj^T in (the
     per-sample adjoint and input rows written by surf_sdf_backward / surf_sdf_smooth_backward / surf_blend_backward and the
     sparse U-Net's out_lin) are rounded to bf16 on load and multiplied on the matrix cores with fp32 accumulation.  Master
-    weights, optimiser state, the forward, the adjoint propagation itself and every gather / scatter kernel stay fp32."""
+    weights, optimiser state, the adjoint propagation of the MLPs and every gather / scatter kernel stay fp32.  Round 5: the
+    wide layers of the sparse U-Net (both channel counts >= 16, the matrix-core kernel) run their TRAINING forward and their
+    input gradients on bf16-rounded operands too - one product per k-step instead of the exact split's six - which is what
+    autocast(bf16) does to a convolution; the thin layers (gather bound) and the inference path are untouched."""
     global colgram_precision
     if name not in TRAIN_PRECISIONS:
         raise ValueError(f"train precision must be one of {sorted(TRAIN_PRECISIONS)}, got {name!r}")
@@ -1181,9 +1184,10 @@ def spconv_pack_weights(weight):
     return packed
 
 
-def spconv(x, in_table, out_coords, mode, weight, bn_scale=None, bn_shift=None, skip=None, packed=None):
+def spconv(x, in_table, out_coords, mode, weight, bn_scale=None, bn_shift=None, skip=None, packed=None, bf16=False):
     """One sparse conv + BN(eval) + ReLU (+ skip).  x (n_in, Cin); weight (27, Cin, Cout); returns (n_out, Cout).
-    packed (spconv_pack_weights(weight)): run the matrix-core kernel instead of the per-voxel one."""
+    packed (spconv_pack_weights(weight)): run the matrix-core kernel instead of the per-voxel one; bf16 (with packed): operands
+    rounded to bf16, one product per k-step (the training policy train_precision = bf16; never used by inference)."""
     _chk(x, torch.float32, "x")
     _chk(in_table, torch.int32, "in_table")
     _chk(out_coords, torch.int32, "out_coords")
@@ -1199,7 +1203,8 @@ def spconv(x, in_table, out_coords, mode, weight, bn_scale=None, bn_shift=None, 
         _chk(packed, torch.uint8, "packed weights")
         assert packed.numel() == _lib.lib().surf_spconv_packed_bytes(cin, cout)
         rc = _lib.lib().surf_spconv_mfma(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords), out_coords.shape[0],
-                                         int(mode), _p(packed), cout, _p(bn_scale), _p(bn_shift), _p(skip), _p(out), _stream())
+                                         int(mode), _p(packed), cout, _p(bn_scale), _p(bn_shift), _p(skip), _p(out), int(bool(bf16)),
+                                         _stream())
         _lib.check(rc, "surf_spconv_mfma")
         return out
     rc = _lib.lib().surf_spconv(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords), out_coords.shape[0], int(mode),
@@ -1254,7 +1259,8 @@ def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight,
     if kernel_events is not None:
         pairs = _pair_counts.get(key, 0)
     with _timed(f"spconv_dgrad<{cout},{cin}>", {"pairs": pairs, "sites": int(in_coords.shape[0])}):
-        dx = spconv(dy, out_table, in_coords, {SUBM: SUBM, DOWN: UP, UP: DOWN}[mode], wt, packed=wt_packed)
+        dx = spconv(dy, out_table, in_coords, {SUBM: SUBM, DOWN: UP, UP: DOWN}[mode], wt, packed=wt_packed,
+                    bf16=colgram_precision == 1)
     dW = torch.zeros_like(weight)
     if out_coords.shape[0] > 0 and x.shape[0] > 0:
         with _timed(f"spconv_wgrad<{cin},{cout}>", {"pairs": pairs, "sites": int(out_coords.shape[0])}):

@@ -95,7 +95,8 @@ class SparseCostRegNet(nn.Module):
         `backward` needs (train mode only: eval mode folds the BN into the convolution epilogue and keeps no raw output)."""
         w, scale, shift, packed = blk.prepared(self.use_mfma)
         if self.training:   # batch statistics, running statistics updated
-            raw = ops.spconv(x, in_site[0], out_site[1], mode, w, None, None, None, packed=packed)
+            raw = ops.spconv(x, in_site[0], out_site[1], mode, w, None, None, None, packed=packed,
+                             bf16=ops.colgram_precision == 1)       # train_precision = bf16: wide layers on bf16 operands
             blk._bn_dirty = True
             saved = {} if tape is not None else None
             y = ops.bn_train_relu(raw, blk.net[1], skip, saved)

@@ -1629,3 +1629,29 @@ def test_spconv_dgrad_mfma_matches_per_voxel_kernel(cin, cout):
         assert ops.dgrad_weights(w, mode, True)[1] is not None and ops.dgrad_weights(w, mode, False)[1] is None
         rel_close(dx_m, dx_v, 2e-6, 2e-6 * float(dx_v.abs().max()))
         rel_close(dW_m, dW_v, 1e-5, 1e-6 * float(dW_v.abs().max()))    # (same kernel either way; summation order may differ)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (64, 32)])
+def test_spconv_mfma_bf16_policy_is_the_bf16_rounded_convolution(cin, cout):
+    """train_precision = bf16 (BASELINE configs[3]): the wide sparse convolutions with both operands rounded to bf16 and ONE
+    product per k-step.  Checked two ways: (i) EXACTLY the fp32-equivalent kernel on inputs and weights that were rounded to
+    bf16 beforehand (same products, fp32 accumulation; tolerance = summation order), (ii) within bf16's 2^-8 operand rounding
+    of the unrounded fp32 result (stated tolerance of the policy: 1.5e-2 of the output scale)."""
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(cin + 7 * cout)
+    D = 20
+    coords = (torch.rand(D, D, D, generator=g) < 0.3).nonzero().to(torch.int32).contiguous().to(d)
+    table = ops.table_from_coords(coords, D)
+    cd, tcd, D2 = ops.down_sites(coords, D, "dilate")
+    w = (torch.randn(27, cin, cout, generator=g) / (27 * cin) ** 0.5).to(d)
+    x_f = torch.randn(coords.shape[0], cin, generator=g).to(d)
+    x_c = torch.randn(cd.shape[0], cin, generator=g).to(d)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)          # noqa: E731  round to nearest even, like v_cvt_pk_bf16_f32
+    for x, tab, oc, mode in ((x_f, table, coords, ops.SUBM), (x_f, table, cd, ops.DOWN), (x_c, tcd, coords, ops.UP)):
+        got = ops.spconv(x, tab, oc, mode, w, packed=ops.spconv_pack_weights(w), bf16=True)
+        exact = ops.spconv(rb(x), tab, oc, mode, rb(w).contiguous(), packed=ops.spconv_pack_weights(rb(w).contiguous()))
+        rel_close(got, exact, 1e-5, 1e-5)
+        full = ops.spconv(x, tab, oc, mode, w, packed=ops.spconv_pack_weights(w))
+        assert float((got - full).abs().max()) < 1.5e-2 * float(full.abs().max())
+        assert float((got - full).abs().max()) > 0          # (it IS a different arithmetic)
