@@ -14,6 +14,14 @@
 // Plain fp32 FMAs, one wavefront per 4 samples, same lane ownership as sdf_smooth.hip (whose packed weight image it reads).
 #include "common.h"
 
+// weight rows in flight per step of the k / neuron loops (the loops wait for one L2 round trip per unrolled group)
+#ifndef SURF_TRAIN_UNROLL
+#define SURF_TRAIN_UNROLL 4
+#endif
+#define SURF_STR2(x) #x
+#define SURF_STR(x) SURF_STR2(x)
+#define SURF_TRAIN_UNROLL_PRAGMA _Pragma(SURF_STR(unroll SURF_TRAIN_UNROLL))
+
 namespace {
 
 constexpr int S = 4, KP = 160, NH = 128, N_E = 27, N_PHI = 28, N_H2 = 101, N_HID = 6;
@@ -24,6 +32,11 @@ constexpr int OFF_W6 = OFF_B + N_HID * NH;
 
 __host__ __device__ constexpr int layer_k(int l) { return l == 0 ? N_E : 156; }
 __host__ __device__ constexpr int layer_n(int l) { return l == 2 ? N_H2 : NH; }
+
+constexpr int XS = 2 * S + 4;   // row stride of the transposed LDS operand arrays (floats)
+#define XIN(q, s, k) xin_t[(k) * XS + (q) * S + (s)]
+#define DL(q, s, k) dl_t[(k) * XS + (q) * S + (s)]
+static_assert(S == 4, "one 16-byte LDS read per stream");
 
 struct BwdArgs {
   const float* pts;
@@ -57,8 +70,10 @@ __device__ __forceinline__ Act softplus100(float t) {
 }
 
 __global__ __launch_bounds__(64) void sdf_bwd_kernel(BwdArgs a) {
-  __shared__ float in_v[S][KP], in_d[S][KP];
-  __shared__ float dl_v[S][NH], dl_d[S][NH];
+  // Round 5: [k][value | tangent][sample] rows (8 values + 4 of padding): the k / neuron loops read a weight pair's eight
+  // broadcast operands as two 16-byte LDS reads instead of eight 4-byte ones (see sdf_smooth_bwd.hip)
+  __shared__ __attribute__((aligned(16))) float xin_t[KP * XS];
+  __shared__ __attribute__((aligned(16))) float dl_t[NH * XS];
   const int lane = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * S;
   const float inv_sqrt2 = 0.70710678118654752440f;
@@ -113,14 +128,14 @@ __global__ __launch_bounds__(64) void sdf_bwd_kernel(BwdArgs a) {
           phid += f * ((sx * wy * wz / vs) * vx[s] + (sy * wx * wz / vs) * vy[s] + (sz * wx * wy / vs) * vz[s]);
         }
       }
-      in_v[s][NH + lane] = phi;
-      in_d[s][NH + lane] = phid;
+      XIN(0, s, NH + lane) = phi;
+      XIN(1, s, NH + lane) = phid;
     } else if (lane < KP - NH) {
-      in_v[s][NH + lane] = 0.f;
-      in_d[s][NH + lane] = 0.f;
+      XIN(0, s, NH + lane) = 0.f;
+      XIN(1, s, NH + lane) = 0.f;
     }
-    in_v[s][lane] = 0.f; in_d[s][lane] = 0.f; in_v[s][lane + 64] = 0.f; in_d[s][lane + 64] = 0.f;   // columns 0..127
-    if (lane < N_E) { in_v[s][lane] = e[s]; in_d[s][lane] = je[s]; }
+    XIN(0, s, lane) = 0.f; XIN(1, s, lane) = 0.f; XIN(0, s, lane + 64) = 0.f; XIN(1, s, lane + 64) = 0.f;   // columns 0..127
+    if (lane < N_E) { XIN(0, s, lane) = e[s]; XIN(1, s, lane) = je[s]; }
   }
   __syncthreads();
   auto dump_inputs = [&](int l) {
@@ -131,7 +146,7 @@ __global__ __launch_bounds__(64) void sdf_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const int k = lane + 64 * j;
-          if (k < KP) { a.in_v[o + k] = in_v[s][k]; a.in_d[o + k] = in_d[s][k]; }
+          if (k < KP) { a.in_v[o + k] = XIN(0, s, k); a.in_d[o + k] = XIN(1, s, k); }
         }
       }
   };
@@ -148,12 +163,13 @@ __global__ __launch_bounds__(64) void sdf_bwd_kernel(BwdArgs a) {
 #pragma unroll
       for (int s = 0; s < S; ++s) acc[j][s] = accd[j][s] = 0.f;
     const int K = layer_k(l);
-#pragma unroll 4
+SURF_TRAIN_UNROLL_PRAGMA
     for (int k = 0; k < K; ++k) {
       const float w0 = wt[k * NH + lane], w1 = wt[k * NH + 64 + lane];
+      const f32x4 xv4 = *reinterpret_cast<const f32x4*>(&xin_t[k * XS]), xd4 = *reinterpret_cast<const f32x4*>(&xin_t[k * XS + S]);
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        const float x = in_v[s][k], xd = in_d[s][k];
+        const float x = xv4[s], xd = xd4[s];
         acc[0][s] = fmaf(w0, x, acc[0][s]);
         acc[1][s] = fmaf(w1, x, acc[1][s]);
         accd[0][s] = fmaf(w0, xd, accd[0][s]);
@@ -173,8 +189,8 @@ __global__ __launch_bounds__(64) void sdf_bwd_kernel(BwdArgs a) {
         const bool real = nrn < N;
         s1[l][j][s] = real ? t.s1 : 0.f;
         s2t[l][j][s] = real ? t.s2 * accd[j][s] : 0.f;
-        in_v[s][nrn] = real ? t.h * post : 0.f;
-        in_d[s][nrn] = real ? t.s1 * accd[j][s] * post : 0.f;
+        XIN(0, s, nrn) = real ? t.h * post : 0.f;
+        XIN(1, s, nrn) = real ? t.s1 * accd[j][s] * post : 0.f;
       }
     }
     if (l == 2) {
@@ -182,8 +198,8 @@ __global__ __launch_bounds__(64) void sdf_bwd_kernel(BwdArgs a) {
       if (lane < N_E) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          in_v[s][N_H2 + lane] = e[s] * inv_sqrt2;
-          in_d[s][N_H2 + lane] = je[s] * inv_sqrt2;
+          XIN(0, s, N_H2 + lane) = e[s] * inv_sqrt2;
+          XIN(1, s, N_H2 + lane) = je[s] * inv_sqrt2;
         }
       }
     }
@@ -214,13 +230,14 @@ __global__ __launch_bounds__(64) void sdf_bwd_kernel(BwdArgs a) {
         for (int s = 0; s < S; ++s) g[j][s] = gd[j][s] = 0.f;
       const int N = layer_n(l);
       const bool third = lane < KP - 128;
-#pragma unroll 4
+SURF_TRAIN_UNROLL_PRAGMA
       for (int nrn = 0; nrn < N; ++nrn) {
         const float w0 = w[nrn * KP + lane], w1 = w[nrn * KP + 64 + lane];
         const float w2 = third ? w[nrn * KP + 128 + lane] : 0.f;
+        const f32x4 dv4 = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS]), dd4 = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS + S]);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          const float d = dl_v[s][nrn], dd = dl_d[s][nrn];
+          const float d = dv4[s], dd = dd4[s];
           g[0][s] = fmaf(w0, d, g[0][s]);
           g[1][s] = fmaf(w1, d, g[1][s]);
           g[2][s] = fmaf(w2, d, g[2][s]);
@@ -242,8 +259,8 @@ __global__ __launch_bounds__(64) void sdf_bwd_kernel(BwdArgs a) {
         const float hb = g[j][s] * pre, hdb = gd[j][s] * pre;       // adjoints of (h, h') of layer l-1 (zero weight beyond its width)
         const float tbv = fmaf(s2t[l - 1][j][s], hdb, s1[l - 1][j][s] * hb);
         const float tdbv = s1[l - 1][j][s] * hdb;
-        dl_v[s][k] = tbv;
-        dl_d[s][k] = tdbv;
+        DL(0, s, k) = tbv;
+        DL(1, s, k) = tdbv;
         if (live[s]) {
           const int64_t o = ((int64_t)(l - 1) * a.n + base + s) * NH + k;
           a.tb[o] = tbv;

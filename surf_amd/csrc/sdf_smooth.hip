@@ -19,6 +19,14 @@
 // image per wavefront out of L2; 2 x 2 x 99 k MACs per point.
 #include "common.h"
 
+// weight rows in flight per step of the k / neuron loops (the loops wait for one L2 round trip per unrolled group)
+#ifndef SURF_TRAIN_UNROLL
+#define SURF_TRAIN_UNROLL 4
+#endif
+#define SURF_STR2(x) #x
+#define SURF_STR(x) SURF_STR2(x)
+#define SURF_TRAIN_UNROLL_PRAGMA _Pragma(SURF_STR(unroll SURF_TRAIN_UNROLL))
+
 namespace {
 
 constexpr int S = 4;          // points per wavefront
@@ -35,6 +43,11 @@ constexpr int PACKED_FLOATS = OFF_W6 + KP;
 
 __host__ __device__ constexpr int layer_k(int l) { return l == 0 ? N_E : 156; }
 __host__ __device__ constexpr int layer_n(int l) { return l == 2 ? N_H2 : NH; }
+
+constexpr int XS = 2 * S + 4;   // row stride of the transposed LDS operand arrays (floats)
+#define XIN(q, s, k) xin_t[(k) * XS + (q) * S + (s)]
+#define DL(q, s, k) dl_t[(k) * XS + (q) * S + (s)]
+static_assert(S == 4, "one 16-byte LDS read per stream");
 
 struct SmoothArgs {
   const float* pts;
@@ -65,8 +78,10 @@ __device__ __forceinline__ Act softplus100(float t) {
 }
 
 __global__ __launch_bounds__(64) void sdf_smooth_kernel(SmoothArgs a) {
-  __shared__ float in_v[S][KP], in_d[S][KP];     // layer input and its derivative along u
-  __shared__ float dl_v[S][NH], dl_d[S][NH];     // adjoint of the pre-activations and its derivative
+  // layer input and its derivative along u / adjoint of the pre-activations and its derivative.  Round 5: [k][value | derivative]
+  // [sample] rows (8 values + 4 of padding): two 16-byte LDS reads per weight pair instead of eight 4-byte ones (sdf_smooth_bwd.hip)
+  __shared__ __attribute__((aligned(16))) float xin_t[KP * XS];
+  __shared__ __attribute__((aligned(16))) float dl_t[NH * XS];
   __shared__ float ge_v[S][32], ge_d[S][32];     // skip-layer share of G_e
   const int lane = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * S;
@@ -132,15 +147,15 @@ __global__ __launch_bounds__(64) void sdf_smooth_kernel(SmoothArgs a) {
           mp[s][2] += f * (dxz + dyz);
         }
       }
-      in_v[s][NH + lane] = phi;
-      in_d[s][NH + lane] = jp[s][0] + jp[s][1] + jp[s][2];
+      XIN(0, s, NH + lane) = phi;
+      XIN(1, s, NH + lane) = jp[s][0] + jp[s][1] + jp[s][2];
     } else if (lane < KP - NH) {
-      in_v[s][NH + lane] = 0.f;
-      in_d[s][NH + lane] = 0.f;
+      XIN(0, s, NH + lane) = 0.f;
+      XIN(1, s, NH + lane) = 0.f;
     }
     if (lane < N_E) {
-      in_v[s][lane] = e[s];
-      in_d[s][lane] = je[s];
+      XIN(0, s, lane) = e[s];
+      XIN(1, s, lane) = je[s];
     }
   }
   __syncthreads();
@@ -156,12 +171,13 @@ __global__ __launch_bounds__(64) void sdf_smooth_kernel(SmoothArgs a) {
 #pragma unroll
       for (int s = 0; s < S; ++s) acc[j][s] = accd[j][s] = 0.f;
     const int K = layer_k(l);
-#pragma unroll 4
+SURF_TRAIN_UNROLL_PRAGMA
     for (int k = 0; k < K; ++k) {
       const float w0 = wt[k * NH + lane], w1 = wt[k * NH + 64 + lane];
+      const f32x4 xv4 = *reinterpret_cast<const f32x4*>(&xin_t[k * XS]), xd4 = *reinterpret_cast<const f32x4*>(&xin_t[k * XS + S]);
 #pragma unroll
       for (int s = 0; s < S; ++s) {
-        const float x = in_v[s][k], xd = in_d[s][k];
+        const float x = xv4[s], xd = xd4[s];
         acc[0][s] = fmaf(w0, x, acc[0][s]);
         acc[1][s] = fmaf(w1, x, acc[1][s]);
         accd[0][s] = fmaf(w0, xd, accd[0][s]);
@@ -182,11 +198,11 @@ __global__ __launch_bounds__(64) void sdf_smooth_kernel(SmoothArgs a) {
         s1[l][j][s] = real ? t.s1 : 0.f;
         s2t[l][j][s] = real ? t.s2 * accd[j][s] : 0.f;
         if (real) {
-          in_v[s][nrn] = t.h * post;
-          in_d[s][nrn] = t.s1 * accd[j][s] * post;
+          XIN(0, s, nrn) = t.h * post;
+          XIN(1, s, nrn) = t.s1 * accd[j][s] * post;
         } else {                                      // l == 2: slots 101..127 take the encoding of the skip connection
-          in_v[s][nrn] = 0.f;
-          in_d[s][nrn] = 0.f;
+          XIN(0, s, nrn) = 0.f;
+          XIN(1, s, nrn) = 0.f;
         }
       }
     }
@@ -195,8 +211,8 @@ __global__ __launch_bounds__(64) void sdf_smooth_kernel(SmoothArgs a) {
       if (lane < N_E) {
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          in_v[s][N_H2 + lane] = e[s] * inv_sqrt2;
-          in_d[s][N_H2 + lane] = je[s] * inv_sqrt2;
+          XIN(0, s, N_H2 + lane) = e[s] * inv_sqrt2;
+          XIN(1, s, N_H2 + lane) = je[s] * inv_sqrt2;
         }
       }
     }
@@ -226,13 +242,14 @@ __global__ __launch_bounds__(64) void sdf_smooth_kernel(SmoothArgs a) {
         for (int s = 0; s < S; ++s) g[j][s] = gd[j][s] = 0.f;
       const int N = layer_n(l);
       const bool third = lane < KP - 128;
-#pragma unroll 4
+SURF_TRAIN_UNROLL_PRAGMA
       for (int nrn = 0; nrn < N; ++nrn) {
         const float w0 = w[nrn * KP + lane], w1 = w[nrn * KP + 64 + lane];
         const float w2 = third ? w[nrn * KP + 128 + lane] : 0.f;
+        const f32x4 dv4 = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS]), dd4 = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS + S]);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          const float d = dl_v[s][nrn], dd = dl_d[s][nrn];
+          const float d = dv4[s], dd = dd4[s];
           g[0][s] = fmaf(w0, d, g[0][s]);
           g[1][s] = fmaf(w1, d, g[1][s]);
           g[2][s] = fmaf(w2, d, g[2][s]);
@@ -267,8 +284,8 @@ __global__ __launch_bounds__(64) void sdf_smooth_kernel(SmoothArgs a) {
           ge_v[s][k - N_H2] = gv;
           ge_d[s][k - N_H2] = gdv;
         }
-        dl_v[s][k] = s1[l - 1][j][s] * gv;            // s1 = s2t = 0 on the 27 slots lin2 does not have
-        dl_d[s][k] = fmaf(s2t[l - 1][j][s], gv, s1[l - 1][j][s] * gdv);
+        DL(0, s, k) = s1[l - 1][j][s] * gv;            // s1 = s2t = 0 on the 27 slots lin2 does not have
+        DL(1, s, k) = fmaf(s2t[l - 1][j][s], gv, s1[l - 1][j][s] * gdv);
       }
     }
     __syncthreads();

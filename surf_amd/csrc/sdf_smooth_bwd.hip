@@ -17,6 +17,14 @@
 // Plain fp32 FMAs, one wavefront per 4 samples, same lane ownership and packed weight image as sdf_bwd.hip / sdf_smooth.hip.
 #include "common.h"
 
+// weight rows in flight per step of the k / neuron loops (the loops wait for one L2 round trip per unrolled group)
+#ifndef SURF_TRAIN_UNROLL
+#define SURF_TRAIN_UNROLL 2
+#endif
+#define SURF_STR2(x) #x
+#define SURF_STR(x) SURF_STR2(x)
+#define SURF_TRAIN_UNROLL_PRAGMA _Pragma(SURF_STR(unroll SURF_TRAIN_UNROLL))
+
 namespace {
 
 constexpr int S = 4, KP = 160, NH = 128, N_E = 27, N_PHI = 28, N_H2 = 101, N_HID = 6, NS = 4;   // NS streams
@@ -27,6 +35,11 @@ constexpr int OFF_W6 = OFF_B + N_HID * NH;
 
 __host__ __device__ constexpr int layer_k(int l) { return l == 0 ? N_E : 156; }
 __host__ __device__ constexpr int layer_n(int l) { return l == 2 ? N_H2 : NH; }
+
+constexpr int XS = NS * S + 4;   // row stride of the transposed LDS operand arrays (floats): 16-byte aligned, 8 banks apart
+#define XIN(q, s, k) xin_t[(k) * XS + (q) * S + (s)]
+#define DL(q, s, k) dl_t[(k) * XS + (q) * S + (s)]
+static_assert(S == 4, "one 16-byte LDS read per stream");
 
 struct SmBwdArgs {
   const float* pts;
@@ -58,8 +71,11 @@ __device__ __forceinline__ Act3 softplus100_3(float t) {
 }
 
 __global__ __launch_bounds__(64) void sdf_smooth_bwd_kernel(SmBwdArgs a) {
-  __shared__ float xin[NS][S][KP];
-  __shared__ float dl[NS][S][NH];
+  // Round 5: [k][stream][sample] rows (16 values + 4 of padding) instead of [stream][sample][k]: the k / neuron loops below read
+  // the 16 broadcast operands of a weight pair as FOUR 16-byte LDS reads instead of sixteen 4-byte ones (the loops were bound by
+  // their LDS instructions: 16 ds_read per 32 FMAs, at one wavefront per SIMD).
+  __shared__ __attribute__((aligned(16))) float xin_t[KP * XS];
+  __shared__ __attribute__((aligned(16))) float dl_t[NH * XS];
   const int lane = threadIdx.x;
   const int64_t base = (int64_t)blockIdx.x * S;
   const float inv_sqrt2 = 0.70710678118654752440f;
@@ -121,8 +137,8 @@ __global__ __launch_bounds__(64) void sdf_smooth_bwd_kernel(SmBwdArgs a) {
     }
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
-      xin[q][s][lane] = 0.f; xin[q][s][lane + 64] = 0.f;                         // columns 0..127
-      if (lane < KP - NH) xin[q][s][NH + lane] = lane < N_PHI ? phi[q] : 0.f;
+      XIN(q, s, lane) = 0.f; XIN(q, s, lane + 64) = 0.f;                         // columns 0..127
+      if (lane < KP - NH) XIN(q, s, NH + lane) = lane < N_PHI ? phi[q] : 0.f;
     }
   }
   __syncthreads();
@@ -130,7 +146,7 @@ __global__ __launch_bounds__(64) void sdf_smooth_bwd_kernel(SmBwdArgs a) {
   for (int s = 0; s < S; ++s)
     if (lane < N_E) {
 #pragma unroll
-      for (int q = 0; q < NS; ++q) xin[q][s][lane] = e[q][s];
+      for (int q = 0; q < NS; ++q) XIN(q, s, lane) = e[q][s];
     }
   __syncthreads();
   auto dump_inputs = [&](int l) {
@@ -143,7 +159,7 @@ __global__ __launch_bounds__(64) void sdf_smooth_bwd_kernel(SmBwdArgs a) {
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const int k = lane + 64 * j;
-            if (k < KP) a.in[o + k] = xin[q][s][k];
+            if (k < KP) a.in[o + k] = XIN(q, s, k);
           }
         }
   };
@@ -162,17 +178,18 @@ __global__ __launch_bounds__(64) void sdf_smooth_bwd_kernel(SmBwdArgs a) {
 #pragma unroll
         for (int s = 0; s < S; ++s) acc[q][j][s] = 0.f;
     const int K = layer_k(l);
-#pragma unroll 2
+SURF_TRAIN_UNROLL_PRAGMA
     for (int k = 0; k < K; ++k) {
       const float w0 = wt[k * NH + lane], w1 = wt[k * NH + 64 + lane];
 #pragma unroll
-      for (int q = 0; q < NS; ++q)
+      for (int q = 0; q < NS; ++q) {
+        const f32x4 xq = *reinterpret_cast<const f32x4*>(&xin_t[k * XS + q * S]);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-          const float x = xin[q][s][k];
-          acc[q][0][s] = fmaf(w0, x, acc[q][0][s]);
-          acc[q][1][s] = fmaf(w1, x, acc[q][1][s]);
+          acc[q][0][s] = fmaf(w0, xq[s], acc[q][0][s]);
+          acc[q][1][s] = fmaf(w1, xq[s], acc[q][1][s]);
         }
+      }
     }
     __syncthreads();
     const int N = layer_n(l);
@@ -190,10 +207,10 @@ __global__ __launch_bounds__(64) void sdf_smooth_bwd_kernel(SmBwdArgs a) {
         cu[l][j][s] = real ? t.s2 * au : 0.f;
         cs_[l][j][s] = real ? t.s2 * as : 0.f;
         cm[l][j][s] = real ? fmaf(t.s3 * au, as, t.s2 * am) : 0.f;
-        xin[0][s][nrn] = real ? t.h * post : 0.f;
-        xin[1][s][nrn] = real ? t.s1 * au * post : 0.f;
-        xin[2][s][nrn] = real ? t.s1 * as * post : 0.f;
-        xin[3][s][nrn] = real ? fmaf(t.s2 * au, as, t.s1 * am) * post : 0.f;
+        XIN(0, s, nrn) = real ? t.h * post : 0.f;
+        XIN(1, s, nrn) = real ? t.s1 * au * post : 0.f;
+        XIN(2, s, nrn) = real ? t.s1 * as * post : 0.f;
+        XIN(3, s, nrn) = real ? fmaf(t.s2 * au, as, t.s1 * am) * post : 0.f;
       }
     }
     if (l == 2) {
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(64) void sdf_smooth_bwd_kernel(SmBwdArgs a) {
 #pragma unroll
         for (int q = 0; q < NS; ++q)
 #pragma unroll
-          for (int s = 0; s < S; ++s) xin[q][s][N_H2 + lane] = e[q][s] * inv_sqrt2;
+          for (int s = 0; s < S; ++s) XIN(q, s, N_H2 + lane) = e[q][s] * inv_sqrt2;
       }
     }
     __syncthreads();
@@ -236,19 +253,20 @@ __global__ __launch_bounds__(64) void sdf_smooth_bwd_kernel(SmBwdArgs a) {
       const float* __restrict__ w = a.packed + OFF_W + l * NH * KP;
       const int N = layer_n(l);
       const bool third = lane < KP - 128;
-#pragma unroll 2
+SURF_TRAIN_UNROLL_PRAGMA
       for (int nrn = 0; nrn < N; ++nrn) {
         const float w0 = w[nrn * KP + lane], w1 = w[nrn * KP + 64 + lane];
         const float w2 = third ? w[nrn * KP + 128 + lane] : 0.f;
 #pragma unroll
-        for (int q = 0; q < NS; ++q)
+        for (int q = 0; q < NS; ++q) {
+          const f32x4 dq = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS + q * S]);
 #pragma unroll
           for (int s = 0; s < S; ++s) {
-            const float d = dl[q][s][nrn];
-            g[q][0][s] = fmaf(w0, d, g[q][0][s]);
-            g[q][1][s] = fmaf(w1, d, g[q][1][s]);
-            g[q][2][s] = fmaf(w2, d, g[q][2][s]);
+            g[q][0][s] = fmaf(w0, dq[s], g[q][0][s]);
+            g[q][1][s] = fmaf(w1, dq[s], g[q][1][s]);
+            g[q][2][s] = fmaf(w2, dq[s], g[q][2][s]);
           }
+        }
       }
       __syncthreads();
     }
@@ -268,7 +286,7 @@ __global__ __launch_bounds__(64) void sdf_smooth_bwd_kernel(SmBwdArgs a) {
         const float ab1 = fmaf(ks, hmb, k1 * hub);
         const float ab2 = fmaf(ku, hmb, k1 * hsb);
         const float ab3 = k1 * hmb;
-        dl[0][s][k] = ab0; dl[1][s][k] = ab1; dl[2][s][k] = ab2; dl[3][s][k] = ab3;
+        DL(0, s, k) = ab0; DL(1, s, k) = ab1; DL(2, s, k) = ab2; DL(3, s, k) = ab3;
         if (live[s]) {
           const int64_t o = ((int64_t)(l - 1) * NS * a.n + base + s) * NH + k;
           const int64_t qs = a.n * NH;

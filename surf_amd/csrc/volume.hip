@@ -474,44 +474,10 @@ __device__ __forceinline__ void bilinear_texel4_scatter_coop(float* __restrict__
   }
 }
 
-// Round 5: the texel adds of ONE view go through an LDS hash first.  A workgroup is 256 voxels in lattice order; at the stages
-// where the kernel spends its time their projections fall on top of each other (a 352^3 voxel is 0.3 texels of pyramid level 2,
-// a 704^3 voxel 0.07 texels of level 3), so that the 2 x 256 x levels memory-side requests a view costs above (one per tap row,
-// the rate that bounds the kernel) are a few dozen DISTINCT texels: the taps are summed in LDS (ds_add_f32) under the key
-// (level, y, x) and every distinct texel is flushed once, its four channels by four adjacent lanes (one 16-byte request).
-// A tap that finds no slot within CVH_PROBES probes (a table fuller than it ever is at the shipped sizes) goes to memory itself.
-constexpr int CVH = 2048, CVH_LOG = 11, CVH_PROBES = 24;
-constexpr unsigned CVH_EMPTY = 0xffffffffu;
-__device__ __forceinline__ void cv_hash_add(unsigned* hkey, float* hval, float* __restrict__ map, int H, int W, int level, float x, float y,
-                                            const float g[4]) {
-  const float fx = floorf(x), fy = floorf(y);
-  const float tx = x - fx, ty = y - fy;
-  const int x0 = (int)fx, y0 = (int)fy;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int xi = x0 + (t & 1), yi = y0 + (t >> 1);
-    const float w = ((t & 1) ? tx : 1.0f - tx) * ((t >> 1) ? ty : 1.0f - ty);
-    if (!((xi >= 0) & (xi < W) & (yi >= 0) & (yi < H)) || w == 0.f) continue;
-    const unsigned key = ((unsigned)level << 22) | ((unsigned)yi << 11) | (unsigned)xi;   // H, W <= 2048 (checked at launch)
-    unsigned sl = (key * 2654435761u) >> (32 - CVH_LOG);
-    int slot = -1;
-#pragma unroll 1
-    for (int probe = 0; probe < CVH_PROBES; ++probe) {
-      unsigned cur = hkey[sl];
-      if (cur == CVH_EMPTY) { cur = atomicCAS(&hkey[sl], CVH_EMPTY, key); if (cur == CVH_EMPTY) cur = key; }
-      if (cur == key) { slot = (int)sl; break; }
-      sl = (sl + 1) & (CVH - 1);
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float v = w * g[c];
-      if (v == 0.f) continue;
-      if (slot >= 0) atomicAdd(&hval[slot * 4 + c], v);
-      else atomicAdd(map + ((int64_t)yi * W + xi) * 4 + c, v);
-    }
-  }
-}
-
+// (Round 5, measured and removed: summing one view's texel adds in an LDS hash per 256-voxel workgroup - key (level, y, x),
+// ds_add_f32, one 16-byte flush per distinct texel - to cut the memory-side requests 3x.  13.15 ms per step against 12.94 with
+// the direct octet-cooperative atomics below: the voxels that share a texel sit in the SAME wavefront, so the LDS adds
+// serialise on their bank just as the L2 adds do on their line.  With the scatter compiled out the kernel takes 2.9 ms.)
 // K2 backward for the kept voxels (coords of the stage's rows): recomputes the warp and the view softmax, then
 //   d wf_v = g_mean + 2 g_var (wf_v - mean);  d f_v = d wf_v w_v + W1^T d h_v;  d w_v = d wf_v . f_v;
 //   d logit_v = w_v (d w_v - sum_u w_u d w_u)  (views outside the frustum have a constant logit);
@@ -538,12 +504,7 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(CostVolBwdArgs a) {
   // maps measured 30 % slower - the kernel is bound by the locality of its gathers and atomics, not by same-line contention)
   const int64_t i_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i_ < a.n;
-  const int64_t i = live ? i_ : a.n - 1;        // every lane runs the whole body (the flush below is cooperative)
-  __shared__ unsigned hkey[CVH];
-  __shared__ float hval[CVH * 4];
-  for (int e = threadIdx.x; e < CVH; e += 256) hkey[e] = CVH_EMPTY;
-  for (int e = threadIdx.x; e < CVH * 4; e += 256) hval[e] = 0.f;
-  __syncthreads();
+  const int64_t i = live ? i_ : a.n - 1;        // every lane runs the whole body (the scatter below is octet-cooperative)
   float gacc[49];
 #pragma unroll
   for (int k = 0; k < 49; ++k) gacc[k] = 0.f;
@@ -636,33 +597,10 @@ __global__ __launch_bounds__(256) void costvol_bwd_kernel(CostVolBwdArgs a) {
           }
         }
         const bool act = live && !(df[0] == 0.f && df[1] == 0.f && df[2] == 0.f && df[3] == 0.f);   // views outside the frustum: 0
-#ifdef SURF_CV_DIRECT   // (A/B: round 4's direct octet-cooperative atomics)
         for (int l = a.stage; l < 4; ++l) {
           const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
           bilinear_texel4_scatter_coop(a.gfeats[l] + (int64_t)v * H * W * 4, H, W, unnorm_act(nxv[v], W), unnorm_act(nyv[v], H), df, act);
         }
-#else
-        if (act)
-          for (int l = a.stage; l < 4; ++l) {
-            const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
-            cv_hash_add(hkey, hval, a.gfeats[l] + (int64_t)v * H * W * 4, H, W, l, unnorm_act(nxv[v], W), unnorm_act(nyv[v], H), df);
-          }
-        __syncthreads();
-        // flush this view's distinct texels (lanes 4 s .. 4 s + 3 = the channels of slot s: 16 contiguous bytes per request) and
-        // empty the table for the next view (the four lanes of a slot read its key in the same instruction, before lane 0's store)
-        for (int e = threadIdx.x; e < CVH * 4; e += 256) {
-          const unsigned key = hkey[e >> 2];
-          if (key != CVH_EMPTY) {
-            const int l = (int)(key >> 22), yi = (int)((key >> 11) & 2047u), xi = (int)(key & 2047u);
-            const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
-            const float val = hval[e];
-            if (val != 0.f) atomicAdd(a.gfeats[l] + (int64_t)v * H * W * 4 + ((int64_t)yi * W + xi) * 4 + (e & 3), val);
-            hval[e] = 0.f;
-            if ((e & 3) == 0) hkey[e >> 2] = CVH_EMPTY;
-          }
-        }
-        __syncthreads();
-#endif
       }
     }
   }
@@ -822,7 +760,6 @@ extern "C" int surf_costvol_backward(const int32_t* coords, const float* g, int6
     a.gfeats[l] = h_gfeats[l];
     a.hw[2 * l] = h_hw[2 * l];
     a.hw[2 * l + 1] = h_hw[2 * l + 1];
-    if (h_hw[2 * l] > 2048 || h_hw[2 * l + 1] > 2048) return SURF_E_LIMIT;   // 11-bit texel coordinates in the LDS hash keys
   }
   fill_views(a.vs, nv, h_intrs, h_w2c);
   for (int k = 0; k < 32; ++k) a.w1[k] = h_agg[k];

@@ -482,10 +482,11 @@ class ImplicitSurface(nn.Module):
                 raise ValueError("extract_geometry needs either (volumes, sparse_idxes) or scene=SceneVolumes")
             scene = _LatticeScene(volumes, sparse_idxes)
         u = self.sdf_grid(scene, bound_min, bound_max, resolution)
-        vertices, triangles = marching_cubes(u, threshold)
         b_max_np = bound_max.detach().cpu().numpy()
         b_min_np = bound_min.detach().cpu().numpy()
-        vertices = vertices / (resolution - 1.0) * (b_max_np - b_min_np)[None, :] + b_min_np[None, :]
+        # vertices / (resolution - 1.0) * (b_max - b_min) + b_min (:354-356) in float64 on the device, before the one copy to the host
+        vertices, triangles = marching_cubes(u, threshold, rescale=(resolution - 1.0, (b_max_np - b_min_np).astype(np.float64),
+                                                                     b_min_np.astype(np.float64)))
         return vertices, triangles
 
     def validate(self, rays_o, rays_d, near, far, scene, bound_min, bound_max, hw, cos_anneal_ratio=1.0, step=None,
@@ -511,38 +512,36 @@ class ImplicitSurface(nn.Module):
             nrms.append(o["normal_val"])
             sdeps.append(o["sdf_depth"])
             rdeps.append(o["render_depth"])
-        # Round 5: the four image outputs leave the device as ONE pinned buffer on a side stream while the lattice kernels of
-        # extract_geometry run (the reference's order - geometry first, then one .cpu() per output, :363-399 - serialises 15 MB
-        # of pageable copies behind 270 ms of kernels); the host waits for the copy once, after the mesh is there.
-        dev_imgs = torch.cat([torch.cat(cols), torch.cat(nrms), torch.cat(sdeps).reshape(-1, 1), torch.cat(rdeps).reshape(-1, 1)], dim=1)
-        host_imgs, copied = self._to_host_async(dev_imgs)
+        # Round 5: the image post-processing of :377-399 (x 256 / rot . n x 128 + 128, clip) runs on the device and the five arrays
+        # leave it as ONE pinned buffer on a side stream while the lattice kernels of extract_geometry run (the reference's order -
+        # geometry first, then one .cpu() per output and numpy post-processing - serialises ~20 ms of copies and host passes
+        # behind 270 ms of kernels); the host waits for the copy once, after the mesh is there.
+        R = rays_o.shape[0]
+        color, nrm = torch.cat(cols), torch.cat(nrms)
+        rot = torch.from_numpy(np.ascontiguousarray(scene.cams.rot_ref)).to(color.device, torch.float32)
+        img = (color * 256).clamp(0, 255)
+        nimg = ((nrm @ rot.t()) * 128 + 128).clamp(0, 255)
+        flat = torch.cat([color.reshape(-1), img.reshape(-1), nimg.reshape(-1), torch.cat(sdeps).reshape(-1), torch.cat(rdeps).reshape(-1)])
+        host, copied = self._to_host_async(flat)
         if extract_geometry:
             v, t = self.extract_geometry(None, None, bound_min, bound_max, mesh_resolution, threshold, scene=scene)
             outputs["vertices"], outputs["triangles"] = v, t
         if copied is not None:
             copied.synchronize()
-        host_imgs = host_imgs.clone()                        # (the pinned staging buffer is reused by the next call)
-        color_fine = host_imgs[:, 0:3].contiguous()
-        outputs["color_fine"] = color_fine
-        outputs["img_fine"] = (color_fine.numpy().reshape([height, width, 3]) * 256).clip(0, 255)
-        normal_img = host_imgs[:, 3:6].numpy()
-        rot = scene.cams.rot_ref
-        outputs["normal_img"] = (np.matmul(rot[None, :, :], normal_img[:, :, None]).reshape([height, width, 3]) * 128
-                                 + 128).clip(0, 255)
-        outputs["sdf_depth"] = host_imgs[:, 6].numpy().reshape([height, width]).copy()
-        outputs["render_depth"] = host_imgs[:, 7].numpy().reshape([height, width]).copy()
+        outputs["color_fine"] = host[:3 * R].view(R, 3)
+        outputs["img_fine"] = host[3 * R:6 * R].numpy().reshape([height, width, 3])
+        outputs["normal_img"] = host[6 * R:9 * R].numpy().reshape([height, width, 3])
+        outputs["sdf_depth"] = host[9 * R:10 * R].numpy().reshape([height, width])
+        outputs["render_depth"] = host[10 * R:11 * R].numpy().reshape([height, width])
         return outputs
 
     def _to_host_async(self, t):
-        """Device tensor -> (pinned host tensor, event) copied on a side stream that waits for the work queued so far; the caller
-        synchronises on the event before reading.  CPU tensors pass through (event None)."""
+        """Device tensor -> (pinned host tensor, event): copied on a side stream that waits for the work queued so far; the caller
+        synchronises on the event before reading.  The buffer comes from torch's caching host allocator and belongs to the
+        result (views of it are what validate returns).  CPU tensors pass through (event None)."""
         if not t.is_cuda:
             return t, None
-        key = (tuple(t.shape), t.dtype)
-        buf = getattr(self, "_pinned", {}).get(key)
-        if buf is None:
-            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-            self._pinned = {key: buf}                         # one staging buffer (the last image size)
+        buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
         if getattr(self, "_copy_stream", None) is None or self._copy_stream.device != t.device:
             self._copy_stream = torch.cuda.Stream(device=t.device)
         ready = torch.cuda.Event()
