@@ -19,7 +19,7 @@
 
 // weight rows in flight per step of the k / neuron loops (the loops wait for one L2 round trip per unrolled group)
 #ifndef SURF_TRAIN_UNROLL
-#define SURF_TRAIN_UNROLL 2
+#define SURF_TRAIN_UNROLL 4
 #endif
 #define SURF_STR2(x) #x
 #define SURF_STR(x) SURF_STR2(x)

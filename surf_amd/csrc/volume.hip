@@ -474,15 +474,15 @@ __device__ __forceinline__ void bilinear_texel4_scatter_coop(float* __restrict__
   }
 }
 
-// (Round 5, measured and removed: summing one view's texel adds in an LDS hash per 256-voxel workgroup - key (level, y, x),
-// ds_add_f32, one 16-byte flush per distinct texel - to cut the memory-side requests 3x.  13.15 ms per step against 12.94 with
-// the direct octet-cooperative atomics below: the voxels that share a texel sit in the SAME wavefront, so the LDS adds
-// serialise on their bank just as the L2 adds do on their line.  With the scatter compiled out the kernel takes 2.9 ms.)
-// K2 backward for the kept voxels (coords of the stage's rows): recomputes the warp and the view softmax, then
-//   d wf_v = g_mean + 2 g_var (wf_v - mean);  d f_v = d wf_v w_v + W1^T d h_v;  d w_v = d wf_v . f_v;
-//   d logit_v = w_v (d w_v - sum_u w_u d w_u)  (views outside the frustum have a constant logit);
-//   agg_mlp gradients are reduced over the wavefront and added atomically (49 floats: w1 | b1 | w2 | b2);
-//   d f_v goes to the bilinear taps of every summed level's gradient map (texel4, atomics).
+// Round 5, measured and removed - three ways of sending fewer texel adds to memory, all at 12.9-13.2 ms per step against 12.94 for
+// the octet-cooperative scatter above (with the scatter compiled out the kernel takes 2.9 ms):
+//  (i)   one view's adds summed in an LDS hash per 256-voxel workgroup (key (level, y, x), ds_add_f32, one 16-byte flush per
+//        distinct texel): 13.15 ms - the voxels that share a texel sit in the same wavefront and serialise on their LDS bank;
+//  (ii)  adjacent lanes of an octet that hit the same 2 x 2 block summed by a segmented shuffle scan, only run heads served: 12.96;
+//  (iii) the same with the heads served by rank, so that the atomic wave-instructions drop with the merge: 12.94.
+// Only stage 3 (0.18 texels of level 3 per 704^3 voxel) and half of stage 2 have neighbours on one block - a third of the adds -
+// and float atomics cost per wave-instruction at the memory side (MI355X_MICROARCH.md, Global float atomics), which none of the
+// three changes enough.  What would: a gather-form backward per texel tile (needs the voxel -> texel lists; not built).
 constexpr int CV_REPLICAS = 64;
 
 struct CostVolBwdArgs {
