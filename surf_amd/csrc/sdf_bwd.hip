@@ -16,7 +16,7 @@
 
 // weight rows in flight per step of the k / neuron loops (the loops wait for one L2 round trip per unrolled group)
 #ifndef SURF_TRAIN_UNROLL
-#define SURF_TRAIN_UNROLL 8
+#define SURF_TRAIN_UNROLL 4
 #endif
 #define SURF_STR2(x) #x
 #define SURF_STR(x) SURF_STR2(x)
@@ -152,7 +152,9 @@ __global__ __launch_bounds__(64) void sdf_bwd_kernel(BwdArgs a) {
   };
 
   // ---- forward sweep with tangents -----------------------------------------------------------------------------------------
-  float s1[N_HID][2][S], s2t[N_HID][2][S];
+  // Round 5: sp'(t) and sp''(t) t' of every layer (96 values a lane) wait for the reverse sweep in TB / TDB themselves - row l of
+  // each (n, 128) is their shape and is only written when the reverse sweep reaches layer l, by the same lane at the same
+  // addresses - instead of in registers (sdf_smooth_bwd.hip has the same arrangement)
 #pragma unroll
   for (int l = 0; l < N_HID; ++l) {
     dump_inputs(l);
@@ -187,8 +189,11 @@ SURF_TRAIN_UNROLL_PRAGMA
       for (int s = 0; s < S; ++s) {
         const Act t = softplus100(acc[j][s] + b);
         const bool real = nrn < N;
-        s1[l][j][s] = real ? t.s1 : 0.f;
-        s2t[l][j][s] = real ? t.s2 * accd[j][s] : 0.f;
+        if (live[s]) {
+          const int64_t o = ((int64_t)l * a.n + base + s) * NH + nrn;
+          a.tb[o] = real ? t.s1 : 0.f;
+          a.tdb[o] = real ? t.s2 * accd[j][s] : 0.f;
+        }
         XIN(0, s, nrn) = real ? t.h * post : 0.f;
         XIN(1, s, nrn) = real ? t.s1 * accd[j][s] * post : 0.f;
       }
@@ -213,6 +218,15 @@ SURF_TRAIN_UNROLL_PRAGMA
   for (int s = 0; s < S; ++s) pbar[s] = pdbar[s] = 0.f;
 #pragma unroll
   for (int l = N_HID; l >= 1; --l) {
+    float c1[2][S], c2[2][S];   // sp' and sp'' t' of layer l - 1 for this lane's two neurons (dead samples: zeros)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int64_t o = ((int64_t)(l - 1) * a.n + base + (live[s] ? s : 0)) * NH + lane + 64 * j;
+        c1[j][s] = live[s] ? a.tb[o] : 0.f;
+        c2[j][s] = live[s] ? a.tdb[o] : 0.f;
+      }
     float g[3][S], gd[3][S];
     if (l == N_HID) {   // tbar_6 = ybar e_0, t'bar_6 = e_0
 #pragma unroll
@@ -257,8 +271,8 @@ SURF_TRAIN_UNROLL_PRAGMA
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         const float hb = g[j][s] * pre, hdb = gd[j][s] * pre;       // adjoints of (h, h') of layer l-1 (zero weight beyond its width)
-        const float tbv = fmaf(s2t[l - 1][j][s], hdb, s1[l - 1][j][s] * hb);
-        const float tdbv = s1[l - 1][j][s] * hdb;
+        const float tbv = fmaf(c2[j][s], hdb, c1[j][s] * hb);
+        const float tdbv = c1[j][s] * hdb;
         DL(0, s, k) = tbv;
         DL(1, s, k) = tdbv;
         if (live[s]) {

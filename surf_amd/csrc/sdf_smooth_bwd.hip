@@ -165,7 +165,11 @@ __global__ __launch_bounds__(64) void sdf_smooth_bwd_kernel(SmBwdArgs a) {
   };
 
   // ---- forward sweep with the three tangent streams --------------------------------------------------------------------
-  float c1[N_HID][2][S], cu[N_HID][2][S], cs_[N_HID][2][S], cm[N_HID][2][S];
+  // Round 5: the four softplus-coefficient streams c1 | cu | cs | cm of every layer (192 values a lane) wait for the reverse sweep
+  // in the AB buffer itself - AB[l] (4, n, 128) is exactly their shape and is only written when the reverse sweep reaches layer
+  // l, by the same lane at the same addresses - instead of in registers: 256 + 99 registers (one wavefront per SIMD) -> see the
+  // resource remarks; the weight loads of the k / neuron loops are the latency the extra wavefronts hide.
+  const int64_t qs = a.n * NH;
 #pragma unroll
   for (int l = 0; l < N_HID; ++l) {
     dump_inputs(l);
@@ -203,10 +207,13 @@ SURF_TRAIN_UNROLL_PRAGMA
         const Act3 t = softplus100_3(acc[0][j][s] + b);
         const bool real = nrn < N;
         const float au = acc[1][j][s], as = acc[2][j][s], am = acc[3][j][s];
-        c1[l][j][s] = real ? t.s1 : 0.f;
-        cu[l][j][s] = real ? t.s2 * au : 0.f;
-        cs_[l][j][s] = real ? t.s2 * as : 0.f;
-        cm[l][j][s] = real ? fmaf(t.s3 * au, as, t.s2 * am) : 0.f;
+        if (live[s]) {
+          const int64_t o = ((int64_t)l * NS * a.n + base + s) * NH + nrn;
+          a.ab[o] = real ? t.s1 : 0.f;
+          a.ab[o + qs] = real ? t.s2 * au : 0.f;
+          a.ab[o + 2 * qs] = real ? t.s2 * as : 0.f;
+          a.ab[o + 3 * qs] = real ? fmaf(t.s3 * au, as, t.s2 * am) : 0.f;
+        }
         XIN(0, s, nrn) = real ? t.h * post : 0.f;
         XIN(1, s, nrn) = real ? t.s1 * au * post : 0.f;
         XIN(2, s, nrn) = real ? t.s1 * as * post : 0.f;
@@ -234,6 +241,15 @@ SURF_TRAIN_UNROLL_PRAGMA
     for (int s = 0; s < S; ++s) pbar[q][s] = 0.f;
 #pragma unroll
   for (int l = N_HID; l >= 1; --l) {
+    float ck[2][S][NS];   // c1 | cu | cs | cm of layer l - 1 for this lane's two neurons (dead samples: zeros)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const int64_t o = ((int64_t)(l - 1) * NS * a.n + base + (live[s] ? s : 0)) * NH + lane + 64 * j;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) ck[j][s][q] = live[s] ? a.ab[o + q * qs] : 0.f;
+      }
     float g[NS][3][S];
 #pragma unroll
     for (int q = 0; q < NS; ++q)
@@ -281,7 +297,7 @@ SURF_TRAIN_UNROLL_PRAGMA
 #pragma unroll
       for (int s = 0; s < S; ++s) {
         const float hb = g[0][j][s] * pre, hub = g[1][j][s] * pre, hsb = g[2][j][s] * pre, hmb = g[3][j][s] * pre;
-        const float k1 = c1[l - 1][j][s], ku = cu[l - 1][j][s], ks = cs_[l - 1][j][s], km = cm[l - 1][j][s];
+        const float k1 = ck[j][s][0], ku = ck[j][s][1], ks = ck[j][s][2], km = ck[j][s][3];
         const float ab0 = fmaf(km, hmb, fmaf(ks, hsb, fmaf(ku, hub, k1 * hb)));
         const float ab1 = fmaf(ks, hmb, k1 * hub);
         const float ab2 = fmaf(ku, hmb, k1 * hsb);
@@ -289,7 +305,6 @@ SURF_TRAIN_UNROLL_PRAGMA
         DL(0, s, k) = ab0; DL(1, s, k) = ab1; DL(2, s, k) = ab2; DL(3, s, k) = ab3;
         if (live[s]) {
           const int64_t o = ((int64_t)(l - 1) * NS * a.n + base + s) * NH + k;
-          const int64_t qs = a.n * NH;
           a.ab[o] = ab0; a.ab[o + qs] = ab1; a.ab[o + 2 * qs] = ab2; a.ab[o + 3 * qs] = ab3;
         }
       }
