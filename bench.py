@@ -332,6 +332,7 @@ def mesh_grid_timing(model, scene, dev, resolution):
     torch.cuda.synchronize()
     ev, model.kernel_events = model.kernel_events, None
     k_ms = sum(x.elapsed_time(y) for name, x, y in ev if name == "sdf_grid")
+    mesh_grid_timing.launches = sum(1 for name, x, y in ev if name == "sdf_grid")      # 1 in lattice mode (round 5)
     inside = int((u > 0).sum())
     # marching cubes on that lattice (row f1; mcubes.marching_cubes at implicit_surface.py:353), device side only
     from surf_amd import ops
@@ -1017,8 +1018,10 @@ def run_rank(args):
             result["mesh_grid"] = {"resolution": args.mesh_grid, "points": n_lat, "total_ms": total_ms, "sdf_kernel_ms": k_ms,
                                    "lattice_points_inside": inside, **mc}
             roofline_kernels.append({"kernel": fk, "bound": "mfma", "achieved": ach, "peak": fpeak / fprod, "unit": "TFLOP/s",
-                                     "frac": ach / (fpeak / fprod), "traffic": None, "avg_launch_ms": k_ms / max(1, -(-n_lat // (1 << 24))),
-                                     "flop_per_sample": FLOP_PER_SAMPLE_SDF_FWD, "samples_per_launch": min(n_lat, 1 << 24),
+                                     "frac": ach / (fpeak / fprod), "traffic": None,
+                                     "avg_launch_ms": k_ms / max(1, getattr(mesh_grid_timing, "launches", 1)),
+                                     "flop_per_sample": FLOP_PER_SAMPLE_SDF_FWD,
+                                     "samples_per_launch": n_lat // max(1, getattr(mesh_grid_timing, "launches", 1)),
                                      "pipe": fpipe, "frac_of_fp32_mfma_peak": ach / 157.3,
                                      "note": f"{args.mesh_grid}^3 lattice of extract_geometry (row a16), forward only"})
         if world == 1 and args.cpu_seconds > 0 and sc0["cpu"] is not None:
