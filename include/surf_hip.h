@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 31
+#define SURF_ABI_VERSION 32
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -487,6 +487,13 @@ int surf_ptloss_backward(const float* imgs_t4, int nv, int H, int W, const float
  */
 int surf_spconv_wgrad(const float* x, int cin, const int32_t* in_table, int D_in, const int32_t* out_coords, int64_t n_out,
                       int mode, const float* dy, int cout, float* dW, void* stream);
+/* The same weight gradient on the matrix cores (per offset the GEMM X_k^T dY over the sites: 64-site tiles, the 27 offsets dealt
+ * over the four wavefronts, dy split once per tile; exact three-way bf16 split, six products: fp32-equivalent) for the channel
+ * pairs where it beats the per-voxel kernels - surf_spconv_wgrad_mfma_supported returns 1 for those ((8,16), (16,32), (32,16),
+ * (32,32)), 0 otherwise. */
+int surf_spconv_wgrad_mfma_supported(int cin, int cout);
+int surf_spconv_wgrad_mfma(const float* x, int cin, const int32_t* in_table, int D_in, const int32_t* out_coords, int64_t n_out,
+                           int mode, const float* dy, int cout, float* dW, void* stream);
 
 /* bbox (device int32[6]) = [min x, min y, min z, max x, max y, max z] of coords (n,3) */
 int surf_coords_bbox(const int32_t* coords, int64_t n, int32_t* bbox, void* stream);

@@ -1264,8 +1264,13 @@ def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight,
     dW = torch.zeros_like(weight)
     if out_coords.shape[0] > 0 and x.shape[0] > 0:
         with _timed(f"spconv_wgrad<{cin},{cout}>", {"pairs": pairs, "sites": int(out_coords.shape[0])}):
-            rc = _lib.lib().surf_spconv_wgrad(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords), out_coords.shape[0],
-                                              int(mode), _p(dy), cout, _p(dW), _stream())
+            if use_mfma and _lib.lib().surf_spconv_wgrad_mfma_supported(cin, cout):
+                # round 5: the channel pairs for which the matrix-core form wins (spconv_wgrad_mfma.hip), fp32-equivalent
+                rc = _lib.lib().surf_spconv_wgrad_mfma(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords),
+                                                       out_coords.shape[0], int(mode), _p(dy), cout, _p(dW), _stream())
+            else:
+                rc = _lib.lib().surf_spconv_wgrad(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords),
+                                                  out_coords.shape[0], int(mode), _p(dy), cout, _p(dW), _stream())
         _lib.check(rc, "surf_spconv_wgrad")
     return dx, dW
 

@@ -1655,3 +1655,32 @@ def test_spconv_mfma_bf16_policy_is_the_bf16_rounded_convolution(cin, cout):
         full = ops.spconv(x, tab, oc, mode, w, packed=ops.spconv_pack_weights(w))
         assert float((got - full).abs().max()) < 1.5e-2 * float(full.abs().max())
         assert float((got - full).abs().max()) > 0          # (it IS a different arithmetic)
+
+
+@pytest.mark.parametrize("cin,cout", [(8, 16), (16, 32), (32, 16), (32, 32)])
+def test_spconv_wgrad_mfma_matches_per_voxel_kernel(cin, cout):
+    """Round 5: the sparse convolutions' weight gradient on the matrix cores (surf_spconv_wgrad_mfma: per offset the GEMM X_k^T dY
+    over the sites, exact bf16x3 split = fp32-equivalent) against the fp32 per-voxel kernels (use_mfma = False), entry by entry,
+    for the three modes and a site count that leaves a partial 64-site tile; the pairs the per-voxel kernels keep say so."""
+    from surf_amd import _lib, ops
+    d = dev()
+    g = torch.Generator().manual_seed(11 * cin + cout)
+    D = 22
+    coords = (torch.rand(D, D, D, generator=g) < 0.3).nonzero().to(torch.int32).contiguous().to(d)
+    coords = coords[: coords.shape[0] - (coords.shape[0] % 64) + 21].contiguous()
+    cd, tc, D2 = ops.down_sites(coords, D, "dilate")
+    tf = ops.table_from_coords(coords, D)
+    w = (torch.randn(27, cin, cout, generator=g) / (27 * cin) ** 0.5).to(d)
+    L = _lib.lib()
+    assert L.surf_spconv_wgrad_mfma_supported(cin, cout) == 1
+    assert [L.surf_spconv_wgrad_mfma_supported(a, b) for a, b in ((16, 8), (16, 16), (8, 8), (64, 64))] == [0, 0, 0, 0]
+    for mode, n_in, n_out, args in ((ops.SUBM, coords.shape[0], coords.shape[0], (tf, coords, tf, coords)),
+                                    (ops.DOWN, coords.shape[0], cd.shape[0], (tf, coords, tc, cd)),
+                                    (ops.UP, cd.shape[0], coords.shape[0], (tc, cd, tf, coords))):
+        x = torch.randn(n_in, cin, generator=g).to(d)
+        dy = torch.randn(n_out, cout, generator=g).to(d)
+        _, dW_m = ops.spconv_backward(x, *args, mode, w, dy, use_mfma=True)
+        _, dW_v = ops.spconv_backward(x, *args, mode, w, dy, use_mfma=False)
+        scale = float(dW_v.abs().max())
+        assert scale > 0.1
+        rel_close(dW_m, dW_v, 1e-5, 2e-6 * scale)
