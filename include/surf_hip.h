@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 32
+#define SURF_ABI_VERSION 33
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -433,6 +433,13 @@ int surf_bn_relu_apply(const float* x, int64_t n, int channels, const float* sca
 int surf_bn_relu_backward(const float* x, const float* dy, int64_t n, int channels, const float* scale, const float* shift,
                           const float* mean, const float* invstd, int train, void* workspace, float* dgamma, float* dbeta,
                           float* dx, void* stream);
+/* InstanceNorm + ReLU (+ skip) backward of an FPN layer (models/modules/feature_network.py: nn.InstanceNorm2d, no affine
+ * parameters) for all N views in three launches: x, dy, dx (N, hw, C) NHWC; stats (N, C, 2) = mean | rstd as surf_inorm_relu
+ * wrote them; workspace: surf_inorm_backward_workspace_bytes(N, C) device bytes.  (= surf_bn_relu_backward per view with
+ * scale = rstd, shift = -mean rstd, which is what the FPN backward called N times per layer until round 5.) */
+int64_t surf_inorm_backward_workspace_bytes(int N, int channels);
+int surf_inorm_relu_backward(const float* x, const float* dy, int N, int64_t hw, int channels, const float* stats, void* workspace,
+                             float* dx, void* stream);
 
 /* ---- backward of the volume build (train mode; the autograd of surf.py:80-131 under loss.backward(), runner.py:163) ----
  * surf_matching_depth_backward: same geometry arguments as surf_matching_depth; g_full (nv,H,W) = d loss / d depth maps

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
 # must equal SURF_ABI_VERSION of include/surf_hip.h (tests/test_host_modules.py compares the two texts); lib() refuses a
 # library built from another header
-ABI_VERSION = 32
+ABI_VERSION = 33
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -104,6 +104,8 @@ SIGNATURES = {
     "surf_ptloss_backward": (c_int, [c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_sdf_smooth_backward": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_bn_relu_backward": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_inorm_backward_workspace_bytes": (c_i64, [c_int, c_int]),
+    "surf_inorm_relu_backward": (c_int, [c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_bn_relu_apply": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_spconv_wgrad": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr]),
     "surf_spconv_wgrad_mfma_supported": (c_int, [c_int, c_int]),

@@ -144,7 +144,86 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   dx[i] = scale[c] * v;                                               // gamma invstd = the forward's scale
 }
 
+// ---- InstanceNorm + ReLU backward for ALL views of an FPN layer in three launches (round 5) ---------------------------------
+// InstanceNorm = the BatchNorm above over one view's pixels without affine parameters (scale = rstd, shift = -mean rstd).  Until
+// round 5 the FPN backward called surf_bn_relu_backward once per view: 11 layers x 5 views x (3 kernels + ~8 torch helpers that
+// sliced the statistics and copied the result back) = ~600 launches of a few microseconds per training step.  Here blockIdx.y is
+// the view; stats (N, C, 2) = mean | rstd as surf_inorm_relu wrote them.
+template <int C>
+__global__ __launch_bounds__(256) void inorm_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t n,
+                                                                const float* __restrict__ stats, double* __restrict__ part) {
+  constexpr int G = 256 / C;
+  __shared__ double sh[2][256];
+  const int c = threadIdx.x % C, g = threadIdx.x / C, v = blockIdx.y;
+  const float mu = stats[((int64_t)v * C + c) * 2], is = stats[((int64_t)v * C + c) * 2 + 1];
+  const float* __restrict__ xv = x + (int64_t)v * n * C;
+  const float* __restrict__ dv = dy + (int64_t)v * n * C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * G + g; r < n; r += (int64_t)gridDim.x * G) {
+    const float xh = (xv[r * C + c] - mu) * is;
+    const float zb = xh > 0.f ? dv[r * C + c] : 0.f;                 // relu(xhat) > 0: the forward's own pre-activation
+    s1 += (double)zb;
+    s2 += (double)zb * (double)xh;
+  }
+  sh[0][threadIdx.x] = s1;
+  sh[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < G; ++k) { a += sh[0][k * C + threadIdx.x]; b += sh[1][k * C + threadIdx.x]; }
+    double* pv = part + (int64_t)v * gridDim.x * 2 * C;
+    pv[((int64_t)blockIdx.x * 2 + 0) * C + threadIdx.x] = a;
+    pv[((int64_t)blockIdx.x * 2 + 1) * C + threadIdx.x] = b;
+  }
+}
+
+__global__ void inorm_bwd_finalize_kernel(const double* __restrict__ part, int blocks, int C, float* __restrict__ sums /* (N, 2, C) */) {
+  double s1, s2;
+  const int v = blockIdx.x;
+  if (!reduce_partials(part + (int64_t)v * blocks * 2 * C, blocks, C, s1, s2)) return;
+  sums[((int64_t)v * 2 + 0) * C + threadIdx.x] = (float)s1;
+  sums[((int64_t)v * 2 + 1) * C + threadIdx.x] = (float)s2;
+}
+
+__global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t n, int C,
+                                                              int N, const float* __restrict__ stats, const float* __restrict__ sums,
+                                                              float* __restrict__ dx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)N * n * C) return;
+  const int c = (int)(i % C), v = (int)(i / (n * C));
+  const float mu = stats[((int64_t)v * C + c) * 2], is = stats[((int64_t)v * C + c) * 2 + 1];
+  const float xh = (x[i] - mu) * is;
+  const float zb = xh > 0.f ? dy[i] : 0.f;
+  dx[i] = is * (zb - sums[((int64_t)v * 2 + 0) * C + c] / (float)n - xh * (sums[((int64_t)v * 2 + 1) * C + c] / (float)n));
+}
+
 }  // namespace
+
+extern "C" int64_t surf_inorm_backward_workspace_bytes(int N, int channels) {
+  return (int64_t)N * BN_BLOCKS * 2 * channels * sizeof(double) + (int64_t)N * 2 * channels * sizeof(float);
+}
+
+extern "C" int surf_inorm_relu_backward(const float* x, const float* dy, int N, int64_t hw, int channels, const float* stats,
+                                        void* workspace, float* dx, void* stream) {
+  if (!x || !dy || !stats || !workspace || !dx || N <= 0 || hw <= 0) return SURF_E_ARG;
+  if (N > 65535) return SURF_E_LIMIT;
+  const int64_t want = (hw * channels + 255) / 256;
+  const int blocks = (int)(want < BN_BLOCKS ? want : BN_BLOCKS);
+  double* part = (double*)workspace;
+  float* sums = (float*)((char*)workspace + (int64_t)N * BN_BLOCKS * 2 * channels * sizeof(double));
+  hipStream_t s = (hipStream_t)stream;
+  switch (channels) {
+    case 8: hipLaunchKernelGGL(inorm_bwd_partial_kernel<8>, dim3(blocks, N), dim3(256), 0, s, x, dy, hw, stats, part); break;
+    case 16: hipLaunchKernelGGL(inorm_bwd_partial_kernel<16>, dim3(blocks, N), dim3(256), 0, s, x, dy, hw, stats, part); break;
+    case 32: hipLaunchKernelGGL(inorm_bwd_partial_kernel<32>, dim3(blocks, N), dim3(256), 0, s, x, dy, hw, stats, part); break;
+    case 64: hipLaunchKernelGGL(inorm_bwd_partial_kernel<64>, dim3(blocks, N), dim3(256), 0, s, x, dy, hw, stats, part); break;
+    default: return SURF_E_LIMIT;
+  }
+  hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(N), dim3(256), 0, s, part, blocks, channels, sums);
+  const int64_t total = (int64_t)N * hw * channels;
+  hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, dy, hw, channels, N, stats, sums, dx);
+  return surf_check_launch();
+}
 
 extern "C" int surf_bn_relu_backward(const float* x, const float* dy, int64_t n, int channels, const float* scale,
                                      const float* shift, const float* mean, const float* invstd, int train, void* workspace,

@@ -1376,15 +1376,17 @@ def conv3x3_wgrad(big, small, stride=1):
 
 def inorm_relu_backward(raw, dy, stats):
     """Backward of inorm_relu_ (the skip's gradient is dy itself): raw (N,H,W,C) the convolution output before the in-place
-    normalisation, stats (N,C,2) = mean | rstd.  InstanceNorm = BatchNorm over one view's pixels: surf_bn_relu_backward per
-    view with scale = rstd, shift = -mean rstd."""
+    normalisation, stats (N,C,2) = mean | rstd.  One call for all views (surf_inorm_relu_backward: blockIdx.y = view; until
+    round 5 a Python loop of surf_bn_relu_backward per view with sliced statistics: ~600 small launches per training step)."""
+    _chk(raw, torch.float32, "raw")
+    _chk(dy, torch.float32, "dy")
+    _chk(stats, torch.float32, "stats")
     N, H, W, C = raw.shape
+    assert tuple(dy.shape) == tuple(raw.shape) and tuple(stats.shape) == (N, C, 2)
     dx = torch.empty_like(raw)
-    for n in range(N):
-        mean, rstd = stats[n, :, 0].contiguous(), stats[n, :, 1].contiguous()
-        st = torch.cat([mean, rstd])
-        d, _, _ = bn_relu_backward(raw[n].reshape(H * W, C), dy[n].reshape(H * W, C), rstd, (-mean * rstd).contiguous(), st, train=True)
-        dx[n] = d.reshape(H, W, C)
+    ws = torch.empty(_lib.lib().surf_inorm_backward_workspace_bytes(N, C), dtype=torch.uint8, device=raw.device)
+    rc = _lib.lib().surf_inorm_relu_backward(_p(raw), _p(dy), N, H * W, C, _p(stats), _p(ws), _p(dx), _stream())
+    _lib.check(rc, "surf_inorm_relu_backward")
     return dx
 
 
