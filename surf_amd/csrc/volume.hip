@@ -480,9 +480,15 @@ __device__ __forceinline__ void bilinear_texel4_scatter_coop(float* __restrict__
 //        distinct texel): 13.15 ms - the voxels that share a texel sit in the same wavefront and serialise on their LDS bank;
 //  (ii)  adjacent lanes of an octet that hit the same 2 x 2 block summed by a segmented shuffle scan, only run heads served: 12.96;
 //  (iii) the same with the heads served by rank, so that the atomic wave-instructions drop with the merge: 12.94.
-// Only stage 3 (0.18 texels of level 3 per 704^3 voxel) and half of stage 2 have neighbours on one block - a third of the adds -
-// and float atomics cost per wave-instruction at the memory side (MI355X_MICROARCH.md, Global float atomics), which none of the
-// three changes enough.  What would: a gather-form backward per texel tile (needs the voxel -> texel lists; not built).
+//  (iv)  round r serving the eight ADJACENT voxels 8 r .. 8 r + 7 (one per octet) instead of every octet its own r-th voxel, so
+//        that the eight 32-byte tap rows of an instruction fall into few 64-byte segments: 12.90;
+//  (v)   16 replicas of the gradient maps (workgroup b adds into replica b % 16), summed afterwards: 12.48 - it is not
+//        cross-workgroup contention on the small coarse-level maps either.
+// scripts/microbench/atomic_shapes.hip (profiles/r05_microbench_atomic_shapes.txt) prices a float atomic at ~12.2 ns per CU
+// for every distinct 64-byte segment its lanes touch; 100 M (voxel, view, level) units x 2 tap rows at that price are 9.6 of
+// the kernel's 12.9 ms, and none of (i)-(v) made the segments fewer in a way the memory side noticed (neighbouring voxels'
+// footprints OVERLAP, and same-address adds inside one instruction serialise).  What would: a gather-form backward per texel
+// tile (needs voxel -> tile lists per view; not built).
 constexpr int CV_REPLICAS = 64;
 
 struct CostVolBwdArgs {
