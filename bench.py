@@ -399,6 +399,68 @@ def train_kernel_rooflines(per_kernel):
     return out
 
 
+def cpu_train_baseline(nv=5, H=144, W=200, base_dim=24, rays=256, n_samples=(64, 32, 16, 16)):
+    """`cpu_baseline` of the `--workload train` line: ONE training step of the CPU oracle (oracle/surf_oracle.py: fpn_forward ->
+    build_volumes with BatchNorm batch statistics and the matching-field jitter -> render with the patch warp -> colour /
+    eikonal / per-stage photometric / patch-NCC terms -> torch autograd backward through all of it) on this host.  A BOUNDED
+    SAMPLE of the workload: the bench's scene generator at nv views of H x W, a base_dim^3 -> (8 base_dim)^3 pyramid and `rays`
+    rays instead of 5 x 576x800, 88^3 -> 704^3, 512 rays - at the bench shape the oracle's sparse U-Net alone (27-offset loops
+    over 10 M voxels, recorded for autograd) is many minutes and tens of GB per step.  Kind "port"; context, not a target."""
+    from oracle import surf_oracle as O
+    from surf_amd import conf, synthetic
+    from surf_amd.surf import SuRF
+    torch.manual_seed(0)
+    model = SuRF(conf.from_dict(surf_conf(base_dim, n_samples)))                    # CPU: only its randomly initialised state_dict
+    sd = {k: v.detach().clone().float() for k, v in model.state_dict().items()}
+    names = [k for k, _ in model.named_parameters()]
+    for k in names:
+        sd[k].requires_grad_(True)
+    intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
+    imgs = synthetic.procedural_images(nv, H, W, 0, "cpu")
+    rays_o, rays_d = synthetic.pixel_rays(intrs[0], c2ws[0], H, W, 1, "cpu")
+    sel = torch.randperm(rays_o.shape[0], generator=torch.Generator().manual_seed(1000))[:rays]
+    ipts = {"imgs": imgs, "intrs": intrs, "c2ws": c2ws, "near_fars": near_fars, "near": near_fars[0, 0].reshape(1, 1),
+            "far": near_fars[0, 1].reshape(1, 1)}
+    cfg = {"range_ratios": [1.0, 0.4, 0.1, 0.01], "base_volume_dim": base_dim, "n_samples_depths": [128, 64, 32, 16],
+           "depth_res_levels": [4, 2, 2, 1]}
+
+    def reg_fn(f, c, d, stage):          # the bench's analytic matching logit on top of the real U-Net (as training_step_setup)
+        out, mid = O.sparse_unet(sd, f, c.long(), d, stage, training=True)
+        out = torch.cat([synthetic.sphere_logit(c, d).reshape(-1, 1), out[:, 1:]], dim=1)
+        return out, mid
+
+    t0 = time.perf_counter()
+    feats = O.fpn_forward(sd, imgs)
+    bv = O.build_volumes(sd, ipts, feats, cfg, reg_fn=reg_fn, perturb=True, src_idx=1, training=True)
+    vols, tabs, masks = bv["volumes"][::-1], bv["tables"][::-1], bv["masks"][::-1]
+    near = ipts["near"].repeat(rays, 1)
+    far = ipts["far"].repeat(rays, 1)
+    out = O.render(sd, rays_o[sel], rays_d[sel], near, far, bv["matching_volume"], vols, tabs, masks, feats[::-1], imgs, intrs, c2ws,
+                   list(n_samples), [1.0, 0.4, 0.1, 0.01], 256, 1.0, patch_warp=True)
+    target = torch.rand(rays, 3, generator=torch.Generator().manual_seed(5))
+    loss = (out["color_fine"] - target).abs().mean()
+    if torch.is_tensor(out.get("gradient_error")):
+        loss = loss + 0.1 * out["gradient_error"].mean()
+    if "ref_gray_val" in out:
+        loss = loss + 0.5 * O.lncc(out["ref_gray_val"], out["sampled_gray_val"]).mean()
+    ones = torch.ones(H, W)
+    for i, w in enumerate((0.25, 0.5, 0.75, 1.0)):
+        d_ref, d_src = bv["depths"][i][0], bv["depths"][i][1]
+        loss = loss + w * (O.photometric_loss(d_ref, imgs, ones, intrs, c2ws, 0, 2)[0]
+                           + O.photometric_loss(d_src, imgs, ones, intrs, c2ws, 1, 1)[0])
+    t1 = time.perf_counter()
+    loss.backward()
+    dt = time.perf_counter() - t0
+    n_grad = sum(1 for k in names if sd[k].grad is not None)
+    return {"value": rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "threads": torch.get_num_threads(),
+            "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"ONE oracle training step (forward {t1 - t0:.1f} s + autograd backward {dt - (t1 - t0):.1f} s) at a reduced scene: "
+                      f"{nv} views {H}x{W}, {base_dim}^3 -> {base_dim * 8}^3 pyramid ({[int(c.shape[0]) for c in bv['coords']]} voxels), "
+                      f"{rays} rays x {sum(n_samples)} samples; colour + eikonal + patch-NCC + per-stage photometric terms; "
+                      f"{n_grad} of {len(names)} parameter tensors received a gradient",
+            "loss": float(loss.detach())}
+
+
 class _DryTrainModel(torch.nn.Module):
     """--dry: a CPU stand-in with SuRF's parameter count (1.41 M floats) and forward signature."""
 
@@ -522,6 +584,9 @@ def run_rank_train(args):
             "roofline_kernels": rk,
             "cpu_baseline": None,
         }
+        if not dry and world == 1 and args.cpu_seconds > 0:
+            torch.set_num_threads(CPU_THREADS)
+            result["cpu_baseline"] = cpu_train_baseline()
         if not dry:
             result["voxels_per_stage"] = getattr(model, "last_voxels_per_stage", None)
         result["collective_backend"] = (args.backend + (" (all ranks on cuda:0)" if args.one_gpu else "")) if world > 1 else None
