@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void ptloss_terms_kernel(PtArgs a) {
 // ---- backward w.r.t. the depth map (train mode) --------------------------------------------------------------------
 // loss = sum_t T_t / (M_t + 1e-8); coef[t] = upstream / (M_t + 1e-8) (device, 4 floats: l1, gx, gy, ssim).
 //   ptloss_bwd_terms_kernel  one thread per pixel: recomputes the four per-source values, selects the topk sources of each
-//                            term like the forward, and scatters d loss / d warped rgb into g_warp (ns,H,W,4) (atomics: the
+//                            term like the forward, and scatters d loss / d warped rgb into g_warp (ns, 4 planes, H W) (atomics: the
 //                            gradient and SSIM windows overlap);
 //   ptloss_bwd_depth_kernel  one thread per pixel: d warped / d depth = bilinear derivative x d(u,v)/d depth (the pixel's
 //                            projection is affine in its depth: p(d) = d a + b), summed over the sources.
@@ -159,7 +159,11 @@ __device__ __forceinline__ void pt_source(const PtArgs& a, const PtBwd& b, int s
   const int64_t per = (int64_t)a.H * a.W;
   const f32x4* __restrict__ ref = reinterpret_cast<const f32x4*>(a.imgs) + (int64_t)a.ref * per;
   const f32x4* __restrict__ w = reinterpret_cast<const f32x4*>(a.warp) + (int64_t)s * per;
+  // Round 5: g_warp is CHANNEL-PLANAR, (ns, 4, H W) - the 64 lanes of an add are 64 adjacent pixels of one channel: contiguous
+  // dwords = four 64-byte segments per instruction instead of sixteen in the texel4 layout (a float atomic costs ~12.2 ns per
+  // CU and distinct segment: scripts/microbench/atomic_shapes.hip)
   float* gw = BWD ? b.g_warp + (int64_t)s * per * 4 : nullptr;
+#define GW(q, c) (gw + (int64_t)(c) * per + (q))
   const f32x4 r0 = ref[p], w0 = w[p];
   const bool hx = x + 1 < a.W, hy = y + 1 < a.H;
   const f32x4 rxn = hx ? ref[p + 1] : r0, ryn = hy ? ref[p + a.W] : r0;
@@ -177,14 +181,14 @@ __device__ __forceinline__ void pt_source(const PtArgs& a, const PtBwd& b, int s
       if ((sel & 2u) && hx) {
         const float g = b.coef[1] * mx * smooth_l1_grad(d1) / 3.0f;
         g0 += g;
-        if (g != 0.f) atomicAdd(gw + (p + 1) * 4 + c, -g);
+        if (g != 0.f) atomicAdd(GW(p + 1, c), -g);
       }
       if ((sel & 4u) && hy) {
         const float g = b.coef[2] * my * smooth_l1_grad(d2) / 3.0f;
         g0 += g;
-        if (g != 0.f) atomicAdd(gw + (p + a.W) * 4 + c, -g);
+        if (g != 0.f) atomicAdd(GW(p + a.W, c), -g);
       }
-      if (g0 != 0.f) atomicAdd(gw + p * 4 + c, g0);
+      if (g0 != 0.f) atomicAdd(GW(p, c), g0);
     }
   }
   float w_mu[3] = {0, 0, 0}, w_sq[3] = {0, 0, 0}, wr[3] = {0, 0, 0}, mpool = 0.f;
@@ -230,11 +234,12 @@ __device__ __forceinline__ void pt_source(const PtArgs& a, const PtBwd& b, int s
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           const float g = (dmu[c] + 2.0f * t[c] * dsq[c] + r[c] * dwr[c]) / 9.0f;
-          if (g != 0.f) atomicAdd(gw + q * 4 + c, g);
+          if (g != 0.f) atomicAdd(GW(q, c), g);
         }
       }
   }
   v4[0] = l1 / 3.0f; v4[1] = gx / 3.0f; v4[2] = gy / 3.0f; v4[3] = ssim / 3.0f;
+#undef GW
 }
 
 __global__ __launch_bounds__(256) void ptloss_bwd_terms_kernel(PtArgs a, PtBwd b) {
@@ -298,7 +303,8 @@ __global__ __launch_bounds__(256) void ptloss_bwd_depth_kernel(PtArgs a, PtBwd b
   const float wx = ax * d + a.c2w[3], wy = ay * d + a.c2w[7], wz = az * d + a.c2w[11];
   float acc = 0.f;
   for (int s = 0; s < a.ns; ++s) {
-    const f32x4 g = reinterpret_cast<const f32x4*>(b.g_warp)[(int64_t)s * per + p];
+    const float* gs = b.g_warp + (int64_t)s * per * 4;                    // channel planes (see pt_source)
+    const float g[3] = {gs[p], gs[per + p], gs[2 * per + p]};
     if (g[0] == 0.f && g[1] == 0.f && g[2] == 0.f) continue;
     const float* M = a.w2c[s];
     const float* K = a.K[s];
