@@ -87,7 +87,10 @@ __device__ __forceinline__ float matvec_t(const float* __restrict__ W, const flo
 }
 
 __global__ __launch_bounds__(64) void blend_bwd_kernel(BbArgs a) {
-  __shared__ float L[MAXV][F_LEN];
+  // (round 5: sized by the launch for the views that exist - V x F_LEN floats instead of MAXV x F_LEN: 16 instead of 22 KB per
+  // one-wavefront workgroup at 4 source views, 10 instead of 7 of them per CU)
+  extern __shared__ float L_dyn[];
+  float (*L)[F_LEN] = reinterpret_cast<float (*)[F_LEN]>(L_dyn);
   __shared__ float meanv[DF], varv[DF], meanb[DF], varb[DF], adj[64], tmp[64];
   const int lane = threadIdx.x;
   const int64_t s = blockIdx.x;
@@ -429,6 +432,6 @@ extern "C" int surf_blend_backward(const float* pts, const int32_t* idx, int64_t
     for (int r = 0; r < 3; ++r) a.cpos[v][r] = h_c2w[sidx * 16 + r * 4 + 3];
   }
   if (n > 0x7fffffff) return SURF_E_LIMIT;
-  hipLaunchKernelGGL(blend_bwd_kernel, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(blend_bwd_kernel, dim3((unsigned)n), dim3(64), (size_t)(nv - 1) * F_LEN * sizeof(float), (hipStream_t)stream, a);
   return surf_check_launch();
 }

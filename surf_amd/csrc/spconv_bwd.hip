@@ -146,15 +146,27 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgArgs a) {
 // step on <8,16>) and stays in use.
 template <int CIN, int COUT>
 struct ThinCfg {
-  static constexpr int TS = CIN <= 16 ? 128 : 64;       // sites per tile (C_in = 32: the row cache holds fewer rows)
+// Round 5: 64-site tiles with a 256-row cache and 1,024 hash slots for C_in <= 16 (was 128 / 512 / 2,048): 37 instead of 75 KB of
+// LDS, four instead of two workgroups per CU - <16,8> 7.79 -> 5.56 ms per training step; 32 sites 6.58; 512 hash slots overflow
+// into the global-atomic fallback (<16,16> 1.3 -> 172 ms): profiles/r05_wgrad_thin_tiles.txt.
+#ifndef SURF_THIN_TS
+#define SURF_THIN_TS 64
+#endif
+#ifndef SURF_THIN_CAP
+#define SURF_THIN_CAP 256
+#endif
+#ifndef SURF_THIN_HS
+#define SURF_THIN_HS 1024
+#endif
+  static constexpr int TS = CIN <= 16 ? SURF_THIN_TS : 64;       // sites per tile (C_in = 32: the row cache holds fewer rows)
   // register block of a (offset, block) pair: 4 input x BC output channels.  4 x 4 where that still gives most threads a pair
   // (one LDS index + two 16-byte reads per 16 FMAs), 4 x 2 otherwise (<8,8>: 108 pairs of 4 x 4 would idle 148 threads)
   static constexpr int BC = (COUT % 4 == 0 && 27 * (CIN / 4) * (COUT / 4) >= 200) ? 4 : 2;
   static constexpr int NB = (CIN / 4) * (COUT / BC);
   static constexpr int NPAIR = 27 * NB;
   static constexpr int PER = (NPAIR + 255) / 256;
-  static constexpr int CAP = CIN <= 16 ? 512 : 320;     // distinct neighbour rows cached per tile
-  static constexpr int HS = 2048;                       // hash slots (>= the distinct rows of any realistic tile)
+  static constexpr int CAP = CIN <= 16 ? SURF_THIN_CAP : 320;     // distinct neighbour rows cached per tile
+  static constexpr int HS = SURF_THIN_HS;               // hash slots (>= the distinct rows of any realistic tile)
   static constexpr int XS = CIN + 4, DS = COUT + 4;     // padded row strides (16-byte aligned vector reads)
   static constexpr int NJ = (27 * TS + 255) / 256;      // (site, offset) references per thread
 };
