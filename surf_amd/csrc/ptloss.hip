@@ -8,6 +8,13 @@
 // Byte-bound image-space work; sources <= SURF_MAX_VIEWS - 1.
 #include "common.h"
 
+// wavefronts per SIMD the forward term kernel is compiled for (round 5: 3 - 168 registers, 20 bytes spilled: 98 -> 83 us per
+// launch; 4 spills 172 bytes and is slower, 132 us).  The backward term kernel stays at 2 (237 registers): at 3 it spills 352
+// bytes and takes 473 instead of 332 us.
+#ifndef SURF_PT_WAVES
+#define SURF_PT_WAVES 3
+#endif
+
 namespace {
 
 struct PtArgs {
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(256) void ptloss_warp_kernel(PtArgs a) {
 
 __device__ __forceinline__ int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
 
-__global__ __launch_bounds__(256) void ptloss_terms_kernel(PtArgs a) {
+__global__ __launch_bounds__(256, SURF_PT_WAVES) void ptloss_terms_kernel(PtArgs a) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t per = (int64_t)a.H * a.W;
   if (p >= per) return;
@@ -242,7 +249,7 @@ __device__ __forceinline__ void pt_source(const PtArgs& a, const PtBwd& b, int s
 #undef GW
 }
 
-__global__ __launch_bounds__(256) void ptloss_bwd_terms_kernel(PtArgs a, PtBwd b) {
+__global__ __launch_bounds__(256, 2) void ptloss_bwd_terms_kernel(PtArgs a, PtBwd b) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t per = (int64_t)a.H * a.W;
   if (p >= per) return;

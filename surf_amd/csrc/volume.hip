@@ -505,7 +505,12 @@ struct CostVolBwdArgs {
   float* gagg;            // CV_REPLICAS x 64 floats (49 used per replica)
 };
 
-__global__ __launch_bounds__(256) void costvol_bwd_kernel(CostVolBwdArgs a) {
+// (round 5: compiled for three wavefronts per SIMD - 168 registers, 20 bytes spilled - instead of the 171 the allocator takes by
+// itself, one over the three-wave limit: 3.23 -> 3.16 ms per launch)
+#ifndef SURF_CVB_WAVES
+#define SURF_CVB_WAVES 3
+#endif
+__global__ __launch_bounds__(256, SURF_CVB_WAVES) void costvol_bwd_kernel(CostVolBwdArgs a) {
   // voxels in lattice order: neighbouring threads hit neighbouring texels (a strided order that spreads the atomics over the
   // maps measured 30 % slower - the kernel is bound by the locality of its gathers and atomics, not by same-line contention)
   const int64_t i_ = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
