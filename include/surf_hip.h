@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 33
+#define SURF_ABI_VERSION 34
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -220,9 +220,10 @@ int surf_lncc_backward(const float* ref, const float* src, const float* g_out, i
  * Per-pixel terms of the photometric loss of one depth map (training).  Replaces compute_ptloss + SSIM
  * (models/losses/photometric_loss.py:54-125, :6-33): the other nv-1 views are warped into view ref_idx through `depth` (H,W)
  * (bilinear, zeros, align_corners=True) into `warp` (nv-1,H,W,4: rgb + validity); terms (H,W,8) =
- * [l1 m, grad_x mx, grad_y my, ssim m | m, mx, my, 0], every loss value being the SUM of its topk smallest source views
+ * [l1 m, grad_x mx, grad_y my, ssim m | m, mx, my, m], every loss value being the SUM of its topk smallest source views
  * and m / mx / my the reference mask and its products with the right / lower neighbour.  The loss is
- * sum(col0)/(sum(col4)+1e-8) + sum(col1)/(sum(col5)+1e-8) + sum(col2)/(sum(col6)+1e-8) + sum(col3)/(sum(col4)+1e-8).
+ * sum(col0)/(sum(col4)+1e-8) + sum(col1)/(sum(col5)+1e-8) + sum(col2)/(sum(col6)+1e-8) + sum(col3)/(sum(col7)+1e-8)
+ * (col7 repeats col4 so that the four quotients are one vector division).
  * imgs_t4 (nv,H,W,4) texel4; h_intrs / h_c2w / h_w2c: host (nv,4,4) intrinsics, camera-to-world and their inverses.
  */
 int surf_ptloss_terms(const float* imgs_t4, int nv, int H, int W, const float* depth, const float* mask, int ref_idx, int topk,
@@ -533,6 +534,10 @@ int surf_deconv3x3_s2(const float* in, const float* weight, int N, int H, int W,
  * workspace: surf_inorm_workspace_doubles(N,H,W,C) doubles; stats (N,C,2) receives mean and 1/sqrt(var+1e-5). */
 int64_t surf_inorm_workspace_doubles(int N, int H, int W, int C);
 int surf_inorm_relu(float* x, int N, int H, int W, int C, const float* skip, double* workspace, float* stats, void* stream);
+/* The same into `out` (N,H,W,C), x left as it is: a recording (train-mode) forward keeps the raw convolution output for
+ * surf_inorm_relu_backward and needs no copy of it. */
+int surf_inorm_relu_out(const float* x, int N, int H, int W, int C, const float* skip, double* workspace, float* stats,
+                        float* out, void* stream);
 
 /*
  * Surface patches for the LNCC loss (training outputs ref_gray_val / sampled_gray_val).  Replaces render_core's tail
@@ -550,6 +555,34 @@ int surf_surface_points(const float* rays_o, const float* rays_d, const float* z
 int surf_patch_warp(const float* pts, const float* grads, int n_rays, const float* const* h_maps, int nv, int H, int W,
                     const float* h_intrs, const float* h_kinv_ref, const float* h_c2w, int patch_size, float* ref_out,
                     float* src_out, void* stream);
+
+/* =====================================================================================================
+ * Small fused helpers of the training step (csrc/train_small.hip): chains of tiny torch ops as single launches.
+ * ===================================================================================================== */
+
+/* lookup_volume(pts, mask_volumes, 'nearest').any(-1) (models/modules/implicit_surface.py:175; the mask volume of a level is
+ * 1 exactly where its index table is >= 0, volume.py:112-130): out[i] = 1 when the voxel nearest to pts[i] (grid_sample
+ * 'nearest', align_corners=False: round-half-even of ((p + 1) D - 1) / 2, zeros outside) is occupied on ANY level.
+ * pts (n,3) device; h_tables / h_dims: HOST arrays of `levels` device index tables (D^3 int32) and their D; out (n) bytes. */
+int surf_occupied_any(const float* pts, int64_t n, const int32_t* const* h_tables, const int* h_dims, int levels, uint8_t* out,
+                      void* stream);
+
+/* sum(|pred - target| mask) / (sum(mask) + 1e-8) over n elements: the masked L1 of the depth terms of models/losses/loss.py
+ * (:71-93).  mask_kind 0: mask = n floats; 1: n bytes (torch.bool); 2: mask = target > 0 (`mask` unused).  Sums in fp64, in a
+ * fixed order.  workspace: surf_masked_l1_workspace_bytes() device bytes; counter: one device uint32 that is 0 on entry (the
+ * kernel leaves it 0: allocate and clear it once per stream); out2[0] = the loss, out2[1] = 1 / (sum(mask) + 1e-8).
+ * The backward: g_pred[i] = upstream[0] out2[1] sgn(pred - target) mask  (upstream: a device scalar). */
+int64_t surf_masked_l1_workspace_bytes(void);
+int surf_masked_l1(const float* pred, const float* target, const void* mask, int mask_kind, int64_t n, void* workspace,
+                   unsigned* counter, float* out2, void* stream);
+int surf_masked_l1_backward(const float* pred, const float* target, const void* mask, int mask_kind, int64_t n, const float* out2,
+                            const float* upstream, float* g_pred, void* stream);
+
+/* Backward of the weight-norm re-parameterisation W = g v / |v|_row (models/modules/sdf_network.py:88-89, nn.utils.weight_norm)
+ * of `layers` (<= 8) linear layers in one launch: dg = <dW, v>_row / |v|, dv = (g / |v|) (dW - (dg / |v|) v).
+ * HOST arrays of device pointers: v, dW, dv (rows[l] x cols[l]), g, dg (rows[l]). */
+int surf_weight_norm_backward(int layers, const float* const* h_v, const float* const* h_g, const float* const* h_dW,
+                              const int* h_rows, const int* h_cols, float* const* h_dv, float* const* h_dg, void* stream);
 
 /*
  * Marching cubes on a (nx, ny, nz) fp32 lattice u[x][y][z] (z fastest).  Replaces mcubes.marching_cubes(u, isovalue)

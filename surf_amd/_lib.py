@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
 # must equal SURF_ABI_VERSION of include/surf_hip.h (tests/test_host_modules.py compares the two texts); lib() refuses a
 # library built from another header
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -122,6 +122,12 @@ SIGNATURES = {
     "surf_deconv3x3_s2": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "surf_inorm_workspace_doubles": (c_i64, [c_int, c_int, c_int, c_int]),
     "surf_inorm_relu": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_inorm_relu_out": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_occupied_any": (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_int, c_ptr, c_ptr]),
+    "surf_masked_l1_workspace_bytes": (c_i64, []),
+    "surf_masked_l1": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_masked_l1_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_weight_norm_backward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_matching_depth": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr,
                                     c_ptr, c_int, c_ptr, c_float, c_float, c_ptr, c_ptr, c_ptr, c_ptr]),
 }

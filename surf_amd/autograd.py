@@ -76,15 +76,12 @@ class _Render(torch.autograd.Function):
         with ops.precision_scope(ctx.precision):
             dvols = isurf.backward_render(g["color_fine"], g["render_depth"], _scalar(g["gradient_error"]), g["sparse_sdf"], None,
                                           gfeats_t4=gfeats, g_smooth_error=_scalar(g["smooth_error"]), g_pseudo_sdf=g.get("pseudo_sdf"),
-                                          g_patches=None if patches == (None, None) else patches, ctx=rec, sink=sink)
+                                          g_patches=None if patches == (None, None) else patches, ctx=rec, sink=sink, rows8=True)
         ctx.rec = None
         rows = []
-        for dv, w in zip(dvols, ctx.row_widths):                   # (N_s, 7) -> the input's own width ([logit | 7] rows: logit 0)
-            if w == 8:
-                full = torch.zeros(dv.shape[0], 8, dtype=dv.dtype, device=dv.device)
-                full[:, 1:] = dv
-                dv = full
-            rows.append(dv)
+        for dv, w in zip(dvols, ctx.row_widths):   # the kernels' [7 features | 0] rows -> the input's own width
+            # [logit | 7] rows (logit gradient 0): the zero column moves to the front - one pass instead of slice + fill + copy
+            rows.append(torch.roll(dv, 1, dims=1) if w == 8 else dv[:, :7].contiguous())
         feats = [None] * ctx.n_feats
         if want_feats:
             feats = [gf.permute(0, 3, 1, 2)[:, :4].contiguous() if ctx.feat_layout == "nchw" else gf for gf in gfeats]
@@ -193,15 +190,45 @@ class _Photometric(torch.autograd.Function):
     @staticmethod
     def forward(ctx, depth, imgs_t4, mask, cams, ref_idx, topk):
         depth = depth.float().contiguous()
-        ctx.save_for_backward(depth, imgs_t4, mask)
-        ctx.cams, ctx.ref_idx, ctx.topk = cams, ref_idx, topk
-        return ops.photometric_loss(depth, imgs_t4, mask, cams, ref_idx=ref_idx, topk=topk)
+        loss, (warp, sums) = ops.photometric_loss(depth, imgs_t4, mask, cams, ref_idx=ref_idx, topk=topk, return_state=True)
+        ctx.save_for_backward(depth, imgs_t4, mask, warp, sums)      # the warped images (29 MB a call at 5 x 576 x 800) are kept
+        ctx.cams, ctx.ref_idx, ctx.topk = cams, ref_idx, topk         # rather than produced again by a second forward launch
+        return loss
 
     @staticmethod
     def backward(ctx, g):
-        depth, imgs_t4, mask = ctx.saved_tensors
-        return ops.photometric_loss_backward(depth, imgs_t4, mask, ctx.cams, ctx.ref_idx, ctx.topk, upstream=g), None, None, None, None, None
+        depth, imgs_t4, mask, warp, sums = ctx.saved_tensors
+        return ops.photometric_loss_backward(depth, imgs_t4, mask, ctx.cams, ctx.ref_idx, ctx.topk, upstream=g,
+                                             state=(warp, sums)), None, None, None, None, None
 
 
 def photometric_loss(depth, imgs_t4, mask, cams, ref_idx=0, topk=2):
     return _Photometric.apply(depth, imgs_t4, mask, cams, ref_idx, topk)
+
+
+class _MaskedL1(torch.autograd.Function):
+    """sum(|pred - target| mask) / (sum(mask) + 1e-8) (losses/loss.py:71-93) = surf_masked_l1, backward surf_masked_l1_backward:
+    two launches instead of ~13 small torch kernels per term."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask):
+        pred_c = pred.float().contiguous()
+        target_c = target.detach().float().contiguous()
+        out2 = ops.masked_l1(pred_c, target_c, mask)
+        keep = (pred_c, target_c, out2) + (() if isinstance(mask, str) else (mask,))
+        ctx.save_for_backward(*keep)
+        ctx.mask_str = mask if isinstance(mask, str) else None
+        ctx.shape = pred.shape
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        pred_c, target_c, out2 = saved[:3]
+        mask = ctx.mask_str if ctx.mask_str is not None else saved[3]
+        return ops.masked_l1_backward(pred_c, target_c, mask, out2, g).view(ctx.shape), None, None
+
+
+def masked_l1(pred, target, mask):
+    """mask: a float / bool tensor of pred's size, or the string "target>0"."""
+    return _MaskedL1.apply(pred, target, mask)

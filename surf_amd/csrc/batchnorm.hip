@@ -44,42 +44,37 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   }
 }
 
-// Sum the per-block partials (blocks, 2, C) with one 256-thread workgroup: thread (g, c) takes the blocks b = g (mod 256 / C),
-// the slices meet in LDS in a fixed order (deterministic).  Returns true for the C threads that hold the totals.
-__device__ __forceinline__ bool reduce_partials(const double* __restrict__ part, int blocks, int C, double& s1, double& s2) {
-  __shared__ double red[2][256];
-  const int G = 256 / C, c = threadIdx.x % C, g = threadIdx.x / C;
+// Sum of the per-block partials (blocks, 2, C) of one channel.
+// One CHANNEL per workgroup (round 5, second pass: a single workgroup walking blocks x C partials was a chain of L2 round trips -
+// 12-13 us per layer at 1,024 partial blocks, 80 such launches a training step): thread t takes the blocks b = t (mod 256), a
+// wavefront sum by xor shuffles and the four wavefronts' sums in LDS, all in a fixed order (deterministic).  True for thread 0.
+__device__ __forceinline__ bool reduce_partials_channel(const double* __restrict__ part, int blocks, int C, int c, double& s1,
+                                                        double& s2) {
+  __shared__ double red[2][4];
   double a = 0.0, b2 = 0.0;
-  if (g < G) {
-    // four loads of each sum in flight (one load per iteration made the walk a chain of L2 round trips: 17 us for 512 blocks)
-    double a1 = 0.0, a2 = 0.0, a3 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0;
-    int b = g;
-    for (; b + 3 * G < blocks; b += 4 * G) {
-      a += part[((int64_t)b * 2 + 0) * C + c];             b2 += part[((int64_t)b * 2 + 1) * C + c];
-      a1 += part[((int64_t)(b + G) * 2 + 0) * C + c];       c1 += part[((int64_t)(b + G) * 2 + 1) * C + c];
-      a2 += part[((int64_t)(b + 2 * G) * 2 + 0) * C + c];   c2 += part[((int64_t)(b + 2 * G) * 2 + 1) * C + c];
-      a3 += part[((int64_t)(b + 3 * G) * 2 + 0) * C + c];   c3 += part[((int64_t)(b + 3 * G) * 2 + 1) * C + c];
-    }
-    for (; b < blocks; b += G) { a += part[((int64_t)b * 2 + 0) * C + c]; b2 += part[((int64_t)b * 2 + 1) * C + c]; }
-    a = (a + a1) + (a2 + a3);
-    b2 = (b2 + c1) + (c2 + c3);
+  for (int b = threadIdx.x; b < blocks; b += 256) {
+    a += part[((int64_t)b * 2 + 0) * C + c];
+    b2 += part[((int64_t)b * 2 + 1) * C + c];
   }
-  red[0][threadIdx.x] = a;
-  red[1][threadIdx.x] = b2;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b2 += __shfl_xor(b2, o);
+  }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b2; }
   __syncthreads();
-  s1 = s2 = 0.0;
-  if (threadIdx.x >= C) return false;
-  for (int k = 0; k < G; ++k) { s1 += red[0][k * C + threadIdx.x]; s2 += red[1][k * C + threadIdx.x]; }
-  return true;
+  s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  return threadIdx.x == 0;
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ part, int blocks, int C, int64_t n, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ part, int blocks, int C, int64_t n, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, float momentum, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, float* __restrict__ scale, float* __restrict__ shift,
                                    float* __restrict__ batch_stats) {
   double s1, s2;
-  if (!reduce_partials(part, blocks, C, s1, s2)) return;
-  const int c = threadIdx.x;
+  const int c = blockIdx.x;
+  if (!reduce_partials_channel(part, blocks, C, c, s1, s2)) return;
   const double mean = s1 / (double)n;
   double var = s2 / (double)n - mean * mean;      // biased (what the normalisation uses)
   if (var < 0.0) var = 0.0;
@@ -155,11 +150,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* __restrict__ part, int blocks, int C, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta) {
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* __restrict__ part, int blocks, int C,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
   double s1, s2;
-  if (!reduce_partials(part, blocks, C, s1, s2)) return;
-  const int c = threadIdx.x;
+  const int c = blockIdx.x;
+  if (!reduce_partials_channel(part, blocks, C, c, s1, s2)) return;
   dbeta[c] = (float)s1;
   dgamma[c] = (float)s2;
 }
@@ -213,12 +208,13 @@ __global__ __launch_bounds__(256) void inorm_bwd_partial_kernel(const float* __r
   }
 }
 
-__global__ void inorm_bwd_finalize_kernel(const double* __restrict__ part, int blocks, int C, float* __restrict__ sums /* (N, 2, C) */) {
+__global__ __launch_bounds__(256) void inorm_bwd_finalize_kernel(const double* __restrict__ part, int blocks, int C,
+                                                                 float* __restrict__ sums /* (N, 2, C) */) {
   double s1, s2;
-  const int v = blockIdx.x;
-  if (!reduce_partials(part + (int64_t)v * blocks * 2 * C, blocks, C, s1, s2)) return;
-  sums[((int64_t)v * 2 + 0) * C + threadIdx.x] = (float)s1;
-  sums[((int64_t)v * 2 + 1) * C + threadIdx.x] = (float)s2;
+  const int v = blockIdx.x, c = blockIdx.y;
+  if (!reduce_partials_channel(part + (int64_t)v * blocks * 2 * C, blocks, C, c, s1, s2)) return;
+  sums[((int64_t)v * 2 + 0) * C + c] = (float)s1;
+  sums[((int64_t)v * 2 + 1) * C + c] = (float)s2;
 }
 
 __global__ __launch_bounds__(256) void inorm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t n, int C,
@@ -255,7 +251,7 @@ extern "C" int surf_inorm_relu_backward(const float* x, const float* dy, int N, 
     case 64: hipLaunchKernelGGL(inorm_bwd_partial_kernel<64>, dim3(blocks, N), dim3(256), 0, s, x, dy, hw, stats, part); break;
     default: return SURF_E_LIMIT;
   }
-  hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(N), dim3(256), 0, s, part, blocks, channels, sums);
+  hipLaunchKernelGGL(inorm_bwd_finalize_kernel, dim3(N, channels), dim3(256), 0, s, part, blocks, channels, sums);
   const int64_t total = (int64_t)N * hw * channels;
   hipLaunchKernelGGL(inorm_bwd_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, dy, hw, channels, N, stats, sums, dx);
   return surf_check_launch();
@@ -276,7 +272,7 @@ extern "C" int surf_bn_relu_backward(const float* x, const float* dy, int64_t n,
     case 64: hipLaunchKernelGGL(bn_bwd_partial_kernel<64>, dim3(blocks), dim3(256), 0, s, x, dy, n, scale, shift, mean, invstd, part); break;
     default: return SURF_E_LIMIT;
   }
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(256), 0, s, part, blocks, channels, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(channels), dim3(256), 0, s, part, blocks, channels, dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n * channels + 255) / 256)), dim3(256), 0, s, x, dy, n, channels,
                      scale, shift, mean, invstd, dgamma, dbeta, train, dx);
   return surf_check_launch();
@@ -300,7 +296,7 @@ extern "C" int surf_bn_train_affine(const float* x, int64_t n, int channels, con
     case 64: hipLaunchKernelGGL(bn_partial_kernel<64>, dim3(blocks), dim3(256), 0, s, x, n, part); break;
     default: return SURF_E_LIMIT;
   }
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, s, part, blocks, channels, n, gamma, beta, eps, momentum,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(channels), dim3(256), 0, s, part, blocks, channels, n, gamma, beta, eps, momentum,
                      running_mean, running_var, scale, shift, batch_stats);
   return surf_check_launch();
 }

@@ -156,15 +156,15 @@ __global__ __launch_bounds__(64) void inorm_finalize_kernel(const double* __rest
   stats[t * 2 + 1] = (float)(1.0 / sqrt(var + 1e-5));
 }
 
-// y = relu((x - mean) * rstd) (+ skip), in place on x
-__global__ __launch_bounds__(256) void inorm_relu_kernel(float* __restrict__ x, const float* __restrict__ stats,
+// y = relu((x - mean) * rstd) (+ skip); y may be x (in place) or another buffer (train mode keeps x for the backward)
+__global__ __launch_bounds__(256) void inorm_relu_kernel(const float* x, float* y, const float* __restrict__ stats,
                                                          const float* __restrict__ skip, int N, int HW, int C) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // one f32x4 per thread
   const int c4n = C / 4;
   if (t >= (int64_t)N * HW * c4n) return;
   const int c4 = (int)(t % c4n);
   const int n = (int)(t / ((int64_t)HW * c4n));
-  f32x4 v = reinterpret_cast<f32x4*>(x)[t];
+  f32x4 v = reinterpret_cast<const f32x4*>(x)[t];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int c = c4 * 4 + q;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void inorm_relu_kernel(float* __restrict__ x, 
     v[q] = fmaxf((v[q] - mean) * rstd, 0.f);
   }
   if (skip) v += reinterpret_cast<const f32x4*>(skip)[t];
-  reinterpret_cast<f32x4*>(x)[t] = v;
+  reinterpret_cast<f32x4*>(y)[t] = v;
 }
 
 
@@ -337,16 +337,21 @@ extern "C" int64_t surf_inorm_workspace_doubles(int N, int H, int W, int C) {
   return (int64_t)N * nblk * C * 2;
 }
 
-extern "C" int surf_inorm_relu(float* x, int N, int H, int W, int C, const float* skip, double* workspace, float* stats,
-                               void* stream) {
-  if (!x || !workspace || !stats || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || C > 64 || 256 % C) return SURF_E_ARG;
+extern "C" int surf_inorm_relu_out(const float* x, int N, int H, int W, int C, const float* skip, double* workspace, float* stats,
+                                   float* out, void* stream) {
+  if (!x || !out || !workspace || !stats || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || C > 64 || 256 % C) return SURF_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int HW = H * W;
   const int nblk = (HW + ST_PIX - 1) / ST_PIX;
   hipLaunchKernelGGL(inorm_partial_kernel, dim3(nblk, N), dim3(256), 0, st, x, HW, C, nblk, workspace);
   hipLaunchKernelGGL(inorm_finalize_kernel, dim3(N * C), dim3(64), 0, st, workspace, N, nblk, C, HW, stats);
-  hipLaunchKernelGGL(inorm_relu_kernel, grid1d((int64_t)N * HW * (C / 4), 256), dim3(256), 0, st, x, stats, skip, N, HW, C);
+  hipLaunchKernelGGL(inorm_relu_kernel, grid1d((int64_t)N * HW * (C / 4), 256), dim3(256), 0, st, x, out, stats, skip, N, HW, C);
   return surf_check_launch();
+}
+
+extern "C" int surf_inorm_relu(float* x, int N, int H, int W, int C, const float* skip, double* workspace, float* stats,
+                               void* stream) {
+  return surf_inorm_relu_out(x, N, H, W, C, skip, workspace, stats, x, stream);
 }
 
 extern "C" int64_t surf_conv3x3_wgrad_workspace_floats(int N, int Hs, int Ws, int cb, int cs) {

@@ -4,7 +4,7 @@
 // the horizontal / vertical image gradients, SSIM (3x3 means, reflection padding, masked); each reduced to the SUM of its
 // `topk` smallest source views (torch.topk(largest=False)) and weighted by the reference mask.
 //   ptloss_warp_kernel   one thread per (source, pixel): texel4 (rgb, valid) of the warped image
-//   ptloss_terms_kernel  one thread per pixel: [l1 m, gx mx, gy my, ssim m | m, mx, my, 0]; the caller sums the columns
+//   ptloss_terms_kernel  one thread per pixel: [l1 m, gx mx, gy my, ssim m | m, mx, my, m]; the caller sums the columns
 // Byte-bound image-space work; sources <= SURF_MAX_VIEWS - 1.
 #include "common.h"
 
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, SURF_PT_WAVES) void ptloss_terms_kernel(PtArgs
     for (int k = 0; k < a.topk; ++k) sum[t] += best[t][k];
   f32x4* out = reinterpret_cast<f32x4*>(a.terms) + p * 2;
   out[0] = f32x4{sum[0] * mref, sum[1] * mx, sum[2] * my, sum[3] * mref};
-  out[1] = f32x4{mref, mx, my, 0.f};
+  out[1] = f32x4{mref, mx, my, mref};     // column 7 = column 4: the SSIM term's denominator, so that rows 0-3 / rows 4-7 is one division
 }
 
 // ---- backward w.r.t. the depth map (train mode) --------------------------------------------------------------------

@@ -70,9 +70,8 @@ class FeatureNetwork(nn.Module):
         def norm(y, skip=None):
             if not rec:
                 return ops.inorm_relu_(y, skip=skip), None, None
-            raw = y.clone()
-            y, stats = ops.inorm_relu_(y, skip=skip, want_stats=True)
-            return y, raw, stats
+            out, stats = ops.inorm_relu_(y, skip=skip, want_stats=True, in_place=False)    # y stays: the raw convolution output
+            return out, y, stats
 
         enc, enc_rec = [], []
         for i in range(self.num_stage):

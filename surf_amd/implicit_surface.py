@@ -130,14 +130,7 @@ class SceneVolumes:
     def occupied_any(self, pts):
         """lookup_volume(pts, mask_volumes, 'nearest').any(-1) (implicit_surface.py:175): is the nearest voxel of any
         level occupied; the mask volume is 1 exactly where the index table is >= 0 (volume.py:112-130)."""
-        occ = torch.zeros(pts.shape[0], dtype=torch.bool, device=pts.device)
-        for table in self.sv.tables:
-            D = table.shape[0]
-            g = torch.round(((pts + 1.0) * D - 1.0) / 2.0).long()      # align_corners=False, half-to-even like grid_sample
-            ok = ((g >= 0) & (g < D)).all(dim=-1)
-            g = g.clamp(0, D - 1)
-            occ |= ok & (table[g[:, 0], g[:, 1], g[:, 2]] >= 0)
-        return occ
+        return ops.occupied_any(pts.float().contiguous(), self.sv)       # one launch (until round 5: 15 torch ops per level)
 
     def warp_maps(self, use_match=False):
         """implicit_surface.py:229-241: FPN levels 0, 1, 2 at the finest level's size (texel4), from `features` or - once
@@ -338,7 +331,7 @@ class ImplicitSurface(nn.Module):
 
     @torch.no_grad()
     def backward_render(self, g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None, gfeats_t4=None,
-                        g_smooth_error=0.0, g_pseudo_sdf=None, g_patches=None, ctx=None, sink=None):
+                        g_smooth_error=0.0, g_pseudo_sdf=None, g_patches=None, ctx=None, sink=None, rows8=False):
         """Partial backward of the last training forward (`render_scene(patch_warp=True)`), SURVEY 8f-f2: given the loss's
         gradients w.r.t. `color_fine` (R,3), `render_depth` (R), `gradient_error` (scalar), `sparse_sdf` ((1024 + R*S),1) and
         the per-ray patch NCC (R,1) (= compute_LNCC2 of ref_gray_val / sampled_gray_val, the mfc term),
@@ -355,7 +348,8 @@ class ImplicitSurface(nn.Module):
         the patch stacks themselves (the reference's Loss: compute_LNCC2 in torch, losses/loss.py:43): contracted with the
         patches' tangents along the ray into d loss / d z0 (the patches depend on the network through z0 alone,
         implicit_surface.py:217-245).  ctx: the record of the forward to differentiate (default: the module's last one);
-        sink: a grads.GradSink that receives the parameter gradients instead of `.grad` (surf_amd.autograd)."""
+        sink: a grads.GradSink that receives the parameter gradients instead of `.grad` (surf_amd.autograd).
+        rows8: return the kernels' own (N_s, 8) rows = [7 features | 0] instead of their (N_s, 7) slices (no copy)."""
         c = ctx if ctx is not None else self._ctx
         st, act, scene = c["st"], c["act"], c["scene"]
         dev = c["sdf"].device
@@ -400,18 +394,20 @@ class ImplicitSurface(nn.Module):
             sm, ins = c["smooth"][idx], c["inside"][idx]
             nrm = torch.linalg.norm(sm, ord=2, dim=-1, keepdim=True)
             sbar = float(g_smooth_error) / (float(c["inside"].sum()) + 1e-5) * ins[:, None] * sm / nrm.clamp_min(1e-30)
-            rs = ops.sdf_smooth_backward(st["pts"][idx].contiguous(), sbar.contiguous(), scene.sv, self.smooth_weights(dev))
+            rs = ops.sdf_smooth_backward(st["pts"][idx].contiguous(), sbar.contiguous(), scene.sv, self.smooth_weights(dev),
+                                         dvols=res["volumes"])           # accumulates into the first backward's rows
             for l in range(7):
                 res["weight"][l] = res["weight"][l] + rs["weight"][l]
                 res["bias"][l] = res["bias"][l] + rs["bias"][l]
-            res["volumes"] = [a_ + b_ for a_, b_ in zip(res["volumes"], rs["volumes"])]
-        for l in range(7):           # weight norm W = g v / |v|_row (sdf_network.py:88-89), its backward in closed form:
-            lin = getattr(self.sdf_network, f"lin{l}")          # dg = <dW, v>/|v|,  dv = (g/|v|) (dW - (dg/|v|) v)
-            v, g, dW = lin.weight_v.detach().float(), lin.weight_g.detach().float(), res["weight"][l]
-            nrm = torch.linalg.norm(v, dim=1, keepdim=True)
-            dg = (dW * v).sum(dim=1, keepdim=True) / nrm
-            accumulate(lin.weight_g, dg, sink)
-            accumulate(lin.weight_v, (g / nrm) * (dW - (dg / nrm) * v), sink)
+        # weight norm W = g v / |v|_row (sdf_network.py:88-89), its backward in closed form for the seven layers in one launch
+        # (ops.weight_norm_backward):  dg = <dW, v>/|v|,  dv = (g/|v|) (dW - (dg/|v|) v)
+        lins = [getattr(self.sdf_network, f"lin{l}") for l in range(7)]
+        dvs, dgs = ops.weight_norm_backward([lin.weight_v.detach().float().contiguous() for lin in lins],
+                                            [lin.weight_g.detach().float().contiguous() for lin in lins],
+                                            [res["weight"][l].contiguous() for l in range(7)])
+        for l, lin in enumerate(lins):
+            accumulate(lin.weight_g, dgs[l], sink)
+            accumulate(lin.weight_v, dvs[l], sink)
             accumulate(lin.bias, res["bias"][l], sink)
         cn = dict(self.color_network.named_parameters())     # raw parameter buffer in state_dict order, built on the device
         raw_w = torch.cat([cn[k].detach().reshape(-1).float() for k in ops.BLEND_KEYS]).contiguous()
@@ -422,7 +418,7 @@ class ImplicitSurface(nn.Module):
         raw = float(torch.exp(var.detach() * 10.0))
         dvar = d_is * 10.0 * inv_s if 1e-6 < raw < 1e6 else torch.zeros((), device=dev)
         accumulate(var, dvar, sink)
-        return [g[:, :7].contiguous() for g in res["volumes"]]
+        return list(res["volumes"]) if rows8 else [g[:, :7].contiguous() for g in res["volumes"]]
 
     def draw_jitter(self, n_rays, ref_chunk=None):
         """The `torch.rand([batch, 1]) - 0.5` draws of ImplicitSurface.render (:274-277, :304-306) on the CPU generator,

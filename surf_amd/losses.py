@@ -27,7 +27,12 @@ class Loss(nn.Module):
 
     @staticmethod
     def _masked_l1(pred, target, mask):
-        mask = mask.float()
+        """sum(|pred - target| mask) / (sum(mask) + 1e-8); mask: a tensor, or "target>0".  On the GPU one fused launch each way
+        (autograd.masked_l1) when the three have the same size; the torch expression otherwise."""
+        if torch.is_tensor(pred) and pred.is_cuda and pred.shape == target.shape and pred.numel() > 0 and \
+                (isinstance(mask, str) or mask.shape == pred.shape):
+            return autograd.masked_l1(pred, target.to(pred.device), mask)
+        mask = (target > 0).float() if isinstance(mask, str) else mask.float()
         return ((pred - target).abs() * mask).sum() / (mask.sum() + 1e-8)
 
     def forward(self, preds, targets, step=None, mode="train"):
@@ -56,8 +61,8 @@ class Loss(nn.Module):
                 ref_photo = autograd.photometric_loss(preds[f"depth_stage{i}"], imgs_t4, mask_ref, cams)
                 src_photo = autograd.photometric_loss(preds[f"depth_src_stage{i}"], imgs_t4, mask_src, cams, ref_idx=src_idx, topk=1)
                 photo_loss = photo_loss + (ref_photo + src_photo) * self.stage_weights[i]
-                pa = self._masked_l1(preds[f"depth_stage{i}"], targets["pseudo_depth_ref"], targets["pseudo_depth_ref"] > 0)
-                spa = self._masked_l1(preds[f"depth_src_stage{i}"], targets["pseudo_depth_src"], targets["pseudo_depth_src"] > 0)
+                pa = self._masked_l1(preds[f"depth_stage{i}"], targets["pseudo_depth_ref"], "target>0")
+                spa = self._masked_l1(preds[f"depth_src_stage{i}"], targets["pseudo_depth_src"], "target>0")
                 pseudo_auxi = pseudo_auxi + (pa + spa) * self.stage_weights[i]
             auxi = self._masked_l1(preds[f"depth_stage{n - 1}"], targets["depth_ref"], targets["mask_ref"])
             src_auxi = self._masked_l1(preds[f"depth_src_stage{n - 1}"], targets["depth_src"], targets["mask_src"])
@@ -65,9 +70,9 @@ class Loss(nn.Module):
             src_auxi0 = self._masked_l1(preds["depth_src_stage0"], targets["depth_src"], targets["mask_src"])
 
         pseudo_sdf_loss = preds["pseudo_sdf"].abs().mean() if "pseudo_sdf" in preds else zero
-        pseudo_depth_loss = (self._masked_l1(preds["render_depth"], targets["pseudo_depth"], targets["pseudo_depth"] > 0)
+        pseudo_depth_loss = (self._masked_l1(preds["render_depth"], targets["pseudo_depth"], "target>0")
                              if "pseudo_depth" in targets else zero)
-        depth_loss = (self._masked_l1(preds["render_depth"], targets["depth"], targets["depth"] > 0)
+        depth_loss = (self._masked_l1(preds["render_depth"], targets["depth"], "target>0")
                       if "depth" in targets else zero)
         loss = (color_loss * self.color_weight + eikonal_loss * self.igr_weight + sparse_loss * self.sparse_weight
                 + mfc_loss * self.mfc_weight + smooth_loss * self.smooth_weight + depth_loss * self.depth_weight

@@ -44,6 +44,42 @@ class _timed:
         return False
 
 
+class _ZeroPool:
+    """Small zero-initialised buffers carved out of one pre-zeroed block per device: a training step asks for ~100 of them
+    (the 27 x C_in x C_out weight-gradient accumulators of the sparse U-Net, 1.2 MB a stage) and each torch.zeros is a ~5 us
+    fill launch on a stream that is never idle.  A slice is handed out ONCE (never recycled: it lives as long as its views do),
+    the block is replaced when it runs out."""
+    BLOCK = 4 << 20          # floats (16 MB)
+    LIMIT = 1 << 18          # larger requests fill for themselves
+
+    def __init__(self):
+        self._blocks = {}
+
+    def take(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        if n > self.LIMIT or n == 0:
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        key = (device.type, device.index)
+        blk = self._blocks.get(key)
+        step = (n + 63) & ~63   # 256-byte slices
+        if blk is None or blk[1] + step > self.BLOCK:
+            blk = [torch.zeros(self.BLOCK, dtype=torch.float32, device=device), 0]
+            self._blocks[key] = blk
+        out = blk[0][blk[1]:blk[1] + n].view(shape)
+        blk[1] += step
+        return out
+
+
+_zero_pool = _ZeroPool()
+
+
+def small_zeros(shape, device):
+    """fp32 zeros(shape) on `device`, from the pool above when small."""
+    return _zero_pool.take(tuple(shape), torch.device(device))
+
+
 def _p(t):
     t = getattr(t, "tensor", t)            # PackedBlend
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
@@ -476,17 +512,21 @@ def sdf_backward(pts, ybar, gbar, volumes, packed, want_dvols=True):
     return {"weight": dW, "bias": db, "volumes": dvols}
 
 
-def sdf_smooth_backward(pts, sbar, volumes, packed, want_dvols=True):
+def sdf_smooth_backward(pts, sbar, volumes, packed, want_dvols=True, dvols=None):
     """Gradients of sum_n sbar_n . smooth_n (smooth = H.1 of the SDF, sdf_network.py:143-150) w.r.t. the EFFECTIVE matrices /
     biases of lin0..lin6 and the sparse feature rows (surf_sdf_smooth_backward; the batch reductions are surf_colgram).
-    Returns the same dictionary as sdf_backward."""
+    Returns the same dictionary as sdf_backward.  dvols: the (N_s, 8) gradient rows of an earlier sdf_backward to ACCUMULATE into
+    (the kernel adds with atomics either way: saves a zero fill and a sum over ~10 M rows)."""
     _chk(pts, torch.float32, "pts")
     _chk(sbar, torch.float32, "sbar")
     _chk(packed, torch.float32, "packed weights")
     n, dev = pts.shape[0], pts.device
     xin = torch.empty(7, 4, n, 160, dtype=torch.float32, device=dev)
     ab = torch.empty(6, 4, n, 128, dtype=torch.float32, device=dev)
-    dvols = [torch.zeros_like(v) for v in volumes.vols] if want_dvols else None
+    if dvols is not None:
+        assert len(dvols) == volumes.n and all(d.shape == v.shape and d.is_contiguous() for d, v in zip(dvols, volumes.vols))
+    else:
+        dvols = [torch.zeros_like(v) for v in volumes.vols] if want_dvols else None
     with _timed("sdf_smooth_bwd", n):
         rc = _lib.lib().surf_sdf_smooth_backward(_p(pts), _p(sbar), n, volumes._vp, volumes._tp, volumes._dp, volumes.n,
                                                  _ptr_array(dvols) if dvols is not None else None, _p(packed), _p(xin), _p(ab), _stream())
@@ -764,9 +804,10 @@ def patch_warp(pts, grads, maps_t4, cams, patch_size=11):
     return ref, src
 
 
-def photometric_loss(depth, imgs_t4, mask_ref, cams, ref_idx=0, topk=2, return_warp=False):
+def photometric_loss(depth, imgs_t4, mask_ref, cams, ref_idx=0, topk=2, return_warp=False, return_state=False):
     """compute_ptloss (losses/photometric_loss.py:54-125) of one (H,W) depth map of view ref_idx: scalar tensor.
-    imgs_t4 (nv,H,W,4) texel4; cams: ops.Cameras (host matrices)."""
+    imgs_t4 (nv,H,W,4) texel4; cams: ops.Cameras (host matrices).  return_state: (loss, (warp, column sums)) - what
+    photometric_loss_backward would otherwise recompute with a second run of the forward kernel."""
     _chk(depth, torch.float32, "depth")
     _chk(imgs_t4, torch.float32, "imgs_t4")
     _chk(mask_ref, torch.float32, "mask_ref")
@@ -780,25 +821,31 @@ def photometric_loss(depth, imgs_t4, mask_ref, cams, ref_idx=0, topk=2, return_w
     rc = _lib.lib().surf_ptloss_terms(_p(imgs_t4), nv, H, W, _p(depth), _p(mask_ref), int(ref_idx), int(topk), _np_ptr(intr16),
                                       _np_ptr(cams.c2w), _np_ptr(cams.w2c), _p(warp), _p(terms), _stream())
     _lib.check(rc, "surf_ptloss_terms")
-    t = terms.view(-1, 8).sum(dim=0, dtype=torch.float64)
-    loss = (t[0] / (t[4] + 1e-8) + t[1] / (t[5] + 1e-8) + t[2] / (t[6] + 1e-8) + t[3] / (t[4] + 1e-8)).float()
+    t = terms.view(-1, 8).sum(dim=0, dtype=torch.float64)       # columns [l1 m, gx mx, gy my, ssim m | m, mx, my, m]
+    loss = (t[:4] / (t[4:] + 1e-8)).sum().float()
+    if return_state:
+        return loss, (warp, t)
     return (loss, warp) if return_warp else loss
 
 
-def photometric_loss_backward(depth, imgs_t4, mask_ref, cams, ref_idx=0, topk=2, upstream=1.0):
-    """d (upstream * photometric_loss(depth, ...)) / d depth (H,W) (surf_ptloss_backward; the forward kernels are re-run for
-    the warped images and the mask sums).  upstream: float or 0-d device tensor."""
+def photometric_loss_backward(depth, imgs_t4, mask_ref, cams, ref_idx=0, topk=2, upstream=1.0, state=None):
+    """d (upstream * photometric_loss(depth, ...)) / d depth (H,W) (surf_ptloss_backward).  state: the forward's (warp, column
+    sums) (photometric_loss(..., return_state=True)); None: the forward kernel is re-run for them.  upstream: float or 0-d
+    device tensor."""
     _chk(depth, torch.float32, "depth")
     nv, H, W, _ = imgs_t4.shape
     dev = depth.device
-    warp = torch.empty(nv - 1, H, W, 4, dtype=torch.float32, device=dev)
-    terms = torch.empty(H, W, 8, dtype=torch.float32, device=dev)
     intr16 = np.ascontiguousarray(cams.intrs.reshape(nv, -1))
-    rc = _lib.lib().surf_ptloss_terms(_p(imgs_t4), nv, H, W, _p(depth), _p(mask_ref), int(ref_idx), int(topk), _np_ptr(intr16),
-                                      _np_ptr(cams.c2w), _np_ptr(cams.w2c), _p(warp), _p(terms), _stream())
-    _lib.check(rc, "surf_ptloss_terms")
-    t = terms.view(-1, 8).sum(dim=0, dtype=torch.float64)
-    coef = (upstream / (torch.stack([t[4], t[5], t[6], t[4]]) + 1e-8)).float().contiguous()
+    if state is not None:
+        warp, t = state
+    else:
+        warp = torch.empty(nv - 1, H, W, 4, dtype=torch.float32, device=dev)
+        terms = torch.empty(H, W, 8, dtype=torch.float32, device=dev)
+        rc = _lib.lib().surf_ptloss_terms(_p(imgs_t4), nv, H, W, _p(depth), _p(mask_ref), int(ref_idx), int(topk), _np_ptr(intr16),
+                                          _np_ptr(cams.c2w), _np_ptr(cams.w2c), _p(warp), _p(terms), _stream())
+        _lib.check(rc, "surf_ptloss_terms")
+        t = terms.view(-1, 8).sum(dim=0, dtype=torch.float64)
+    coef = (upstream / (t[4:] + 1e-8)).float().contiguous()
     g_warp = torch.empty_like(warp)
     g_depth = torch.empty(H, W, dtype=torch.float32, device=dev)
     rc = _lib.lib().surf_ptloss_backward(_p(imgs_t4), nv, H, W, _p(depth), _p(mask_ref), int(ref_idx), int(topk), _np_ptr(intr16),
@@ -1261,7 +1308,7 @@ def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight,
     with _timed(f"spconv_dgrad<{cout},{cin}>", {"pairs": pairs, "sites": int(in_coords.shape[0])}):
         dx = spconv(dy, out_table, in_coords, {SUBM: SUBM, DOWN: UP, UP: DOWN}[mode], wt, packed=wt_packed,
                     bf16=colgram_precision == 1)
-    dW = torch.zeros_like(weight)
+    dW = small_zeros(weight.shape, weight.device)       # the kernels accumulate into it
     if out_coords.shape[0] > 0 and x.shape[0] > 0:
         with _timed(f"spconv_wgrad<{cin},{cout}>", {"pairs": pairs, "sites": int(out_coords.shape[0])}):
             if use_mfma and _lib.lib().surf_spconv_wgrad_mfma_supported(cin, cout):
@@ -1275,10 +1322,12 @@ def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight,
     return dx, dW
 
 
-def bn_train_relu(x, bn, skip=None, saved=None):
+def bn_train_relu(x, bn, skip=None, saved=None, counters=None):
     """spnn.BatchNorm in train mode + ReLU (+ skip) on raw convolution outputs x (n, C): batch statistics, running
     statistics updated in place like torch (reg_network.py:14-15,28-29).  bn: the block's nn.BatchNorm1d.
-    saved: a dict that receives what bn_relu_backward needs (scale, shift, stats = mean | invstd)."""
+    saved: a dict that receives what bn_relu_backward needs (scale, shift, stats = mean | invstd).
+    counters: a list that receives bn.num_batches_tracked INSTEAD of its increment - the caller bumps all of a network's
+    counters with one torch._foreach_add_ (ten launches less per U-Net)."""
     _chk(x, torch.float32, "x")
     n, C = x.shape
     dev = x.device
@@ -1296,7 +1345,10 @@ def bn_train_relu(x, bn, skip=None, saved=None):
                                          _p(scale), _p(shift), _p(stats), _p(ws), _stream())
     _lib.check(rc, "surf_bn_train_affine")
     if track:
-        bn.num_batches_tracked += 1
+        if counters is not None:
+            counters.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
     if saved is not None:
         saved.update(scale=scale, shift=shift, stats=stats)
     _lib.check(_lib.lib().surf_bn_relu_apply(_p(x), n, C, _p(scale), _p(shift), _p(skip), _p(out), _stream()), "surf_bn_relu_apply")
@@ -1312,10 +1364,10 @@ def bn_relu_backward(x, dy, scale, shift, stats, train=True):
     n, C = x.shape
     dev = x.device
     dx = torch.empty_like(x)
-    dgamma = torch.zeros(C, dtype=torch.float32, device=dev)
-    dbeta = torch.zeros(C, dtype=torch.float32, device=dev)
     if n == 0:
-        return dx, dgamma, dbeta
+        return dx, small_zeros((C,), dev), small_zeros((C,), dev)
+    dgb = torch.empty(2, C, dtype=torch.float32, device=dev)       # bn_bwd_finalize_kernel writes (not accumulates) both rows
+    dgamma, dbeta = dgb[0], dgb[1]
     ws = torch.empty(_lib.lib().surf_bn_workspace_bytes(C), dtype=torch.uint8, device=dev)
     mean, invstd = stats[:C], stats[C:]
     rc = _lib.lib().surf_bn_relu_backward(_p(x), _p(dy), n, C, _p(scale), _p(shift), _p(mean), _p(invstd), int(bool(train)),
@@ -1390,11 +1442,92 @@ def inorm_relu_backward(raw, dy, stats):
     return dx
 
 
-def inorm_relu_(x, skip=None, want_stats=False):
-    """In place x = relu(instance_norm(x)) (+ skip); x (N,H,W,C) NHWC."""
+def inorm_relu_(x, skip=None, want_stats=False, in_place=True):
+    """x = relu(instance_norm(x)) (+ skip); x (N,H,W,C) NHWC.  in_place (default): x is overwritten and returned; False: x is
+    left as it is (a recording forward keeps it as the raw convolution output) and a new tensor is returned."""
     _chk(x, torch.float32, "x")
     N, H, W, C = x.shape
     ws = torch.empty(_lib.lib().surf_inorm_workspace_doubles(N, H, W, C), dtype=torch.float64, device=x.device)
     stats = torch.empty(N, C, 2, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().surf_inorm_relu(_p(x), N, H, W, C, _p(skip), _p(ws), _p(stats), _stream()), "surf_inorm_relu")
-    return (x, stats) if want_stats else x
+    out = x if in_place else torch.empty_like(x)
+    _lib.check(_lib.lib().surf_inorm_relu_out(_p(x), N, H, W, C, _p(skip), _p(ws), _p(stats), _p(out), _stream()),
+               "surf_inorm_relu_out")
+    return (out, stats) if want_stats else out
+
+
+# ------------------------------------------------------------------------------------------------
+# small fused helpers of the training step (csrc/train_small.hip)
+# ------------------------------------------------------------------------------------------------
+
+def occupied_any(pts, volumes):
+    """lookup_volume(pts, mask_volumes, 'nearest').any(-1) (implicit_surface.py:175) in one launch: (n,) bool."""
+    _chk(pts, torch.float32, "pts")
+    assert pts.dim() == 2 and pts.shape[1] == 3
+    out = torch.empty(pts.shape[0], dtype=torch.bool, device=pts.device)
+    if pts.shape[0] == 0:
+        return out
+    rc = _lib.lib().surf_occupied_any(_p(pts), pts.shape[0], volumes._tp, volumes._dp, volumes.n, _p(out), _stream())
+    _lib.check(rc, "surf_occupied_any")
+    return out
+
+
+_l1_counters = {}
+
+
+def _l1_mask(mask, ref):
+    """(tensor or None, mask_kind of surf_masked_l1) for a mask given as a float / bool tensor or the string "target>0"."""
+    if isinstance(mask, str):
+        assert mask == "target>0"
+        return None, 2
+    assert mask.numel() == ref.numel() and mask.device == ref.device
+    if mask.dtype == torch.bool or mask.dtype == torch.uint8:
+        return mask.contiguous(), 1
+    return _chk(mask.float().contiguous(), torch.float32, "mask"), 0
+
+
+def masked_l1(pred, target, mask):
+    """sum(|pred - target| mask) / (sum(mask) + 1e-8) as ONE launch (loss.py:71-93; fp64 sums in a fixed order).  mask: a float /
+    bool tensor of pred's size, or "target>0".  Returns out2 (2,) fp32: [0] the loss, [1] 1 / (sum(mask) + 1e-8)."""
+    _chk(pred, torch.float32, "pred")
+    _chk(target, torch.float32, "target")
+    assert pred.numel() == target.numel() and pred.numel() > 0
+    dev = pred.device
+    m, kind = _l1_mask(mask, pred)
+    key = (dev.index, torch.cuda.current_stream().cuda_stream)
+    if key not in _l1_counters:        # one self-resetting arrival counter per stream
+        _l1_counters[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = torch.empty(_lib.lib().surf_masked_l1_workspace_bytes(), dtype=torch.uint8, device=dev)
+    out2 = torch.empty(2, dtype=torch.float32, device=dev)
+    rc = _lib.lib().surf_masked_l1(_p(pred), _p(target), _p(m), kind, pred.numel(), _p(ws), _p(_l1_counters[key]), _p(out2), _stream())
+    _lib.check(rc, "surf_masked_l1")
+    return out2
+
+
+def masked_l1_backward(pred, target, mask, out2, upstream):
+    """d (upstream * masked_l1) / d pred; upstream: a 0-d fp32 device tensor."""
+    m, kind = _l1_mask(mask, pred)
+    up = _chk(upstream.reshape(1).float().contiguous(), torch.float32, "upstream")
+    g = torch.empty_like(pred)
+    rc = _lib.lib().surf_masked_l1_backward(_p(pred), _p(target), _p(m), kind, pred.numel(), _p(out2), _p(up), _p(g), _stream())
+    _lib.check(rc, "surf_masked_l1_backward")
+    return g
+
+
+def weight_norm_backward(vs, gs, dWs):
+    """Backward of W_l = g_l v_l / |v_l|_row (sdf_network.py:88-89) for a list of layers in ONE launch: ([dv_l], [dg_l]),
+    dg_l shaped like g_l."""
+    n = len(vs)
+    assert n == len(gs) == len(dWs) and n >= 1
+    for v, g, dW in zip(vs, gs, dWs):
+        _chk(v, torch.float32, "weight_v")
+        _chk(g, torch.float32, "weight_g")
+        _chk(dW, torch.float32, "dW")
+        assert v.dim() == 2 and dW.shape == v.shape and g.numel() == v.shape[0]
+    dvs = [torch.empty_like(v) for v in vs]
+    dgs = [torch.empty_like(g) for g in gs]
+    rows = (ctypes.c_int * n)(*[int(v.shape[0]) for v in vs])
+    cols = (ctypes.c_int * n)(*[int(v.shape[1]) for v in vs])
+    rc = _lib.lib().surf_weight_norm_backward(n, _ptr_array(vs), _ptr_array(gs), _ptr_array(dWs), rows, cols, _ptr_array(dvs),
+                                              _ptr_array(dgs), _stream())
+    _lib.check(rc, "surf_weight_norm_backward")
+    return dvs, dgs

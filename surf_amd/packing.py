@@ -83,13 +83,23 @@ def sdf_source_count():
 def _sdf_flat(isdf):
     """The effective (weight-normed) matrices and biases of SDFNetworkSparse as one flat device vector, W_0, b_0, W_1, ...
     (sdf_network.py:88-89: W = g v / |v|_row), computed on the device."""
+    # one flat vector per parameter version: the split-bf16 image of the render kernels and the fp32 image of the training
+    # kernels are both cut from it (44 small launches, twice per training step until round 5)
+    ps = [p for l in range(7) for p in (getattr(isdf, f"lin{l}").weight_v, getattr(isdf, f"lin{l}").weight_g,
+                                        getattr(isdf, f"lin{l}").bias)]
+    key = tuple((p._version, p.data_ptr()) for p in ps)
+    cached = getattr(isdf, "_surf_flat", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
     parts = []
     for l in range(7):
         lin = getattr(isdf, f"lin{l}")
         v, g = lin.weight_v.detach().float(), lin.weight_g.detach().float()
         parts.append((v * (g / torch.linalg.norm(v, dim=1, keepdim=True))).reshape(-1))
         parts.append(lin.bias.detach().float().reshape(-1))
-    return torch.cat(parts)
+    flat = torch.cat(parts)
+    object.__setattr__(isdf, "_surf_flat", (key, flat))
+    return flat
 
 
 def _sdf_split_map(precision):

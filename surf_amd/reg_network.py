@@ -41,16 +41,19 @@ class _Block(nn.Module):
         shift = bn.bias.detach() - bn.running_mean * scale
         return scale.float().contiguous(), shift.float().contiguous()
 
-    def prepared(self, use_mfma=True):
+    def prepared(self, use_mfma=True, affine=True):
         """(kernel, bn scale, bn shift, split-bf16 operand image or None), cached until a parameter or buffer changes
         (optimiser step, load_state_dict, .to(device)): saves five small launches per convolution and the repacking.
         The running statistics are also written by surf_bn_train_affine through raw pointers, which torch's version
-        counters do not see: the train path sets `_bn_dirty`."""
+        counters do not see: the train path sets `_bn_dirty`.  affine=False (train mode: batch statistics, the folded
+        running-statistics affine is not used): scale / shift are None and nothing is computed for them."""
         conv, bn = self.net[0], self.net[1]
         wkey = (conv.kernel._version, conv.kernel.data_ptr(), bool(use_mfma))
         if getattr(self, "_wprep", None) is None or self._wprep[0] != wkey:
             w = conv.kernel.detach().float().contiguous()
             self._wprep = (wkey, w, ops.spconv_pack_weights(w) if use_mfma else None)
+        if not affine:
+            return self._wprep[1], None, None, self._wprep[2]
         ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
         bkey = tuple((t._version, t.data_ptr()) for t in ts)
         if getattr(self, "_bprep", None) is None or self._bprep[0] != bkey or getattr(self, "_bn_dirty", False):
@@ -90,16 +93,16 @@ class SparseCostRegNet(nn.Module):
         self.conv11 = _Block(2 * b, b, stride=2, transposed=True)
         self.out_lin = nn.Linear(b, d_out, bias=False)
 
-    def _conv(self, blk, x, in_site, out_site, mode, skip=None, tape=None):
+    def _conv(self, blk, x, in_site, out_site, mode, skip=None, tape=None, counters=None):
         """One block on x (rows of `in_site` = (table, coords)) -> rows of `out_site`.  tape: a list that receives what
         `backward` needs (train mode only: eval mode folds the BN into the convolution epilogue and keeps no raw output)."""
-        w, scale, shift, packed = blk.prepared(self.use_mfma)
+        w, scale, shift, packed = blk.prepared(self.use_mfma, affine=not self.training)
         if self.training:   # batch statistics, running statistics updated
             raw = ops.spconv(x, in_site[0], out_site[1], mode, w, None, None, None, packed=packed,
                              bf16=ops.colgram_precision == 1)       # train_precision = bf16: wide layers on bf16 operands
             blk._bn_dirty = True
             saved = {} if tape is not None else None
-            y = ops.bn_train_relu(raw, blk.net[1], skip, saved)
+            y = ops.bn_train_relu(raw, blk.net[1], skip, saved, counters=counters)
             if tape is not None:
                 tape.append(dict(blk=blk, x=x, raw=raw, y=y, skip=skip, in_site=in_site, out_site=out_site, mode=mode, w=w, **saved))
             return y
@@ -120,24 +123,27 @@ class SparseCostRegNet(nn.Module):
             q2 = max((q1 - 3) // 2 + 1, 0)
             q3 = max((q2 - 3) // 2 + 1, 0)
             D, table = D + 1, None
+        counters = [] if self.training else None       # the blocks' num_batches_tracked, bumped together below
         t0 = table if table is not None else ops.table_from_coords(coords, D)
         s0 = (t0, coords)
-        c0 = self._conv(self.conv0, feats, s0, s0, ops.SUBM, tape=tape)
+        c0 = self._conv(self.conv0, feats, s0, s0, ops.SUBM, tape=tape, counters=counters)
         cd1, t1, D1 = ops.down_sites(coords, D, self.down_rule, q1)
         s1 = (t1, cd1)
-        x = self._conv(self.conv1, c0, s0, s1, ops.DOWN, tape=tape)
-        c2 = self._conv(self.conv2, x, s1, s1, ops.SUBM, tape=tape)
+        x = self._conv(self.conv1, c0, s0, s1, ops.DOWN, tape=tape, counters=counters)
+        c2 = self._conv(self.conv2, x, s1, s1, ops.SUBM, tape=tape, counters=counters)
         cd2, t2, D2 = ops.down_sites(cd1, D1, self.down_rule, q2)
         s2 = (t2, cd2)
-        x = self._conv(self.conv3, c2, s1, s2, ops.DOWN, tape=tape)
-        c4 = self._conv(self.conv4, x, s2, s2, ops.SUBM, tape=tape)
+        x = self._conv(self.conv3, c2, s1, s2, ops.DOWN, tape=tape, counters=counters)
+        c4 = self._conv(self.conv4, x, s2, s2, ops.SUBM, tape=tape, counters=counters)
         cd3, t3, D3 = ops.down_sites(cd2, D2, self.down_rule, q3)
         s3 = (t3, cd3)
-        x = self._conv(self.conv5, c4, s2, s3, ops.DOWN, tape=tape)
-        x = self._conv(self.conv6, x, s3, s3, ops.SUBM, tape=tape)
-        x = self._conv(self.conv7, x, s3, s2, ops.UP, skip=c4, tape=tape)
-        x = self._conv(self.conv9, x, s2, s1, ops.UP, skip=c2, tape=tape)
-        x = self._conv(self.conv11, x, s1, s0, ops.UP, skip=c0, tape=tape)
+        x = self._conv(self.conv5, c4, s2, s3, ops.DOWN, tape=tape, counters=counters)
+        x = self._conv(self.conv6, x, s3, s3, ops.SUBM, tape=tape, counters=counters)
+        x = self._conv(self.conv7, x, s3, s2, ops.UP, skip=c4, tape=tape, counters=counters)
+        x = self._conv(self.conv9, x, s2, s1, ops.UP, skip=c2, tape=tape, counters=counters)
+        x = self._conv(self.conv11, x, s1, s0, ops.UP, skip=c0, tape=tape, counters=counters)
+        if counters:
+            torch._foreach_add_(counters, 1)
         out = ops.row_linear8(x, self.out_lin.weight.detach().float().contiguous())
         if tape is not None:
             tape.append(dict(lin=True, x=x, feats=feats))

@@ -155,13 +155,13 @@ class SuRF(nn.Module):
         d_mvol, d_mid = None, None
         for s in range(n - 1, -1, -1):
             r = t["vol"][s]
-            g_out = torch.zeros(r["coords"].shape[0], 8, dtype=torch.float32, device=dev)
             rg = row_grads_f2c[n - 1 - s]
-            if rg is not None:
-                if rg.shape[1] == 8:
-                    g_out += rg
-                else:
-                    g_out[:, 1:] = rg
+            if rg is None:
+                g_out = torch.zeros(r["coords"].shape[0], 8, dtype=torch.float32, device=dev)
+            elif rg.shape[1] == 8:
+                g_out = rg.float().clone()                                  # written into below: never the caller's tensor
+            else:
+                g_out = torch.cat([rg.new_zeros(rg.shape[0], 1), rg], dim=1).float()
             gd = (g_depths or {}).get(s, (None, None))
             if gd[0] is not None or gd[1] is not None:
                 g_full = torch.zeros(nv, H, W, dtype=torch.float32, device=dev)

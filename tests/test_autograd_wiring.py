@@ -59,7 +59,7 @@ FAKE = textwrap.dedent("""
         seen = {}
 
         def backward_render(g_color, g_depth=None, g_gradient_error=0.0, g_sparse_sdf=None, g_ncc=None, gfeats_t4=None,
-                            g_smooth_error=0.0, g_pseudo_sdf=None, g_patches=None, ctx=None, sink=None):
+                            g_smooth_error=0.0, g_pseudo_sdf=None, g_patches=None, ctx=None, sink=None, rows8=False):
             calls.append("render_bwd")
             seen.update(g_color=g_color, g_depth=g_depth, g_eik=g_gradient_error, g_sparse=g_sparse_sdf, g_smooth=g_smooth_error,
                         g_pseudo=g_pseudo_sdf, g_patches=g_patches, ctx=ctx)
@@ -69,6 +69,8 @@ FAKE = textwrap.dedent("""
                     accumulate(p, torch.full_like(p, k), sink)
             for i, gf in enumerate(gfeats_t4):
                 gf += 10.0 * (i + 1)
+            if rows8:       # the kernels' own rows: [7 features | 0] (the graph node asks for these and moves the zero column)
+                return [torch.cat([torch.full((n, 7), 3.0), torch.zeros(n, 1)], dim=1) for n in N[::-1]]
             return [torch.full((n, 7), 3.0) for n in N[::-1]]
 
         def backward_volumes(row_grads_f2c, g_depths=None, tape=None, gfeats=None, sink=None):

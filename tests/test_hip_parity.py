@@ -1684,3 +1684,113 @@ def test_spconv_wgrad_mfma_matches_per_voxel_kernel(cin, cout):
         scale = float(dW_v.abs().max())
         assert scale > 0.1
         rel_close(dW_m, dW_v, 1e-5, 2e-6 * scale)
+
+
+def test_occupied_any_is_the_nearest_lookup_of_every_level(gpu_scene):
+    """surf_occupied_any (round 5, one launch) against the torch expression it replaced, bit for bit:
+    lookup_volume(pts, mask_volumes, 'nearest').any(-1) (implicit_surface.py:175) - nearest = round-half-even of the unnormalised
+    coordinate, zeros outside; points on voxel boundaries (exact .5 coordinates) and outside the cube included."""
+    from surf_amd import ops
+    d = dev()
+    sv = gpu_scene["sv"]
+    g = torch.Generator().manual_seed(5)
+    pts = (torch.rand(20001, 3, generator=g) * 2.6 - 1.3)
+    D0 = sv.dims[0]
+    ties = ((torch.randint(0, D0, (4000, 3), generator=g).float() + 0.5) * 2.0 + 1.0) / D0 - 1.0     # unnormalises to k + 0.5
+    pts = torch.cat([pts, ties]).to(d).contiguous()
+    occ = torch.zeros(pts.shape[0], dtype=torch.bool, device=d)
+    for table in sv.tables:
+        D = table.shape[0]
+        gi = torch.round(((pts + 1.0) * D - 1.0) / 2.0).long()
+        ok = ((gi >= 0) & (gi < D)).all(dim=-1)
+        gi = gi.clamp(0, D - 1)
+        occ |= ok & (table[gi[:, 0], gi[:, 1], gi[:, 2]] >= 0)
+    got = ops.occupied_any(pts, sv)
+    assert got.dtype == torch.bool and bool(occ.any()) and not bool(occ.all())
+    assert torch.equal(got, occ)
+    assert ops.occupied_any(pts[:0].contiguous(), sv).shape == (0,)
+
+
+@pytest.mark.parametrize("n", [1, 777, 576 * 800])
+def test_masked_l1_and_its_backward_match_torch(n):
+    """surf_masked_l1 / surf_masked_l1_backward (one launch each; loss.py:71-93) against the torch expression and its autograd,
+    for float masks, bool masks and the `target > 0` form; deterministic (two runs bit-equal); the arrival counter is left 0."""
+    from surf_amd import autograd as A
+    d = dev()
+    g = torch.Generator().manual_seed(n)
+    pred = (torch.randn(n, generator=g) + 2.0).to(d)
+    target = (torch.randn(n, generator=g) + 1.0).to(d)
+    target[::7] = pred[::7]                                   # exact ties: sgn(0) = 0
+    fmask = (torch.rand(n, generator=g) < 0.7).float().to(d)
+    for mask, mt in ((fmask, fmask), (fmask > 0, fmask), ("target>0", (target > 0).float())):
+        p1 = pred.clone().requires_grad_(True)
+        want = ((p1 - target).abs() * mt).sum() / (mt.sum() + 1e-8)
+        want.backward()
+        p2 = pred.clone().requires_grad_(True)
+        got = A.masked_l1(p2, target, mask)
+        (got * 3.0).backward()
+        assert abs(float(got) - float(want)) <= 2e-6 * abs(float(want)) + 1e-12
+        rel_close(p2.grad, 3.0 * p1.grad, 2e-6, 0)
+        again = A.masked_l1(pred, target, mask)
+        assert float(again) == float(got)
+    # an all-zero mask: 0 / 1e-8 = 0, gradient 0
+    p3 = pred.clone().requires_grad_(True)
+    z = A.masked_l1(p3, target, torch.zeros_like(pred))
+    z.backward()
+    assert float(z) == 0.0 and float(p3.grad.abs().max()) == 0.0
+
+
+def test_weight_norm_backward_matches_autograd():
+    """surf_weight_norm_backward (the seven SDF layers in one launch) against autograd through W = g v / |v|_row
+    (sdf_network.py:88-89)."""
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    shapes = [(128, 27), (128, 156), (101, 156), (128, 156), (128, 156), (128, 156), (129, 156)]
+    vs = [torch.randn(r, c, generator=g).to(d) for r, c in shapes]
+    gs = [(torch.rand(r, 1, generator=g) + 0.5).to(d) for r, _ in shapes]
+    dWs = [torch.randn(r, c, generator=g).to(d) for r, c in shapes]
+    dvs, dgs = ops.weight_norm_backward(vs, gs, dWs)
+    for v, gg, dW, dv, dg in zip(vs, gs, dWs, dvs, dgs):
+        v1, g1 = v.clone().requires_grad_(True), gg.clone().requires_grad_(True)
+        W = g1 * v1 / torch.linalg.norm(v1, dim=1, keepdim=True)
+        (W * dW).sum().backward()
+        assert dg.shape == gg.shape
+        rel_close(dv, v1.grad, 1e-5, 1e-6)
+        rel_close(dg, g1.grad, 1e-5, 1e-6)
+
+
+def test_inorm_relu_out_of_place_equals_in_place_and_keeps_its_input():
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 40, 56, 16, generator=g).to(d)
+    skip = torch.randn(3, 40, 56, 16, generator=g).to(d)
+    keep = x.clone()
+    out, st = ops.inorm_relu_(x, skip=skip, want_stats=True, in_place=False)
+    assert torch.equal(x, keep) and out.data_ptr() != x.data_ptr()
+    y, st2 = ops.inorm_relu_(x, skip=skip, want_stats=True)
+    assert y.data_ptr() == x.data_ptr()
+    assert torch.equal(out, y) and torch.equal(st, st2)
+
+
+def test_photometric_backward_from_the_saved_forward_state_equals_the_recomputed_one(scene, golden_pipe, golden_train):
+    """autograd.photometric_loss keeps the forward's warped images and column sums for its backward (round 5); the gradient must
+    be the one of the stateless call, which runs the forward kernel again."""
+    from surf_amd import ops
+    d = dev()
+    imgs_t4 = ops.pack_texel4(scene["imgs"].to(d).contiguous())
+    cams = ops.Cameras(scene["intrs"], scene["c2ws"])
+    H, W = imgs_t4.shape[1:3]
+    g = torch.Generator().manual_seed(2)
+    depth = (2.0 + 0.3 * torch.rand(H, W, generator=g)).to(d)
+    mask = (torch.rand(H, W, generator=g) < 0.9).float().to(d)
+    for ref_idx, topk in ((0, 2), (1, 1)):
+        loss, state = ops.photometric_loss(depth, imgs_t4, mask, cams, ref_idx=ref_idx, topk=topk, return_state=True)
+        plain = ops.photometric_loss(depth, imgs_t4, mask, cams, ref_idx=ref_idx, topk=topk)
+        assert float(loss) == float(plain)
+        up = torch.tensor(0.7, device=d)
+        g1 = ops.photometric_loss_backward(depth, imgs_t4, mask, cams, ref_idx, topk, upstream=up, state=state)
+        g2 = ops.photometric_loss_backward(depth, imgs_t4, mask, cams, ref_idx, topk, upstream=up)
+        assert float(g1.abs().max()) > 0
+        rel_close(g1, g2, 1e-5, 1e-6 * float(g2.abs().max()))      # (the backward scatters with float atomics: order-dependent bits)
