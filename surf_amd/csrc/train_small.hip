@@ -1,4 +1,4 @@
-// K13 (round 5): the launch-bound tail of a training step (runner.py:152-165).  With every heavy kernel of the step in HIP,
+// K12c (round 5): the launch-bound tail of a training step (runner.py:152-165).  With every heavy kernel of the step in HIP,
 // 11 of its 98 ms were torch's own elementwise / fill / reduce helpers: ~1,900 launches of ~5 us each on a stream that is never
 // idle (profiles/r05_train_kernel_stats.csv, scripts/count_aten_ops.py books them to the Python lines that issue them).  The
 // three worst offenders, each a chain of tiny torch ops on small tensors, as single launches:
