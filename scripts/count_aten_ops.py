@@ -42,6 +42,23 @@ class Book(TorchDispatchMode):
                 if ("surf_amd" in fn or fn.endswith("bench.py")) and "count_aten_ops" not in fn:
                     site = f"{os.path.relpath(fn, ROOT)}:{fr.lineno} {fr.name}"
                     break
+            if name.startswith(("aten._to_copy", "aten.copy_", "aten._local_scalar_dense", "aten.clone", "aten.zeros", "aten.full",
+                                "aten.add.", "aten.add_", "aten.cat")):
+                # where the bytes move and how many: host<->device copies and large fills are what the launch count hides
+                flat = []
+                for a in list(args) + list((kwargs or {}).values()):
+                    flat.extend(a if isinstance(a, (list, tuple)) else [a])
+                ts = [a for a in flat if torch.is_tensor(a)]
+                devs = "/".join(sorted({t.device.type for t in ts})) or "-"
+                kw = kwargs or {}
+                if "device" in kw and kw["device"] is not None:
+                    devs += "->" + torch.device(kw["device"]).type
+                numel = max([t.numel() for t in ts] + [0])
+                if not ts and args and isinstance(args[0], (list, tuple)) and all(isinstance(d, int) for d in args[0]):
+                    numel = 1
+                    for d in args[0]:
+                        numel *= d
+                name += f" [{devs} {'big' if numel >= (1 << 20) else 'small'}]"
             self.sites[(name, site)] += 1
             self.ops[name] += 1
         return func(*args, **(kwargs or {}))
@@ -64,7 +81,7 @@ def main():
         print(f"{n:6d}  {name}")
     print("== per site")
     for (name, site), n in book.sites.most_common(400):
-        print(f"{n:6d}  {name:42s} {site}")
+        print(f"{n:6d}  {name:58s} {site}")
 
 
 if __name__ == "__main__":
