@@ -289,7 +289,7 @@ def training_step_setup(dev, H=576, W=800, nv=5, base_dim=88, rays=512, device_j
     return model, ipts, targets, loss_fn, opt
 
 
-def training_step_timing(args, dev, steps=3):
+def training_step_timing(args, dev, steps=5):
     """Wall time of one full training step (runner.py:152-165: forward -> Loss -> loss.backward() = the HIP backward of the
     render, the 4-stage volume build and the FPN -> Adam) on the bench scene, reported beside the render metric,
     for both training-precision policies."""
@@ -301,19 +301,21 @@ def training_step_timing(args, dev, steps=3):
         for _ in range(2):
             out = training.train_step(model, ipts, targets, loss_fn, opt, 1.0, 3)
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        per_step = []
+        for _ in range(steps):            # a step ends with the host reading its loss values: timing steps one by one adds no sync
+            t0 = time.perf_counter()
             out = training.train_step(model, ipts, targets, loss_fn, opt, 1.0, 3)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
-        res[precision] = {"ms_per_step": ms, "loss": out["loss"]}
+            torch.cuda.synchronize()
+            per_step.append((time.perf_counter() - t0) * 1e3)
+        ms = sorted(per_step)[len(per_step) // 2]          # median: one slow step (allocator growth, clocks) is not the policy
+        res[precision] = {"ms_per_step": ms, "loss": out["loss"], "steps_ms": [round(v, 2) for v in per_step]}
         voxels = model.last_voxels_per_stage
         rays = int(ipts["rays_o"].shape[0])
         del model, opt
     ops.set_train_precision("fp32")
     return {"ms_per_step": res["fp32"]["ms_per_step"], "rays": rays, "samples_per_ray": 128, "voxels_per_stage": voxels,
-            "loss": res["fp32"]["loss"], "train_precision_bf16": res["bf16"],
-            "what": "forward (FPN, volume build, render) + loss + loss.backward() (HIP backward of all of it) + Adam; every term of "
+            "loss": res["fp32"]["loss"], "steps_ms": res["fp32"]["steps_ms"], "train_precision_bf16": res["bf16"],
+            "what": "median of 5 steps of: forward (FPN, volume build, render) + loss + loss.backward() (HIP backward of all of it) + Adam; every term of "
                     "losses/loss.py; matching-field jitter on the device generator; train_precision_bf16: the same step with the "
                     "weight-gradient reductions on bf16 operands (model conf train_precision = bf16)"}
 

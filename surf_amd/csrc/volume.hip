@@ -428,6 +428,67 @@ __global__ __launch_bounds__(256) void dense_init_bwd_kernel(const float* __rest
   }
 }
 
+// Round 5 (second pass): the same transposed x2 upsample in GATHER form, no atomics.  Along one axis the fine voxel i hands
+// 0.75 / 0.25 of its gradient to the coarse cells (i - 1) / 2 and (i + 1) / 2 (align_corners=False, scale 0.5: src = i / 2 - 0.25),
+// so coarse cell c collects from the fine voxels 2c - 1 .. 2c + 2 with the weights {0.25, 0.75, 0.75, 0.25}; at the two ends the
+// clamped source index gives fine voxel 0 and fine voxel D - 1 entirely (weight 1) to cells 0 and Dp - 1.  A workgroup owns a
+// 4 x 4 x 32 tile of coarse cells, stages the masked fine gradient of its (10 x 10 x 66)-voxel footprint in LDS (background
+// voxels only: table < 0, looked up only where the gradient is non-zero), leaves if all of it is zero - the dense gradient is
+// mostly zero - and otherwise every thread sums the 4 x 4 x 4 windows of its two cells.  The scatter form above paid eight
+// float atomics per non-zero fine voxel (2.3 ms for the 704^3 stage).
+constexpr int DG_TX = 4, DG_TY = 4, DG_TZ = 32;
+constexpr int DG_FX = 2 * DG_TX + 2, DG_FY = 2 * DG_TY + 2, DG_FZ = 2 * DG_TZ + 2;
+
+__global__ __launch_bounds__(256) void dense_init_bwd_gather_kernel(const float* __restrict__ g_dense, const int32_t* __restrict__ table,
+                                                                    int D, float* __restrict__ g_prev) {
+  __shared__ float tile[DG_FX * DG_FY * DG_FZ];
+  const int Dp = D / 2;
+  const int tz = (Dp + DG_TZ - 1) / DG_TZ, ty = (Dp + DG_TY - 1) / DG_TY;
+  const int bz = blockIdx.x % tz, by = (blockIdx.x / tz) % ty, bx = blockIdx.x / (tz * ty);
+  const int cx0 = bx * DG_TX, cy0 = by * DG_TY, cz0 = bz * DG_TZ;
+  const int fx0 = 2 * cx0 - 1, fy0 = 2 * cy0 - 1, fz0 = 2 * cz0 - 1;
+  bool nz = false;
+  for (int e = threadIdx.x; e < DG_FX * DG_FY * DG_FZ; e += 256) {
+    const int lz = e % DG_FZ, ly = (e / DG_FZ) % DG_FY, lx = e / (DG_FZ * DG_FY);
+    const int x = fx0 + lx, y = fy0 + ly, z = fz0 + lz;
+    float g = 0.f;
+    if ((x >= 0) & (x < D) & (y >= 0) & (y < D) & (z >= 0) & (z < D)) {
+      const int64_t i = ((int64_t)x * D + y) * D + z;
+      g = g_dense[i];
+      if (g != 0.f && table[i] >= 0) g = 0.f;       // a scattered site: its gradient went to the stage's rows
+    }
+    tile[e] = g;
+    nz = nz || g != 0.f;
+  }
+  if (!__syncthreads_or(nz ? 1 : 0)) return;
+#pragma unroll
+  for (int h = 0; h < (DG_TX * DG_TY * DG_TZ) / 256; ++h) {
+    const int v = threadIdx.x + 256 * h;
+    const int lz = v % DG_TZ, ly = (v / DG_TZ) % DG_TY, lx = v / (DG_TZ * DG_TY);
+    const int cx = cx0 + lx, cy = cy0 + ly, cz = cz0 + lz;
+    if (cx >= Dp || cy >= Dp || cz >= Dp) continue;
+    float wx[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wy[4] = {0.25f, 0.75f, 0.75f, 0.25f}, wz[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    if (cx == 0) wx[1] = 1.0f;
+    if (cx == Dp - 1) wx[2] = 1.0f;
+    if (cy == 0) wy[1] = 1.0f;
+    if (cy == Dp - 1) wy[2] = 1.0f;
+    if (cz == 0) wz[1] = 1.0f;
+    if (cz == Dp - 1) wz[2] = 1.0f;
+    float acc = 0.f;
+#pragma unroll
+    for (int jx = 0; jx < 4; ++jx) {
+      float ax = 0.f;
+#pragma unroll
+      for (int jy = 0; jy < 4; ++jy) {
+        const float* row = tile + ((2 * lx + jx) * DG_FY + (2 * ly + jy)) * DG_FZ + 2 * lz;
+        ax += wy[jy] * (wz[0] * row[0] + wz[1] * row[1] + wz[2] * row[2] + wz[3] * row[3]);
+      }
+      acc += wx[jx] * ax;
+    }
+    if (acc != 0.f) g_prev[((int64_t)cx * Dp + cy) * Dp + cz] += acc;      // this thread owns the cell: no atomic
+  }
+}
+
 // backward of gather_rows: g_src[idx[i] >> shift, 0:w] += g_dst[i, off : off + w]
 __global__ __launch_bounds__(256) void scatter_rows_add_kernel(const float* __restrict__ g_dst, const int32_t* __restrict__ idx,
                                                                int64_t n, int w, int shift, int dst_stride, int dst_off,
@@ -741,6 +802,13 @@ extern "C" int surf_densify_backward(const int32_t* coords, int64_t n, int D, co
   if (g_prev)
   {
     const int64_t total = (int64_t)D * D * D;
+    const int Dp = D / 2;
+    const int64_t tiles = (int64_t)((Dp + DG_TX - 1) / DG_TX) * ((Dp + DG_TY - 1) / DG_TY) * ((Dp + DG_TZ - 1) / DG_TZ);
+#ifndef SURF_DENSE_BWD_SCATTER
+    if (tiles <= 0x7fffffffLL && Dp >= 2)
+      hipLaunchKernelGGL(dense_init_bwd_gather_kernel, dim3((unsigned)tiles), dim3(256), 0, st, g_dense, table, D, g_prev);
+    else
+#endif
     if (D % 4 == 0)
       hipLaunchKernelGGL((dense_init_bwd_kernel<4, 8>), grid1d(total / 4, 256 * 8), dim3(256), 0, st, g_dense, table, D, g_prev);
     else

@@ -69,7 +69,7 @@ def test_matching_depth_backward(scene, golden_pipe, golden_train, stage, pertur
     grad_close(dm, mvol.grad)
 
 
-@pytest.mark.parametrize("D", [8, 10, 12, 32])
+@pytest.mark.parametrize("D", [4, 8, 10, 12, 32, 70])      # 70: two z-tiles of the gather kernel, ragged in x / y / z
 def test_densify_backward(D):
     from surf_amd import ops
     d = dev()
@@ -94,6 +94,18 @@ def test_densify_backward(D):
     g_rows2 = torch.zeros(n, 8, device=d)
     ops.densify_backward(coords.to(d).contiguous(), table, Gd.to(d).contiguous(), g_rows2, None)
     assert torch.equal(g_rows2, g_rows)
+    # a mostly-zero dense gradient (what training produces: the gather kernel's workgroups leave when their footprint is zero),
+    # accumulated INTO a non-zero g_prev
+    Gs = torch.zeros(D, D, D)
+    Gs[D // 2:, :2, 1] = Gd[D // 2:, :2, 1]
+    Gs[0, 0, 0], Gs[D - 1, D - 1, D - 1] = 1.5, -2.5
+    logit.grad, prev.grad = None, None
+    dense2, _ = O.sparse2dense(logit, coords, D, prev)
+    (dense2 * Gs).sum().backward()
+    base = torch.randn(D // 2, D // 2, D // 2, generator=g)
+    g_prev3 = base.to(d).clone()
+    ops.densify_backward(coords.to(d).contiguous(), table, Gs.to(d).contiguous(), torch.zeros(n, 8, device=d), g_prev3)
+    grad_close(g_prev3 - base.to(d), prev.grad)
 
 
 def test_scatter_rows_add():
