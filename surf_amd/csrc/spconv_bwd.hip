@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void spconv_wgrad_kernel(WgArgs a) {
   const int64_t n_tiles = (a.n_out + TS - 1) / TS;
   const int g = NB >= 256 ? 0 : threadIdx.x / NB;
   const int b0 = NB >= 256 ? threadIdx.x : threadIdx.x % NB;
-  for (int k = 0; k < 27; ++k) {
+  // offsets k = blockIdx.y (mod gridDim.y): the launch spreads the 27 offsets over the grid for the wide pairs (round 5) - one
+  // workgroup walking all 27 for its tiles was a chain of 27 x tiles gather -> barrier -> FMA phases, ~200 us even for the
+  // few-thousand-site coarse lattices
+  for (int k = blockIdx.y; k < 27; k += gridDim.y) {
     const int ox = k % 3 - 1, oy = (k / 3) % 3 - 1, oz = k / 9 - 1;
     float acc[PERB][4][2];
 #pragma unroll
@@ -348,6 +351,13 @@ extern "C" int surf_spconv_wgrad(const float* x, int cin, const int32_t* in_tabl
   const int ts = thin ? 128 : ((cin + cout <= 48) ? 256 : 64);
   const int64_t tiles = (n_out + ts - 1) / ts;
   const unsigned grid = (unsigned)(tiles < 1024 ? tiles : 1024);
+  // the per-offset kernel (wide pairs, stride-2 thin pairs): one offset per workgroup row, >= 4 tiles per workgroup where there
+  // are that many (each workgroup ends with one atomic per entry of its offset's slice), <= 256 x 27 workgroups
+#ifndef SURF_WGRAD_WIDE_KY
+#define SURF_WGRAD_WIDE_KY 27
+#endif
+  const int64_t gx = tiles / 4 < 1 ? 1 : (tiles / 4 > 256 ? 256 : tiles / 4);
+  const dim3 wide_grid = SURF_WGRAD_WIDE_KY > 1 ? dim3((unsigned)gx, SURF_WGRAD_WIDE_KY) : dim3(grid);
 #define X(CI, CO)                                                                                                \
   if (cin == CI && cout == CO) {                                                                                 \
     if constexpr (CI + CO <= 48) {                                                                               \
@@ -356,7 +366,7 @@ extern "C" int surf_spconv_wgrad(const float* x, int cin, const int32_t* in_tabl
         return surf_check_launch();                                                                              \
       }                                                                                                          \
     }                                                                                                            \
-    hipLaunchKernelGGL((spconv_wgrad_kernel<CI, CO>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a);          \
+    hipLaunchKernelGGL((spconv_wgrad_kernel<CI, CO>), wide_grid, dim3(256), 0, (hipStream_t)stream, a);           \
     return surf_check_launch();                                                                                  \
   }
   WG_CASES(X)
