@@ -1283,6 +1283,9 @@ def dgrad_weights(weight, mode, use_mfma=True):
     return wt, (spconv_pack_weights(wt) if use_mfma else None)
 
 
+wgrad_up_from_coarse = True     # False: the transposed layers' weight gradient walks the fine sites (the form until round 5; A/B)
+
+
 def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight, dy, use_mfma=True, dgrad=None):
     """Backward of y = spconv(x, in_table, out_coords, mode, weight) (no BN / ReLU / skip).  Returns (dx (n_in, Cin),
     dW (27, Cin, Cout)).  dx is a sparse convolution of dy over the OUTPUT lattice (`out_table` indexes out_coords):
@@ -1308,17 +1311,30 @@ def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight,
     with _timed(f"spconv_dgrad<{cout},{cin}>", {"pairs": pairs, "sites": int(in_coords.shape[0])}):
         dx = spconv(dy, out_table, in_coords, {SUBM: SUBM, DOWN: UP, UP: DOWN}[mode], wt, packed=wt_packed,
                     bf16=colgram_precision == 1)
-    dW = small_zeros(weight.shape, weight.device)       # the kernels accumulate into it
-    if out_coords.shape[0] > 0 and x.shape[0] > 0:
-        with _timed(f"spconv_wgrad<{cin},{cout}>", {"pairs": pairs, "sites": int(out_coords.shape[0])}):
-            if use_mfma and _lib.lib().surf_spconv_wgrad_mfma_supported(cin, cout):
-                # round 5: the channel pairs for which the matrix-core form wins (spconv_wgrad_mfma.hip), fp32-equivalent
-                rc = _lib.lib().surf_spconv_wgrad_mfma(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords),
-                                                       out_coords.shape[0], int(mode), _p(dy), cout, _p(dW), _stream())
-            else:
-                rc = _lib.lib().surf_spconv_wgrad(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords),
-                                                  out_coords.shape[0], int(mode), _p(dy), cout, _p(dW), _stream())
-        _lib.check(rc, "surf_spconv_wgrad")
+    if out_coords.shape[0] == 0 or x.shape[0] == 0:
+        return dx, small_zeros(weight.shape, weight.device)
+    # the weight gradient of a TRANSPOSED layer is computed from the coarse side (round 5): fine site c takes from coarse site q
+    # through offset o when c = 2 q + o, which is the stride-2 DOWN relation with the lattices' roles swapped - so
+    # dW[k][ci][co] = sum_q x[q][ci] dy[fine(2 q + o_k)][co] is the DOWN-mode weight gradient of (input = dy on the fine lattice,
+    # output sites = the coarse ones, upstream = x), transposed.  Walking the FINE sites instead, seven of eight (site, offset)
+    # references are ruled out by parity and only found absent after the lookup: 8 x the sites for the same sum.
+    swap = mode == UP and wgrad_up_from_coarse
+    if swap:
+        wx, wtab, wcoords, wmode, wdy, wci, wco = dy, out_table, in_coords, DOWN, x, cout, cin
+    else:
+        wx, wtab, wcoords, wmode, wdy, wci, wco = x, in_table, out_coords, mode, dy, cin, cout
+    dW = small_zeros((27, wci, wco), weight.device)       # the kernels accumulate into it
+    with _timed(f"spconv_wgrad<{cin},{cout}>", {"pairs": pairs, "sites": int(out_coords.shape[0])}):
+        if use_mfma and _lib.lib().surf_spconv_wgrad_mfma_supported(wci, wco):
+            # round 5: the channel pairs for which the matrix-core form wins (spconv_wgrad_mfma.hip), fp32-equivalent
+            rc = _lib.lib().surf_spconv_wgrad_mfma(_p(wx), wci, _p(wtab), int(wtab.shape[0]), _p(wcoords), wcoords.shape[0],
+                                                   int(wmode), _p(wdy), wco, _p(dW), _stream())
+        else:
+            rc = _lib.lib().surf_spconv_wgrad(_p(wx), wci, _p(wtab), int(wtab.shape[0]), _p(wcoords), wcoords.shape[0],
+                                              int(wmode), _p(wdy), wco, _p(dW), _stream())
+    _lib.check(rc, "surf_spconv_wgrad")
+    if swap:
+        dW = dW.transpose(1, 2)
     return dx, dW
 
 

@@ -1794,3 +1794,30 @@ def test_photometric_backward_from_the_saved_forward_state_equals_the_recomputed
         g2 = ops.photometric_loss_backward(depth, imgs_t4, mask, cams, ref_idx, topk, upstream=up)
         assert float(g1.abs().max()) > 0
         rel_close(g1, g2, 1e-5, 1e-6 * float(g2.abs().max()))      # (the backward scatters with float atomics: order-dependent bits)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 8), (32, 16), (64, 32)])
+def test_spconv_wgrad_of_a_transposed_layer_from_the_coarse_side(cin, cout):
+    """Round 5: the weight gradient of a transposed (UP) layer is the DOWN-mode weight gradient with the lattices' roles swapped
+    (ops.spconv_backward: c = 2 q + o either way), transposed - against the walk over the fine sites it replaces, entry by entry."""
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(5 * cin + cout)
+    D = 22
+    coords = (torch.rand(D, D, D, generator=g) < 0.3).nonzero().to(torch.int32).contiguous().to(d)
+    cd, tc, D2 = ops.down_sites(coords, D, "dilate")
+    tf = ops.table_from_coords(coords, D)
+    w = (torch.randn(27, cin, cout, generator=g) / (27 * cin) ** 0.5).to(d)
+    x = torch.randn(cd.shape[0], cin, generator=g).to(d)
+    dy = torch.randn(coords.shape[0], cout, generator=g).to(d)
+    assert ops.wgrad_up_from_coarse
+    _, dW_c = ops.spconv_backward(x, tc, cd, tf, coords, ops.UP, w, dy)
+    ops.wgrad_up_from_coarse = False
+    try:
+        _, dW_f = ops.spconv_backward(x, tc, cd, tf, coords, ops.UP, w, dy)
+    finally:
+        ops.wgrad_up_from_coarse = True
+    assert dW_c.shape == dW_f.shape == w.shape
+    scale = float(dW_f.abs().max())
+    assert scale > 0.1
+    rel_close(dW_c, dW_f, 1e-5, 2e-6 * scale)
