@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 34
+#define SURF_ABI_VERSION 35
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -378,12 +378,13 @@ int surf_densify(const int32_t* coords, const float* rows, int row_stride, int64
  *   pre_depths (nv,H,W) or NULL (stage 0); ratio_cur/ratio_prev = range_ratios[stage], [stage-1]
  * jitter (optional, device, (nv, h*w, 2)): the train-mode `torch.rand([batch, 1]) - 0.5` of every ray and band
  * (matching_field.py:33-35; zeros for the views rendered without it, :129-133)
- * outputs: depth_lr (nv,h,w) and depth_full (nv,H,W) = bilinear upsample (align_corners=False)
+ * outputs: depth_lr (nv,h,w) and depth_full (nv,H,W) = bilinear upsample (align_corners=False);
+ * stats (nv,h,w,4) or NULL: per ray (max logit, softmax denominator, expected z, 0) for surf_matching_depth_backward
  */
 int surf_matching_depth(const float* mvol, int D, int nv, const float* h_kinv, const float* h_c2w, const float* h_rinv,
                         const float* h_near_fars, int H, int W, int h, int w, const float* lin_x, const float* lin_y,
                         const float* lin_n, int n, const float* pre_depths, float ratio_cur, float ratio_prev,
-                        const float* jitter, float* depth_lr, float* depth_full, void* stream);
+                        const float* jitter, float* depth_lr, float* depth_full, float* stats, void* stream);
 
 /* =====================================================================================================
  * Sparse 3D U-Net pieces (reg_network.py:38-88 over torchsparse 2.1.0 -- third party, PARITY UNPINNED).
@@ -446,7 +447,8 @@ int surf_inorm_relu_backward(const float* x, const float* dy, int N, int64_t hw,
  * surf_matching_depth_backward: same geometry arguments as surf_matching_depth; g_full (nv,H,W) = d loss / d depth maps
  * of the two views that carry gradient, view0 and view1 (the reference view and src_idx, matching_field.py:129-133; view1 < 0
  * or == view0: one view); the other views' maps are ignored; g_lr (nv,h,w) scratch; dmvol (D,D,D) ACCUMULATED.
- * The bands are constants (pre_depths are detached, matching_field.py:104).
+ * The bands are constants (pre_depths are detached, matching_field.py:104).  stats: what surf_matching_depth wrote for the
+ * same arguments (same jitter), or NULL - then the softmax statistics are recomputed by a first walk over the samples.
  * surf_densify_backward: g_rows[i * row_stride] += g_dense[coords[i]]; g_prev (D/2)^3 (may be NULL) accumulates the
  * background's share through the transposed x2 trilinear upsample (sites of the index table pass nothing).
  * surf_scatter_rows_add: backward of surf_gather_rows (float rows, atomics).
@@ -457,7 +459,7 @@ int surf_matching_depth_backward(const float* mvol, int D, int nv, const float* 
                                  const float* h_near_fars, int H, int W, int h, int w, const float* lin_x, const float* lin_y,
                                  const float* lin_n, int n, const float* pre_depths, float ratio_cur, float ratio_prev,
                                  const float* jitter, const float* g_full, int view0, int view1, float* g_lr, float* dmvol,
-                                 void* stream);
+                                 const float* stats, void* stream);
 int surf_densify_backward(const int32_t* coords, int64_t n, int D, const int32_t* table, const float* g_dense, int row_stride,
                           float* g_rows, float* g_prev, void* stream);
 int surf_scatter_rows_add(const float* g_dst, const int32_t* idx, int64_t n, int row_words, int idx_shift, int dst_stride_words,

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
 # must equal SURF_ABI_VERSION of include/surf_hip.h (tests/test_host_modules.py compares the two texts); lib() refuses a
 # library built from another header
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -94,7 +94,8 @@ SIGNATURES = {
     "surf_bn_workspace_bytes": (c_i64, [c_int]),
     "surf_bn_train_affine": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, ctypes.c_float, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_matching_depth_backward": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr,
-                                              c_int, c_ptr, ctypes.c_float, ctypes.c_float, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+                                              c_int, c_ptr, ctypes.c_float, ctypes.c_float, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr,
+                                              c_ptr]),
     "surf_densify_backward": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
     "surf_scatter_rows_add": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "surf_costvol_backward_workspace_floats": (c_i64, []),
@@ -129,7 +130,7 @@ SIGNATURES = {
     "surf_masked_l1_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_weight_norm_backward": (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_matching_depth": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr,
-                                    c_ptr, c_int, c_ptr, c_float, c_float, c_ptr, c_ptr, c_ptr, c_ptr]),
+                                    c_ptr, c_int, c_ptr, c_float, c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
 }
 
 _lib = None

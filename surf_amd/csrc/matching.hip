@@ -27,6 +27,8 @@ struct MatchArgs {
   float ratio_cur, ratio_prev;
   const float* jitter; // (nv, h*w, 2) train-mode `rand - 0.5` per ray and band, or null (matching_field.py:33-35)
   float* out;          // (nv,h,w)
+  float* stats;        // (nv,h,w,4) or null: the forward writes (max logit, softmax denominator, expected z, 0) per ray, the
+                       // backward reads them instead of walking the samples a first time (round 5)
 };
 
 __device__ __forceinline__ void band(float zc, float half, float n0, float f0, float& lo, float& hi) {
@@ -110,7 +112,10 @@ __global__ __launch_bounds__(256) void matching_depth_kernel(MatchArgs a) {
       m = mn;
     }
   }
-  if (j == 0) a.out[i] = (num / den) * cosz;
+  if (j == 0) {
+    a.out[i] = (num / den) * cosz;
+    if (a.stats) reinterpret_cast<f32x4*>(a.stats)[i] = f32x4{m, den, num / den, 0.f};
+  }
 }
 
 // F.interpolate(size=(H,W), mode='bilinear', align_corners=False) of (nv,h,w) maps  (matching_field.py:137)
@@ -264,8 +269,14 @@ __global__ __launch_bounds__(256) void matching_depth_bwd_kernel(MatchArgs a, co
     const int cdx = j >> 2, cdy = (j >> 1) & 1, cdz = j & 1;
     const int D = a.D;
     float m = -INFINITY, den = 0.f, num = 0.f;
-    for (int pass = 0; pass < 2; ++pass) {
-      const float E = pass ? num / den : 0.f;
+    float Es = 0.f;
+    const bool have = a.stats != nullptr;                // the forward's statistics: one walk over the samples instead of two
+    if (have) {
+      const f32x4 st = reinterpret_cast<const f32x4*>(a.stats)[i];
+      m = st[0]; den = st[1]; Es = st[2];
+    }
+    for (int pass = have ? 1 : 0; pass < 2; ++pass) {
+      const float E = pass ? (have ? Es : num / den) : 0.f;
       for (int b = 0; b < nb; ++b) {
         const float rng = hi[b] - lo[b];
         const float shift = a.jitter ? a.jitter[i * 2 + b] * rng / (float)a.n : 0.f;
@@ -328,7 +339,7 @@ extern "C" int surf_matching_depth(const float* mvol, int D, int nv, const float
                                    const float* h_rinv, const float* h_near_fars, int H, int W, int h, int w,
                                    const float* lin_x, const float* lin_y, const float* lin_n, int n, const float* pre_depths,
                                    float ratio_cur, float ratio_prev, const float* jitter, float* depth_lr, float* depth_full,
-                                   void* stream) {
+                                   float* stats, void* stream) {
   if (!mvol || !h_kinv || !h_c2w || !h_rinv || !h_near_fars || !lin_x || !lin_y || !lin_n || !depth_lr || !depth_full)
     return SURF_E_ARG;
   if (D < 2 || H < 1 || W < 1 || h < 1 || w < 1 || n < 1) return SURF_E_ARG;
@@ -336,6 +347,7 @@ extern "C" int surf_matching_depth(const float* mvol, int D, int nv, const float
   MatchArgs a;
   a.mvol = mvol; a.D = D; a.nv = nv; a.H = H; a.W = W; a.h = h; a.w = w; a.lin_x = lin_x; a.lin_y = lin_y; a.lin_n = lin_n;
   a.n = n; a.pre = pre_depths; a.ratio_cur = ratio_cur; a.ratio_prev = ratio_prev; a.jitter = jitter; a.out = depth_lr;
+  a.stats = stats;
   fill_match_args(a, nv, h_kinv, h_c2w, h_rinv, h_near_fars);
   hipStream_t st = (hipStream_t)stream;
   const int64_t n_lr = (int64_t)nv * h * w, n_full = (int64_t)nv * H * W;
@@ -352,7 +364,8 @@ extern "C" int surf_matching_depth_backward(const float* mvol, int D, int nv, co
                                             const float* h_rinv, const float* h_near_fars, int H, int W, int h, int w,
                                             const float* lin_x, const float* lin_y, const float* lin_n, int n,
                                             const float* pre_depths, float ratio_cur, float ratio_prev, const float* jitter,
-                                            const float* g_full, int view0, int view1, float* g_lr, float* dmvol, void* stream) {
+                                            const float* g_full, int view0, int view1, float* g_lr, float* dmvol,
+                                            const float* stats, void* stream) {
   if (!mvol || !h_kinv || !h_c2w || !h_rinv || !h_near_fars || !lin_x || !lin_y || !lin_n || !g_full || !g_lr || !dmvol)
     return SURF_E_ARG;
   if (D < 2 || H < 1 || W < 1 || h < 1 || w < 1 || n < 1) return SURF_E_ARG;
@@ -360,6 +373,7 @@ extern "C" int surf_matching_depth_backward(const float* mvol, int D, int nv, co
   MatchArgs a;
   a.mvol = mvol; a.D = D; a.nv = nv; a.H = H; a.W = W; a.h = h; a.w = w; a.lin_x = lin_x; a.lin_y = lin_y; a.lin_n = lin_n;
   a.n = n; a.pre = pre_depths; a.ratio_cur = ratio_cur; a.ratio_prev = ratio_prev; a.jitter = jitter; a.out = nullptr;
+  a.stats = const_cast<float*>(stats);
   fill_match_args(a, nv, h_kinv, h_c2w, h_rinv, h_near_fars);
   hipStream_t st = (hipStream_t)stream;
   const int64_t n_lr = (int64_t)nv * h * w, n_full = (int64_t)nv * H * W;

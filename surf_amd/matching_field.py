@@ -46,14 +46,15 @@ class MatchingField(nn.Module):
             saved["jitter"] = jitter
         return ops.matching_depth(matching_volume, cams, near_fars, H, W, self.depth_res_levels[stage_idx],
                                   self.n_samples_depths[stage_idx], pre_depths, range_ratios[stage_idx],
-                                  range_ratios[stage_idx - 1] if stage_idx > 0 else 1.0, return_lr=return_lr, jitter=jitter)
+                                  range_ratios[stage_idx - 1] if stage_idx > 0 else 1.0, return_lr=return_lr, jitter=jitter,
+                                  saved=saved)          # + "stats": the per-ray softmax statistics for the backward
 
     def backward(self, cams, near_fars, hw, matching_volume, stage_idx, range_ratios, g_full, pre_depths=None, jitter=None,
-                 dmvol=None, src_idx=0):
+                 dmvol=None, src_idx=0, stats=None):
         """d loss / d matching volume from g_full (nv,H,W) = d loss / d this stage's depth maps (zero for the views rendered
         under no_grad, matching_field.py:132); accumulates into `dmvol` if given."""
         H, W = hw
         return ops.matching_depth_backward(matching_volume, cams, near_fars, H, W, self.depth_res_levels[stage_idx],
                                            self.n_samples_depths[stage_idx], g_full, pre_depths, range_ratios[stage_idx],
                                            range_ratios[stage_idx - 1] if stage_idx > 0 else 1.0, jitter=jitter, dmvol=dmvol,
-                                           views=(0, src_idx))
+                                           views=(0, src_idx), stats=stats)

@@ -1028,9 +1028,10 @@ def densify(coords, rows, D, prev=None):
 
 
 def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, ratio_cur=1.0, ratio_prev=1.0, return_lr=False,
-                   jitter=None):
+                   jitter=None, saved=None):
     """matching_field.py:73-141.  Returns depth maps (nv,H,W) (and, with return_lr, the (nv,h,w) maps rendered at the
-    reduced resolution before the bilinear upsample).  jitter (nv, h*w, 2): the train-mode per-ray, per-band z shifts."""
+    reduced resolution before the bilinear upsample).  jitter (nv, h*w, 2): the train-mode per-ray, per-band z shifts.
+    saved: a dict that receives "stats" (nv,h,w,4) = the per-ray softmax statistics matching_depth_backward can start from."""
     _chk(mvol, torch.float32, "matching volume")
     dev = mvol.device
     h, w = H // res_level, W // res_level
@@ -1043,19 +1044,23 @@ def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, r
     if jitter is not None:
         _chk(jitter, torch.float32, "jitter")
         assert tuple(jitter.shape) == (cams.nv, h * w, 2)
+    stats = torch.empty(cams.nv, h, w, 4, dtype=torch.float32, device=dev) if saved is not None else None
     rc = _lib.lib().surf_matching_depth(_p(mvol), int(mvol.shape[0]), cams.nv, _np_ptr(cams.kinv), _np_ptr(cams.c2w),
                                         _np_ptr(cams.rinv), _np_ptr(nf), H, W, h, w, _p(lin_x), _p(lin_y), _p(lin_n), int(n),
                                         _p(pre_depths), ctypes.c_float(float(ratio_cur)), ctypes.c_float(float(ratio_prev)),
-                                        _p(jitter), _p(lr), _p(full), _stream())
+                                        _p(jitter), _p(lr), _p(full), _p(stats), _stream())
+    if saved is not None:
+        saved["stats"] = stats
     _lib.check(rc, "surf_matching_depth")
     return (full, lr) if return_lr else full
 
 
 def matching_depth_backward(mvol, cams, near_fars, H, W, res_level, n, g_full, pre_depths=None, ratio_cur=1.0, ratio_prev=1.0,
-                            jitter=None, dmvol=None, views=(0, 0)):
+                            jitter=None, dmvol=None, views=(0, 0), stats=None):
     """Backward of matching_depth w.r.t. the matching volume: g_full (nv,H,W) = d loss / d depth maps; only the maps of
     `views` = (reference view, src_idx) are read (the reference renders the others under no_grad).  Returns dmvol (D,D,D),
-    accumulated into `dmvol` if given."""
+    accumulated into `dmvol` if given.  stats: the forward's per-ray softmax statistics (matching_depth(..., saved=)) for the SAME
+    arguments and jitter - the kernel then walks the samples once instead of twice."""
     _chk(mvol, torch.float32, "matching volume")
     _chk(g_full, torch.float32, "g_full")
     dev = mvol.device
@@ -1066,6 +1071,9 @@ def matching_depth_backward(mvol, cams, near_fars, H, W, res_level, n, g_full, p
     lin_n = _linspace_dev(0.0, 1.0, n, dev)
     nf = np.ascontiguousarray(near_fars.detach().to("cpu", torch.float32).numpy())
     g_lr = torch.empty(cams.nv, h, w, dtype=torch.float32, device=dev)
+    if stats is not None:
+        _chk(stats, torch.float32, "stats")
+        assert tuple(stats.shape) == (cams.nv, h, w, 4)
     if dmvol is None:
         dmvol = torch.zeros_like(mvol)
     n_views = len(set(int(v) for v in views))
@@ -1074,7 +1082,7 @@ def matching_depth_backward(mvol, cams, near_fars, H, W, res_level, n, g_full, p
                                                      _np_ptr(cams.rinv), _np_ptr(nf), H, W, h, w, _p(lin_x), _p(lin_y), _p(lin_n),
                                                      int(n), _p(pre_depths), ctypes.c_float(float(ratio_cur)),
                                                      ctypes.c_float(float(ratio_prev)), _p(jitter), _p(g_full), int(views[0]), int(views[1]),
-                                                     _p(g_lr), _p(dmvol), _stream())
+                                                     _p(g_lr), _p(dmvol), _p(stats), _stream())
     _lib.check(rc, "surf_matching_depth_backward")
     return dmvol
 

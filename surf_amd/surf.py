@@ -170,7 +170,8 @@ class SuRF(nn.Module):
                 if gd[1] is not None:
                     g_full[t["src_idx"]] += gd[1]
                 d_mvol = self.matching_field.backward(cams, t["near_fars"], (H, W), r["mvol"], s, self.range_ratios, g_full,
-                                                      r["pre_depths"], r.get("jitter"), dmvol=d_mvol, src_idx=t["src_idx"])
+                                                      r["pre_depths"], r.get("jitter"), dmvol=d_mvol, src_idx=t["src_idx"],
+                                                      stats=r.get("stats"))
             d_prev = None
             if d_mvol is not None:
                 if s > 0:

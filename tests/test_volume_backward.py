@@ -67,6 +67,19 @@ def test_matching_depth_backward(scene, golden_pipe, golden_train, stage, pertur
                                      CFG["range_ratios"][stage - 1] if stage > 0 else 1.0, jitter=jitter, views=(0, src_idx))
     assert float(mvol.grad.abs().max()) > 0
     grad_close(dm, mvol.grad)
+    # round 5: the backward started from the forward's per-ray softmax statistics (one walk over the samples instead of two)
+    saved = {}
+    ops.matching_depth(gp[f"s{stage}_mvol"].to(d).contiguous(), _cams(scene), scene["near_fars"], H, W, lvl,
+                       CFG["n_samples_depths"][stage], None if pre is None else pre.to(d).contiguous(), CFG["range_ratios"][stage],
+                       CFG["range_ratios"][stage - 1] if stage > 0 else 1.0, jitter=jitter, saved=saved)
+    assert tuple(saved["stats"].shape) == (nv, H // lvl, W // lvl, 4)
+    dm2 = ops.matching_depth_backward(gp[f"s{stage}_mvol"].to(d).contiguous(), _cams(scene), scene["near_fars"], H, W, lvl,
+                                      CFG["n_samples_depths"][stage], G.to(d).contiguous(),
+                                      None if pre is None else pre.to(d).contiguous(), CFG["range_ratios"][stage],
+                                      CFG["range_ratios"][stage - 1] if stage > 0 else 1.0, jitter=jitter, views=(0, src_idx),
+                                      stats=saved["stats"])
+    grad_close(dm2, mvol.grad)
+    grad_close(dm2, dm, rtol=1e-4)
 
 
 @pytest.mark.parametrize("D", [4, 8, 10, 12, 32, 70])      # 70: two z-tiles of the gather kernel, ragged in x / y / z
