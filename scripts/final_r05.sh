@@ -4,6 +4,7 @@
 set -u
 O=gpurun_out/r05final; mkdir -p $O
 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -2 $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.json; echo
 bash scripts/profile_bench.sh r05 > $O/profile_bench.log 2>&1
 SURF_PREC=bf16x3 TSDF_ARGS=576 bash scripts/pmc_time_sdf.sh > $O/sdf_sq_bf16x3.txt 2>&1
