@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 35
+#define SURF_ABI_VERSION 36
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -454,7 +454,8 @@ int surf_inorm_relu_backward(const float* x, const float* dy, int N, int64_t hw,
  * surf_scatter_rows_add: backward of surf_gather_rows (float rows, atomics).
  * surf_costvol_backward: for the kept voxels `coords` (n,3) of a stage and g (n,8) = [d mean | d var], accumulates the
  * gradients of the summed feature levels into h_gfeats[l] (texel4 maps like h_feats[l], l >= stage) and of agg_mlp
- * (w1 | b1 | w2 | b2, 49 floats, device) into g_agg.  workspace: surf_costvol_backward_workspace_floats() device floats. */
+ * (w1 | b1 | w2 | b2, 49 floats, device) into g_agg.  workspace: surf_costvol_backward_workspace_floats(n, nv, H, W) device
+ * floats, (H, W) = the finest feature level (the kernel sorts its (view, voxel) adds by image tile: 9 floats per pair). */
 int surf_matching_depth_backward(const float* mvol, int D, int nv, const float* h_kinv, const float* h_c2w, const float* h_rinv,
                                  const float* h_near_fars, int H, int W, int h, int w, const float* lin_x, const float* lin_y,
                                  const float* lin_n, int n, const float* pre_depths, float ratio_cur, float ratio_prev,
@@ -464,7 +465,7 @@ int surf_densify_backward(const int32_t* coords, int64_t n, int D, const int32_t
                           float* g_rows, float* g_prev, void* stream);
 int surf_scatter_rows_add(const float* g_dst, const int32_t* idx, int64_t n, int row_words, int idx_shift, int dst_stride_words,
                           int dst_offset_words, float* g_src, void* stream);
-int64_t surf_costvol_backward_workspace_floats(void);
+int64_t surf_costvol_backward_workspace_floats(int64_t n, int nv, int H, int W);
 int surf_costvol_backward(const int32_t* coords, const float* g, int64_t n, int D, const float* const* h_feats,
                           float* const* h_gfeats, const int* h_hw, int stage, int nv, const float* h_intrs, const float* h_w2c,
                           const float* h_agg, float* workspace, float* g_agg, void* stream);

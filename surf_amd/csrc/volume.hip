@@ -564,6 +564,8 @@ struct CostVolBwdArgs {
   ViewSet vs;
   float w1[32], b1[8], w2[8], b2;
   float* gagg;            // CV_REPLICAS x 64 floats (49 used per replica)
+  float* units;           // binned form (below): (nv, n, 8) = [d feature (4) | nx, ny | active | 0] per (view, voxel), or null
+  unsigned* gmax;         // binned form: bits of max |d feature| over the call (atomicMax on the bit patterns of non-negative floats)
 };
 
 // (round 5: compiled for three wavefronts per SIMD - 168 registers, 20 bytes spilled - instead of the 171 the allocator takes by
@@ -578,6 +580,7 @@ __global__ __launch_bounds__(256, SURF_CVB_WAVES) void costvol_bwd_kernel(CostVo
   const bool live = i_ < a.n;
   const int64_t i = live ? i_ : a.n - 1;        // every lane runs the whole body (the scatter below is octet-cooperative)
   float gacc[49];
+  float dfmax = 0.f;
 #pragma unroll
   for (int k = 0; k < 49; ++k) gacc[k] = 0.f;
   {
@@ -669,15 +672,28 @@ __global__ __launch_bounds__(256, SURF_CVB_WAVES) void costvol_bwd_kernel(CostVo
           }
         }
         const bool act = live && !(df[0] == 0.f && df[1] == 0.f && df[2] == 0.f && df[3] == 0.f);   // views outside the frustum: 0
-        for (int l = a.stage; l < 4; ++l) {
-          const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
-          bilinear_texel4_scatter_coop(a.gfeats[l] + (int64_t)v * H * W * 4, H, W, unnorm_act(nxv[v], W), unnorm_act(nyv[v], H), df, act);
+        if (a.units) {                      // binned form: the scatter happens per image tile in costvol_tile_kernel
+          if (act) dfmax = fmaxf(dfmax, fmaxf(fmaxf(fabsf(df[0]), fabsf(df[1])), fmaxf(fabsf(df[2]), fabsf(df[3]))));
+          if (live) {
+            f32x4* u = reinterpret_cast<f32x4*>(a.units + ((int64_t)v * a.n + i) * 8);
+            u[0] = f32x4{df[0], df[1], df[2], df[3]};
+            u[1] = f32x4{nxv[v], nyv[v], act ? 1.f : 0.f, 0.f};
+          }
+        } else {
+          for (int l = a.stage; l < 4; ++l) {
+            const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
+            bilinear_texel4_scatter_coop(a.gfeats[l] + (int64_t)v * H * W * 4, H, W, unnorm_act(nxv[v], W), unnorm_act(nyv[v], H), df, act);
+          }
         }
       }
     }
   }
   // agg_mlp gradients: wavefront sums -> LDS -> one set of 49 atomics per workgroup into one of CV_REPLICAS replicas (every
   // workgroup adding to the same 49 floats serialises at the memory side: ~12 ns per add and line, 10+ ms at 5 M voxels)
+  if (a.gmax) {
+    dfmax = wave_max(dfmax);
+    if ((threadIdx.x & 63) == 0 && dfmax > 0.f) atomicMax(a.gmax, __float_as_uint(dfmax));
+  }
   __shared__ float red[4][49];
 #pragma unroll
   for (int k = 0; k < 49; ++k) {
@@ -697,6 +713,202 @@ __global__ void costvol_bwd_finalize_kernel(const float* __restrict__ replicas, 
   float t = 0.f;
   for (int r = 0; r < CV_REPLICAS; ++r) t += replicas[r * 64 + k];
   g_agg[k] += t;
+}
+
+// ---- binned scatter of costvol_bwd (round 5, third pass) ------------------------------------------------------------------------
+// The float atomics of the direct scatter are served at the memory side at ~12 ns per CU and 64-byte segment, and no variant
+// that merged requests inside a wavefront moved the kernel (see above): the voxels that share a texel are the ones along a
+// viewing ray, far apart in lattice order.  So the adds are sorted COARSELY instead: costvol_bwd_kernel leaves one 32-byte
+// record per (view, voxel) - the feature gradient and the normalised image position - a counting sort (LDS histograms, one
+// reservation per workgroup and bucket) lists the records of every 32 x 32-pixel tile of every view, and one workgroup per
+// (view, tile) accumulates its records into LDS images of the tile at the pyramid levels the stage reads and sends each touched
+// texel to memory ONCE.  Requests per step: 200 M 32-byte adds -> ~15 M coalesced ones.
+// The LDS images are 64-bit FIXED POINT: ds_add_f32 costs 81 ns per wave-instruction and CU on gfx950, ds_add_u64 5.5
+// (scripts/microbench/lds_atomic_rates.hip, profiles/r05_microbench_lds_atomic_rates.txt; with float LDS atomics this kernel
+// took 8.3 ms of a training step, 7.2 of them the atomics).  The scale is a power of two chosen per workgroup from the largest
+// |d feature| of the call (costvol_bwd_kernel leaves it in `gmax`) and the number of records the workgroup adds, so that the sum
+// cannot overflow and one unit is <= 2^-40 of the largest term: finer than fp32 accumulation, and order-independent.
+constexpr int CVT = 16;                                   // tile edge in finest-level pixels
+constexpr int CVT_E[4] = {6, 8, 12, 20};                  // LDS image edge per level (coarse -> fine): (16 >> (3 - l)) + margins
+constexpr int CVT_OFF[5] = {0, 36, 36 + 64, 36 + 64 + 144, 36 + 64 + 144 + 400};
+constexpr int CVT_MAX_BUCKETS = 16384;
+
+struct CvBinArgs {
+  const float* units;     // (nv, n, 8)
+  int64_t n;
+  int nv;
+  int H3, W3;             // finest level
+  int ntx, nty;           // tiles per view
+  int* counts;            // (nv ntx nty)
+  int* offsets;           // (nv ntx nty + 1), exclusive prefix of counts
+  int* cursor;            // (nv ntx nty)
+  int* order;             // (nv n) record ids grouped by bucket
+};
+
+__device__ __forceinline__ int cv_bucket(const CvBinArgs& a, int v, float nx, float ny) {
+  int x0 = (int)floorf(unnorm_act(nx, a.W3)), y0 = (int)floorf(unnorm_act(ny, a.H3));
+  x0 = min(max(x0, 0), a.W3 - 1);
+  y0 = min(max(y0, 0), a.H3 - 1);
+  return (v * a.nty + y0 / CVT) * a.ntx + x0 / CVT;
+}
+
+// PASS 0: counts;  PASS 1: placement (cursor starts at the bucket offsets)
+template <int PASS>
+__global__ __launch_bounds__(1024) void costvol_bin_kernel(CvBinArgs a) {
+  extern __shared__ int hist[];
+  const int nb = a.nv * a.ntx * a.nty;
+  for (int b = threadIdx.x; b < nb; b += 1024) hist[b] = 0;
+  __syncthreads();
+  const int64_t q = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  int bucket = -1, local = 0;
+  if (q < a.n * a.nv) {
+    const f32x4 u = reinterpret_cast<const f32x4*>(a.units)[q * 2 + 1];
+    if (u[2] != 0.f) {
+      bucket = cv_bucket(a, (int)(q / a.n), u[0], u[1]);
+      local = atomicAdd(&hist[bucket], 1);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nb; b += 1024) {
+    const int c = hist[b];
+    if (c) {
+      if (PASS == 0) atomicAdd(&a.counts[b], c);
+      else hist[b] = atomicAdd(&a.cursor[b], c);          // this workgroup's range in the bucket
+    }
+  }
+  if (PASS == 1) {
+    __syncthreads();
+    if (bucket >= 0) a.order[hist[bucket] + local] = (int)q;
+  }
+}
+
+// exclusive prefix sum of <= CVT_MAX_BUCKETS counts with one workgroup; cursor = offsets
+__global__ __launch_bounds__(1024) void costvol_scan_kernel(const int* __restrict__ counts, int nb, int* __restrict__ offsets,
+                                                            int* __restrict__ cursor) {
+  __shared__ int part[1024];
+  constexpr int PER = CVT_MAX_BUCKETS / 1024;
+  int v[PER], s = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int b = threadIdx.x * PER + k;
+    v[k] = b < nb ? counts[b] : 0;
+    s += v[k];
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int t = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+    __syncthreads();
+    part[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - s;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int b = threadIdx.x * PER + k;
+    if (b < nb) { offsets[b] = run; cursor[b] = run; }
+    run += v[k];
+  }
+  if (threadIdx.x == 1023) offsets[nb] = part[1023];
+}
+
+struct CvTileArgs {
+  const float* units;
+  const int* offsets;
+  const int* order;
+  int64_t n;
+  int nv, ntx, nty, stage;
+  int hw[8];
+  float* gfeats[4];
+  const unsigned* gmax;
+};
+
+// one workgroup per (view, tile); SPLIT workgroups share a bucket's list (blockIdx.y), each with its own LDS images
+__global__ __launch_bounds__(256) void costvol_tile_kernel(CvTileArgs a) {
+  __shared__ unsigned long long img[CVT_OFF[4] * 4];          // 64-bit fixed point, channel-planar per level
+  const int bucket = blockIdx.x;
+  const int beg = a.offsets[bucket], end = a.offsets[bucket + 1];
+  const int share = (end - beg + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int p0 = beg + share * (int)blockIdx.y, p1 = min(p0 + share, end);
+  if (p0 >= p1) return;
+  const int v = bucket / (a.ntx * a.nty), tile = bucket % (a.ntx * a.nty);
+  const int ty = tile / a.ntx, tx = tile % a.ntx;
+  for (int e = threadIdx.x; e < CVT_OFF[4] * 4; e += 256) img[e] = 0ull;
+  // one unit = 2^-k: largest term < 2^(ex + 1), at most 4 (p1 - p0) terms per word (every record, all four taps on one texel)
+  const int ex = (int)((*a.gmax >> 23) & 0xff) - 127;
+  const int k = 60 - ex - (32 - __clz(p1 - p0));
+  // level-l origin of the LDS image: the tile's first finest-level pixel mapped to level l, one texel of margin
+  int ox[4], oy[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    const int H = a.hw[2 * l], W = a.hw[2 * l + 1];
+    const float rx = (float)(W - 1) / (float)(a.hw[7] - 1), ry = (float)(H - 1) / (float)(a.hw[6] - 1);
+    ox[l] = max((int)floorf((float)(tx * CVT) * rx) - 1, 0);
+    oy[l] = max((int)floorf((float)(ty * CVT) * ry) - 1, 0);
+  }
+  __syncthreads();
+  // thread t walks its own contiguous share of the list: the records of a bucket arrive in runs of lattice order, and the 64
+  // lanes of an instruction taking 64 CONSECUTIVE records (voxels a pixel or less apart) would serialise on the same LDS words
+  const int chunk = (p1 - p0 + 255) / 256;
+  const int q0 = p0 + (int)threadIdx.x * chunk, q1 = min(q0 + chunk, p1);
+  for (int p = q0; p < q1; ++p) {
+    const int q = a.order[p];
+    const f32x4 g = reinterpret_cast<const f32x4*>(a.units)[(int64_t)q * 2];
+    const f32x4 pos = reinterpret_cast<const f32x4*>(a.units)[(int64_t)q * 2 + 1];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) {
+      if (l < a.stage) continue;
+      const int H = a.hw[2 * l], W = a.hw[2 * l + 1], E = CVT_E[l];
+      const float x = unnorm_act(pos[0], W), y = unnorm_act(pos[1], H);
+      const float fx = floorf(x), fy = floorf(y);
+      const float tx_ = x - fx, ty_ = y - fy;
+      const int x0 = (int)fx, y0 = (int)fy;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy) {
+        const int yi = y0 + dy;
+        if ((yi < 0) | (yi >= H)) continue;
+        const float wy = dy ? ty_ : 1.0f - ty_;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const int xi = x0 + dx;
+          if ((xi < 0) | (xi >= W)) continue;
+          const float w = (dx ? tx_ : 1.0f - tx_) * wy;
+          const int lx = xi - ox[l], ly = yi - oy[l];
+          if ((unsigned)lx < (unsigned)E && (unsigned)ly < (unsigned)E) {
+            unsigned long long* d = img + CVT_OFF[l] * 4 + ly * E + lx;   // channel-planar: neighbouring texels, neighbouring banks
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float val = w * g[c];
+              if (val != 0.f) atomicAdd(d + c * E * E, (unsigned long long)__double2ll_rn(ldexp((double)val, k)));
+            }
+          } else {                                              // outside the LDS image (an irregular pyramid): straight to memory
+            float* d = a.gfeats[l] + (((int64_t)v * H + yi) * W + xi) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float val = w * g[c];
+              if (val != 0.f) atomicAdd(d + c, val);
+            }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // flush: every touched float once; the 64 lanes of an add cover 16 consecutive texels of an image row
+#pragma unroll
+  for (int l = 0; l < 4; ++l) {
+    if (l < a.stage) continue;
+    const int H = a.hw[2 * l], W = a.hw[2 * l + 1], E = CVT_E[l];
+    float* map = a.gfeats[l] + (int64_t)v * H * W * 4;
+    for (int e = threadIdx.x; e < E * E * 4; e += 256) {
+      const int c = e & 3, lx = (e >> 2) % E, ly = (e >> 2) / E;
+      const long long acc = (long long)img[CVT_OFF[l] * 4 + c * E * E + ly * E + lx];
+      if (acc == 0) continue;
+      const float val = (float)ldexp((double)acc, -k);
+      const int xi = ox[l] + lx, yi = oy[l] + ly;
+      if (xi < W && yi < H) atomicAdd(map + ((int64_t)yi * W + xi) * 4 + c, val);
+    }
+  }
 }
 
 void fill_views(ViewSet& vs, int nv, const float* h_intrs, const float* h_w2c) {
@@ -825,6 +1037,26 @@ extern "C" int surf_scatter_rows_add(const float* g_dst, const int32_t* idx, int
   return surf_check_launch();
 }
 
+// the binned form needs a regular pyramid (level l = finest >> (3 - l): what the LDS image edges assume) and <= 16,384 (view, tile)
+// buckets (5 views of 576 x 800: 9,000); otherwise - the Tanks&Temples shape - the direct scatter runs
+#ifndef SURF_CVB_BINNED
+#define SURF_CVB_BINNED 1
+#endif
+static bool cv_binned_ok(int64_t n, int nv, const int* hw) {
+  if (!SURF_CVB_BINNED || n * nv > 0x7fffffffLL) return false;
+  const int H3 = hw[6], W3 = hw[7];
+  for (int l = 0; l < 4; ++l)
+    if (hw[2 * l] != (H3 >> (3 - l)) || hw[2 * l + 1] != (W3 >> (3 - l)) || hw[2 * l] < 2 || hw[2 * l + 1] < 2) return false;
+  const int64_t nb = (int64_t)nv * ((W3 + CVT - 1) / CVT) * ((H3 + CVT - 1) / CVT);
+  return nb <= CVT_MAX_BUCKETS;
+}
+
+extern "C" int64_t surf_costvol_backward_workspace_floats(int64_t n, int nv, int H, int W) {
+  // agg replicas | units (nv n 8) | order (nv n) | counts, offsets (+1), cursor
+  const int64_t nb = (int64_t)nv * ((W + CVT - 1) / CVT) * ((H + CVT - 1) / CVT);
+  return (int64_t)CV_REPLICAS * 64 + n * nv * 9 + 3 * nb + 8;
+}
+
 extern "C" int surf_costvol_backward(const int32_t* coords, const float* g, int64_t n, int D, const float* const* h_feats,
                                      float* const* h_gfeats, const int* h_hw, int stage, int nv, const float* h_intrs,
                                      const float* h_w2c, const float* h_agg, float* workspace, float* g_agg, void* stream) {
@@ -844,11 +1076,42 @@ extern "C" int surf_costvol_backward(const int32_t* coords, const float* g, int6
   for (int k = 0; k < 32; ++k) a.w1[k] = h_agg[k];
   for (int k = 0; k < 8; ++k) { a.b1[k] = h_agg[32 + k]; a.w2[k] = h_agg[40 + k]; }
   a.b2 = h_agg[48];
-  const hipError_t e = hipMemsetAsync(workspace, 0, CV_REPLICAS * 64 * sizeof(float), (hipStream_t)stream);
+  hipStream_t st = (hipStream_t)stream;
+  const bool binned = cv_binned_ok(n, nv, h_hw);
+  const int H3 = h_hw[6], W3 = h_hw[7];
+  const int ntx = (W3 + CVT - 1) / CVT, nty = (H3 + CVT - 1) / CVT, nb = nv * ntx * nty;
+  float* units = workspace + CV_REPLICAS * 64;
+  int* order = reinterpret_cast<int*>(units + n * nv * 8);
+  int* counts = order + n * nv;
+  int* offsets = counts + nb;
+  int* cursor = offsets + nb + 1;
+  unsigned* gmax = reinterpret_cast<unsigned*>(cursor + nb);
+  a.units = binned ? units : nullptr;
+  a.gmax = binned ? gmax : nullptr;
+  hipError_t e = hipMemsetAsync(workspace, 0, CV_REPLICAS * 64 * sizeof(float), st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(costvol_bwd_kernel, grid1d(n, 256), dim3(256), 0, (hipStream_t)stream, a);
-  hipLaunchKernelGGL(costvol_bwd_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, g_agg);
+  if (binned) {
+    e = hipMemsetAsync(counts, 0, (size_t)(3 * nb + 2) * sizeof(int), st);       // counts ... cursor, gmax
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(costvol_bwd_kernel, grid1d(n, 256), dim3(256), 0, st, a);
+  if (binned) {
+    CvBinArgs b;
+    b.units = units; b.n = n; b.nv = nv; b.H3 = H3; b.W3 = W3; b.ntx = ntx; b.nty = nty;
+    b.counts = counts; b.offsets = offsets; b.cursor = cursor; b.order = order;
+    const dim3 bgrid = grid1d(n * nv, 1024);
+    hipLaunchKernelGGL(costvol_bin_kernel<0>, bgrid, dim3(1024), (size_t)nb * sizeof(int), st, b);
+    hipLaunchKernelGGL(costvol_scan_kernel, dim3(1), dim3(1024), 0, st, counts, nb, offsets, cursor);
+    hipLaunchKernelGGL(costvol_bin_kernel<1>, bgrid, dim3(1024), (size_t)nb * sizeof(int), st, b);
+    CvTileArgs t;
+    t.units = units; t.offsets = offsets; t.order = order; t.n = n; t.nv = nv; t.ntx = ntx; t.nty = nty; t.stage = stage;
+    for (int l = 0; l < 4; ++l) { t.hw[2 * l] = h_hw[2 * l]; t.hw[2 * l + 1] = h_hw[2 * l + 1]; t.gfeats[l] = h_gfeats[l]; }
+    t.gmax = gmax;
+    // a bucket holds n nv / nb records on average and several times that at the image centre: SPLIT workgroups per bucket
+    const int64_t avg = n * nv / nb;
+    const int split = avg > 16384 ? 8 : (avg > 4096 ? 4 : (avg > 1024 ? 2 : 1));
+    hipLaunchKernelGGL(costvol_tile_kernel, dim3(nb, split), dim3(256), 0, st, t);
+  }
+  hipLaunchKernelGGL(costvol_bwd_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, g_agg);
   return surf_check_launch();
 }
-
-extern "C" int64_t surf_costvol_backward_workspace_floats(void) { return CV_REPLICAS * 64; }

@@ -1118,7 +1118,8 @@ def costvol_backward(feats_t4_c2f, gfeats_t4_c2f, stage, D, cams, agg, coords, g
     assert g.shape[1] == 8 and g_agg.numel() == 49
     hw = (ctypes.c_int * 8)(*[int(v) for f in feats_t4_c2f for v in f.shape[1:3]])
     agg = np.ascontiguousarray(agg, dtype=np.float32)
-    ws = torch.empty(_lib.lib().surf_costvol_backward_workspace_floats(), dtype=torch.float32, device=g.device)
+    ws = torch.empty(_lib.lib().surf_costvol_backward_workspace_floats(coords.shape[0], cams.nv, int(hw[6]), int(hw[7])),
+                     dtype=torch.float32, device=g.device)
     with _timed("costvol_bwd", int(coords.shape[0]) * cams.nv * (4 - int(stage))):
         rc = _lib.lib().surf_costvol_backward(_p(coords), _p(g), coords.shape[0], int(D), _ptr_array(feats_t4_c2f),
                                               _ptr_array(gfeats_t4_c2f), hw, int(stage), cams.nv, _np_ptr(cams.intrs),
