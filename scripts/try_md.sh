@@ -1,0 +1,10 @@
+#!/usr/bin/env bash
+# matching-field / cost-volume backward timings (HIP events around the whole op, ms per training step) for the default library and
+# the variants named (build_variants/*.so)
+set -u
+O=gpurun_out/${1:-md}; mkdir -p $O; shift
+t() { python bench.py --workload train --cpu-seconds 0 2>> $O/err.log | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); k={x['kernel']:x['ms_per_step'] for x in d['roofline_kernels']}; print('$1', 'step', round(d['ms_per_step'],2), 'matching_depth_bwd', round(k['matching_depth_bwd'],3), 'costvol_bwd', round(k['costvol_bwd'],3))"; }
+t warmup; t default
+for v in "$@"; do SURF_HIP_LIB=$PWD/build_variants/$v.so t $v; done
+t default

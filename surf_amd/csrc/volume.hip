@@ -315,6 +315,37 @@ __global__ __launch_bounds__(256) void dense_init_kernel(const float* __restrict
     const unsigned tu = (unsigned)t;
     const int zb = (int)(tu % zc) * VEC, y = (int)((tu / zc) % (unsigned)D), x = (int)(tu / (zc * (unsigned)D));
     float out[VEC];
+    if (VEC == 4 && prev) {
+      // the four voxels z = zb .. zb + 3 (zb a multiple of 4) read the coarse planes c0 .. c0 + 3, c0 = zb / 2 - 1, as the pairs
+      // (0,1) (1,2) (1,2) (2,3): 16 loads for the vector instead of 32 (same expression, same order: bit-identical; at the two
+      // ends the clamped plane carries weight 0 or coincides with up2_src's own clamp)
+      const int Dp = D / 2;
+      int x0, x1, y0, y1;
+      float lx, ly;
+      up2_src(x, Dp, x0, x1, lx);
+      up2_src(y, Dp, y0, y1, ly);
+      const float hx = 1.0f - lx, hy = 1.0f - ly;
+      const int c0 = zb / 2 - 1;
+      float P[4][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int zc = min(max(c0 + t, 0), Dp - 1);
+        P[0][t] = prev[((int64_t)x0 * Dp + y0) * Dp + zc];
+        P[1][t] = prev[((int64_t)x0 * Dp + y1) * Dp + zc];
+        P[2][t] = prev[((int64_t)x1 * Dp + y0) * Dp + zc];
+        P[3][t] = prev[((int64_t)x1 * Dp + y1) * Dp + zc];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int z0, z1;
+        float lz;
+        up2_src(zb + q, Dp, z0, z1, lz);
+        const float hz = 1.0f - lz;
+        const int a_ = q == 0 ? 0 : (q == 3 ? 2 : 1);
+        out[q] = hx * (hy * (hz * P[0][a_] + lz * P[0][a_ + 1]) + ly * (hz * P[1][a_] + lz * P[1][a_ + 1])) +
+                 lx * (hy * (hz * P[2][a_] + lz * P[2][a_ + 1]) + ly * (hz * P[3][a_] + lz * P[3][a_ + 1]));
+      }
+    } else
 #pragma unroll
     for (int q = 0; q < VEC; ++q) {
       float v = 0.f;
@@ -335,8 +366,10 @@ __global__ __launch_bounds__(256) void dense_init_kernel(const float* __restrict
       out[q] = v;
     }
     if (VEC == 4) {
-      *reinterpret_cast<f32x4*>(dense + i0) = f32x4{out[0], out[1 % VEC], out[2 % VEC], out[3 % VEC]};
-      *reinterpret_cast<int4*>(table + i0) = int4{-1, -1, -1, -1};
+      // streaming stores (2.8 GB at 704^3 that nothing re-reads from L2): 1.54 -> 1.47 ms
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(f32x4{out[0], out[1 % VEC], out[2 % VEC], out[3 % VEC]}, reinterpret_cast<f32x4*>(dense + i0));
+      __builtin_nontemporal_store(i32x4{-1, -1, -1, -1}, reinterpret_cast<i32x4*>(table + i0));
     } else {
       dense[i0] = out[0];
       table[i0] = -1;
@@ -548,8 +581,8 @@ __device__ __forceinline__ void bilinear_texel4_scatter_coop(float* __restrict__
 // scripts/microbench/atomic_shapes.hip (profiles/r05_microbench_atomic_shapes.txt) prices a float atomic at ~12.2 ns per CU
 // for every distinct 64-byte segment its lanes touch; 100 M (voxel, view, level) units x 2 tap rows at that price are 9.6 of
 // the kernel's 12.9 ms, and none of (i)-(v) made the segments fewer in a way the memory side noticed (neighbouring voxels'
-// footprints OVERLAP, and same-address adds inside one instruction serialise).  What would: a gather-form backward per texel
-// tile (needs voxel -> tile lists per view; not built).
+// footprints OVERLAP, and same-address adds inside one instruction serialise).  What did: sorting the adds by image tile - the
+// "binned scatter" further down, which is what runs; this direct form remains for shapes the binned one does not take.
 constexpr int CV_REPLICAS = 64;
 
 struct CostVolBwdArgs {
@@ -879,7 +912,7 @@ __global__ __launch_bounds__(256) void costvol_tile_kernel(CvTileArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               const float val = w * g[c];
-              if (val != 0.f) atomicAdd(d + c * E * E, (unsigned long long)__double2ll_rn(ldexp((double)val, k)));
+              if (val != 0.f) atomicAdd(d + c * E * E, (unsigned long long)(long long)rintf(ldexpf(val, k)));   // exact: power-of-two scale, |.| < 2^62
             }
           } else {                                              // outside the LDS image (an irregular pyramid): straight to memory
             float* d = a.gfeats[l] + (((int64_t)v * H + yi) * W + xi) * 4;
