@@ -273,3 +273,45 @@ def test_precision_scope_restores_the_process_wide_policy():
     except KeyError:
         pass
     assert ops.colgram_precision == 0
+
+
+def test_small_zero_pool_hands_out_disjoint_zero_slices_once():
+    """ops.small_zeros (round 5): the weight-gradient accumulators of a training step come from one pre-zeroed block instead of a
+    fill launch each - every slice is zero, 256-byte aligned, disjoint from every other one, and never handed out twice; a request
+    above the limit, or a block that has run out, gets fresh zeros."""
+    from surf_amd import ops
+    dev = torch.device("cpu")
+    pool = ops._ZeroPool()
+    a = pool.take((27, 16, 8), dev)
+    b = pool.take((8,), dev)
+    c = pool.take((0, 4), dev)
+    assert a.shape == (27, 16, 8) and b.shape == (8,) and c.shape == (0, 4)
+    assert float(a.abs().sum()) == 0.0 and float(b.abs().sum()) == 0.0
+    assert a.data_ptr() % 256 == b.data_ptr() % 256                      # slices start on 64-float boundaries of one block
+    a.fill_(1.0)
+    assert float(b.abs().sum()) == 0.0                                    # disjoint
+    big = pool.take((pool.LIMIT + 1,), dev)
+    assert big.numel() == pool.LIMIT + 1 and float(big.abs().sum()) == 0.0
+    blk = pool._blocks[(dev.type, dev.index)][0]
+    n_before = pool._blocks[(dev.type, dev.index)][1]
+    for _ in range(pool.BLOCK // pool.LIMIT + 2):                         # exhaust the block: a new one takes over
+        t = pool.take((pool.LIMIT,), dev)
+        assert float(t.abs().sum()) == 0.0
+        t.fill_(2.0)
+    assert pool._blocks[(dev.type, dev.index)][0] is not blk and n_before > 0
+    assert float(b.abs().sum()) == 0.0 and float(a.min()) == 1.0          # the old block lives on through its views
+
+
+def test_masked_l1_host_expression_for_the_three_mask_forms():
+    """Loss._masked_l1 off the GPU (and for mismatched shapes on it) is the reference's expression
+    sum(|pred - target| mask) / (sum(mask) + 1e-8), with the mask given as floats, booleans or "target>0" (loss.py:71-93)."""
+    from surf_amd.losses import Loss
+    g = torch.Generator().manual_seed(4)
+    pred, target = torch.randn(7, 9, generator=g), torch.randn(7, 9, generator=g)
+    fm = (torch.rand(7, 9, generator=g) < 0.6).float()
+    want = ((pred - target).abs() * fm).sum() / (fm.sum() + 1e-8)
+    assert torch.equal(Loss._masked_l1(pred, target, fm), want)
+    assert torch.equal(Loss._masked_l1(pred, target, fm > 0), want)
+    pos = (target > 0).float()
+    assert torch.equal(Loss._masked_l1(pred, target, "target>0"), ((pred - target).abs() * pos).sum() / (pos.sum() + 1e-8))
+    assert float(Loss._masked_l1(pred, target, torch.zeros(7, 9))) == 0.0
