@@ -3,6 +3,8 @@
 //
 // Restates Volume.up_sample / depth_filtering / back_proj_multiscale / sparse2dense / get_index
 //          volume.py:35-52, 134-168, 54-97, 99-121, 123-132  and the row selections of surf.py:104-109.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -1077,6 +1079,7 @@ extern "C" int surf_scatter_rows_add(const float* g_dst, const int32_t* idx, int
 #endif
 static bool cv_binned_ok(int64_t n, int nv, const int* hw) {
   if (!SURF_CVB_BINNED || n * nv > 0x7fffffffLL) return false;
+  if (getenv("SURF_CVB_DIRECT")) return false;            // tests: keep the direct scatter (the fallback of the shapes below) exercised
   const int H3 = hw[6], W3 = hw[7];
   for (int l = 0; l < 4; ++l)
     if (hw[2 * l] != (H3 >> (3 - l)) || hw[2 * l + 1] != (W3 >> (3 - l)) || hw[2 * l] < 2 || hw[2 * l + 1] < 2) return false;

@@ -161,6 +161,22 @@ def test_costvol_backward(scene, weights, golden_fpn, golden_pipe, stage):
     ref_agg = torch.cat([sd["volume.agg_mlp.0.weight"].grad.reshape(-1), sd["volume.agg_mlp.0.bias"].grad.reshape(-1),
                          sd["volume.agg_mlp.2.weight"].grad.reshape(-1), sd["volume.agg_mlp.2.bias"].grad.reshape(-1)])
     grad_close(g_agg, ref_agg)
+    # round 5: what ran above is the BINNED form (adds sorted by image tile, 64-bit fixed-point LDS images); the direct scatter
+    # remains as the fallback of shapes with more than 16,384 (view, tile) buckets - SURF_CVB_DIRECT forces it: same gradients
+    import os
+    gfeats2 = [torch.zeros_like(f) for f in feats_t4]
+    g_agg2 = torch.zeros(49, device=d)
+    os.environ["SURF_CVB_DIRECT"] = "1"
+    try:
+        ops.costvol_backward(feats_t4, gfeats2, stage, D, _cams(scene), ops.agg_mlp_host(weights), coords.to(d).contiguous(),
+                             G.to(d).contiguous(), g_agg2)
+    finally:
+        del os.environ["SURF_CVB_DIRECT"]
+    for l in range(stage, 4):
+        grad_close(gfeats2[l].permute(0, 3, 1, 2), feats[l].grad)
+        scale = float(gfeats2[l].abs().max())
+        assert scale > 0 and float((gfeats[l] - gfeats2[l]).abs().max()) <= 2e-5 * scale      # the two forms agree far inside the bar
+    grad_close(g_agg2, ref_agg)
 
 
 def test_fpn_backward_matches_autograd(scene):
