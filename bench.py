@@ -293,28 +293,42 @@ def training_step_timing(args, dev, steps=5):
     """Wall time of one full training step (runner.py:152-165: forward -> Loss -> loss.backward() = the HIP backward of the
     render, the 4-stage volume build and the FPN -> Adam) on the bench scene, reported beside the render metric,
     for both training-precision policies."""
+    from surf_amd import dist as D
     from surf_amd import ops, training
     res = {}
     for precision in ("fp32", "bf16"):
         model, ipts, targets, loss_fn, opt = training_step_setup(dev, args.height, args.width, args.views, args.base_dim,
                                                                  precision=precision)
-        for _ in range(2):
-            out = training.train_step(model, ipts, targets, loss_fn, opt, 1.0, 3)
-        torch.cuda.synchronize()
-        per_step = []
-        for _ in range(steps):            # a step ends with the host reading its loss values: timing steps one by one adds no sync
-            t0 = time.perf_counter()
-            out = training.train_step(model, ipts, targets, loss_fn, opt, 1.0, 3)
+        def timed(stepper, sync):
+            for _ in range(2):
+                out = training.train_step(stepper, ipts, targets, loss_fn, opt, 1.0, 3, sync=sync)
             torch.cuda.synchronize()
-            per_step.append((time.perf_counter() - t0) * 1e3)
-        ms = sorted(per_step)[len(per_step) // 2]          # median: one slow step (allocator growth, clocks) is not the policy
+            per_step = []
+            for _ in range(steps):        # a step ends with the host reading its loss values: timing steps one by one adds no sync
+                t0 = time.perf_counter()
+                out = training.train_step(stepper, ipts, targets, loss_fn, opt, 1.0, 3, sync=sync)
+                torch.cuda.synchronize()
+                per_step.append((time.perf_counter() - t0) * 1e3)
+            return sorted(per_step)[len(per_step) // 2], per_step, out     # median: one slow step (allocator, clocks) is not the policy
+
+        # the single-GPU step, as every earlier round measured it: no gradient averaging (sync=False beside the forced group)
+        ms, per_step, out = timed(model, False)
         res[precision] = {"ms_per_step": ms, "loss": out["loss"], "steps_ms": [round(v, 2) for v in per_step]}
+        if D._active():                   # the same step as runner.py:102 runs it on N GPUs: wrapped in DDP over the (world-1) RCCL group
+            ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], gradient_as_bucket_view=True)
+            ms_d, per_d, _ = timed(ddp, True)
+            res[precision]["ddp_ms_per_step"] = ms_d
+            res[precision]["ddp_steps_ms"] = [round(v, 2) for v in per_d]
+            del ddp
         voxels = model.last_voxels_per_stage
         rays = int(ipts["rays_o"].shape[0])
         del model, opt
     ops.set_train_precision("fp32")
     return {"ms_per_step": res["fp32"]["ms_per_step"], "rays": rays, "samples_per_ray": 128, "voxels_per_stage": voxels,
             "loss": res["fp32"]["loss"], "steps_ms": res["fp32"]["steps_ms"], "train_precision_bf16": res["bf16"],
+            "ddp_ms_per_step": res["fp32"].get("ddp_ms_per_step"),
+            "data_parallel": ("ddp_ms_per_step: the same step with the model wrapped in DistributedDataParallel over " + D.backend_note()
+                              + " (bucket hooks, buffer broadcast, the 5.6 MB all-reduce with one peer)") if D._active() else None,
             "what": "median of 5 steps of: forward (FPN, volume build, render) + loss + loss.backward() (HIP backward of all of it) + Adam; every term of "
                     "losses/loss.py; matching-field jitter on the device generator; train_precision_bf16: the same step with the "
                     "weight-gradient reductions on bf16 operands (model conf train_precision = bf16)"}
@@ -348,6 +362,73 @@ def mesh_grid_timing(model, scene, dev, resolution):
     mc = {"marching_cubes_ms": c.elapsed_time(d), "vertices": int(v.shape[0]), "triangles": int(t.shape[0])}
     del u, v, t
     return a.elapsed_time(b), k_ms, inside, mc
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# process group: RCCL for N > 1, and (default) a FORCED world-size-1 RCCL group at N = 1
+# ----------------------------------------------------------------------------------------------------------------------
+
+GROUP_NOTE = {"error": None}
+
+
+def init_group(args, dev, world):
+    """Bring up the process group of this rank.  N > 1: RCCL (or gloo with --backend gloo).  N = 1 with --force-group 1 (the
+    default): a world-size-1 group over the same backend, so that the barrier, the MAX all-reduce of the elapsed time on a
+    DEVICE tensor, the record gather, gather_rows' padded device all_gather, the gradient bucket's all-reduce and
+    DistributedDataParallel's hooks all execute over RCCL on a one-GPU box - the calls an 8-GPU run makes, with one peer.
+    A failure of the forced group is reported in the line (`collective_backend`) and the run continues without a group; a
+    failure at N > 1 is fatal."""
+    from surf_amd import dist as D
+    force = bool(args.force_group) and world == 1 and not torch.distributed.is_initialized()
+    try:
+        D.init_from_env(args.backend, dev, force=force, timeout_s=args.group_timeout)
+    except Exception as e:       # noqa: BLE001
+        if world > 1:
+            raise
+        GROUP_NOTE["error"] = f"none (forced world-1 {args.backend} group failed: {type(e).__name__}: {str(e)[:200]})"
+
+
+def collective_note(args):
+    from surf_amd import dist as D
+    if GROUP_NOTE["error"]:
+        return GROUP_NOTE["error"]
+    return D.backend_note(args.one_gpu)
+
+
+def collective_probe(dev, n_floats=1_410_000, iters=10):
+    """The collectives of the N-rank runs on this rank's group, timed: the all-reduce of ONE flat gradient bucket of SuRF's size
+    (1.41 M floats = 5.6 MB: DDP's single bucket), the padded device all_gather of gather_rows on an image-sized
+    (R, 3) tensor with its identity check, the barrier.  None without a group."""
+    from surf_amd import dist as D
+    if not D._active():
+        return None
+    flat = torch.arange(n_floats, dtype=torch.float32, device=dev)
+    ref = flat.clone()
+    for _ in range(3):
+        torch.distributed.all_reduce(flat)
+    torch.cuda.synchronize()
+    world = torch.distributed.get_world_size()
+    ok = bool(torch.equal(flat, ref)) if world == 1 else None
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        torch.distributed.all_reduce(flat)
+    torch.cuda.synchronize()
+    ar_ms = (time.perf_counter() - t0) / iters * 1e3
+    rows = torch.rand(460800 // world, 3, device=dev)
+    D.gather_rows(rows)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = D.gather_rows(rows)
+    torch.cuda.synchronize()
+    ag_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    D.barrier()
+    torch.cuda.synchronize()
+    b_ms = (time.perf_counter() - t0) * 1e3
+    return {"world": world, "backend": torch.distributed.get_backend(),
+            "gradient_bucket_allreduce_ms": D.max_over_ranks(ar_ms, dev), "bucket_bytes": n_floats * 4,
+            "allreduce_identity_at_world_1": ok, "gather_rows_ms": ag_ms,
+            "gather_rows_identity_at_world_1": (bool(torch.equal(got, rows)) if world == 1 else None), "barrier_ms": b_ms}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -492,9 +573,10 @@ def run_rank_train(args):
             local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        D.init_from_env(args.backend, dev)
+        init_group(args, dev, world)
     if args.fail_rank == rank:
         sys.exit(3)
+    grouped = D._active()          # N > 1, or the forced world-1 group: wrap in DDP, time the bucket's all-reduce
 
     def sync():
         if not dry:
@@ -506,14 +588,15 @@ def run_rank_train(args):
         inputs = {"x": torch.tensor(float(rank))}
         opt = torch.optim.SGD(model.parameters(), lr=0.0)
         loss_of = lambda outputs: outputs["color_fine"].sum()          # noqa: E731
-        ddp = DistributedDataParallel(model) if world > 1 else model
+        ddp = DistributedDataParallel(model) if grouped else model
     else:
         from surf_amd import ops
         model, ipts, targets, loss_fn, opt = training_step_setup(dev, H, W, nv, args.base_dim, rays=rays, scene_seed=rank,
                                                                  precision=args.train_precision)
         inputs = {**targets, **ipts}                                    # the runner hands ONE dictionary to model and loss
         loss_of = lambda outputs: loss_fn(outputs, inputs, 3.0)["loss"]  # noqa: E731
-        ddp = DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model      # runner.py:102
+        ddp = (DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)   # runner.py:102
+               if grouped else model)
 
     def step():                                                        # runner.py:155-164
         outputs = ddp("train", inputs, cos_anneal_ratio=1.0, step=3.0)
@@ -547,7 +630,7 @@ def run_rank_train(args):
     # the gradient all-reduce alone: one flat bucket of the trainable parameters' size (DDP's single 5.6 MB bucket)
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
     allreduce_ms = None
-    if world > 1:
+    if grouped:
         flat = torch.zeros(n_params, dtype=torch.float32, device=dev)
         for _ in range(3):
             torch.distributed.all_reduce(flat)
@@ -577,7 +660,7 @@ def run_rank_train(args):
             "config": {"workload": ("DRY RUN of the train control flow: no kernels executed" if dry else
                                     f"training step: {nv} views {H}x{W}, {rays} rays x 128 samples and one synthetic scene per rank, "
                                     f"{args.base_dim}^3 -> {args.base_dim * 8}^3 pyramid, every term of losses/loss.py, Adam"),
-                       "rays_per_rank_step": rays, "parallelism": f"ddp{world}" if world > 1 else "single",
+                       "rays_per_rank_step": rays, "parallelism": f"ddp{world}" if grouped else "single",
                        "train_precision": args.train_precision,
                        "trainable_parameters": n_params},
             "steps_per_s": args.steps / elapsed, "gradient_allreduce_ms": allreduce_ms,
@@ -591,10 +674,9 @@ def run_rank_train(args):
             result["cpu_baseline"] = cpu_train_baseline()
         if not dry:
             result["voxels_per_stage"] = getattr(model, "last_voxels_per_stage", None)
-        result["collective_backend"] = (args.backend + (" (all ranks on cuda:0)" if args.one_gpu else "")) if world > 1 else None
-        print(json.dumps(result))
-    if world > 1:
-        D.shutdown()
+        result["collective_backend"] = collective_note(args)
+        return result
+    return None
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -696,6 +778,14 @@ def parse_args(argv):
     ap.add_argument("--check-split", action="store_true",
                     help="(--split rays) rank 0 also renders the whole image and the whole lattice alone and reports whether the "
                          "stitched results are bit-equal")
+    ap.add_argument("--force-group", type=int, default=1,
+                    help="N = 1: create a world-size-1 process group over --backend anyway (default 1), so that every collective of "
+                         "the N-rank runs (barrier, device-tensor MAX, record gather, gather_rows, gradient bucket, DDP) executes over "
+                         "RCCL on a one-GPU box; 0 = no group at N = 1")
+    ap.add_argument("--group-timeout", type=float, default=600.0, help="process-group timeout in seconds")
+    ap.add_argument("--other-configs", type=int, default=1,
+                    help="default N = 1 dtu line: also measure configs[4] (T&T shape), configs[2] (15 scenes on this GPU) and the "
+                         "single-scene ray split, reported under other_configs")
     ap.add_argument("--fail-rank", type=int, default=-1, help="(tests) this rank exits 3 before the first barrier")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend of a multi-rank run: nccl (= RCCL, the measured configuration) or gloo (tests: "
@@ -723,7 +813,13 @@ def main(argv=None):
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with matching values "
               f"(or leave WORLD_SIZE unset and let bench.py start the ranks)", file=sys.stderr)
         sys.exit(2)
-    run_rank(args)
+    result = run_rank(args)
+    if result is not None:
+        print(json.dumps(result))
+        sys.stdout.flush()
+    if torch.distributed.is_initialized():
+        from surf_amd import dist as D
+        D.shutdown()
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -753,7 +849,7 @@ def run_rank_split(args):
     local_rank = 0 if args.one_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    D.init_from_env(args.backend, dev)
+    init_group(args, dev, world)
     if args.fail_rank == rank:
         sys.exit(3)
     n_samples = [int(x) for x in args.n_samples.split(",")]
@@ -828,7 +924,7 @@ def run_rank_split(args):
             ops.sdf_lattice(axes, sc.sv, sdf_w, u1, 0, res, sign=-1.0)
             check["lattice_bit_equal"] = bool(torch.equal(u1, u_all))
     if rank == 0:
-        print(json.dumps({
+        return ({
             "metric": WORKLOADS[args.workload]["metric"], "value": R * args.steps / elapsed, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
@@ -840,12 +936,13 @@ def run_rank_split(args):
                        "rays_per_rank": [(k + 1) * R // world - k * R // world for k in range(world)]},
             "split": {"render_ms_max_over_ranks": render_ms, "step_ms": elapsed / args.steps * 1e3, "lattice": lattice, "check": check},
             "roofline": None, "cpu_baseline": None,
-            "collective_backend": (args.backend + (" (all ranks on cuda:0)" if args.one_gpu else "")) if world > 1 else None}))
-    if world > 1:
-        D.shutdown()
+            "collective_backend": collective_note(args)})
+    return None
 
 
 def run_rank(args):
+    """One rank of the job `args` names.  Returns the result line as a dict on rank 0 (None elsewhere); main() prints it and
+    leaves the process group."""
     if args.workload == "train":
         return run_rank_train(args)
     if args.split == "rays":
@@ -863,7 +960,7 @@ def run_rank(args):
             local_rank = 0
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
-        D.init_from_env(args.backend, dev)    # RCCL; only the barrier, the MAX of the elapsed time and the record gather
+        init_group(args, dev, world)          # RCCL; only the barrier, the MAX of the elapsed time and the record gather
     if torch.distributed.is_initialized():
         assert torch.distributed.get_world_size() == world == args.gpus
     if args.fail_rank == rank:
@@ -967,16 +1064,14 @@ def run_rank(args):
     if dry:
         if rank == 0:
             recs = sorted((r for per_rank in records for r in per_rank), key=lambda r: r["scene"])
-            print(json.dumps({
+            return ({
                 "metric": WORKLOADS[args.workload]["metric"], "value": rays_per_step_job * args.steps / elapsed, "unit": "rays/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none (dry run)",
                 "data": "dry-run", "config": {"workload": f"DRY RUN of the {args.workload} control flow: no kernels executed",
                                               "scenes": n_scenes_total, "rays_per_step": rays_per_step_job},
-                "scenes": recs}))
-        if world > 1:
-            D.shutdown()
-        return
+                "scenes": recs})
+        return None
 
     # ---- per-kernel durations from the HIP events recorded inside the timed region -----------------------
     per_kernel = {}
@@ -1116,10 +1211,45 @@ def run_rank(args):
                 result["scene"] = scene_timing(args, dev, args.mesh_grid)
         if world == 1 and args.train_step and args.workload == "dtu":
             result["training_step"] = training_step_timing(args, dev)
-        result["collective_backend"] = (args.backend + (" (all ranks on cuda:0)" if args.one_gpu else "")) if world > 1 else None
-        print(json.dumps(result))
-    if world > 1:
-        D.shutdown()
+        result["collective_backend"] = collective_note(args)
+        result["collectives"] = collective_probe(dev)
+        if world == 1 and args.other_configs and args.workload == "dtu" and args.scenes == 0:
+            del scenes, sc0, out
+            torch.cuda.empty_cache()
+            result["other_configs"] = other_configs(args)
+        return result
+    return None
+
+
+def other_configs(args):
+    """The BASELINE configs the headline line does not quote, measured in this same process after it (N = 1, default run):
+    configs[4] the Tanks&Temples shape, configs[2] the 15-scan split dealt onto this one GPU, and SURVEY 8e's single-scene ray
+    split with its bit-equality check.  Each entry is that job's own line (own `config.workload`, `ms_per_step`, `roofline.frac`)
+    without its CPU / build / training legs; the headline's timed region is over before any of them starts."""
+    import copy
+    jobs = [("tnt", ["--workload", "tnt", "--steps", "3", "--warmup", "1"]),
+            ("scenes15", ["--scenes", "15", "--steps", "1", "--warmup", "1"]),
+            ("split_rays", ["--split", "rays", "--check-split", "--steps", "3", "--warmup", "1", "--mesh-grid", "512"])]
+    common = ["--gpus", "1", "--cpu-seconds", "0", "--build", "0", "--train-step", "0", "--also", "", "--other-configs", "0",
+              "--sdf-precision", args.sdf_precision, "--base-dim", str(args.base_dim)]
+    res = {}
+    for name, argv in jobs:
+        a = parse_args(argv + common + ([] if "--mesh-grid" in argv else ["--mesh-grid", "0"]))
+        t0 = time.perf_counter()
+        try:
+            r = run_rank(a)
+        except Exception as e:       # noqa: BLE001 - a failing extra must not take the headline line with it
+            r = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        torch.cuda.synchronize()
+        r["wall_s_incl_scene_setup"] = time.perf_counter() - t0
+        if isinstance(r.get("scenes"), list) and len(r["scenes"]) > 4:
+            ms = [x["ms_per_render"] for x in r["scenes"]]
+            r["scenes"] = {"count": len(ms), "ms_per_render_min": min(ms), "ms_per_render_max": max(ms), "ms_per_render_mean": sum(ms) / len(ms)}
+        for k in ("kernel_launches_per_step",):
+            r.pop(k, None)
+        res[name] = r
+        torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":

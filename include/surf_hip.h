@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 36
+#define SURF_ABI_VERSION 37
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -455,7 +455,11 @@ int surf_inorm_relu_backward(const float* x, const float* dy, int N, int64_t hw,
  * surf_costvol_backward: for the kept voxels `coords` (n,3) of a stage and g (n,8) = [d mean | d var], accumulates the
  * gradients of the summed feature levels into h_gfeats[l] (texel4 maps like h_feats[l], l >= stage) and of agg_mlp
  * (w1 | b1 | w2 | b2, 49 floats, device) into g_agg.  workspace: surf_costvol_backward_workspace_floats(n, nv, H, W) device
- * floats, (H, W) = the finest feature level (the kernel sorts its (view, voxel) adds by image tile: 9 floats per pair). */
+ * floats, (H, W) = the finest feature level (the kernel sorts its (view, voxel) adds by image tile: 9 floats per pair - 1.1 to
+ * 1.5 GB of transient memory at the finest DTU stage, ~6 M voxels x 5 views); an upper bound for every pyramid.
+ * surf_costvol_backward_workspace_floats_for(n, nv, h_hw): the exact need for the pyramid h_hw (4 x (H, W), coarse to fine, as
+ * passed to surf_costvol_backward): 4,096 floats when the tile-sorted form will not run (irregular pyramid such as the
+ * Tanks&Temples shape, more than 16,384 (view, tile) buckets) and the direct scatter is used instead. */
 int surf_matching_depth_backward(const float* mvol, int D, int nv, const float* h_kinv, const float* h_c2w, const float* h_rinv,
                                  const float* h_near_fars, int H, int W, int h, int w, const float* lin_x, const float* lin_y,
                                  const float* lin_n, int n, const float* pre_depths, float ratio_cur, float ratio_prev,
@@ -466,6 +470,7 @@ int surf_densify_backward(const int32_t* coords, int64_t n, int D, const int32_t
 int surf_scatter_rows_add(const float* g_dst, const int32_t* idx, int64_t n, int row_words, int idx_shift, int dst_stride_words,
                           int dst_offset_words, float* g_src, void* stream);
 int64_t surf_costvol_backward_workspace_floats(int64_t n, int nv, int H, int W);
+int64_t surf_costvol_backward_workspace_floats_for(int64_t n, int nv, const int* h_hw);
 int surf_costvol_backward(const int32_t* coords, const float* g, int64_t n, int D, const float* const* h_feats,
                           float* const* h_gfeats, const int* h_hw, int stage, int nv, const float* h_intrs, const float* h_w2c,
                           const float* h_agg, float* workspace, float* g_agg, void* stream);
@@ -534,7 +539,10 @@ int surf_conv3x3(const float* in, const float* weight, int N, int H, int W, int 
 /* ConvTranspose2d(3x3, stride 2, padding 1, output_padding 1), no bias (feature_network.py:66,155).  out (N,2H,2W,cout). */
 int surf_deconv3x3_s2(const float* in, const float* weight, int N, int H, int W, int cin, int cout, float* out, void* stream);
 /* In place: x = relu(InstanceNorm2d(x)) (+ skip)  (feature_network.py:16-17,21-24; skip add :170).
- * workspace: surf_inorm_workspace_doubles(N,H,W,C) doubles; stats (N,C,2) receives mean and 1/sqrt(var+1e-5). */
+ * workspace: surf_inorm_workspace_doubles(N,H,W,C) doubles; stats (N,C,2) receives mean and 1/sqrt(var+1e-5).
+ * C must be a multiple of 4 that divides 256 (4, 8, 16, 32, 64: the channel counts surf_conv3x3 / surf_deconv3x3_s2 are
+ * instantiated for; since round 5 the statistics pass assigns 256 / C pixels to a workgroup row); any other C is SURF_E_ARG.
+ * surf_inorm_relu_backward: C in {8, 16, 32, 64}. */
 int64_t surf_inorm_workspace_doubles(int N, int H, int W, int C);
 int surf_inorm_relu(float* x, int N, int H, int W, int C, const float* skip, double* workspace, float* stats, void* stream);
 /* The same into `out` (N,H,W,C), x left as it is: a recording (train-mode) forward keeps the raw convolution output for

@@ -17,6 +17,11 @@ Measurement harness, not a training / serving control plane: no logging framewor
 --down_rule {dilate,floor,pad0}: which stride-2 site rule of torchsparse the checkpoint's sparse U-Net was trained under
 (row a5 is parity-unpinned: torchsparse is not available to the build; with three rules behind one switch the authors'
 checkpoint picks its own - the right rule is the one that reproduces the published Chamfer, README.md:87-106).
+--kernel_order {xfast,zfast} / --transposed_pairing {same,mirrored}: the two other torchsparse conventions a loaded checkpoint
+depends on (surf_amd.reg_network.slice_permutation): the enumeration of the 27 kernel slices and which slice a transposed layer
+pairs with which offset.  --sweep runs all 3 x 2 x 2 = 12 combinations on ONE loaded model (set_conventions between runs, one mesh
+and one evaluation each), prints one line per combination and a final line naming the combination whose Chamfer is closest to
+--reference_chamfer: twelve candidates and a one-command discriminator instead of one guess that may scramble the checkpoint.
 --reference_chamfer X: the reference's own number for this scan (or the published mean 1.05); "delta" = ours - X is then the
 quantity north_star bounds by 0.01."""
 import argparse
@@ -41,6 +46,11 @@ def parse_args(argv=None):
     ap.add_argument("--ref_view", type=int, default=None, help="overrides val_dataset.ref_view")
     ap.add_argument("--out_dir", default="./outputs")
     ap.add_argument("--down_rule", default=None, choices=["dilate", "floor", "pad0"], help="model.reg_network.down_rule")
+    ap.add_argument("--kernel_order", default=None, choices=["xfast", "zfast"], help="model.reg_network.kernel_order")
+    ap.add_argument("--transposed_pairing", default=None, choices=["same", "mirrored"], help="model.reg_network.transposed_pairing")
+    ap.add_argument("--sweep", action="store_true",
+                    help="evaluate every (down_rule, kernel_order, transposed_pairing) combination and report the one closest to "
+                         "--reference_chamfer")
     ap.add_argument("--sdf_precision", default=None, choices=["f32", "bf16x3", "f16x2"])
     ap.add_argument("--mesh_resolution", type=int, default=512)
     ap.add_argument("--clean_mesh", action="store_true", help="runner.py --clean_mesh: drop faces outside the dilated masks / frusta")
@@ -72,8 +82,9 @@ def run(args):
     if args.ref_view is not None:
         dconf["ref_view"] = [args.ref_view]
     mconf = cfg["model"]
-    if args.down_rule is not None:
-        mconf["reg_network"]["down_rule"] = args.down_rule
+    for key in ("down_rule", "kernel_order", "transposed_pairing"):
+        if getattr(args, key) is not None:
+            mconf["reg_network"][key] = getattr(args, key)
     if args.sdf_precision is not None:
         mconf["implicit_surface"]["render"]["sdf_precision"] = args.sdf_precision
 
@@ -97,34 +108,66 @@ def run(args):
         model.logit_override = synthetic.sphere_logit
     t_load = time.perf_counter() - t0
 
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        out = model("val", inputs, cos_anneal_ratio=1.0)                                          # runner.py:216
-    if dev.type == "cuda":
-        torch.cuda.synchronize()
-    t_val = time.perf_counter() - t0
-    v, t = np.asarray(out["vertices"]), np.asarray(out["triangles"])
-    if len(t) == 0:
-        raise SystemExit("dtu_chamfer: the SDF lattice has no zero crossing inside the bounding box (empty mesh)")
-    if args.clean_mesh:
-        v, t = CM.clean_mesh(v, t, item["masks"], item["intrs"], item["c2ws"], device=dev.type)
-    mesh_path = os.path.join(args.out_dir, "meshes", "final", f"scan{args.scan}.ply")
-    os.makedirs(os.path.dirname(mesh_path), exist_ok=True)
-    mesh_io.export_mesh(mesh_path, v, t, item["scale_mat"])                                       # runner.py:236-240
+    def evaluate(tag=""):
+        """One val forward + mesh + DTU evaluation of `model` under its current torchsparse conventions."""
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            out = model("val", inputs, cos_anneal_ratio=1.0)                                      # runner.py:216
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        t_val = time.perf_counter() - t0
+        conv = model.reg_network.conventions()
+        v, t = np.asarray(out["vertices"]), np.asarray(out["triangles"])
+        if len(t) == 0:
+            if tag:                      # a sweep candidate that scrambles the checkpoint may well produce no surface at all
+                return {"scan": args.scan, "chamfer": None, "error": "empty mesh", **conv}
+            raise SystemExit("dtu_chamfer: the SDF lattice has no zero crossing inside the bounding box (empty mesh)")
+        if args.clean_mesh:
+            v, t = CM.clean_mesh(v, t, item["masks"], item["intrs"], item["c2ws"], device=dev.type)
+        mesh_path = os.path.join(args.out_dir, "meshes", "final" + tag, f"scan{args.scan}.ply")
+        os.makedirs(os.path.dirname(mesh_path), exist_ok=True)
+        mesh_io.export_mesh(mesh_path, v, t, item["scale_mat"])                                   # runner.py:236-240
+        t0 = time.perf_counter()
+        d2s, s2d, overall = dtu_eval.evaluate_scan(mesh_path, args.eval_dir, args.scan, patch_size=args.patch_size,
+                                                   max_dist=args.max_dist, downsample_density=args.downsample_density,
+                                                   rng=np.random.default_rng(args.shuffle_seed))
+        t_eval = time.perf_counter() - t0
+        return {"scan": args.scan, "d2s": d2s, "s2d": s2d, "chamfer": overall, "reference_chamfer": args.reference_chamfer,
+                "delta": None if args.reference_chamfer is None else overall - args.reference_chamfer,
+                "mesh": mesh_path, "vertices": int(len(v)), "triangles": int(len(t)), "mesh_resolution": args.mesh_resolution,
+                "views": int(item["imgs"].shape[0]), "render_hw": [int(x) for x in out["img_fine"].shape[:2]],
+                **conv, "sdf_precision": model.implicit_surface.sdf_precision,
+                "checkpoint": args.ckpt, "missing_keys": missing, "unexpected_keys": unexpected, "cleaned": bool(args.clean_mesh),
+                "seconds": {"load": t_load, "val_forward": t_val, "evaluate": t_eval}}
 
-    t0 = time.perf_counter()
-    d2s, s2d, overall = dtu_eval.evaluate_scan(mesh_path, args.eval_dir, args.scan, patch_size=args.patch_size, max_dist=args.max_dist,
-                                               downsample_density=args.downsample_density,
-                                               rng=np.random.default_rng(args.shuffle_seed))
-    t_eval = time.perf_counter() - t0
-    rec = {"scan": args.scan, "d2s": d2s, "s2d": s2d, "chamfer": overall, "reference_chamfer": args.reference_chamfer,
-           "delta": None if args.reference_chamfer is None else overall - args.reference_chamfer,
-           "mesh": mesh_path, "vertices": int(len(v)), "triangles": int(len(t)), "mesh_resolution": args.mesh_resolution,
-           "views": int(item["imgs"].shape[0]), "render_hw": [int(x) for x in out["img_fine"].shape[:2]],
-           "down_rule": model.reg_network.nets[0].down_rule, "sdf_precision": model.implicit_surface.sdf_precision,
-           "checkpoint": args.ckpt, "missing_keys": missing, "unexpected_keys": unexpected, "cleaned": bool(args.clean_mesh),
-           "seconds": {"load": t_load, "val_forward": t_val, "evaluate": t_eval}}
-    with open(os.path.join(args.out_dir, f"chamfer_scan{args.scan}.json"), "w") as f:
+    if not args.sweep:
+        rec = evaluate()
+        with open(os.path.join(args.out_dir, f"chamfer_scan{args.scan}.json"), "w") as f:
+            json.dump(rec, f)
+        return rec
+    # ---- the 3 x 2 x 2 grid of torchsparse conventions on the one loaded model ----
+    grid = []
+    for rule in ("pad0", "dilate", "floor"):
+        for order in ("xfast", "zfast"):
+            for pairing in ("same", "mirrored"):
+                model.reg_network.set_conventions(rule, order, pairing)
+                r = evaluate(f"_{rule}_{order}_{pairing}")
+                grid.append(r)
+                print(json.dumps({k: r.get(k) for k in ("down_rule", "kernel_order", "transposed_pairing", "chamfer", "d2s", "s2d",
+                                                        "delta", "triangles", "error")}), flush=True)
+    ok = [r for r in grid if r["chamfer"] is not None]
+    if not ok:
+        raise SystemExit("dtu_chamfer --sweep: every combination produced an empty mesh")
+    target = args.reference_chamfer
+    best = min(ok, key=(lambda r: abs(r["chamfer"] - target)) if target is not None else (lambda r: r["chamfer"]))
+    rec = {"scan": args.scan, "sweep": [{k: r.get(k) for k in ("down_rule", "kernel_order", "transposed_pairing", "chamfer", "delta",
+                                                              "error")} for r in grid],
+           "selected_by": "closest to --reference_chamfer" if target is not None else "lowest Chamfer (no --reference_chamfer given)",
+           "best": best, "reference_chamfer": target,
+           "within_0.01_of_reference": None if target is None else [
+               {k: r[k] for k in ("down_rule", "kernel_order", "transposed_pairing", "chamfer")} for r in ok
+               if abs(r["chamfer"] - target) <= 0.01]}
+    with open(os.path.join(args.out_dir, f"chamfer_sweep_scan{args.scan}.json"), "w") as f:
         json.dump(rec, f)
     return rec
 

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
 # must equal SURF_ABI_VERSION of include/surf_hip.h (tests/test_host_modules.py compares the two texts); lib() refuses a
 # library built from another header
-ABI_VERSION = 36
+ABI_VERSION = 37
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -99,6 +99,7 @@ SIGNATURES = {
     "surf_densify_backward": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr]),
     "surf_scatter_rows_add": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
     "surf_costvol_backward_workspace_floats": (c_i64, [c_i64, c_int, c_int, c_int]),
+    "surf_costvol_backward_workspace_floats_for": (c_i64, [c_i64, c_int, c_ptr]),
     "surf_costvol_backward": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_conv3x3_wgrad_workspace_floats": (c_i64, [c_int, c_int, c_int, c_int, c_int]),
     "surf_conv3x3_wgrad": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),

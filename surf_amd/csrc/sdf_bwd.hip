@@ -11,8 +11,9 @@
 //   weights   dW_l = sum_n tbar_l (x) in_l + t'bar_l (x) in'_l,  db_l = sum_n tbar_l      (left to the caller as GEMMs over
 //             the per-sample buffers this kernel writes: IN / IND (n,160) and TB / TDB (n,128) per layer)
 //   features  dF[row_c] += w_c phibar + (grad w_c . v) phi'bar     (float atomics into the sparse volumes' gradient rows)
-// Plain fp32 FMAs, one wavefront per 4 samples, same lane ownership as sdf_smooth.hip (whose packed weight image it reads).
-#include "common.h"
+// Plain fp32 FMAs, one wavefront per 4 samples, same lane ownership as sdf_smooth.hip (whose packed weight image it reads);
+// round 6: SURF_TRAIN_WAVES wavefronts per workgroup share the weight stream through LDS (sdf_train_common.h).
+#include "sdf_train_common.h"
 
 // weight rows in flight per step of the k / neuron loops (the loops wait for one L2 round trip per unrolled group)
 #ifndef SURF_TRAIN_UNROLL
@@ -69,13 +70,16 @@ __device__ __forceinline__ Act softplus100(float t) {
   return a;
 }
 
-__global__ __launch_bounds__(64) void sdf_bwd_kernel(BwdArgs a) {
+__global__ __launch_bounds__(surf_train::NT) void sdf_bwd_kernel(BwdArgs a) {
   // Round 5: [k][value | tangent][sample] rows (8 values + 4 of padding): the k / neuron loops read a weight pair's eight
   // broadcast operands as two 16-byte LDS reads instead of eight 4-byte ones (see sdf_smooth_bwd.hip)
-  __shared__ __attribute__((aligned(16))) float xin_t[KP * XS];
-  __shared__ __attribute__((aligned(16))) float dl_t[NH * XS];
-  const int lane = threadIdx.x;
-  const int64_t base = (int64_t)blockIdx.x * S;
+  __shared__ __attribute__((aligned(16))) float xin_all[surf_train::NW][KP * XS];
+  __shared__ __attribute__((aligned(16))) float dl_all[surf_train::NW][NH * XS];
+  __shared__ __attribute__((aligned(16))) float wbuf[surf_train::WBUF_FLOATS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* const xin_t = xin_all[wave];
+  float* const dl_t = dl_all[wave];
+  const int64_t base = ((int64_t)blockIdx.x * surf_train::NW + wave) * S;
   const float inv_sqrt2 = 0.70710678118654752440f;
   float e[S], je[S];
   float px[S], py[S], pz[S], vx[S], vy[S], vz[S], yb[S];
@@ -165,9 +169,8 @@ __global__ __launch_bounds__(64) void sdf_bwd_kernel(BwdArgs a) {
 #pragma unroll
       for (int s = 0; s < S; ++s) acc[j][s] = accd[j][s] = 0.f;
     const int K = layer_k(l);
-SURF_TRAIN_UNROLL_PRAGMA
-    for (int k = 0; k < K; ++k) {
-      const float w0 = wt[k * NH + lane], w1 = wt[k * NH + 64 + lane];
+    surf_train::stream_rows<NH>(wt, K, wbuf, [&](int k, const float* __restrict__ wr) {
+      const float w0 = wr[lane], w1 = wr[64 + lane];
       const f32x4 xv4 = *reinterpret_cast<const f32x4*>(&xin_t[k * XS]), xd4 = *reinterpret_cast<const f32x4*>(&xin_t[k * XS + S]);
 #pragma unroll
       for (int s = 0; s < S; ++s) {
@@ -177,7 +180,7 @@ SURF_TRAIN_UNROLL_PRAGMA
         accd[0][s] = fmaf(w0, xd, accd[0][s]);
         accd[1][s] = fmaf(w1, xd, accd[1][s]);
       }
-    }
+    });
     __syncthreads();
     const int N = layer_n(l);
     const float post = l == 2 ? inv_sqrt2 : 1.0f;
@@ -244,10 +247,9 @@ SURF_TRAIN_UNROLL_PRAGMA
         for (int s = 0; s < S; ++s) g[j][s] = gd[j][s] = 0.f;
       const int N = layer_n(l);
       const bool third = lane < KP - 128;
-SURF_TRAIN_UNROLL_PRAGMA
-      for (int nrn = 0; nrn < N; ++nrn) {
-        const float w0 = w[nrn * KP + lane], w1 = w[nrn * KP + 64 + lane];
-        const float w2 = third ? w[nrn * KP + 128 + lane] : 0.f;
+      surf_train::stream_rows<KP>(w, N, wbuf, [&](int nrn, const float* __restrict__ wr) {
+        const float w0 = wr[lane], w1 = wr[64 + lane];
+        const float w2 = third ? wr[128 + lane] : 0.f;
         const f32x4 dv4 = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS]), dd4 = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS + S]);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -259,7 +261,7 @@ SURF_TRAIN_UNROLL_PRAGMA
           gd[1][s] = fmaf(w1, dd, gd[1][s]);
           gd[2][s] = fmaf(w2, dd, gd[2][s]);
         }
-      }
+      });
       __syncthreads();
     }
 #pragma unroll
@@ -334,8 +336,8 @@ extern "C" int surf_sdf_backward(const float* pts, const float* ybar, const floa
     a.dvols[s] = (s < n_vol && h_dvols) ? h_dvols[s] : nullptr;
     if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
   }
-  const int64_t blocks = (n + S - 1) / S;
+  const int64_t blocks = (n + S * surf_train::NW - 1) / (S * surf_train::NW);
   if (blocks > 0x7fffffff) return SURF_E_LIMIT;
-  hipLaunchKernelGGL(sdf_bwd_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(sdf_bwd_kernel, dim3((unsigned)blocks), dim3(surf_train::NT), 0, (hipStream_t)stream, a);
   return surf_check_launch();
 }

@@ -12,12 +12,13 @@
 // where J_e' is the second derivative of the positional encoding (diagonal) and J_phi' the mixed second derivatives of
 // the trilinear gathers summed over the other two axes (a trilinear cell has no pure second derivative).
 //
-// One wavefront per SMOOTH_S points, plain fp32 FMAs (this term multiplies sigmoid'' = 100 s(1-s) layer after layer, so
+// One wavefront per SMOOTH_S points (round 6: SURF_TRAIN_WAVES wavefronts per workgroup sharing the weight stream through LDS,
+// sdf_train_common.h), plain fp32 FMAs (this term multiplies sigmoid'' = 100 s(1-s) layer after layer, so
 // it is kept in full fp32 rather than on the split 16-bit pipes).  Forward: a lane owns output neurons {lane, lane+64}
 // and walks the input index k; the weights come from the transposed copy (coalesced), the inputs from LDS (broadcast).
 // Reverse: a lane owns input indices {lane, lane+64, lane+128} and walks the neurons.  HBM traffic is the 1 MB weight
 // image per wavefront out of L2; 2 x 2 x 99 k MACs per point.
-#include "common.h"
+#include "sdf_train_common.h"
 
 // weight rows in flight per step of the k / neuron loops (the loops wait for one L2 round trip per unrolled group)
 #ifndef SURF_TRAIN_UNROLL
@@ -77,14 +78,19 @@ __device__ __forceinline__ Act softplus100(float t) {
   return a;
 }
 
-__global__ __launch_bounds__(64) void sdf_smooth_kernel(SmoothArgs a) {
+__global__ __launch_bounds__(surf_train::NT) void sdf_smooth_kernel(SmoothArgs a) {
   // layer input and its derivative along u / adjoint of the pre-activations and its derivative.  Round 5: [k][value | derivative]
   // [sample] rows (8 values + 4 of padding): two 16-byte LDS reads per weight pair instead of eight 4-byte ones (sdf_smooth_bwd.hip)
-  __shared__ __attribute__((aligned(16))) float xin_t[KP * XS];
-  __shared__ __attribute__((aligned(16))) float dl_t[NH * XS];
-  __shared__ float ge_v[S][32], ge_d[S][32];     // skip-layer share of G_e
-  const int lane = threadIdx.x;
-  const int64_t base = (int64_t)blockIdx.x * S;
+  __shared__ __attribute__((aligned(16))) float xin_all[surf_train::NW][KP * XS];
+  __shared__ __attribute__((aligned(16))) float dl_all[surf_train::NW][NH * XS];
+  __shared__ float ge_v_all[surf_train::NW][S][32], ge_d_all[surf_train::NW][S][32];     // skip-layer share of G_e
+  __shared__ __attribute__((aligned(16))) float wbuf[surf_train::WBUF_FLOATS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* const xin_t = xin_all[wave];
+  float* const dl_t = dl_all[wave];
+  float (*const ge_v)[32] = ge_v_all[wave];
+  float (*const ge_d)[32] = ge_d_all[wave];
+  const int64_t base = ((int64_t)blockIdx.x * surf_train::NW + wave) * S;
   const float inv_sqrt2 = 0.70710678118654752440f;
 
   // ---- inputs: lane c < 27 owns encoding channel c, lane f < 28 owns gathered feature f --------------------------------
@@ -171,9 +177,8 @@ __global__ __launch_bounds__(64) void sdf_smooth_kernel(SmoothArgs a) {
 #pragma unroll
       for (int s = 0; s < S; ++s) acc[j][s] = accd[j][s] = 0.f;
     const int K = layer_k(l);
-SURF_TRAIN_UNROLL_PRAGMA
-    for (int k = 0; k < K; ++k) {
-      const float w0 = wt[k * NH + lane], w1 = wt[k * NH + 64 + lane];
+    surf_train::stream_rows<NH>(wt, K, wbuf, [&](int k, const float* __restrict__ wr) {
+      const float w0 = wr[lane], w1 = wr[64 + lane];
       const f32x4 xv4 = *reinterpret_cast<const f32x4*>(&xin_t[k * XS]), xd4 = *reinterpret_cast<const f32x4*>(&xin_t[k * XS + S]);
 #pragma unroll
       for (int s = 0; s < S; ++s) {
@@ -183,7 +188,7 @@ SURF_TRAIN_UNROLL_PRAGMA
         accd[0][s] = fmaf(w0, xd, accd[0][s]);
         accd[1][s] = fmaf(w1, xd, accd[1][s]);
       }
-    }
+    });
     __syncthreads();                                  // every lane has read in_* before the outputs overwrite it
     const int N = layer_n(l);
     const float post = l == 2 ? inv_sqrt2 : 1.0f;     // lin3's input is cat([h2, e]) / sqrt(2)
@@ -242,10 +247,9 @@ SURF_TRAIN_UNROLL_PRAGMA
         for (int s = 0; s < S; ++s) g[j][s] = gd[j][s] = 0.f;
       const int N = layer_n(l);
       const bool third = lane < KP - 128;
-SURF_TRAIN_UNROLL_PRAGMA
-      for (int nrn = 0; nrn < N; ++nrn) {
-        const float w0 = w[nrn * KP + lane], w1 = w[nrn * KP + 64 + lane];
-        const float w2 = third ? w[nrn * KP + 128 + lane] : 0.f;
+      surf_train::stream_rows<KP>(w, N, wbuf, [&](int nrn, const float* __restrict__ wr) {
+        const float w0 = wr[lane], w1 = wr[64 + lane];
+        const float w2 = third ? wr[128 + lane] : 0.f;
         const f32x4 dv4 = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS]), dd4 = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS + S]);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -257,7 +261,7 @@ SURF_TRAIN_UNROLL_PRAGMA
           gd[1][s] = fmaf(w1, dd, gd[1][s]);
           gd[2][s] = fmaf(w2, dd, gd[2][s]);
         }
-      }
+      });
       __syncthreads();                                // dl_* fully consumed
     }
     if (l == 0) {                                     // lin0 takes the encoding alone: k = lane < 27
@@ -364,8 +368,8 @@ extern "C" int surf_sdf_smooth(const float* pts, const int32_t* idx, int64_t n, 
     a.dims[s] = s < n_vol ? h_dims[s] : 0;
     if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
   }
-  const int64_t blocks = (n + S - 1) / S;
+  const int64_t blocks = (n + S * surf_train::NW - 1) / (S * surf_train::NW);
   if (blocks > 0x7fffffff) return SURF_E_LIMIT;
-  hipLaunchKernelGGL(sdf_smooth_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(sdf_smooth_kernel, dim3((unsigned)blocks), dim3(surf_train::NT), 0, (hipStream_t)stream, a);
   return surf_check_launch();
 }

@@ -362,7 +362,10 @@ extern "C" int surf_spconv_wgrad(const float* x, int cin, const int32_t* in_tabl
   if (cin == CI && cout == CO) {                                                                                 \
     if constexpr (CI + CO <= 48) {                                                                               \
       if (thin) {                                                                                                \
-        hipLaunchKernelGGL((spconv_wgrad_thin_kernel<CI, CO>), dim3(grid), dim3(256), 0, (hipStream_t)stream, a); \
+        /* one workgroup per ThinCfg<CI, CO>::TS-site tile up to 1,024 (the kernel strides over the rest) */      \
+        const int64_t ttiles = (n_out + ThinCfg<CI, CO>::TS - 1) / ThinCfg<CI, CO>::TS;                           \
+        hipLaunchKernelGGL((spconv_wgrad_thin_kernel<CI, CO>), dim3((unsigned)(ttiles < 1024 ? ttiles : 1024)), dim3(256), 0, \
+                           (hipStream_t)stream, a);                                                              \
         return surf_check_launch();                                                                              \
       }                                                                                                          \
     }                                                                                                            \

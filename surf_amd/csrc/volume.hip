@@ -1093,6 +1093,14 @@ extern "C" int64_t surf_costvol_backward_workspace_floats(int64_t n, int nv, int
   return (int64_t)CV_REPLICAS * 64 + n * nv * 9 + 3 * nb + 8;
 }
 
+extern "C" int64_t surf_costvol_backward_workspace_floats_for(int64_t n, int nv, const int* h_hw) {
+  // the exact need of THIS pyramid: the direct scatter (irregular pyramid / Tanks&Temples shape, > 16,384 buckets, SURF_CVB_DIRECT)
+  // only uses the agg_mlp replicas - no 9 floats per (view, voxel) pair (1.1 - 1.5 GB at the finest DTU stage)
+  if (!h_hw || n <= 0 || nv < 1) return 0;
+  if (!cv_binned_ok(n, nv, h_hw)) return (int64_t)CV_REPLICAS * 64;
+  return surf_costvol_backward_workspace_floats(n, nv, h_hw[6], h_hw[7]);
+}
+
 extern "C" int surf_costvol_backward(const int32_t* coords, const float* g, int64_t n, int D, const float* const* h_feats,
                                      float* const* h_gfeats, const int* h_hw, int stage, int nv, const float* h_intrs,
                                      const float* h_w2c, const float* h_agg, float* workspace, float* g_agg, void* stream) {

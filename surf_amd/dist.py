@@ -12,18 +12,97 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend="nccl", device=None):
-    """env:// rendezvous as launched by torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+# True once init_from_env(force=True) has brought up a group at world size 1: the helpers below then ISSUE their collectives
+# instead of short-circuiting, so that every RCCL call of an N-rank run (barrier, MAX all-reduce of a device tensor, the padded
+# device all_gather of gather_rows, the flat gradient bucket, the parameter broadcast, DDP's bucket hooks) executes on a
+# one-GPU box.  At world size 1 each of them is the identity on the data: results must be bit-equal to the no-group run
+# (tests/test_rccl_world1.py).
+FORCED = False
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """File descriptor 1 points at stderr inside the block (and C stdio is flushed on both edges).  librccl prints a version
+    banner ("RCCL version : ... / Librccl path : ...") with printf to STDOUT when it creates its first communicator: on a
+    stdout that carries a result line (bench.py prints exactly one JSON line) the banner must land on stderr instead."""
+    import ctypes
+    import sys
+    try:
+        libc = ctypes.CDLL(None)
+    except OSError:
+        libc = None
+    sys.stdout.flush()
+    if libc is not None:
+        libc.fflush(None)
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        if libc is not None:
+            libc.fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
+def init_from_env(backend="nccl", device=None, force=False, timeout_s=None):
+    """env:// rendezvous as launched by torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
+    A group is created when WORLD_SIZE > 1 (utils/distribute.py:66-88 of the reference) or, with `force`, at world size 1 too:
+    one rank that is its own peer, rendezvous on a free 127.0.0.1 port.  For "nccl" (= RCCL) the caller must have called
+    torch.cuda.set_device(device) before; the group is bound to it (device_id) so that the communicator is created eagerly."""
+    global FORCED
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         kw = {}
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
-        dist.init_process_group(backend, **kw)
+        if timeout_s is not None:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=timeout_s)
+        with stdout_to_stderr():                        # RCCL's banner (communicator creation) -> stderr
+            dist.init_process_group(backend, **kw)
+            if backend == "nccl" and device is not None:
+                dist.barrier(device_ids=[device.index if device.index is not None else torch.cuda.current_device()])
+                torch.cuda.synchronize(device)
+        FORCED = bool(force) and world == 1
     return rank, local_rank, world
+
+
+def _active():
+    """Collectives are issued when a group is up and it has peers - or when it was forced at world size 1."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCED)
+
+
+def backend_note(one_gpu=False):
+    """What bench.py prints as `collective_backend`."""
+    if not dist.is_initialized():
+        return None
+    w = dist.get_world_size()
+    lib = ""
+    if dist.get_backend() == "nccl":
+        try:
+            lib = " = RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:       # noqa: BLE001 - version query only
+            lib = " = RCCL"
+    return f"{dist.get_backend()}{lib} (world {w}" + (", all ranks on cuda:0" if one_gpu else "") + ")"
 
 
 def shard_scenes(n_scenes, rank, world):
@@ -60,13 +139,15 @@ def gather_rows(t, dst=0):
     The data-path collective of the single-scene split (bench.py --split rays: rank r renders rays [r R / N, (r + 1) R / N) of ONE
     image, the image is stitched on rank 0).  RCCL: one padded all_gather of device tensors over xGMI; gloo (tests): through
     host copies (gloo has no device all_gather)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return t
     world, rank = dist.get_world_size(), dist.get_rank()
     backend = dist.get_backend()
     counts = [None] * world
     dist.all_gather_object(counts, int(t.shape[0]))
     m = max(counts)
+    if m == 0:                                 # nothing anywhere: no tensor collective (RCCL rejects empty buffers)
+        return t if rank == dst else None
     src = t if backend == "nccl" else t.cpu()
     if src.shape[0] < m:
         pad = torch.zeros((m - src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
@@ -83,7 +164,7 @@ def all_reduce_gradients(params, bucket_bytes=25 << 20):
     gradients are flattened into buckets of at most `bucket_bytes` (DDP's default 25 MB: the ~1.4 M parameters of SuRF, 5.6 MB,
     make ONE bucket - a single ring all-reduce over xGMI, latency-bound), summed with all_reduce and divided by the world
     size.  Parameters without a gradient contribute zeros so that every rank issues the same collectives."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return 0
     params = [p for p in params if p.requires_grad]
     world = dist.get_world_size()
@@ -116,7 +197,7 @@ def broadcast_module_state(module, src=0, buffers_only=False):
     `broadcast_buffers=True`, runner.py:102).  Without it replicas started from different seeds, or a checkpoint loaded on
     rank 0 only, stay different forever under a gradient-only all-reduce.  Call once before the first step and with
     `buffers_only=True` before evaluation / checkpointing (or every step, like DDP).  Returns the number of tensors sent."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return 0
     tensors = list(module.buffers()) if buffers_only else list(module.parameters()) + list(module.buffers())
     n = 0
@@ -139,8 +220,10 @@ def shutdown():
     """Leave the process group in step: barrier, then destroy_process_group().  A rank that simply exits while another is
     still inside its last collective makes gloo's (and RCCL's) background thread abort the slower one
     ("terminate called without an active exception").  Every spawned worker and bench.py end with this."""
+    global FORCED
     if dist.is_initialized():
         try:
             dist.barrier()
         finally:
             dist.destroy_process_group()
+            FORCED = False

@@ -198,8 +198,11 @@ class ImplicitSurface(nn.Module):
     def invalidate_packed(self):
         """Drop the cached MFMA weight re-layouts.  The cache key is (Parameter._version, data_ptr) of every parameter,
         which optimiser steps, `copy_` on the parameter and `load_state_dict` all change; an in-place write through
-        `param.data` (e.g. `p.data.mul_(2)`) changes neither, so call this after such an edit."""
+        `param.data` (e.g. `p.data.mul_(2)`) changes neither, so call this after such an edit.  Also drops the flat
+        effective-weight vector both SDF images are cut from (packing._sdf_flat, cached on the SDF network under the same key)."""
         self._packed = None
+        if getattr(self.sdf_network, "_surf_flat", None) is not None:
+            object.__setattr__(self.sdf_network, "_surf_flat", None)
 
     def train(self, mode=True):
         self.invalidate_packed()

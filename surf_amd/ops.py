@@ -1118,7 +1118,8 @@ def costvol_backward(feats_t4_c2f, gfeats_t4_c2f, stage, D, cams, agg, coords, g
     assert g.shape[1] == 8 and g_agg.numel() == 49
     hw = (ctypes.c_int * 8)(*[int(v) for f in feats_t4_c2f for v in f.shape[1:3]])
     agg = np.ascontiguousarray(agg, dtype=np.float32)
-    ws = torch.empty(_lib.lib().surf_costvol_backward_workspace_floats(coords.shape[0], cams.nv, int(hw[6]), int(hw[7])),
+    # 9 floats per (view, voxel) pair when the tile-sorted form runs (1.1 - 1.5 GB at the finest DTU stage), 4,096 floats otherwise
+    ws = torch.empty(_lib.lib().surf_costvol_backward_workspace_floats_for(coords.shape[0], cams.nv, hw),
                      dtype=torch.float32, device=g.device)
     with _timed("costvol_bwd", int(coords.shape[0]) * cams.nv * (4 - int(stage))):
         rc = _lib.lib().surf_costvol_backward(_p(coords), _p(g), coords.shape[0], int(D), _ptr_array(feats_t4_c2f),
@@ -1460,6 +1461,8 @@ def inorm_relu_backward(raw, dy, stats):
     _chk(stats, torch.float32, "stats")
     N, H, W, C = raw.shape
     assert tuple(dy.shape) == tuple(raw.shape) and tuple(stats.shape) == (N, C, 2)
+    if C not in (8, 16, 32, 64):
+        raise ValueError(f"inorm_relu_backward: C = {C} channels; instantiated for C in (8, 16, 32, 64)")
     dx = torch.empty_like(raw)
     ws = torch.empty(_lib.lib().surf_inorm_backward_workspace_bytes(N, C), dtype=torch.uint8, device=raw.device)
     rc = _lib.lib().surf_inorm_relu_backward(_p(raw), _p(dy), N, H * W, C, _p(stats), _p(ws), _p(dx), _stream())
@@ -1472,6 +1475,9 @@ def inorm_relu_(x, skip=None, want_stats=False, in_place=True):
     left as it is (a recording forward keeps it as the raw convolution output) and a new tensor is returned."""
     _chk(x, torch.float32, "x")
     N, H, W, C = x.shape
+    if C not in (4, 8, 16, 32, 64):
+        raise ValueError(f"inorm_relu_: C = {C} channels; the FPN kernels are instantiated for C in (4, 8, 16, 32, 64) "
+                         "(feature_network d_base = 8; include/surf_hip.h: surf_inorm_relu)")
     ws = torch.empty(_lib.lib().surf_inorm_workspace_doubles(N, H, W, C), dtype=torch.float64, device=x.device)
     stats = torch.empty(N, C, 2, dtype=torch.float32, device=x.device)
     out = x if in_place else torch.empty_like(x)

@@ -18,6 +18,29 @@ from . import ops
 from .grads import accumulate
 
 
+KERNEL_ORDERS = ("xfast", "zfast")
+TRANSPOSED_PAIRINGS = ("same", "mirrored")
+
+
+def slice_permutation(kernel_order="xfast", mirrored=False):
+    """perm (27,) with  kernel_as_the_HIP_kernels_walk_it[k] = checkpoint_kernel[perm[k]].  The kernels enumerate the 27 offsets
+    with x fastest and z slowest (csrc/spconv.hip) and a transposed layer's slice k serves offset k; which enumeration torchsparse
+    2.1.0 stores, and which slice its transposed layers pair with which offset, cannot be established here (third party, absent:
+    PARITY UNPINNED), so both are conf keys like `down_rule` - a host-side permutation of the slices, no kernel change:
+    reg_network.kernel_order        xfast (default) | zfast (checkpoint slice (x+1) 9 + (y+1) 3 + (z+1))
+    reg_network.transposed_pairing  same (default)  | mirrored (an up layer's slice k serves offset -k, i.e. slice 26 - k)
+    Both permutations are involutions and commute, so the composed one is its own inverse (used for the weight gradient)."""
+    if kernel_order not in KERNEL_ORDERS:
+        raise ValueError(f"reg_network.kernel_order must be one of {KERNEL_ORDERS}, got {kernel_order!r}")
+    perm = []
+    for z in (-1, 0, 1):
+        for y in (-1, 0, 1):
+            for x in (-1, 0, 1):
+                a, b, c = (-x, -y, -z) if mirrored else (x, y, z)
+                perm.append((a + 1) * 9 + (b + 1) * 3 + (c + 1) if kernel_order == "zfast" else (c + 1) * 9 + (b + 1) * 3 + (a + 1))
+    return perm
+
+
 class _SpConv3d(nn.Module):
     def __init__(self, inc, outc, transposed=False):
         super().__init__()
@@ -34,6 +57,27 @@ class _Block(nn.Module):
         super().__init__()
         self.stride, self.transposed = stride, transposed
         self.net = nn.Sequential(_SpConv3d(inc, outc, transposed), nn.BatchNorm1d(outc), nn.ReLU(True))
+        self._perm = None           # slice_permutation of this block (None = identity), SparseCostRegNet.set_conventions
+        self._perm_dev = None
+
+    def set_slice_permutation(self, perm):
+        self._perm = None if perm is None or list(perm) == list(range(27)) else list(perm)
+        self._perm_dev = None
+        self._wprep = self._tprep = None
+
+    def slice_index(self, device):
+        """The permutation as a device index tensor (None = identity)."""
+        if self._perm is None:
+            return None
+        if self._perm_dev is None or self._perm_dev.device != device:
+            self._perm_dev = torch.tensor(self._perm, dtype=torch.long, device=device)
+        return self._perm_dev
+
+    def walk_kernel(self):
+        """The kernel in the order the HIP kernels walk it: checkpoint slices permuted by the torchsparse conventions in force."""
+        w = self.net[0].kernel.detach().float()
+        idx = self.slice_index(w.device)
+        return (w if idx is None else w.index_select(0, idx)).contiguous()
 
     def bn_affine(self):
         bn = self.net[1]
@@ -50,7 +94,7 @@ class _Block(nn.Module):
         conv, bn = self.net[0], self.net[1]
         wkey = (conv.kernel._version, conv.kernel.data_ptr(), bool(use_mfma))
         if getattr(self, "_wprep", None) is None or self._wprep[0] != wkey:
-            w = conv.kernel.detach().float().contiguous()
+            w = self.walk_kernel()
             self._wprep = (wkey, w, ops.spconv_pack_weights(w) if use_mfma else None)
         if not affine:
             return self._wprep[1], None, None, self._wprep[2]
@@ -67,12 +111,12 @@ class _Block(nn.Module):
         conv = self.net[0]
         key = (conv.kernel._version, conv.kernel.data_ptr(), int(mode), bool(use_mfma))
         if getattr(self, "_tprep", None) is None or self._tprep[0] != key:
-            self._tprep = (key, ops.dgrad_weights(conv.kernel.detach().float().contiguous(), mode, use_mfma))
+            self._tprep = (key, ops.dgrad_weights(self.walk_kernel(), mode, use_mfma))
         return self._tprep[1]
 
 
 class SparseCostRegNet(nn.Module):
-    def __init__(self, d_in, d_out=8, d_base=8, down_rule=ops.DEFAULT_DOWN_RULE):
+    def __init__(self, d_in, d_out=8, d_base=8, down_rule=ops.DEFAULT_DOWN_RULE, kernel_order="xfast", transposed_pairing="same"):
         super().__init__()
         if down_rule not in ops.DOWN_RULES:
             raise ValueError(f"reg_network.down_rule must be one of {sorted(ops.DOWN_RULES)}, got {down_rule!r}")
@@ -92,6 +136,19 @@ class SparseCostRegNet(nn.Module):
         self.conv9 = _Block(4 * b, 2 * b, stride=2, transposed=True)
         self.conv11 = _Block(2 * b, b, stride=2, transposed=True)
         self.out_lin = nn.Linear(b, d_out, bias=False)
+        self.set_conventions(kernel_order, transposed_pairing)
+
+    def blocks(self):
+        return [getattr(self, f"conv{i}") for i in (0, 1, 2, 3, 4, 5, 6, 7, 9, 11)]
+
+    def set_conventions(self, kernel_order="xfast", transposed_pairing="same"):
+        """Which slice enumeration / transposed pairing of torchsparse the stored kernels follow (slice_permutation): takes effect
+        at the next forward (the weight re-layout caches are dropped); the parameters themselves stay in checkpoint order."""
+        if transposed_pairing not in TRANSPOSED_PAIRINGS:
+            raise ValueError(f"reg_network.transposed_pairing must be one of {TRANSPOSED_PAIRINGS}, got {transposed_pairing!r}")
+        self.kernel_order, self.transposed_pairing = kernel_order, transposed_pairing
+        for blk in self.blocks():
+            blk.set_slice_permutation(slice_permutation(kernel_order, blk.transposed and transposed_pairing == "mirrored"))
 
     def _conv(self, blk, x, in_site, out_site, mode, skip=None, tape=None, counters=None):
         """One block on x (rows of `in_site` = (table, coords)) -> rows of `out_site`.  tape: a list that receives what
@@ -189,9 +246,17 @@ class SparseCostRegNet(nn.Module):
             dx, dW = ops.spconv_backward(e["x"], e["in_site"][0], e["in_site"][1], e["out_site"][0], e["out_site"][1], e["mode"],
                                          e["w"], draw, use_mfma=self.use_mfma,
                                          dgrad=e["blk"].prepared_dgrad(e["mode"], self.use_mfma))
-            acc(e["blk"].net[0].kernel, dW)
+            idx = e["blk"].slice_index(dW.device)          # back to checkpoint slice order (the permutation is an involution)
+            acc(e["blk"].net[0].kernel, dW if idx is None else dW.index_select(0, idx))
             add(e["x"], dx)
         return grads.pop(id(feats))
+
+
+def _has(confs, key):
+    try:
+        return key in confs
+    except TypeError:
+        return confs.get_string(key, None) is not None
 
 
 class SparseCostRegNetList(nn.Module):
@@ -201,7 +266,38 @@ class SparseCostRegNetList(nn.Module):
         self.num_stages = len(d_in)
         # optional key (ours): which stride-2 output-site rule of torchsparse the checkpoint was trained with
         rule = confs.get_string("down_rule", ops.DEFAULT_DOWN_RULE)
-        self.nets = nn.ModuleList([SparseCostRegNet(d_in[i], d_out[i], d_base[i], rule) for i in range(self.num_stages)])
+        # optional keys (ours): the two other torchsparse conventions a loaded checkpoint depends on (slice_permutation)
+        order = confs.get_string("kernel_order", "xfast")
+        pairing = confs.get_string("transposed_pairing", "same")
+        self.conventions_named = all(_has(confs, k) for k in ("down_rule", "kernel_order", "transposed_pairing"))
+        self.nets = nn.ModuleList([SparseCostRegNet(d_in[i], d_out[i], d_base[i], rule, order, pairing)
+                                   for i in range(self.num_stages)])
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._warn_unnamed_conventions())
+
+    def conventions(self):
+        """The torchsparse conventions in force, as the conf keys a checkpoint's conf should carry (they are NOT in the
+        state_dict: its keys are the reference's, so that checkpoints stay loadable on both sides)."""
+        n = self.nets[0]
+        return {"down_rule": n.down_rule, "kernel_order": n.kernel_order, "transposed_pairing": n.transposed_pairing}
+
+    def set_conventions(self, down_rule=None, kernel_order=None, transposed_pairing=None):
+        cur = self.conventions()
+        if down_rule is not None and down_rule not in ops.DOWN_RULES:
+            raise ValueError(f"reg_network.down_rule must be one of {sorted(ops.DOWN_RULES)}, got {down_rule!r}")
+        for n in self.nets:
+            n.down_rule = down_rule or cur["down_rule"]
+            n.set_conventions(kernel_order or cur["kernel_order"], transposed_pairing or cur["transposed_pairing"])
+        self.conventions_named = True
+
+    def _warn_unnamed_conventions(self):
+        if not self.conventions_named and not getattr(self, "_warned", False):
+            import warnings
+            self._warned = True
+            warnings.warn("SparseCostRegNetList: a checkpoint was loaded but the conf names none / not all of reg_network.down_rule, "
+                          f".kernel_order, .transposed_pairing; using {self.conventions()} (PARITY UNPINNED: torchsparse 2.1.0's "
+                          "conventions are recollections; checkpoints trained with surf_amd before round 5 used down_rule = dilate). "
+                          "Name the three keys in the conf that travels with the checkpoint; scripts/dtu_chamfer.py --sweep "
+                          "finds the combination that reproduces a reference Chamfer.", stacklevel=3)
 
     def forward(self, feats, coords, D, stage_idx, table=None, tape=None):
         return self.nets[stage_idx](feats, coords, D, table, tape)

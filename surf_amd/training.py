@@ -29,16 +29,17 @@ def _sync_gradients(model, optimizer):
     """Data-parallel step without DDP: average the gradients over the ranks (RCCL on GPUs, gloo in the CPU tests)."""
     if _is_ddp(model):
         return
-    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+    if dist._active():          # a group with peers, or one forced at world size 1 (dist.init_from_env(force=True))
         dist.all_reduce_gradients([p for g in optimizer.param_groups for p in g["params"]])
 
 
-def _step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio, step, mode):
+def _step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio, step, mode, sync=True):
     outputs = model("train", ipts, cos_anneal_ratio=cos_anneal_ratio, step=step)          # runner.py:155
     out = loss_fn(outputs, targets, step=step, mode=mode)                                  # runner.py:159
     optimizer.zero_grad(set_to_none=True)
     out["loss"].backward()                                                                 # runner.py:163
-    _sync_gradients(model, optimizer)
+    if sync:
+        _sync_gradients(model, optimizer)
     optimizer.step()
     return {k: (float(v.detach()) if torch.is_tensor(v) else float(v)) for k, v in out.items()}
 
@@ -55,13 +56,14 @@ def finetune_step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio=1.0
     return _step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio, step, "finetune")
 
 
-def train_step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio=1.0, step=0):
+def train_step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio=1.0, step=0, sync=True):
     """runner.py:152-165 for a volume-building model in train mode (model.train(): BatchNorm batch statistics, matching-field
     jitter).  targets: what losses/loss.py reads in mode "train" (color, imgs, intrs, c2ws, src_idx, mask_ref / mask_src,
-    pseudo_depth_ref / pseudo_depth_src, depth_ref / depth_src, ...)."""
+    pseudo_depth_ref / pseudo_depth_src, depth_ref / depth_src, ...).  sync=False: no gradient averaging even when a process
+    group is up (a deliberately local step: bench.py's single-GPU `training_step` beside the forced world-1 group)."""
     core = model.module if _is_ddp(model) else model
     if core.has_vol:
         raise ValueError("train_step drives a volume-building model; use finetune_step for has_vol models")
     if not core.training:
         raise RuntimeError("train_step: call model.train() first (the sparse U-Net's backward is that of batch-statistics BatchNorm)")
-    return _step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio, step, "train")
+    return _step(model, ipts, targets, loss_fn, optimizer, cos_anneal_ratio, step, "train", sync)

@@ -141,3 +141,32 @@ def test_dtu_files_to_chamfer(tmp_path):
         "--conf", str(conf_path), "--eval_dir", str(ev), "--scan", "24", "--ref_view", "1", "--out_dir", str(tmp_path / "exp3"),
         "--mesh_resolution", "64", "--downsample_density", str(density), "--logit_override", "sphere", "--down_rule", "dilate"]))
     assert rec0["down_rule"] == "dilate" and np.isfinite(rec0["chamfer"])
+    # ---- --sweep: the 3 x 2 x 2 grid of torchsparse conventions on ONE loaded model, the discriminator of VERDICT r5 item 3 ----
+    # A fresh SDF network ignores its feature columns (geometric initialisation zeroes them: every candidate would give the same
+    # mesh), so the sweep runs on a CHECKPOINT whose lin1..lin5 read the sparse features.  The "reference" number is the
+    # pad0 / zfast / mirrored network's own Chamfer: the sweep must single that combination out of the twelve.
+    torch.manual_seed(0)
+    ck_model = SuRF(conf.from_dict(mcfg))
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for l in range(1, 6):
+            wv = getattr(ck_model.implicit_surface.sdf_network, f"lin{l}").weight_v
+            wv[:, -28:] += 0.05 * torch.randn(wv.shape[0], 28, generator=g)
+    ckpt_path = tmp_path / "ckpt_features.pth"
+    torch.save({"model": ck_model.state_dict()}, ckpt_path)
+    base = ["--conf", str(conf_path), "--ckpt", str(ckpt_path), "--eval_dir", str(ev), "--scan", "24", "--ref_view", "1",
+            "--mesh_resolution", "64", "--downsample_density", str(density), "--logit_override", "sphere"]
+    target = dtu_chamfer.run(dtu_chamfer.parse_args(base + ["--out_dir", str(tmp_path / "exp4"), "--kernel_order", "zfast",
+                                                            "--transposed_pairing", "mirrored"]))
+    assert (target["down_rule"], target["kernel_order"], target["transposed_pairing"]) == ("pad0", "zfast", "mirrored")
+    assert target["missing_keys"] == [] and target["unexpected_keys"] == []
+    sw = dtu_chamfer.run(dtu_chamfer.parse_args(base + ["--out_dir", str(tmp_path / "exp5"), "--sweep",
+                                                        "--reference_chamfer", repr(target["chamfer"])]))
+    assert len(sw["sweep"]) == 12 and len({(r["down_rule"], r["kernel_order"], r["transposed_pairing"]) for r in sw["sweep"]}) == 12
+    chamfers = [r["chamfer"] for r in sw["sweep"] if r["chamfer"] is not None]
+    assert len({round(c, 7) for c in chamfers}) >= 8, chamfers                       # the candidates are different networks
+    best = sw["best"]
+    assert (best["down_rule"], best["kernel_order"], best["transposed_pairing"]) == ("pad0", "zfast", "mirrored"), sw["sweep"]
+    assert abs(best["chamfer"] - target["chamfer"]) < 1e-9
+    assert [(r["down_rule"], r["kernel_order"], r["transposed_pairing"]) for r in sw["within_0.01_of_reference"]][:1] != []
+    assert os.path.exists(tmp_path / "exp5" / "chamfer_sweep_scan24.json")

@@ -85,7 +85,8 @@ def test_bench_train_workload_line_on_one_gpu():
     assert len(lines) == 1, res.stdout[-2000:]
     r = json.loads(lines[0])
     assert r["n_gpus"] == 1 and r["steps"] == 2 and r["scaling"] == "weak" and r["data"] == "synthetic" and r["unit"] == "rays/s"
-    assert r["config"]["rays_per_rank_step"] == 128 and r["config"]["parallelism"] == "single" and r["config"]["train_precision"] == "fp32"
+    assert r["config"]["rays_per_rank_step"] == 128 and r["config"]["parallelism"] == "ddp1" and r["config"]["train_precision"] == "fp32"      # the forced world-1 RCCL group
+    assert r["collective_backend"].startswith("nccl") and r["gradient_allreduce_ms"] > 0
     assert abs(r["value"] - 128 * r["steps_per_s"]) < 1e-6 * r["value"] and r["loss"] == r["loss"]
     names = {e["kernel"] for e in r["roofline_kernels"]}
     assert {"costvol_bwd", "matching_depth_bwd", "sdf_bwd", "blend_bwd", "colgram"} <= names

@@ -385,6 +385,53 @@ def test_sparse_unet_matches_oracle(golden_pipe, rule):
         rel_close(out, out_v, 1e-5, 2e-6)
 
 
+@pytest.mark.parametrize("order,pairing", [("zfast", "same"), ("xfast", "mirrored"), ("zfast", "mirrored")])
+def test_sparse_unet_conventions_match_oracle(golden_pipe, order, pairing):
+    """Row a5, the two other torchsparse recollections (reg_network.kernel_order / .transposed_pairing: a host-side permutation
+    of the 27 kernel slices, no kernel change): forward in eval mode against the oracle under the same conventions, then the
+    train-mode backward against torch autograd through the oracle - the kernel gradients arrive in CHECKPOINT slice order."""
+    from surf_amd import conf
+    from surf_amd.reg_network import SparseCostRegNetList
+    d = dev()
+    torch.manual_seed(13)
+    net = SparseCostRegNetList(conf.from_dict({"d_in": [8, 16, 16, 16], "d_out": [8] * 4, "d_base": [8] * 4, "down_rule": "pad0",
+                                               "kernel_order": order, "transposed_pairing": pairing}))
+    s, D = 1, 16
+    coords = golden_pipe[f"s{s}_coords"].to(torch.int32)
+    feats = golden_pipe[f"s{s}_reg_in"].contiguous()
+    sd = {"reg_network." + k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        ev_ref, _ = O.sparse_unet(sd, feats, coords.long(), D, s, kernel_order=order, transposed_pairing=pairing)
+        plain, _ = O.sparse_unet(sd, feats, coords.long(), D, s)
+    assert float((ev_ref - plain).abs().max()) > 1e-3                       # the conventions matter
+    net = net.to(d).eval()
+    ev, _ = net(feats.to(d), coords.to(d).contiguous(), D, s)
+    rel_close(ev, ev_ref, 1e-3, 1e-4)
+    g = torch.Generator().manual_seed(4)
+    d_out = torch.randn(feats.shape[0], 8, generator=g)
+    d_mid = torch.randn(feats.shape[0], 8, generator=g)
+    f_ref = feats.clone().requires_grad_(True)
+    out_ref, mid_ref = O.sparse_unet(sd, f_ref, coords.long(), D, s, training=True, kernel_order=order, transposed_pairing=pairing)
+    ((out_ref * d_out).sum() + (mid_ref * d_mid).sum()).backward()
+    net.train()
+    tape = []
+    out, mid = net(feats.to(d), coords.to(d).contiguous(), D, s, tape=tape)
+    rel_close(out, out_ref.detach(), 1e-3, 1e-4)
+    d_feats = net.nets[s].backward(tape, d_out.to(d), d_mid.to(d))
+    rel_close(d_feats, f_ref.grad, 2e-3, 2e-4 * float(f_ref.grad.abs().max()))
+    for name, p_ in net.nets[s].named_parameters():
+        ref = sd[f"reg_network.nets.{s}.{name}"].grad
+        assert ref is not None and p_.grad is not None, name
+        rel_close(p_.grad, ref, 2e-3, 2e-4 * max(float(ref.abs().max()), 1e-3))
+    # switching conventions on a live module drops the cached re-layouts
+    net.eval()
+    net.set_conventions(kernel_order="xfast", transposed_pairing="same")
+    back, _ = net(feats.to(d), coords.to(d).contiguous(), D, s)
+    with torch.no_grad():
+        sd_now = {"reg_network." + k: v.detach().cpu() for k, v in net.state_dict().items()}
+        rel_close(back, O.sparse_unet(sd_now, feats, coords.long(), D, s)[0], 1e-3, 1e-4)
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 32), (32, 16)])
 def test_spconv_mfma_matches_per_voxel_kernel(cin, cout):
     """surf_spconv_mfma (bf16x3 split on the matrix cores) against surf_spconv (fp32 FMAs) on a random sparse lattice:
@@ -1821,3 +1868,39 @@ def test_spconv_wgrad_of_a_transposed_layer_from_the_coarse_side(cin, cout):
     scale = float(dW_f.abs().max())
     assert scale > 0.1
     rel_close(dW_c, dW_f, 1e-5, 2e-6 * scale)
+
+
+def test_invalidate_packed_after_a_param_data_edit_changes_the_render():
+    """an in-place write through `param.data` changes neither `_version` nor `data_ptr`, so the caches keep serving the
+    old weights until `invalidate_packed()` - which must drop the flat effective-weight vector (packing._sdf_flat) too, or both SDF
+    images are rebuilt from stale values."""
+    from bench import model_conf
+    from surf_amd import synthetic
+    from surf_amd.implicit_surface import ImplicitSurface
+    d = dev()
+    n_samples = [16, 8, 8, 8]
+    H, W, nv = 32, 48, 3
+    torch.manual_seed(0)
+    model = ImplicitSurface(model_conf(n_samples)).to(d)
+    intrs, c2ws, near_fars = synthetic.ring_cameras(nv, H, W)
+    imgs = synthetic.procedural_images(nv, H, W, 0, d)
+    feats = synthetic.feature_pyramid(nv, H, W, 0, d)
+    vols, tabs, mvol = synthetic.sphere_pyramid(8, d, bands=(float("inf"), 0.92, 0.3, 0.1))
+    sc = model.scene(mvol, vols[::-1], tabs[::-1], None, feats, imgs, intrs.to(d), c2ws.to(d))
+    rays_o, rays_d = synthetic.pixel_rays(intrs[0], c2ws[0], H, W, 4, d)
+    R = rays_o.shape[0]
+    near = near_fars[0, 0].reshape(1, 1).repeat(R, 1).to(d)
+    far = near_fars[0, 1].reshape(1, 1).repeat(R, 1).to(d)
+    sdf0 = model.render_scene(rays_o, rays_d, near, far, sc, 1.0)["sdf"].clone()
+    lin = model.sdf_network.lin6
+    lin.bias.data.add_(0.25)                                  # sdf = lin6(...)[0] + ...: the edit shifts every SDF value
+    stale = model.render_scene(rays_o, rays_d, near, far, sc, 1.0)["sdf"]
+    assert torch.equal(stale, sdf0)                           # documented: the caches cannot see a .data edit
+    model.invalidate_packed()
+    sdf1 = model.render_scene(rays_o, rays_d, near, far, sc, 1.0)["sdf"]
+    m = sdf0 != 0
+    assert float((sdf1 - sdf0)[m].abs().min()) > 0.2, "invalidate_packed() left a stale weight image in place"
+    sm = model.smooth_weights(d)                              # the fp32 image of the training kernels is cut from the same vector
+    lin.bias.data.add_(0.25)
+    model.invalidate_packed()
+    assert not torch.equal(model.smooth_weights(d), sm)

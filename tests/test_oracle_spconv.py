@@ -113,3 +113,60 @@ def test_unet_runs_with_every_down_rule():
     outs = {rule: O.sparse_unet(sd, x, coords, D, 1, rule=rule)[0] for rule in ("dilate", "floor", "pad0")}
     assert all(o.shape == (coords.shape[0], 8) and torch.isfinite(o).all() for o in outs.values())
     assert float((outs["pad0"] - outs["dilate"]).abs().max()) > 1e-3        # the rules are different networks
+
+
+def test_kernel_order_and_transposed_pairing_hedges():
+    """the two other torchsparse recollections a loaded checkpoint depends on, hedged like `rule`.
+    zfast == the xfast network on coordinates with x and z exchanged (a slice enumeration IS an axis naming); mirrored == the up
+    layers' kernels flipped (slice 26 - k); the host module's permutation is the oracle's; all four combinations are different
+    networks; both permutations are involutions (the weight gradient is mapped back with the same index)."""
+    from surf_amd import conf
+    from surf_amd.reg_network import SparseCostRegNetList, slice_permutation
+    g = torch.Generator().manual_seed(7)
+    D = 20
+    coords = O.init_coords(D).long()
+    coords = coords[torch.rand(coords.shape[0], generator=g) < 0.3]
+    torch.manual_seed(1)
+    net = SparseCostRegNetList(conf.from_dict({"d_in": [8, 16], "d_out": [8, 8], "d_base": [8, 8]})).eval()
+    sd = {"reg_network." + k: v.detach() for k, v in net.state_dict().items()}
+    x = torch.randn(coords.shape[0], 16, generator=g)
+    outs = {}
+    for order in ("xfast", "zfast"):
+        for pairing in ("same", "mirrored"):
+            outs[order, pairing] = O.sparse_unet(sd, x, coords, D, 1, kernel_order=order, transposed_pairing=pairing)[0]
+            for mirrored in (False, True):
+                perm = O.slice_permutation(order, mirrored)
+                assert perm.tolist() == slice_permutation(order, mirrored)
+                assert torch.equal(perm[perm], torch.arange(27))
+    keys = list(outs)
+    for i in range(4):
+        for j in range(i + 1, 4):
+            assert float((outs[keys[i]] - outs[keys[j]]).abs().max()) > 1e-3, (keys[i], keys[j])
+    # zfast on (x, y, z) == xfast on (z, y, x): level-0 rows keep their order, so the outputs compare row by row
+    swapped = O.sparse_unet(sd, x, coords.flip(1), D, 1, kernel_order="xfast")[0]
+    assert torch.allclose(outs["zfast", "same"], swapped, atol=1e-5)
+    # mirrored == flipped kernels in the three transposed layers
+    sd_f = dict(sd)
+    for i in (7, 9, 11):
+        k = f"reg_network.nets.1.conv{i}.net.0.kernel"
+        sd_f[k] = sd[k].flip(0)
+    assert torch.allclose(outs["xfast", "mirrored"], O.sparse_unet(sd_f, x, coords, D, 1)[0], atol=1e-6)
+    # the host module: conf keys, set_conventions, validation, the warning when a checkpoint arrives with unnamed conventions
+    import warnings
+    import pytest
+    named = SparseCostRegNetList(conf.from_dict({"d_in": [8], "d_out": [8], "d_base": [8], "down_rule": "floor",
+                                                 "kernel_order": "zfast", "transposed_pairing": "mirrored"}))
+    assert named.conventions() == {"down_rule": "floor", "kernel_order": "zfast", "transposed_pairing": "mirrored"}
+    assert named.nets[0].conv7._perm == slice_permutation("zfast", True) and named.nets[0].conv0._perm == slice_permutation("zfast")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        named.load_state_dict(named.state_dict())
+    with pytest.warns(UserWarning, match="transposed_pairing"):
+        net.load_state_dict(net.state_dict())
+    net.set_conventions(kernel_order="zfast")
+    assert net.conventions() == {"down_rule": "pad0", "kernel_order": "zfast", "transposed_pairing": "same"}
+    assert net.nets[1].conv0._perm is not None and net.nets[1].conv0._wprep is None
+    with pytest.raises(ValueError):
+        SparseCostRegNetList(conf.from_dict({"d_in": [8], "d_out": [8], "d_base": [8], "kernel_order": "yfast"}))
+    with pytest.raises(ValueError):
+        SparseCostRegNetList(conf.from_dict({"d_in": [8], "d_out": [8], "d_base": [8], "transposed_pairing": "flipped"}))

@@ -1,0 +1,237 @@
+"""GPU: every RCCL code path that ONE GPU can execute (utils/distribute.py:66-88, runner.py:101-103 of the
+reference).  `dist.init_from_env("nccl", device, force=True)` brings up a world-size-1 RCCL group in a FRESH process (the group
+is bound to cuda:0 before any collective); the helpers of surf_amd.dist then issue their collectives instead of
+short-circuiting.  With one peer each collective is the identity on its data, so every result must equal the no-group run
+BIT FOR BIT - for the training step: whenever two no-group runs are themselves bit-equal (the step has float atomics in
+`matching_depth_bwd`; when they differ run to run the comparison falls back to the spread of the two no-group runs).
+
+The `device_count() >= 2` tests at the bottom run bench.py's N = 2 jobs over RCCL with one device per rank; they are skipped on
+the one-GPU boxes and go live on a multi-GPU node."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PRELUDE = textwrap.dedent("""
+    import hashlib, json, os, sys
+    sys.path.insert(0, %r)
+    import torch
+    import torch.distributed as td
+    from surf_amd import dist as D
+    mode = sys.argv[1]
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    if mode != "nogroup":
+        D.init_from_env("nccl", dev, force=True, timeout_s=300)
+        assert td.is_initialized() and td.get_world_size() == 1 and td.get_backend() == "nccl" and D.FORCED and D._active()
+""") % ROOT
+
+COLLECTIVES = PRELUDE + textwrap.dedent("""
+    out = {}
+    D.barrier()
+    out["max"] = D.max_over_ranks(3.25, dev)                      # MAX all-reduce of a DEVICE tensor
+    out["records"] = D.gather_records({"scene": 7, "ms": 1.5})
+    g = torch.Generator(device=dev).manual_seed(3)
+    rows = torch.rand(46080, 3, device=dev, generator=g)
+    got = D.gather_rows(rows)                                     # all_gather_object + padded device all_gather
+    out["gather_rows_equal"] = bool(torch.equal(got, rows)) and got.is_cuda and got.data_ptr() != rows.data_ptr()
+    empty = D.gather_rows(rows[:0])
+    out["gather_rows_empty"] = list(empty.shape)
+    # the flat gradient bucket: 1.41 M floats (SuRF's parameter count) in 150 tensors, two of them without a gradient
+    params = [torch.nn.Parameter(torch.randn(9400, device=dev)) for _ in range(150)]
+    for i, p in enumerate(params):
+        if i not in (5, 77):
+            p.grad = torch.randn(9400, device=dev, generator=g)
+    before = [None if p.grad is None else p.grad.clone() for p in params]
+    out["buckets"] = D.all_reduce_gradients(params)
+    out["buckets_small"] = D.all_reduce_gradients(params, bucket_bytes=1 << 20)
+    out["grads_equal"] = all(torch.equal(p.grad, b) if b is not None else bool((p.grad == 0).all()) for p, b in zip(params, before))
+    # parameter / buffer broadcast (what DDP does when it wraps the model)
+    m = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.BatchNorm1d(64)).to(dev)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    versions = [p._version for p in m.parameters()]
+    out["broadcast_n"] = D.broadcast_module_state(m)
+    out["broadcast_equal"] = all(torch.equal(v, sd[k]) for k, v in m.state_dict().items())
+    out["versions_bumped"] = all(p._version > v for p, v in zip(m.parameters(), versions))
+    out["note"] = D.backend_note()
+    torch.cuda.synchronize()
+    print("RESULT " + json.dumps(out))
+    D.shutdown()
+    assert not td.is_initialized() and not D.FORCED
+""")
+
+TRAIN = PRELUDE + textwrap.dedent("""
+    from surf_amd import conf, training
+    from surf_amd.losses import Loss
+    from surf_amd.surf import SuRF
+    from tests.conftest import load_npz
+    from tests.golden.make_golden import MODEL_CONF
+    from tests.golden.make_golden_train import LOSS_CONF
+    scene = load_npz("scene.npz")
+    cfg = dict(MODEL_CONF)
+    cfg["reg_network"] = {"d_in": [8, 16, 16, 16], "d_base": [8] * 4, "d_out": [8] * 4}
+    torch.manual_seed(4)
+    model = SuRF(conf.from_dict(cfg))
+    with torch.no_grad():
+        model.implicit_surface.deviation_network.variance.fill_(0.3)
+        for net in model.reg_network.nets:
+            net.out_lin.weight.mul_(4.0)
+    model = model.to(dev).train()
+    H, W = scene["imgs"].shape[-2:]
+    ipts = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    ipts["src_idx"] = 1
+    ones = torch.ones(H, W, device=dev)
+    R = scene["rays_o"].shape[0]
+    tg = {"color": torch.rand(R, 3, generator=torch.Generator().manual_seed(5)).to(dev), "imgs": ipts["imgs"], "intrs": scene["intrs"],
+          "c2ws": scene["c2ws"], "src_idx": 1, "mask_ref": ones, "mask_src": ones, "pseudo_depth_ref": ones, "pseudo_depth_src": ones,
+          "depth_ref": ones, "depth_src": ones}
+    loss_fn = Loss(conf.from_dict(LOSS_CONF))
+    opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}))
+    stepper = model
+    if mode == "ddp":                                           # runner.py:102
+        stepper = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
+    losses = []
+    for it in range(2):
+        torch.manual_seed(70 + it)
+        if mode == "ddp":                                       # the reference's own sequence, runner.py:152-165
+            outputs = stepper("train", ipts, cos_anneal_ratio=1.0, step=3)
+            loss = loss_fn(outputs, tg, step=3, mode="train")["loss"]
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        else:                                                   # "group": explicit flat-bucket all-reduce inside train_step
+            losses.append(training.train_step(model, ipts, tg, loss_fn, opt, 1.0, 3)["loss"])
+    torch.cuda.synchronize()
+    h = hashlib.sha256()
+    sums = {}
+    for n, p in model.named_parameters():
+        a = p.detach().cpu().contiguous()
+        h.update(n.encode() + a.numpy().tobytes())
+        sums[n] = [float(a.double().sum()), float(a.double().abs().sum())]
+    print("RESULT " + json.dumps({"sha": h.hexdigest(), "sums": sums, "losses": losses}))
+    D.shutdown()
+""")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def _worker(tmp_path, name, text, mode):
+    script = tmp_path / name
+    script.write_text(text)
+    res = subprocess.run([sys.executable, str(script), mode], env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+def test_world1_rccl_collectives_are_the_identity(tmp_path):
+    r = _worker(tmp_path, "coll.py", COLLECTIVES, "group")
+    assert r["max"] == 3.25 and r["records"] == [{"scene": 7, "ms": 1.5}]
+    assert r["gather_rows_equal"] and r["gather_rows_empty"] == [0, 3]
+    assert r["buckets"] == 1 and r["buckets_small"] == 6 and r["grads_equal"]
+    assert r["broadcast_n"] >= 6 and r["broadcast_equal"] and r["versions_bumped"]
+    assert r["note"].startswith("nccl") and "world 1" in r["note"]
+
+
+def _rel(a, b):
+    worst = 0.0
+    for n, (s, ab) in a["sums"].items():
+        worst = max(worst, abs(s - b["sums"][n][0]) / max(ab, 1e-9))
+    return worst
+
+
+def test_world1_rccl_training_step_equals_the_no_group_run(tmp_path):
+    """Two optimiser steps three ways: no group; forced RCCL group with train_step's explicit flat-bucket all-reduce; forced RCCL
+    group with the model wrapped in DistributedDataParallel(device_ids=[0]) driven by the reference's own runner sequence."""
+    a = _worker(tmp_path, "train.py", TRAIN, "nogroup")
+    b = _worker(tmp_path, "train.py", TRAIN, "nogroup")
+    g = _worker(tmp_path, "train.py", TRAIN, "group")
+    d = _worker(tmp_path, "train.py", TRAIN, "ddp")
+    if a["sha"] == b["sha"]:
+        assert g["sha"] == a["sha"], ("explicit all-reduce", _rel(g, a))
+        assert d["sha"] == a["sha"], ("DDP", _rel(d, a))
+        assert g["losses"] == a["losses"] and d["losses"] == a["losses"]
+    else:                       # the step itself is not run-to-run deterministic here (float atomics): bound by its own spread
+        tol = max(10.0 * _rel(a, b), 1e-6)
+        assert _rel(g, a) <= tol and _rel(d, a) <= tol, (_rel(a, b), _rel(g, a), _rel(d, a))
+
+
+def _bench(args, timeout=1200):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=_env(), capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+SMALL = ["--steps", "2", "--warmup", "1", "--height", "48", "--width", "64", "--base-dim", "16", "--cpu-seconds", "0", "--build", "0",
+         "--train-step", "0", "--mesh-grid", "0", "--also", "", "--other-configs", "0"]
+
+
+def test_bench_default_group_is_world1_rccl():
+    """`bench.py --gpus 1` forces the world-1 RCCL group by default: the line names it and carries the timed collectives."""
+    r = _bench(["--gpus", "1"] + SMALL)
+    assert r["collective_backend"].startswith("nccl") and "world 1" in r["collective_backend"]
+    c = r["collectives"]
+    assert c["world"] == 1 and c["backend"] == "nccl" and c["bucket_bytes"] == 5_640_000
+    assert c["allreduce_identity_at_world_1"] and c["gather_rows_identity_at_world_1"] and c["gradient_bucket_allreduce_ms"] > 0
+    r0 = _bench(["--gpus", "1", "--force-group", "0"] + SMALL)
+    assert r0["collective_backend"] is None and r0["collectives"] is None
+
+
+def test_bench_split_and_train_over_world1_rccl():
+    r = _bench(["--split", "rays", "--check-split", "--gpus", "1", "--steps", "1", "--warmup", "1", "--height", "48", "--width", "64",
+                "--base-dim", "16", "--mesh-grid", "32"])
+    assert r["collective_backend"].startswith("nccl") and r["split"]["check"] == {"image_bit_equal": True, "lattice_bit_equal": True}
+    t = _bench(["--workload", "train", "--steps", "2", "--warmup", "1", "--height", "96", "--width", "128", "--base-dim", "16",
+                "--rays", "128", "--cpu-seconds", "0"])
+    assert t["config"]["parallelism"] == "ddp1" and t["gradient_allreduce_ms"] > 0 and t["collective_backend"].startswith("nccl")
+    assert t["loss"] == t["loss"]
+
+
+# ---- N = 2 over RCCL, one device per rank: skipped on one-GPU boxes ---------------------------------------------------------
+
+two_gpus = pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL wants one device per rank)")
+
+
+@two_gpus
+def test_two_gpus_rccl_render():
+    r = _bench(["--gpus", "2"] + SMALL)
+    assert r["n_gpus"] == 2 and r["collective_backend"].startswith("nccl") and "world 2" in r["collective_backend"]
+    assert [x["rank"] for x in r["scenes"]] == [0, 1]
+
+
+@two_gpus
+def test_two_gpus_rccl_scene_dealing():
+    r = _bench(["--gpus", "2", "--scenes", "4"] + SMALL)
+    assert [x["scene"] for x in r["scenes"]] == [0, 1, 2, 3] and [x["rank"] for x in r["scenes"]] == [0, 1, 0, 1]
+    assert abs(r["value"] - 4 * 48 * 64 / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
+
+
+@two_gpus
+def test_two_gpus_rccl_ray_split_is_bit_equal():
+    r = _bench(["--split", "rays", "--check-split", "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "48", "--width", "64",
+                "--base-dim", "16", "--mesh-grid", "48"])
+    assert r["n_gpus"] == 2 and r["scaling"] == "strong" and r["collective_backend"].startswith("nccl")
+    assert r["split"]["check"] == {"image_bit_equal": True, "lattice_bit_equal": True}
+
+
+@two_gpus
+def test_two_gpus_rccl_training_ddp():
+    r = _bench(["--workload", "train", "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "96", "--width", "128",
+                "--base-dim", "16", "--rays", "128"])
+    assert r["n_gpus"] == 2 and r["config"]["parallelism"] == "ddp2" and r["gradient_allreduce_ms"] > 0
+    assert r["collective_backend"].startswith("nccl") and r["loss"] == r["loss"]
