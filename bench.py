@@ -1107,6 +1107,8 @@ def run_rank(args):
         model.sdf_precision = args.sdf_precision
         model.blend_precision = blend_precision
 
+    # the timed collectives of the group (EVERY rank takes part: all-reduce of the gradient bucket, gather_rows, barrier)
+    probe = collective_probe(dev)
     if rank == 0:
         sdf_kernel, sdf_pipe, pipe_peak, n_prod = SDF_KERNELS[args.sdf_precision]
         sdf_ms = kernel_ms["sdf_mlp"]
@@ -1212,7 +1214,7 @@ def run_rank(args):
         if world == 1 and args.train_step and args.workload == "dtu":
             result["training_step"] = training_step_timing(args, dev)
         result["collective_backend"] = collective_note(args)
-        result["collectives"] = collective_probe(dev)
+        result["collectives"] = probe
         if world == 1 and args.other_configs and args.workload == "dtu" and args.scenes == 0:
             del scenes, sc0, out
             torch.cuda.empty_cache()

@@ -484,6 +484,10 @@ int surf_costvol_backward(const int32_t* coords, const float* g, int64_t n, int 
 int64_t surf_conv3x3_wgrad_workspace_floats(int N, int Hs, int Ws, int cb, int cs);
 int surf_conv3x3_wgrad(const float* big, const float* small, int N, int Hs, int Ws, int cb, int cs, int stride,
                        float* workspace, float* out, void* stream);
+/* With a precision argument (as surf_conv3x3_p): pairs with max(cb, cs) >= 16 run on the matrix cores - a GEMM over the pixel
+ * index with both operands read transposed, per-row-group partial sums in the workspace, summed in a fixed order. */
+int surf_conv3x3_wgrad_p(const float* big, const float* small, int N, int Hs, int Ws, int cb, int cs, int stride,
+                         float* workspace, float* out, int precision, void* stream);
 
 /* Backward of surf_ptloss_terms w.r.t. the depth map (train mode; the autograd of losses/photometric_loss.py:54-125):
  * warp = the forward's warped images; coef (device, 4 floats) = upstream / (M_t + 1e-8) for the l1, gx, gy and ssim terms;
@@ -538,6 +542,15 @@ int surf_conv3x3(const float* in, const float* weight, int N, int H, int W, int 
                  void* stream);
 /* ConvTranspose2d(3x3, stride 2, padding 1, output_padding 1), no bias (feature_network.py:66,155).  out (N,2H,2W,cout). */
 int surf_deconv3x3_s2(const float* in, const float* weight, int N, int H, int W, int cin, int cout, float* out, void* stream);
+/* The same two with a precision argument.  Layers with cin >= 16 run on the matrix cores (csrc/fpn_mfma.hip, round 6):
+ * precision 0 = fp32-equivalent (both operands split exactly into three bf16 pieces, six products, fp32 accumulate: what
+ * surf_conv3x3 / surf_deconv3x3_s2 call), 1 = operands rounded to bf16, one product (the bf16 training policy, conf key
+ * train_precision; never used by inference).  cin < 16: the fp32 VALU kernels whatever the precision.  weight: fp32
+ * [ky][kx][cin][cout] as above - split on the fly, there is no packed weight image. */
+int surf_conv3x3_p(const float* in, const float* weight, int N, int H, int W, int cin, int cout, int stride, float* out,
+                   int precision, void* stream);
+int surf_deconv3x3_s2_p(const float* in, const float* weight, int N, int H, int W, int cin, int cout, float* out, int precision,
+                        void* stream);
 /* In place: x = relu(InstanceNorm2d(x)) (+ skip)  (feature_network.py:16-17,21-24; skip add :170).
  * workspace: surf_inorm_workspace_doubles(N,H,W,C) doubles; stats (N,C,2) receives mean and 1/sqrt(var+1e-5).
  * C must be a multiple of 4 that divides 256 (4, 8, 16, 32, 64: the channel counts surf_conv3x3 / surf_deconv3x3_s2 are

@@ -103,6 +103,7 @@ SIGNATURES = {
     "surf_costvol_backward": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_conv3x3_wgrad_workspace_floats": (c_i64, [c_int, c_int, c_int, c_int, c_int]),
     "surf_conv3x3_wgrad": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr]),
+    "surf_conv3x3_wgrad_p": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr]),
     "surf_ptloss_backward": (c_int, [c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_sdf_smooth_backward": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_bn_relu_backward": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
@@ -121,7 +122,9 @@ SIGNATURES = {
     "surf_table_from_coords": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr]),
     "surf_row_linear8": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "surf_conv3x3": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "surf_conv3x3_p": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_int, c_ptr, c_int, c_ptr]),
     "surf_deconv3x3_s2": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr]),
+    "surf_deconv3x3_s2_p": (c_int, [c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_int, c_ptr]),
     "surf_inorm_workspace_doubles": (c_i64, [c_int, c_int, c_int, c_int]),
     "surf_inorm_relu": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_inorm_relu_out": (c_int, [c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),

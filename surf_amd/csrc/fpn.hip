@@ -3,9 +3,11 @@
 //
 // Restates FeatureNetwork.forward  feature_network.py:158-178  (Conv2d :6-25, Deconv2d :57-75).
 //
-// The FPN is ~4.4 GFLOP per view with 8..64 channels: far too thin for MFMA tiles to matter and bound by
-// activation traffic, so the kernels are plain NHWC direct convolutions: one thread = one output pixel and all
-// output channels in registers, 16-byte activation loads, wave-uniform weights through scalar loads.
+// The FPN is ~4.4 GFLOP per view with 8..64 channels.  This file holds the plain NHWC direct convolutions: one thread = one
+// output pixel and all output channels in registers, 16-byte activation loads, wave-uniform weights through scalar loads - what
+// the first level (3 / 8 channels, bound by activation traffic) and the heads' input gradients run on.  Round 6: the layers with
+// C_in >= 16 (forward, input gradient, weight gradient) run on the matrix cores, fpn_mfma.hip; the entry points below dispatch
+// (SURF_FPN_VALU=1 in the environment keeps everything on the kernels of this file: the A/B switch of the tests).
 // InstanceNorm statistics are reduced deterministically in fp64 (per-block partials, then a serial finalise).
 #include "common.h"
 
@@ -312,24 +314,45 @@ inline dim3 grid1d(int64_t n, int block) { return dim3((unsigned)((n + block - 1
     return surf_check_launch();                                                                                        \
   }
 
-extern "C" int surf_conv3x3(const float* in, const float* weight, int N, int H, int W, int cin, int cout, int stride,
-                            float* out, void* stream) {
+// fpn_mfma.hip
+int surf_fpn_conv_mfma(const float* in, const float* weight, int N, int H, int W, int cin, int cout, int mode, float* out,
+                       int bf16_operands, hipStream_t st);
+int64_t surf_fpn_wgrad_mfma_chunks(int N, int Hs);
+int surf_fpn_wgrad_mfma(const float* big, const float* small, int N, int Hs, int Ws, int cb, int cs, int stride, float* part,
+                        int bf16_operands, int thin_too, hipStream_t st);
+static bool fpn_valu_only() { return getenv("SURF_FPN_VALU") != nullptr; }
+
+extern "C" int surf_conv3x3_p(const float* in, const float* weight, int N, int H, int W, int cin, int cout, int stride,
+                              float* out, int precision, void* stream) {
   if (!in || !weight || !out || N <= 0 || H <= 0 || W <= 0) return SURF_E_ARG;
-  if (stride == 2 && ((H | W) & 1)) return SURF_E_ARG;
+  if ((stride != 1 && stride != 2) || (stride == 2 && ((H | W) & 1)) || precision < 0 || precision > 1) return SURF_E_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int Ho = stride == 2 ? H / 2 : H, Wo = stride == 2 ? W / 2 : W;
+  if (!fpn_valu_only() && surf_fpn_conv_mfma(in, weight, N, H, W, cin, cout, stride == 2 ? 1 : 0, out, precision, st))
+    return surf_check_launch();
   CONV_CASE(4, 8, 1) CONV_CASE(8, 8, 1) CONV_CASE(8, 16, 2) CONV_CASE(16, 16, 1) CONV_CASE(16, 32, 2) CONV_CASE(32, 32, 1)
   CONV_CASE(32, 64, 2) CONV_CASE(64, 64, 1) CONV_CASE(8, 4, 1) CONV_CASE(16, 4, 1) CONV_CASE(32, 4, 1) CONV_CASE(64, 4, 1)
   CONV_CASE(4, 16, 1) CONV_CASE(4, 32, 1) CONV_CASE(4, 64, 1) /* the heads' input gradients (train mode) */
   return SURF_E_LIMIT;
 }
 
-extern "C" int surf_deconv3x3_s2(const float* in, const float* weight, int N, int H, int W, int cin, int cout, float* out,
-                                 void* stream) {
-  if (!in || !weight || !out || N <= 0 || H <= 0 || W <= 0) return SURF_E_ARG;
+extern "C" int surf_conv3x3(const float* in, const float* weight, int N, int H, int W, int cin, int cout, int stride,
+                            float* out, void* stream) {
+  return surf_conv3x3_p(in, weight, N, H, W, cin, cout, stride, out, 0, stream);
+}
+
+extern "C" int surf_deconv3x3_s2_p(const float* in, const float* weight, int N, int H, int W, int cin, int cout, float* out,
+                                   int precision, void* stream) {
+  if (!in || !weight || !out || N <= 0 || H <= 0 || W <= 0 || precision < 0 || precision > 1) return SURF_E_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if (!fpn_valu_only() && surf_fpn_conv_mfma(in, weight, N, H, W, cin, cout, 2, out, precision, st)) return surf_check_launch();
   DECONV_CASE(64, 32) DECONV_CASE(32, 16) DECONV_CASE(16, 8)
   return SURF_E_LIMIT;
+}
+
+extern "C" int surf_deconv3x3_s2(const float* in, const float* weight, int N, int H, int W, int cin, int cout, float* out,
+                                 void* stream) {
+  return surf_deconv3x3_s2_p(in, weight, N, H, W, cin, cout, out, 0, stream);
 }
 
 extern "C" int64_t surf_inorm_workspace_doubles(int N, int H, int W, int C) {
@@ -355,15 +378,23 @@ extern "C" int surf_inorm_relu(float* x, int N, int H, int W, int C, const float
 }
 
 extern "C" int64_t surf_conv3x3_wgrad_workspace_floats(int N, int Hs, int Ws, int cb, int cs) {
-  const int64_t nchunk = ((int64_t)N * Hs * Ws + WG_CHUNK - 1) / WG_CHUNK;
-  return nchunk * 9 * cb * cs;
+  const int64_t nchunk = ((int64_t)N * Hs * Ws + WG_CHUNK - 1) / WG_CHUNK;       // VALU kernel: 2,048-pixel chunks
+  const int64_t nchunk_m = surf_fpn_wgrad_mfma_chunks(N, Hs);                      // matrix-core kernel: groups of 4 rows
+  return (nchunk > nchunk_m ? nchunk : nchunk_m) * 9 * cb * cs;
 }
 
-extern "C" int surf_conv3x3_wgrad(const float* big, const float* small, int N, int Hs, int Ws, int cb, int cs, int stride,
-                                  float* workspace, float* out, void* stream) {
-  if (!big || !small || !workspace || !out || N <= 0 || Hs <= 0 || Ws <= 0) return SURF_E_ARG;
+extern "C" int surf_conv3x3_wgrad_p(const float* big, const float* small, int N, int Hs, int Ws, int cb, int cs, int stride,
+                                    float* workspace, float* out, int precision, void* stream) {
+  if (!big || !small || !workspace || !out || N <= 0 || Hs <= 0 || Ws <= 0 || precision < 0 || precision > 1) return SURF_E_ARG;
+  if (stride != 1 && stride != 2) return SURF_E_ARG;
   const int O = cb * cs;
   hipStream_t st = (hipStream_t)stream;
+  if (!fpn_valu_only() &&
+      surf_fpn_wgrad_mfma(big, small, N, Hs, Ws, cb, cs, stride, workspace, precision, getenv("SURF_FPN_WGRAD_THIN_MFMA") != nullptr, st)) {
+    hipLaunchKernelGGL(wgrad_finalize_kernel, grid1d(9 * O, 64), dim3(256), 0, st, workspace, (int)surf_fpn_wgrad_mfma_chunks(N, Hs),
+                       9 * O, out);
+    return surf_check_launch();
+  }
   const int nchunk = (int)(((int64_t)N * Hs * Ws + WG_CHUNK - 1) / WG_CHUNK);
   const int Hb = Hs * stride, Wb = Ws * stride;
   bool done = false;
@@ -380,4 +411,9 @@ extern "C" int surf_conv3x3_wgrad(const float* big, const float* small, int N, i
   if (!done) return SURF_E_LIMIT;
   hipLaunchKernelGGL(wgrad_finalize_kernel, grid1d(9 * O, 64), dim3(256), 0, st, workspace, nchunk, 9 * O, out);
   return surf_check_launch();
+}
+
+extern "C" int surf_conv3x3_wgrad(const float* big, const float* small, int N, int Hs, int Ws, int cb, int cs, int stride,
+                                  float* workspace, float* out, void* stream) {
+  return surf_conv3x3_wgrad_p(big, small, N, Hs, Ws, cb, cs, stride, workspace, out, 0, stream);
 }

@@ -13,6 +13,8 @@
 //   features  dF[row_c] += w_c phibar + (grad w_c . v) phi'bar     (float atomics into the sparse volumes' gradient rows)
 // Plain fp32 FMAs, one wavefront per 4 samples, same lane ownership as sdf_smooth.hip (whose packed weight image it reads);
 // round 6: SURF_TRAIN_WAVES wavefronts per workgroup share the weight stream through LDS (sdf_train_common.h).
+#include <stdlib.h>
+
 #include "sdf_train_common.h"
 
 // weight rows in flight per step of the k / neuron loops (the loops wait for one L2 round trip per unrolled group)
@@ -163,23 +165,17 @@ __global__ __launch_bounds__(surf_train::NT) void sdf_bwd_kernel(BwdArgs a) {
   for (int l = 0; l < N_HID; ++l) {
     dump_inputs(l);
     const float* __restrict__ wt = a.packed + OFF_WT + l * KP * NH;
-    float acc[2][S], accd[2][S];
+    surf_train::V4 acc[2], accd[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int s = 0; s < S; ++s) acc[j][s] = accd[j][s] = 0.f;
+    for (int j = 0; j < 2; ++j) { acc[j].zero(); accd[j].zero(); }
     const int K = layer_k(l);
     surf_train::stream_rows<NH>(wt, K, wbuf, [&](int k, const float* __restrict__ wr) {
       const float w0 = wr[lane], w1 = wr[64 + lane];
       const f32x4 xv4 = *reinterpret_cast<const f32x4*>(&xin_t[k * XS]), xd4 = *reinterpret_cast<const f32x4*>(&xin_t[k * XS + S]);
-#pragma unroll
-      for (int s = 0; s < S; ++s) {
-        const float x = xv4[s], xd = xd4[s];
-        acc[0][s] = fmaf(w0, x, acc[0][s]);
-        acc[1][s] = fmaf(w1, x, acc[1][s]);
-        accd[0][s] = fmaf(w0, xd, accd[0][s]);
-        accd[1][s] = fmaf(w1, xd, accd[1][s]);
-      }
+      acc[0].fma(w0, xv4);
+      acc[1].fma(w1, xv4);
+      accd[0].fma(w0, xd4);
+      accd[1].fma(w1, xd4);
     });
     __syncthreads();
     const int N = layer_n(l);
@@ -230,37 +226,31 @@ __global__ __launch_bounds__(surf_train::NT) void sdf_bwd_kernel(BwdArgs a) {
         c1[j][s] = live[s] ? a.tb[o] : 0.f;
         c2[j][s] = live[s] ? a.tdb[o] : 0.f;
       }
-    float g[3][S], gd[3][S];
+    surf_train::V4 g[3], gd[3];
     if (l == N_HID) {   // tbar_6 = ybar e_0, t'bar_6 = e_0
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int k = lane + 64 * j;
         const float w = k < KP ? a.packed[OFF_W6 + k] : 0.f;
 #pragma unroll
-        for (int s = 0; s < S; ++s) { g[j][s] = w * yb[s]; gd[j][s] = live[s] ? w : 0.f; }
+        for (int s = 0; s < S; ++s) { g[j].set(s, w * yb[s]); gd[j].set(s, live[s] ? w : 0.f); }
       }
     } else {
       const float* __restrict__ w = a.packed + OFF_W + l * NH * KP;
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int s = 0; s < S; ++s) g[j][s] = gd[j][s] = 0.f;
+      for (int j = 0; j < 3; ++j) { g[j].zero(); gd[j].zero(); }
       const int N = layer_n(l);
       const bool third = lane < KP - 128;
       surf_train::stream_rows<KP>(w, N, wbuf, [&](int nrn, const float* __restrict__ wr) {
         const float w0 = wr[lane], w1 = wr[64 + lane];
         const float w2 = third ? wr[128 + lane] : 0.f;
         const f32x4 dv4 = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS]), dd4 = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS + S]);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-          const float d = dv4[s], dd = dd4[s];
-          g[0][s] = fmaf(w0, d, g[0][s]);
-          g[1][s] = fmaf(w1, d, g[1][s]);
-          g[2][s] = fmaf(w2, d, g[2][s]);
-          gd[0][s] = fmaf(w0, dd, gd[0][s]);
-          gd[1][s] = fmaf(w1, dd, gd[1][s]);
-          gd[2][s] = fmaf(w2, dd, gd[2][s]);
-        }
+        g[0].fma(w0, dv4);
+        g[1].fma(w1, dv4);
+        g[2].fma(w2, dv4);
+        gd[0].fma(w0, dd4);
+        gd[1].fma(w1, dd4);
+        gd[2].fma(w2, dd4);
       });
       __syncthreads();
     }
@@ -320,6 +310,12 @@ __global__ __launch_bounds__(surf_train::NT) void sdf_bwd_kernel(BwdArgs a) {
 
 }  // namespace
 
+// sdf_bwd_mfma.hip: the same function on the fp32 matrix pipe, 16 samples per wavefront (round 6; the default).
+// SURF_SDF_TRAIN_VALU=1 in the environment keeps the FMA kernel of this file (A/B switch, tests).
+int surf_sdf_backward_mfma_launch(const float* pts, const float* ybar, const float* gbar, int64_t n, const float* const* h_vols,
+                                  const int32_t* const* h_tables, const int* h_dims, int n_vol, float* const* h_dvols,
+                                  const float* packed, float* in_v, float* in_d, float* tb, float* tdb, hipStream_t stream);
+
 // per-sample buffers (floats): in_v / in_d: 7 n 160 each; tb / tdb: 6 n 128 each
 extern "C" int surf_sdf_backward(const float* pts, const float* ybar, const float* gbar, int64_t n, const float* const* h_vols,
                                  const int32_t* const* h_tables, const int* h_dims, int n_vol, float* const* h_dvols,
@@ -336,6 +332,9 @@ extern "C" int surf_sdf_backward(const float* pts, const float* ybar, const floa
     a.dvols[s] = (s < n_vol && h_dvols) ? h_dvols[s] : nullptr;
     if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
   }
+  if (!getenv("SURF_SDF_TRAIN_VALU"))
+    return surf_sdf_backward_mfma_launch(pts, ybar, gbar, n, h_vols, h_tables, h_dims, n_vol, h_dvols, packed, in_v, in_d, tb, tdb,
+                                         (hipStream_t)stream);
   const int64_t blocks = (n + S * surf_train::NW - 1) / (S * surf_train::NW);
   if (blocks > 0x7fffffff) return SURF_E_LIMIT;
   hipLaunchKernelGGL(sdf_bwd_kernel, dim3((unsigned)blocks), dim3(surf_train::NT), 0, (hipStream_t)stream, a);

@@ -178,24 +178,19 @@ __global__ __launch_bounds__(surf_train::NT) void sdf_smooth_bwd_kernel(SmBwdArg
   for (int l = 0; l < N_HID; ++l) {
     dump_inputs(l);
     const float* __restrict__ wt = a.packed + OFF_WT + l * KP * NH;
-    float acc[NS][2][S];
+    surf_train::V4 acc[NS][2];
 #pragma unroll
     for (int q = 0; q < NS; ++q)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int s = 0; s < S; ++s) acc[q][j][s] = 0.f;
+      for (int j = 0; j < 2; ++j) acc[q][j].zero();
     const int K = layer_k(l);
     surf_train::stream_rows<NH>(wt, K, wbuf, [&](int k, const float* __restrict__ wr) {
       const float w0 = wr[lane], w1 = wr[64 + lane];
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         const f32x4 xq = *reinterpret_cast<const f32x4*>(&xin_t[k * XS + q * S]);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-          acc[q][0][s] = fmaf(w0, xq[s], acc[q][0][s]);
-          acc[q][1][s] = fmaf(w1, xq[s], acc[q][1][s]);
-        }
+        acc[q][0].fma(w0, xq);
+        acc[q][1].fma(w1, xq);
       }
     });
     __syncthreads();
@@ -253,20 +248,18 @@ __global__ __launch_bounds__(surf_train::NT) void sdf_smooth_bwd_kernel(SmBwdArg
 #pragma unroll
         for (int q = 0; q < NS; ++q) ck[j][s][q] = live[s] ? a.ab[o + q * qs] : 0.f;
       }
-    float g[NS][3][S];
+    surf_train::V4 g[NS][3];
 #pragma unroll
     for (int q = 0; q < NS; ++q)
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int s = 0; s < S; ++s) g[q][j][s] = 0.f;
+      for (int j = 0; j < 3; ++j) g[q][j].zero();
     if (l == N_HID) {   // S = w6 . x_m: the adjoint of lin6's mixed input is lin6 row 0
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int k = lane + 64 * j;
         const float w = k < KP ? a.packed[OFF_W6 + k] : 0.f;
 #pragma unroll
-        for (int s = 0; s < S; ++s) g[3][j][s] = live[s] ? w : 0.f;
+        for (int s = 0; s < S; ++s) g[3][j].set(s, live[s] ? w : 0.f);
       }
     } else {
       const float* __restrict__ w = a.packed + OFF_W + l * NH * KP;
@@ -278,12 +271,9 @@ __global__ __launch_bounds__(surf_train::NT) void sdf_smooth_bwd_kernel(SmBwdArg
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
           const f32x4 dq = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS + q * S]);
-#pragma unroll
-          for (int s = 0; s < S; ++s) {
-            g[q][0][s] = fmaf(w0, dq[s], g[q][0][s]);
-            g[q][1][s] = fmaf(w1, dq[s], g[q][1][s]);
-            g[q][2][s] = fmaf(w2, dq[s], g[q][2][s]);
-          }
+          g[q][0].fma(w0, dq);
+          g[q][1].fma(w1, dq);
+          g[q][2].fma(w2, dq);
         }
       });
       __syncthreads();

@@ -19,6 +19,24 @@
 
 namespace surf_train {
 
+// Four samples' accumulators as two packed pairs: acc += w x is two v_pk_fma_f32 (the weight broadcast through op_sel, the
+// operand pairs straight out of the 16-byte LDS read) instead of four v_fma_f32.  Round 6: the k / neuron loops of these
+// kernels are bound by their FMA issue (34 TFLOP/s = 44 % of the plain-FMA rate at 2.1 GHz, rocprofv3: VALU busy), not by the
+// weight stream as assumed in round 5; hipcc's SLP vectoriser had packed a quarter of them.  Same products, same order of
+// accumulation per sample: bit-identical results.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct V4 {
+  f32x2 a, b;
+  __device__ __forceinline__ void zero() { a = f32x2{0.f, 0.f}; b = a; }
+  __device__ __forceinline__ float operator[](int s) const { return s < 2 ? a[s] : b[s - 2]; }
+  __device__ __forceinline__ void set(int s, float v) { if (s < 2) a[s] = v; else b[s - 2] = v; }
+  __device__ __forceinline__ void fma(float w, const f32x4& x) {
+    const f32x2 wv = {w, w};
+    a = __builtin_elementwise_fma(wv, f32x2{x[0], x[1]}, a);
+    b = __builtin_elementwise_fma(wv, f32x2{x[2], x[3]}, b);
+  }
+};
+
 constexpr int NW = SURF_TRAIN_WAVES, NT = 64 * NW, CH = SURF_TRAIN_CH;
 constexpr int WBUF_FLOATS = 2 * CH * 160;      // two chunk buffers of the longer (reverse) rows
 

@@ -66,6 +66,9 @@ class FeatureNetwork(nn.Module):
             raise ValueError("image height and width must be divisible by 8")
         x = ops.pack_texel4(imgs.detach().float().contiguous())
         rec = tape is not None
+        # the layers with C_in >= 16 run on the matrix cores (csrc/fpn_mfma.hip): fp32-equivalent, or - in train mode under the
+        # bf16 policy (conf key train_precision) - on bf16-rounded operands; inference is always fp32-equivalent
+        prec = ops.colgram_precision if self.training else 0
 
         def norm(y, skip=None):
             if not rec:
@@ -77,7 +80,7 @@ class FeatureNetwork(nn.Module):
         for i in range(self.num_stage):
             for blk in self.encoder_layers[i]:
                 x_in = x
-                x = ops.conv3x3(x, _pack_conv(blk.conv.weight), blk.conv.out_channels, blk.stride)
+                x = ops.conv3x3(x, _pack_conv(blk.conv.weight), blk.conv.out_channels, blk.stride, prec)
                 x, raw, stats = norm(x)
                 enc_rec.append(dict(blk=blk, x_in=x_in, raw=raw, stats=stats))
             enc.append(x)
@@ -88,13 +91,13 @@ class FeatureNetwork(nn.Module):
         for i in range(self.num_stage - 2, -1, -1):
             blk = self.decoder_layers[i]
             d_in = d
-            d = ops.deconv3x3_s2(d, _pack_deconv(blk.conv.weight), blk.conv.out_channels)
+            d = ops.deconv3x3_s2(d, _pack_deconv(blk.conv.weight), blk.conv.out_channels, prec)
             d, raw, stats = norm(d, skip=enc[i])
             dec_rec[i] = dict(blk=blk, x_in=d_in, raw=raw, stats=stats)
             dec[i] = d
-        outs = [ops.conv3x3(dec[i], _pack_conv(self.out_layers[i].weight), 4, 1) for i in range(self.num_stage)]
+        outs = [ops.conv3x3(dec[i], _pack_conv(self.out_layers[i].weight), 4, 1, prec) for i in range(self.num_stage)]
         if rec:
-            tape.append(dict(enc=enc_rec, dec=dec_rec, dec_out=dec))
+            tape.append(dict(enc=enc_rec, dec=dec_rec, dec_out=dec, prec=prec))
         return outs[::-1]
 
     def backward(self, tape, g_outs_c2f, sink=None):
@@ -111,13 +114,14 @@ class FeatureNetwork(nn.Module):
 
         t = tape[-1]
         n = self.num_stage
+        prec = t.get("prec", 0)                                                 # the policy the forward ran under
         g_outs = g_outs_c2f[::-1]                                               # index i = level i (0 = finest)
         d_dec = []
         for i in range(n):
             w = self.out_layers[i].weight
             g = g_outs[i].contiguous()
-            d_dec.append(ops.conv3x3(g, flipT(w), w.shape[1], 1))
-            dw = ops.conv3x3_wgrad(t["dec_out"][i], g, 1)                       # [ky][kx][ci][co]
+            d_dec.append(ops.conv3x3(g, flipT(w), w.shape[1], 1, prec))
+            dw = ops.conv3x3_wgrad(t["dec_out"][i], g, 1, prec)                 # [ky][kx][ci][co]
             acc(w, dw.permute(3, 2, 0, 1))
         d_enc = [None] * n
         for i in range(n - 1):                                                  # dec[i] = IN(deconv(dec[i+1])) + enc[i]
@@ -127,8 +131,8 @@ class FeatureNetwork(nn.Module):
             d_enc[i] = g
             d_raw = ops.inorm_relu_backward(r["raw"], g, r["stats"])
             # input gradient of the transposed convolution = stride-2 convolution with [ky][kx][co][ci]
-            d_dec[i + 1] = d_dec[i + 1] + ops.conv3x3(d_raw, w.detach().float().permute(2, 3, 1, 0).contiguous(), w.shape[0], 2)
-            dw = ops.conv3x3_wgrad(d_raw, r["x_in"], 2)                         # [ky][kx][co][ci]
+            d_dec[i + 1] = d_dec[i + 1] + ops.conv3x3(d_raw, w.detach().float().permute(2, 3, 1, 0).contiguous(), w.shape[0], 2, prec)
+            dw = ops.conv3x3_wgrad(d_raw, r["x_in"], 2, prec)                   # [ky][kx][co][ci]
             acc(w, dw.permute(3, 2, 0, 1))
         d_enc[n - 1] = d_dec[n - 1]
         g = d_enc[n - 1]
@@ -137,13 +141,13 @@ class FeatureNetwork(nn.Module):
             r = t["enc"][k]
             w = r["blk"].conv.weight                                            # (Cout, Cin, 3, 3)
             d_raw = ops.inorm_relu_backward(r["raw"], g.contiguous(), r["stats"])
-            dw = ops.conv3x3_wgrad(r["x_in"], d_raw, r["blk"].stride)           # [ky][kx][ci (padded)][co]
+            dw = ops.conv3x3_wgrad(r["x_in"], d_raw, r["blk"].stride, prec)     # [ky][kx][ci (padded)][co]
             acc(w, dw[:, :, :w.shape[1]].permute(3, 2, 0, 1))
             if k == 0:
                 break
             if r["blk"].stride == 1:
-                g = ops.conv3x3(d_raw, flipT(w), w.shape[1], 1)
+                g = ops.conv3x3(d_raw, flipT(w), w.shape[1], 1, prec)
             else:                                                               # stride-2 conv <- transposed conv, [ky][kx][co][ci]
-                g = ops.deconv3x3_s2(d_raw, w.detach().float().permute(2, 3, 0, 1).contiguous(), w.shape[1])
+                g = ops.deconv3x3_s2(d_raw, w.detach().float().permute(2, 3, 0, 1).contiguous(), w.shape[1], prec)
             if j == 0:                                                          # entering stage i - 1's output: add its skip gradient
                 g = g + d_enc[i - 1]

@@ -1416,28 +1416,29 @@ def row_linear8(x, weight):
 # ------------------------------------------------------------------------------------------------
 
 
-def conv3x3(x, w_packed, cout, stride=1):
-    """x (N,H,W,Cin) NHWC, w_packed [3][3][Cin][Cout] -> (N,H/stride,W/stride,Cout)."""
+def conv3x3(x, w_packed, cout, stride=1, precision=0):
+    """x (N,H,W,Cin) NHWC, w_packed [3][3][Cin][Cout] -> (N,H/stride,W/stride,Cout).  precision (layers with Cin >= 16, which run
+    on the matrix cores): 0 = fp32-equivalent (exact bf16x3 split), 1 = operands rounded to bf16 (the bf16 training policy)."""
     _chk(x, torch.float32, "x")
     _chk(w_packed, torch.float32, "weight")
     N, H, W, cin = x.shape
     out = torch.empty(N, H // stride, W // stride, cout, dtype=torch.float32, device=x.device)
-    rc = _lib.lib().surf_conv3x3(_p(x), _p(w_packed), N, H, W, cin, cout, stride, _p(out), _stream())
+    rc = _lib.lib().surf_conv3x3_p(_p(x), _p(w_packed), N, H, W, cin, cout, stride, _p(out), int(precision), _stream())
     _lib.check(rc, f"surf_conv3x3({cin}->{cout}, stride {stride})")
     return out
 
 
-def deconv3x3_s2(x, w_packed, cout):
+def deconv3x3_s2(x, w_packed, cout, precision=0):
     _chk(x, torch.float32, "x")
     _chk(w_packed, torch.float32, "weight")
     N, H, W, cin = x.shape
     out = torch.empty(N, 2 * H, 2 * W, cout, dtype=torch.float32, device=x.device)
-    rc = _lib.lib().surf_deconv3x3_s2(_p(x), _p(w_packed), N, H, W, cin, cout, _p(out), _stream())
+    rc = _lib.lib().surf_deconv3x3_s2_p(_p(x), _p(w_packed), N, H, W, cin, cout, _p(out), int(precision), _stream())
     _lib.check(rc, f"surf_deconv3x3_s2({cin}->{cout})")
     return out
 
 
-def conv3x3_wgrad(big, small, stride=1):
+def conv3x3_wgrad(big, small, stride=1, precision=0):
     """out[ky][kx][cb][cs] = sum big[n][ys S + ky - 1][xs S + kx - 1][cb] small[n][ys][xs][cs]: the weight gradient of a 3x3
     convolution (big = input, small = d output) or of the stride-2 transposed one (big = d output, small = input)."""
     _chk(big, torch.float32, "big")
@@ -1447,7 +1448,7 @@ def conv3x3_wgrad(big, small, stride=1):
     assert tuple(big.shape[:3]) == (N, Hs * stride, Ws * stride)
     ws = torch.empty(_lib.lib().surf_conv3x3_wgrad_workspace_floats(N, Hs, Ws, cb, cs), dtype=torch.float32, device=big.device)
     out = torch.empty(3, 3, cb, cs, dtype=torch.float32, device=big.device)
-    rc = _lib.lib().surf_conv3x3_wgrad(_p(big), _p(small), N, Hs, Ws, cb, cs, int(stride), _p(ws), _p(out), _stream())
+    rc = _lib.lib().surf_conv3x3_wgrad_p(_p(big), _p(small), N, Hs, Ws, cb, cs, int(stride), _p(ws), _p(out), int(precision), _stream())
     _lib.check(rc, f"surf_conv3x3_wgrad({cb}x{cs}, stride {stride})")
     return out
 
