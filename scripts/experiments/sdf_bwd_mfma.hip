@@ -10,14 +10,18 @@
 // chain):
 //   forward   T[neuron][col]  = sum_k W_l[neuron][k] X[k][col]          4 row tiles x K / 2 MFMAs per layer
 //   reverse   G[kin][col]     = sum_n W_l[n][kin]    D[n][col]          5 row tiles x N / 2 MFMAs per layer
-// A operand = the packed weight images of sdf_smooth.hip as they are (k-major for the forward, neuron-major for the reverse:
-// lane (row r = l % 32, k-slot l / 32) reads W[.][32 t + r] - 128-byte coalesced segments out of L2); B operand = the layer's
-// columns in LDS, X[k][col] (one ds_read_b32 per MFMA quadruple); the accumulator tile leaves lane (col, h) with rows
+// A operand = the packed weight images of sdf_smooth.hip as they are (k-major for the forward, neuron-major for the reverse),
+// streamed through LDS in 16-row chunks with the register-prefetch pipeline of sdf_train_common.h (16-byte coalesced loads one
+// chunk = 32 MFMAs ahead; the first form read every A element with its own 4-byte global load and waited for L2 once per k-step:
+// 2.6 ms against the VALU kernel's 1.6): lane (row r = l % 32, k-slot h = l / 32) reads W[2 kk + h][32 t + r] with one
+// ds_read_b32 per MFMA; B operand = the layer's columns in LDS, X[k][col] (one ds_read_b32 per MFMA quadruple); the accumulator tile leaves lane (col, h) with rows
 // (r & 3) + 8 (r >> 2) + 4 h of its column, i.e. four consecutive neurons per register quadruple: the softplus algebra runs on
 // them in registers (the other stream's value of the same (neuron, sample) is lane ^ 16: one cross-lane read), the saved
 // coefficients / adjoints go to TB / TDB as 16-byte stores, the next layer's column back to LDS.
 // Column c = 16 q + s: stream q (0 = value, 1 = tangent), sample s.
-#include "common.h"
+#define SURF_TRAIN_WAVES 1
+#define SURF_TRAIN_CH 16
+#include "sdf_train_common.h"
 
 namespace {
 
@@ -65,8 +69,9 @@ __device__ __forceinline__ Act softplus100(float t) {
 
 #define SURF_MFMA32(av, bv, cv) cv = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, cv, 0, 0, 0)
 
-__global__ __launch_bounds__(64, 2) void sdf_bwd_mfma_kernel(BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float xs[KP * XC];      // X[k][col], then D[n][col]: 20 KB, 8 wavefronts per CU
+__global__ __launch_bounds__(64) void sdf_bwd_mfma_kernel(BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float xs[KP * XC];      // X[k][col], then D[n][col]: 20 KB
+  __shared__ __attribute__((aligned(16))) float wbuf[surf_train::WBUF_FLOATS];   // two 16-row weight chunks: 20 KB (4 wavefronts per CU)
   const int lane = threadIdx.x, c = lane & 31, h = lane >> 5, q = c >> 4, s = c & 15;
   const int part = lane >> 4;                                     // set-up role: (sample s, part = 2 h + q)
   const int64_t ntot = a.n;
@@ -166,23 +171,21 @@ __global__ __launch_bounds__(64, 2) void sdf_bwd_mfma_kernel(BwdArgs a) {
   // ---- forward sweep with tangents ------------------------------------------------------------------------------------------
   for (int l = 0; l < N_HID; ++l) {
     dump_inputs(l);
-    const float* __restrict__ wt = a.packed + OFF_WT + l * KP * NH + c;
     f32x16 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const int Kp = (layer_k(l) + 1) / 2;                            // row layer_k (odd K) is a zero row of both operands
-#pragma unroll 4
-    for (int kk = 0; kk < Kp; ++kk) {
-      const int k = 2 * kk + h;
-      const float b = xs[k * XC + c];
-      const float a0 = wt[k * NH], a1 = wt[k * NH + 32], a2 = wt[k * NH + 64], a3 = wt[k * NH + 96];
+    // (an odd K ends with a zero row of both operands: the loader zero-fills it, X row 27 is zero)
+    surf_train::stream_row_pairs<NH>(a.packed + OFF_WT + l * KP * NH, layer_k(l), wbuf, [&](int kk, const float* __restrict__ wr) {
+      const float b = xs[(2 * kk + h) * XC + c];
+      const float* __restrict__ wa = wr + h * NH + c;
+      const float a0 = wa[0], a1 = wa[32], a2 = wa[64], a3 = wa[96];
       SURF_MFMA32(a0, b, acc[0]);
       SURF_MFMA32(a1, b, acc[1]);
       SURF_MFMA32(a2, b, acc[2]);
       SURF_MFMA32(a3, b, acc[3]);
-    }
+    });
     __syncthreads();                                              // every lane has read X before the outputs overwrite it
     const int N = layer_n(l);
     const float post = l == 2 ? inv_sqrt2 : 1.0f;                 // lin3's input is cat([h2, e]) / sqrt(2)
@@ -227,23 +230,21 @@ __global__ __launch_bounds__(64, 2) void sdf_bwd_mfma_kernel(BwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[t][r] = a.packed[OFF_W6 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h] * seed;
     } else {
-      const float* __restrict__ w = a.packed + OFF_W + l * NH * KP + c;
 #pragma unroll
       for (int t = 0; t < 5; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) g[t][r] = 0.f;
-      const int Np = (layer_n(l) + 1) / 2;                        // row layer_n (odd N) is a zero row of both operands
-#pragma unroll 4
-      for (int nn = 0; nn < Np; ++nn) {
-        const int n = 2 * nn + h;
-        const float b = xs[n * XC + c];
-        const float a0 = w[n * KP], a1 = w[n * KP + 32], a2 = w[n * KP + 64], a3 = w[n * KP + 96], a4 = w[n * KP + 128];
+      // (an odd N ends with a zero row of both operands: D row 101 of the 101-wide layer is zero)
+      surf_train::stream_row_pairs<KP>(a.packed + OFF_W + l * NH * KP, layer_n(l), wbuf, [&](int nn, const float* __restrict__ wr) {
+        const float b = xs[(2 * nn + h) * XC + c];
+        const float* __restrict__ wa = wr + h * KP + c;
+        const float a0 = wa[0], a1 = wa[32], a2 = wa[64], a3 = wa[96], a4 = wa[128];
         SURF_MFMA32(a0, b, g[0]);
         SURF_MFMA32(a1, b, g[1]);
         SURF_MFMA32(a2, b, g[2]);
         SURF_MFMA32(a3, b, g[3]);
         SURF_MFMA32(a4, b, g[4]);
-      }
+      });
       __syncthreads();
     }
 #pragma unroll

@@ -1,0 +1,10 @@
+#!/usr/bin/env bash
+set -u
+O=gpurun_out/r06g; mkdir -p $O
+python -m pytest tests/test_hip_parity.py -q -k "spconv or sparse_unet or smooth" > $O/sp.log 2>&1; echo "rc=$?" >> $O/sp.log; tail -5 $O/sp.log
+python -m pytest tests/test_volume_backward.py tests/test_autograd_runner.py -q > $O/vb.log 2>&1; echo "rc=$?" >> $O/vb.log; tail -4 $O/vb.log
+for i in 1 2 3; do
+  python bench.py --workload train --cpu-seconds 0 --force-group 0 2> $O/train_f$i.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fp32', round(d['ms_per_step'],2))"
+  python bench.py --workload train --cpu-seconds 0 --force-group 0 --train-precision bf16 2> $O/train_b$i.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bf16 thin-mfma', round(d['ms_per_step'],2), [ (e['kernel'], round(e['ms_per_step'],2)) for e in d['roofline_kernels'] if e['kernel'].startswith('spconv_dgrad')][:4])"
+  SURF_BF16_THIN_VALU=1 python bench.py --workload train --cpu-seconds 0 --force-group 0 --train-precision bf16 2> $O/train_v$i.err | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('bf16 thin-valu', round(d['ms_per_step'],2), [ (e['kernel'], round(e['ms_per_step'],2)) for e in d['roofline_kernels'] if e['kernel'].startswith('spconv_dgrad')][:4])"
+done

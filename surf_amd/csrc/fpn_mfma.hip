@@ -1,4 +1,4 @@
-// K1m: the wide layers (C_in >= 16) of the FPN feature extractor on the matrix cores - forward, input gradient and weight gradient.
+// K1m: the wide layers (C_in >= 16, coarse levels) of the FPN feature extractor on the matrix cores - forward, input gradient and weight gradient.
 // Same functions as conv3x3_kernel / deconv3x3_s2_kernel / wgrad_kernel of fpn.hip (FeatureNetwork.forward
 // feature_network.py:158-178; Conv2d :6-25, Deconv2d :57-75, and their autograd under loss.backward(), runner.py:163).
 //
@@ -292,10 +292,14 @@ int surf_fpn_conv_mfma(const float* in, const float* weight, int N, int H, int W
   // forward: encoder (stride 1 / 2), heads (-> 4), decoder (transposed).  Input gradients reuse them through flipped / transposed
   // kernels: stride 1 <- stride 1, transposed <- stride 2 (16 -> 32 is the gradient of the 32 -> 16 decoder layer), stride 2 <-
   // transposed.  C_in < 16 (the first level, the heads' input gradients) stays on the VALU kernels of fpn.hip.
-  FM_CONV(16, 16, FM_S1) FM_CONV(32, 32, FM_S1) FM_CONV(64, 64, FM_S1)
-  FM_CONV(16, 4, FM_S1) FM_CONV(32, 4, FM_S1) FM_CONV(64, 4, FM_S1)
+  // Measured per call at the bench shape, 5 views (profiles/r06_fpn_ab.txt): 64 -> 64 305 -> 45 us, 32 -> 64 s2 156 -> 26,
+  // 64 -> 32 transposed 120 -> 39, 32 -> 32 89 -> 36, 16 -> 32 s2 51 -> 26, 32 -> 16 transposed 66 -> 59.  NOT dispatched here
+  // because the direct kernels win on the pixel-heavy fine levels, where a 32-row tile is mostly padding and the launch is bound by
+  // its gathers: 16 -> 16 (47 vs 56 us), the 4-channel heads (16 -> 4: 28 vs 55, 32 -> 4: 28 vs 33, 64 -> 4: 20 vs 33) and the
+  // 16 -> 8 transposed layer (41 vs 121).
+  FM_CONV(32, 32, FM_S1) FM_CONV(64, 64, FM_S1)
   FM_CONV(16, 32, FM_S2) FM_CONV(32, 64, FM_S2)
-  FM_CONV(64, 32, FM_UP) FM_CONV(32, 16, FM_UP) FM_CONV(16, 8, FM_UP)
+  FM_CONV(64, 32, FM_UP) FM_CONV(32, 16, FM_UP)
   return 0;
 }
 #undef FM_CONV
@@ -319,10 +323,12 @@ int surf_fpn_wgrad_mfma(const float* big, const float* small, int N, int Hs, int
   const int64_t tasks = surf_fpn_wgrad_mfma_chunks(N, Hs) * 9;
   const int64_t blocks = (tasks + 3) / 4;
   if (blocks > 0x7fffffff) return 0;
-  FM_WGRAD(16, 16, 1) FM_WGRAD(32, 32, 1) FM_WGRAD(64, 64, 1) FM_WGRAD(16, 4, 1) FM_WGRAD(32, 4, 1) FM_WGRAD(64, 4, 1)
+  // per call: 64 x 64 298 -> 77 us, 32 x 64 s2 250 -> 63, 16 x 32 s2 228 -> 91, 32 x 32 160 -> 82, 16 x 16 272 -> 213,
+  // 64 x 4 110 -> 56; the VALU kernel keeps 16 x 4 (113 vs 208) and 32 x 4 (66 vs 80)
+  FM_WGRAD(16, 16, 1) FM_WGRAD(32, 32, 1) FM_WGRAD(64, 64, 1) FM_WGRAD(64, 4, 1)
   FM_WGRAD(16, 32, 2) FM_WGRAD(32, 64, 2)
-  if (thin_too) {      // thin pairs: most of a 32 x 32 tile multiplies padding, but the matrix pipe is otherwise idle (A/B in DESIGN K1m)
-    FM_WGRAD(8, 16, 2) FM_WGRAD(8, 8, 1) FM_WGRAD(8, 4, 1) FM_WGRAD(4, 8, 1)
+  if (thin_too) {      // the other pairs (A/B switch SURF_FPN_WGRAD_THIN_MFMA: the training step measured 0.5 ms slower with them)
+    FM_WGRAD(8, 16, 2) FM_WGRAD(8, 8, 1) FM_WGRAD(8, 4, 1) FM_WGRAD(4, 8, 1) FM_WGRAD(16, 4, 1) FM_WGRAD(32, 4, 1)
   }
   return 0;
 }

@@ -14,9 +14,8 @@
 //             this kernel writes: IN (7, 4, n, 160) and AB (6, 4, n, 128), stream order value | u | s | mixed: a layer's four
 //             streams are 4 n contiguous rows, one tall-skinny GEMM per layer)
 //   features  dF[row_c] += w_c pbar + (grad w_c . u) pbar_u + (grad w_c . s) pbar_s + (u^T Hess w_c s) pbar_m
-// Plain fp32 FMAs, one wavefront per 4 samples, same lane ownership and packed weight image as sdf_bwd.hip / sdf_smooth.hip;
-// round 6: SURF_TRAIN_WAVES wavefronts per workgroup share the weight stream through LDS (sdf_train_common.h).
-#include "sdf_train_common.h"
+// Plain fp32 FMAs, one wavefront per 4 samples, same lane ownership and packed weight image as sdf_bwd.hip / sdf_smooth.hip.
+#include "common.h"
 
 // weight rows in flight per step of the k / neuron loops (the loops wait for one L2 round trip per unrolled group)
 #ifndef SURF_TRAIN_UNROLL
@@ -71,17 +70,14 @@ __device__ __forceinline__ Act3 softplus100_3(float t) {
   return a;
 }
 
-__global__ __launch_bounds__(surf_train::NT) void sdf_smooth_bwd_kernel(SmBwdArgs a) {
+__global__ __launch_bounds__(64) void sdf_smooth_bwd_kernel(SmBwdArgs a) {
   // Round 5: [k][stream][sample] rows (16 values + 4 of padding) instead of [stream][sample][k]: the k / neuron loops below read
   // the 16 broadcast operands of a weight pair as FOUR 16-byte LDS reads instead of sixteen 4-byte ones (the loops were bound by
   // their LDS instructions: 16 ds_read per 32 FMAs, at one wavefront per SIMD).
-  __shared__ __attribute__((aligned(16))) float xin_all[surf_train::NW][KP * XS];
-  __shared__ __attribute__((aligned(16))) float dl_all[surf_train::NW][NH * XS];
-  __shared__ __attribute__((aligned(16))) float wbuf[surf_train::WBUF_FLOATS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* const xin_t = xin_all[wave];
-  float* const dl_t = dl_all[wave];
-  const int64_t base = ((int64_t)blockIdx.x * surf_train::NW + wave) * S;
+  __shared__ __attribute__((aligned(16))) float xin_t[KP * XS];
+  __shared__ __attribute__((aligned(16))) float dl_t[NH * XS];
+  const int lane = threadIdx.x;
+  const int64_t base = (int64_t)blockIdx.x * S;
   const float inv_sqrt2 = 0.70710678118654752440f;
   float e[NS][S];
   float px[S], py[S], pz[S], vx[S], vy[S], vz[S];
@@ -178,21 +174,27 @@ __global__ __launch_bounds__(surf_train::NT) void sdf_smooth_bwd_kernel(SmBwdArg
   for (int l = 0; l < N_HID; ++l) {
     dump_inputs(l);
     const float* __restrict__ wt = a.packed + OFF_WT + l * KP * NH;
-    surf_train::V4 acc[NS][2];
+    float acc[NS][2][S];
 #pragma unroll
     for (int q = 0; q < NS; ++q)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[q][j].zero();
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < S; ++s) acc[q][j][s] = 0.f;
     const int K = layer_k(l);
-    surf_train::stream_rows<NH>(wt, K, wbuf, [&](int k, const float* __restrict__ wr) {
-      const float w0 = wr[lane], w1 = wr[64 + lane];
+SURF_TRAIN_UNROLL_PRAGMA
+    for (int k = 0; k < K; ++k) {
+      const float w0 = wt[k * NH + lane], w1 = wt[k * NH + 64 + lane];
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         const f32x4 xq = *reinterpret_cast<const f32x4*>(&xin_t[k * XS + q * S]);
-        acc[q][0].fma(w0, xq);
-        acc[q][1].fma(w1, xq);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          acc[q][0][s] = fmaf(w0, xq[s], acc[q][0][s]);
+          acc[q][1][s] = fmaf(w1, xq[s], acc[q][1][s]);
+        }
       }
-    });
+    }
     __syncthreads();
     const int N = layer_n(l);
     const float post = l == 2 ? inv_sqrt2 : 1.0f;
@@ -248,34 +250,40 @@ __global__ __launch_bounds__(surf_train::NT) void sdf_smooth_bwd_kernel(SmBwdArg
 #pragma unroll
         for (int q = 0; q < NS; ++q) ck[j][s][q] = live[s] ? a.ab[o + q * qs] : 0.f;
       }
-    surf_train::V4 g[NS][3];
+    float g[NS][3][S];
 #pragma unroll
     for (int q = 0; q < NS; ++q)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) g[q][j].zero();
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int s = 0; s < S; ++s) g[q][j][s] = 0.f;
     if (l == N_HID) {   // S = w6 . x_m: the adjoint of lin6's mixed input is lin6 row 0
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int k = lane + 64 * j;
         const float w = k < KP ? a.packed[OFF_W6 + k] : 0.f;
 #pragma unroll
-        for (int s = 0; s < S; ++s) g[3][j].set(s, live[s] ? w : 0.f);
+        for (int s = 0; s < S; ++s) g[3][j][s] = live[s] ? w : 0.f;
       }
     } else {
       const float* __restrict__ w = a.packed + OFF_W + l * NH * KP;
       const int N = layer_n(l);
       const bool third = lane < KP - 128;
-      surf_train::stream_rows<KP>(w, N, wbuf, [&](int nrn, const float* __restrict__ wr) {
-        const float w0 = wr[lane], w1 = wr[64 + lane];
-        const float w2 = third ? wr[128 + lane] : 0.f;
+SURF_TRAIN_UNROLL_PRAGMA
+      for (int nrn = 0; nrn < N; ++nrn) {
+        const float w0 = w[nrn * KP + lane], w1 = w[nrn * KP + 64 + lane];
+        const float w2 = third ? w[nrn * KP + 128 + lane] : 0.f;
 #pragma unroll
         for (int q = 0; q < NS; ++q) {
           const f32x4 dq = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS + q * S]);
-          g[q][0].fma(w0, dq);
-          g[q][1].fma(w1, dq);
-          g[q][2].fma(w2, dq);
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            g[q][0][s] = fmaf(w0, dq[s], g[q][0][s]);
+            g[q][1][s] = fmaf(w1, dq[s], g[q][1][s]);
+            g[q][2][s] = fmaf(w2, dq[s], g[q][2][s]);
+          }
         }
-      });
+      }
       __syncthreads();
     }
 #pragma unroll
@@ -356,8 +364,8 @@ extern "C" int surf_sdf_smooth_backward(const float* pts, const float* sbar, int
     a.dvols[s] = (s < n_vol && h_dvols) ? h_dvols[s] : nullptr;
     if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
   }
-  const int64_t blocks = (n + S * surf_train::NW - 1) / (S * surf_train::NW);
+  const int64_t blocks = (n + S - 1) / S;
   if (blocks > 0x7fffffff) return SURF_E_LIMIT;
-  hipLaunchKernelGGL(sdf_smooth_bwd_kernel, dim3((unsigned)blocks), dim3(surf_train::NT), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(sdf_smooth_bwd_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, a);
   return surf_check_launch();
 }

@@ -1,9 +1,16 @@
-// Shared by the three fp32 training kernels of the SDF network (sdf_smooth.hip, sdf_bwd.hip, sdf_smooth_bwd.hip).
+// Shared by two of the fp32 training kernels of the SDF network (sdf_smooth.hip, sdf_bwd.hip; sdf_smooth_bwd.hip keeps the
+// round-5 form: with its four streams the per-wavefront operand arrays leave room for ONE 4-wavefront workgroup per CU and the
+// shared stream measured slower, 3.5 vs 3.1 ms).
 //
 // Round 6: the weight stream of a sweep is shared by the wavefronts of a workgroup through LDS.  Until round 5 every wavefront
 // (4 samples) read the whole weight image - 0.9 MB for a forward + reverse pair - from L2 by itself: 15,000 wavefronts x 0.9 MB =
-// 13.5 GB per launch at 60 k samples, i.e. the kernels ran at the L2's bandwidth (sdf_smooth: 1.47 ms = 9.2 TB/s) and at 4 - 5 %
-// of the fp32 FMA rate.  Now a workgroup of SURF_TRAIN_WAVES wavefronts (4 samples each, same lane ownership and arithmetic order
+// 13.5 GB per launch at 60 k samples (sdf_smooth: 1.47 ms = 9.2 TB/s of L2 traffic).  Measured gain: small (sdf_smooth 1.47 ->
+// 1.35 ms, sdf_bwd 1.81 -> 1.69): the loops are bound by the LDS return path of their BROADCAST operands (two 16-byte reads that
+// return 2 KB per k-step to the wavefront) and by the FMA issue, both already packed (v_pk_fma_f32) by the compiler - 34 TFLOP/s
+// = 0.22 of the packed-FMA / fp32-MFMA rate.  Also measured and not kept (scripts/experiments/sdf_bwd_mfma.hip): the same
+// function on v_mfma_f32_32x32x2_f32, 16 samples x 2 streams per wavefront, weights through this same LDS pipeline - correct
+// (the parity tests pass) but 1.93 vs 1.69 ms: the fp32 matrix pipe has the packed-FMA rate (MI355X_MICROARCH.md), and the
+// softplus algebra of a 32-column tile cannot overlap its MFMAs at one wavefront per SIMD.  Now a workgroup of SURF_TRAIN_WAVES wavefronts (4 samples each, same lane ownership and arithmetic order
 // as before: results are bit-identical) walks the rows of a layer's matrix in chunks of CH rows: all 256 threads copy chunk c + 1
 // from L2 into registers while every wavefront runs its FMAs on chunk c out of LDS, then park it in the other buffer; one
 // workgroup barrier per chunk.  L2 traffic per sample drops by the number of wavefronts per workgroup.

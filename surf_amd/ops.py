@@ -5,6 +5,7 @@ current stream.  Nothing here computes on the CPU except the one-off weight re-l
 the library) and 4x4 camera inversions.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -548,6 +549,10 @@ def sdf_smooth_backward(pts, sbar, volumes, packed, want_dvols=True, dvols=None)
 # accumulate).  Set through `set_train_precision` (conf key `train_precision` of the model / bench --train-precision).
 TRAIN_PRECISIONS = {"fp32": 0, "bf16": 1}
 colgram_precision = 0
+# thin sparse convolutions (a channel count of 8) on the matrix cores (csrc/spconv_mfma.hip, spconv_thin_mfma_kernel): "none"
+# (default: the per-voxel FMA kernels of spconv.hip - both forms wait for the 27 row gathers of a site and the FMA form hides them
+# better: profiles/r06_train_experiments.txt), "bf16" = under the bf16 training policy, "all" = also fp32-equivalent.  A/B switch.
+thin_mfma = os.environ.get("SURF_THIN_MFMA", "none")
 
 
 def set_train_precision(name):
@@ -1228,11 +1233,14 @@ def down_sites(coords, D, rule=DEFAULT_DOWN_RULE, q_max=None):
     return c2, t2, D2
 
 
-def spconv_pack_weights(weight):
+def spconv_pack_weights(weight, thin=False):
     """(27, Cin, Cout) fp32 device kernel -> split bf16 operand image of surf_spconv_mfma, or None when the channel pair
-    has no matrix-core kernel (Cin or Cout < 16)."""
+    has no matrix-core kernel.  Pairs with Cin or Cout < 16 (the finest lattices) are only packed with thin=True: their
+    matrix-core form pays under the bf16 training policy alone (one product per offset; csrc/spconv_mfma.hip)."""
     _chk(weight, torch.float32, "weight")
     cin, cout = int(weight.shape[1]), int(weight.shape[2])
+    if min(cin, cout) < 16 and not thin:
+        return None
     nbytes = _lib.lib().surf_spconv_packed_bytes(cin, cout)
     if nbytes == 0:
         return None
@@ -1283,14 +1291,14 @@ def set_count_pairs(on):
     count_pairs = bool(on)
 
 
-def dgrad_weights(weight, mode, use_mfma=True):
+def dgrad_weights(weight, mode, use_mfma=True, thin=False):
     """Kernel of the input-gradient convolution of a sparse convolution with `weight` (27, Cin, Cout): slices transposed
     (27, Cout, Cin), offsets mirrored for the submanifold mode; + its split-bf16 operand image for surf_spconv_mfma (None when
     use_mfma is off or a channel count is below 16)."""
     wt = weight.transpose(1, 2).contiguous()
     if mode == SUBM:
         wt = wt.flip(0).contiguous()
-    return wt, (spconv_pack_weights(wt) if use_mfma else None)
+    return wt, (spconv_pack_weights(wt, thin) if use_mfma else None)
 
 
 wgrad_up_from_coarse = True     # False: the transposed layers' weight gradient walks the fine sites (the form until round 5; A/B)

@@ -85,17 +85,17 @@ class _Block(nn.Module):
         shift = bn.bias.detach() - bn.running_mean * scale
         return scale.float().contiguous(), shift.float().contiguous()
 
-    def prepared(self, use_mfma=True, affine=True):
+    def prepared(self, use_mfma=True, affine=True, thin=False):
         """(kernel, bn scale, bn shift, split-bf16 operand image or None), cached until a parameter or buffer changes
         (optimiser step, load_state_dict, .to(device)): saves five small launches per convolution and the repacking.
         The running statistics are also written by surf_bn_train_affine through raw pointers, which torch's version
         counters do not see: the train path sets `_bn_dirty`.  affine=False (train mode: batch statistics, the folded
         running-statistics affine is not used): scale / shift are None and nothing is computed for them."""
         conv, bn = self.net[0], self.net[1]
-        wkey = (conv.kernel._version, conv.kernel.data_ptr(), bool(use_mfma))
+        wkey = (conv.kernel._version, conv.kernel.data_ptr(), bool(use_mfma), bool(thin))
         if getattr(self, "_wprep", None) is None or self._wprep[0] != wkey:
             w = self.walk_kernel()
-            self._wprep = (wkey, w, ops.spconv_pack_weights(w) if use_mfma else None)
+            self._wprep = (wkey, w, ops.spconv_pack_weights(w, thin) if use_mfma else None)
         if not affine:
             return self._wprep[1], None, None, self._wprep[2]
         ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
@@ -105,13 +105,13 @@ class _Block(nn.Module):
             self._bn_dirty = False
         return self._wprep[1], self._bprep[1], self._bprep[2], self._wprep[2]
 
-    def prepared_dgrad(self, mode, use_mfma=True):
+    def prepared_dgrad(self, mode, use_mfma=True, thin=False):
         """ops.dgrad_weights of this block's kernel (transposed / mirrored slices + their split-bf16 image), cached per
         parameter version: one re-layout per optimiser step instead of one per backward call."""
         conv = self.net[0]
-        key = (conv.kernel._version, conv.kernel.data_ptr(), int(mode), bool(use_mfma))
+        key = (conv.kernel._version, conv.kernel.data_ptr(), int(mode), bool(use_mfma), bool(thin))
         if getattr(self, "_tprep", None) is None or self._tprep[0] != key:
-            self._tprep = (key, ops.dgrad_weights(self.walk_kernel(), mode, use_mfma))
+            self._tprep = (key, ops.dgrad_weights(self.walk_kernel(), mode, use_mfma, thin))
         return self._tprep[1]
 
 
@@ -153,10 +153,13 @@ class SparseCostRegNet(nn.Module):
     def _conv(self, blk, x, in_site, out_site, mode, skip=None, tape=None, counters=None):
         """One block on x (rows of `in_site` = (table, coords)) -> rows of `out_site`.  tape: a list that receives what
         `backward` needs (train mode only: eval mode folds the BN into the convolution epilogue and keeps no raw output)."""
-        w, scale, shift, packed = blk.prepared(self.use_mfma, affine=not self.training)
+        # train_precision = bf16: every layer on the matrix cores with bf16-rounded operands, one product per offset - the thin
+        # layers of the finest lattices too (round 6: their weights are only packed under this policy)
+        thin = ops.thin_mfma == "all" or (ops.thin_mfma == "bf16" and self.training and ops.colgram_precision == 1)
+        w, scale, shift, packed = blk.prepared(self.use_mfma, affine=not self.training, thin=thin)
         if self.training:   # batch statistics, running statistics updated
             raw = ops.spconv(x, in_site[0], out_site[1], mode, w, None, None, None, packed=packed,
-                             bf16=ops.colgram_precision == 1)       # train_precision = bf16: wide layers on bf16 operands
+                             bf16=ops.colgram_precision == 1)
             blk._bn_dirty = True
             saved = {} if tape is not None else None
             y = ops.bn_train_relu(raw, blk.net[1], skip, saved, counters=counters)
@@ -245,7 +248,9 @@ class SparseCostRegNet(nn.Module):
             acc(bn.bias, dbeta)
             dx, dW = ops.spconv_backward(e["x"], e["in_site"][0], e["in_site"][1], e["out_site"][0], e["out_site"][1], e["mode"],
                                          e["w"], draw, use_mfma=self.use_mfma,
-                                         dgrad=e["blk"].prepared_dgrad(e["mode"], self.use_mfma))
+                                         dgrad=e["blk"].prepared_dgrad(e["mode"], self.use_mfma,
+                                                                       thin=ops.thin_mfma == "all" or
+                                                                       (ops.thin_mfma == "bf16" and ops.colgram_precision == 1)))
             idx = e["blk"].slice_index(dW.device)          # back to checkpoint slice order (the permutation is an involution)
             acc(e["blk"].net[0].kernel, dW if idx is None else dW.index_select(0, idx))
             add(e["x"], dx)
