@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 37
+#define SURF_ABI_VERSION 38
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -401,6 +401,20 @@ int surf_matching_depth(const float* mvol, int D, int nv, const float* h_kinv, c
 int surf_spconv(const float* in, int cin, const int32_t* in_table, int D_in, const int32_t* out_coords, int64_t n_out,
                 int mode, const float* weight, int cout, const float* bn_scale, const float* bn_shift, const float* skip,
                 float* out, void* stream);
+/* bf16 ROW STORAGE of the sparse U-Net under the bf16 training policy (round 6; conf key train_precision = bf16).  Activations
+ * keep their fp32 rows (BatchNorm statistics, skip sums, the backward's streaming reads) and get a bf16 SHADOW (n, C) uint16 that
+ * the gather side of the next convolution reads instead: surf_bn_relu_apply16 / surf_bn_relu_backward16 = the fp32 entry points
+ * below with the shadow of their output written in the same pass (out16 / dx16 may be NULL), surf_rows_to_bf16 for rows that come
+ * from elsewhere, surf_spconv_rows16 = surf_spconv (no BN epilogue) for the (16, 8) channel pair - the one where halving the row
+ * bytes pays - gathering from the shadow; fp32 weights, accumulation and output.  Never used by inference. */
+int surf_spconv_rows16(const uint16_t* in16, int cin, const int32_t* in_table, int D_in, const int32_t* out_coords, int64_t n_out,
+                       int mode, const float* weight, int cout, float* out, void* stream);
+int surf_rows_to_bf16(const float* x, int64_t n_floats, uint16_t* out16, void* stream);
+int surf_bn_relu_apply16(const float* x, int64_t n, int channels, const float* scale, const float* shift, const float* skip,
+                         float* out, uint16_t* out16, void* stream);
+int surf_bn_relu_backward16(const float* x, const float* dy, int64_t n, int channels, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, int train, void* workspace, float* dgamma, float* dbeta,
+                            float* dx, uint16_t* dx16, void* stream);
 /*
  * The same convolution on the matrix cores for the wide layers (C_in, C_out in {16, 32, 64}): per-offset gather-GEMM,
  * fp32 operands split exactly into three bf16 pieces (fp32-equivalent results).  surf_spconv_packed_bytes returns 0 for a

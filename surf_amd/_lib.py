@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
 # must equal SURF_ABI_VERSION of include/surf_hip.h (tests/test_host_modules.py compares the two texts); lib() refuses a
 # library built from another header
-ABI_VERSION = 37
+ABI_VERSION = 38
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -91,6 +91,10 @@ SIGNATURES = {
     "surf_compose_index": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr]),
     "surf_densify": (c_int, [c_ptr, c_ptr, c_int, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_spconv": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_spconv_rows16": (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr, c_i64, c_int, c_ptr, c_int, c_ptr, c_ptr]),
+    "surf_rows_to_bf16": (c_int, [c_ptr, c_i64, c_ptr, c_ptr]),
+    "surf_bn_relu_apply16": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_bn_relu_backward16": (c_int, [c_ptr, c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_bn_workspace_bytes": (c_i64, [c_int]),
     "surf_bn_train_affine": (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, ctypes.c_float, ctypes.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_matching_depth_backward": (c_int, [c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr,

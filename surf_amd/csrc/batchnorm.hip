@@ -92,9 +92,20 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   }
 }
 
+// bf16 (RNE) of a float as its 16 bits: the row shadows the bf16 training policy gathers from (round 6)
+__device__ __forceinline__ uint16_t bf16_bits(float v) { return __builtin_bit_cast(uint16_t, (__bf16)v); }
+typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restrict__ x, int64_t n4, uint16_t* __restrict__ out16) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+  reinterpret_cast<u16x4*>(out16)[i] = u16x4{bf16_bits(v[0]), bf16_bits(v[1]), bf16_bits(v[2]), bf16_bits(v[3])};
+}
+
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int64_t n4, int C4, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const float* __restrict__ skip,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, uint16_t* __restrict__ out16) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one 4-channel group
   if (i >= n4) return;
   const int c = (int)(i % C4) * 4;
@@ -105,6 +116,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   for (int q = 0; q < 4; ++q) y[q] = fmaxf(v[q] * sc[q] + sh[q], 0.f);
   if (skip) y += reinterpret_cast<const f32x4*>(skip)[i];
   reinterpret_cast<f32x4*>(out)[i] = y;
+  if (out16) reinterpret_cast<u16x4*>(out16)[i] = u16x4{bf16_bits(y[0]), bf16_bits(y[1]), bf16_bits(y[2]), bf16_bits(y[3])};
 }
 
 // ---- backward of y = relu(xhat gamma + beta) (+ skip), xhat = (x - mean) invstd -------------------------------------------
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ dgamma, const float* __restrict__ dbeta, int train,
-                                                           float* __restrict__ dx) {
+                                                           float* __restrict__ dx, uint16_t* __restrict__ dx16) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * C) return;
   const int c = (int)(i % C);
@@ -172,7 +184,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   const float xh = (xv - mean[c]) * invstd[c];
   float v = zb;
   if (train) v = zb - dbeta[c] / (float)n - xh * (dgamma[c] / (float)n);
-  dx[i] = scale[c] * v;                                               // gamma invstd = the forward's scale
+  const float o = scale[c] * v;                                       // gamma invstd = the forward's scale
+  dx[i] = o;
+  if (dx16) dx16[i] = bf16_bits(o);
 }
 
 // ---- InstanceNorm + ReLU backward for ALL views of an FPN layer in three launches (round 5) ---------------------------------
@@ -257,9 +271,9 @@ extern "C" int surf_inorm_relu_backward(const float* x, const float* dy, int N, 
   return surf_check_launch();
 }
 
-extern "C" int surf_bn_relu_backward(const float* x, const float* dy, int64_t n, int channels, const float* scale,
-                                     const float* shift, const float* mean, const float* invstd, int train, void* workspace,
-                                     float* dgamma, float* dbeta, float* dx, void* stream) {
+extern "C" int surf_bn_relu_backward16(const float* x, const float* dy, int64_t n, int channels, const float* scale,
+                                       const float* shift, const float* mean, const float* invstd, int train, void* workspace,
+                                       float* dgamma, float* dbeta, float* dx, uint16_t* dx16, void* stream) {
   if (!x || !dy || !scale || !shift || !mean || !invstd || !workspace || !dgamma || !dbeta || !dx || n <= 0) return SURF_E_ARG;
   const int64_t want = (n * channels + 255) / 256;
   const int blocks = (int)(want < BN_BLOCKS ? want : BN_BLOCKS);
@@ -274,8 +288,14 @@ extern "C" int surf_bn_relu_backward(const float* x, const float* dy, int64_t n,
   }
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(channels), dim3(256), 0, s, part, blocks, channels, dgamma, dbeta);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)((n * channels + 255) / 256)), dim3(256), 0, s, x, dy, n, channels,
-                     scale, shift, mean, invstd, dgamma, dbeta, train, dx);
+                     scale, shift, mean, invstd, dgamma, dbeta, train, dx, dx16);
   return surf_check_launch();
+}
+
+extern "C" int surf_bn_relu_backward(const float* x, const float* dy, int64_t n, int channels, const float* scale,
+                                     const float* shift, const float* mean, const float* invstd, int train, void* workspace,
+                                     float* dgamma, float* dbeta, float* dx, void* stream) {
+  return surf_bn_relu_backward16(x, dy, n, channels, scale, shift, mean, invstd, train, workspace, dgamma, dbeta, dx, nullptr, stream);
 }
 
 extern "C" int64_t surf_bn_workspace_bytes(int channels) { return (int64_t)BN_BLOCKS * 2 * channels * sizeof(double); }
@@ -301,11 +321,23 @@ extern "C" int surf_bn_train_affine(const float* x, int64_t n, int channels, con
   return surf_check_launch();
 }
 
-extern "C" int surf_bn_relu_apply(const float* x, int64_t n, int channels, const float* scale, const float* shift,
-                                  const float* skip, float* out, void* stream) {
+extern "C" int surf_bn_relu_apply16(const float* x, int64_t n, int channels, const float* scale, const float* shift,
+                                    const float* skip, float* out, uint16_t* out16, void* stream) {
   if (!x || !scale || !shift || !out || n <= 0 || channels < 4 || channels % 4) return SURF_E_ARG;
   const int64_t n4 = n * (channels / 4);
   hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n4, channels / 4,
-                     scale, shift, skip, out);
+                     scale, shift, skip, out, out16);
+  return surf_check_launch();
+}
+
+extern "C" int surf_bn_relu_apply(const float* x, int64_t n, int channels, const float* scale, const float* shift,
+                                  const float* skip, float* out, void* stream) {
+  return surf_bn_relu_apply16(x, n, channels, scale, shift, skip, out, nullptr, stream);
+}
+
+extern "C" int surf_rows_to_bf16(const float* x, int64_t n_floats, uint16_t* out16, void* stream) {
+  if (!x || !out16 || n_floats <= 0 || (n_floats & 3)) return SURF_E_ARG;
+  const int64_t n4 = n_floats / 4;
+  hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, n4, out16);
   return surf_check_launch();
 }

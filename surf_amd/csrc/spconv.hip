@@ -17,6 +17,7 @@ enum { MODE_SUBM = 0, MODE_DOWN = 1, MODE_UP = 2 };
 
 struct SpconvArgs {
   const float* in;          // (n_in, CIN)
+  const uint16_t* in16;     // (n_in, CIN) the same rows rounded to bf16 (spconv_pipe_kernel<.., true>), or null
   const int32_t* in_table;  // (Din^3) row of the input site or -1
   int Din;
   const int32_t* out_coords;  // (n_out, 3)
@@ -97,7 +98,10 @@ __global__ __launch_bounds__(256) void spconv_kernel(SpconvArgs a) {
 #ifndef SURF_SPCONV_PIPE
 #define SURF_SPCONV_PIPE 1
 #endif
-template <int CIN, int COUT, int MODE>
+// R16 (round 6, the bf16 training policy): the gathered rows are read from a bf16 copy (half the bytes per neighbour row) and
+// widened in registers; weights, accumulation and output stay fp32.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <int CIN, int COUT, int MODE, bool R16 = false>
 __global__ __launch_bounds__(256) void spconv_pipe_kernel(SpconvArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n_out) return;
@@ -129,18 +133,28 @@ __global__ __launch_bounds__(256) void spconv_pipe_kernel(SpconvArgs a) {
 #pragma unroll
   for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
   f32x4 cur[V], nxt[V];
-  {
-    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.in + (int64_t)max(rows[0], 0) * CIN);
+  auto fetch = [&](int row, f32x4 (&v)[V]) {
+    if constexpr (R16) {
+      const u32x4_t* __restrict__ src = reinterpret_cast<const u32x4_t*>(a.in16 + (int64_t)max(row, 0) * CIN);
 #pragma unroll
-    for (int c4 = 0; c4 < V; ++c4) cur[c4] = src[c4];
-  }
+      for (int c8 = 0; c8 < CIN / 8; ++c8) {
+        const u32x4_t u = src[c8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[2 * c8 + (j >> 1)][2 * (j & 1)] = __builtin_bit_cast(float, u[j] << 16);
+          v[2 * c8 + (j >> 1)][2 * (j & 1) + 1] = __builtin_bit_cast(float, u[j] & 0xffff0000u);
+        }
+      }
+    } else {
+      const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.in + (int64_t)max(row, 0) * CIN);
+#pragma unroll
+      for (int c4 = 0; c4 < V; ++c4) v[c4] = src[c4];
+    }
+  };
+  fetch(rows[0], cur);
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
-    if (k + 1 < 27) {
-      const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.in + (int64_t)max(rows[k + 1], 0) * CIN);
-#pragma unroll
-      for (int c4 = 0; c4 < V; ++c4) nxt[c4] = src[c4];
-    }
+    if (k + 1 < 27) fetch(rows[k + 1], nxt);
     if (rows[k] >= 0) {
       const float* __restrict__ Wk = a.weight + (int64_t)k * CIN * COUT;
 #pragma unroll
@@ -300,12 +314,32 @@ extern "C" int surf_spconv(const float* in, int cin, const int32_t* in_table, in
   if (!in || !in_table || !out_coords || !weight || !out || n_out <= 0 || D_in < 1) return SURF_E_ARG;
   if (mode < 0 || mode > 2 || ((bn_scale == nullptr) != (bn_shift == nullptr))) return SURF_E_ARG;
   SpconvArgs a;
-  a.in = in; a.in_table = in_table; a.Din = D_in; a.out_coords = out_coords; a.n_out = n_out; a.mode = mode;
+  a.in = in; a.in16 = nullptr; a.in_table = in_table; a.Din = D_in; a.out_coords = out_coords; a.n_out = n_out; a.mode = mode;
   a.weight = weight; a.scale = bn_scale; a.shift = bn_shift; a.skip = skip; a.out = out;
   SPCONV_PIPE_CASE(8, 8) SPCONV_PIPE_CASE(16, 8) SPCONV_PIPE_CASE(8, 16) SPCONV_PIPE_CASE(16, 16)     // the thin pairs, pipelined
   SPCONV_CASE(8, 8) SPCONV_CASE(16, 8) SPCONV_CASE(8, 16) SPCONV_CASE(16, 16) SPCONV_CASE(16, 32) SPCONV_CASE(32, 32)
   SPCONV_CASE(32, 64) SPCONV_CASE(64, 64) SPCONV_CASE(64, 32) SPCONV_CASE(32, 16)
   return SURF_E_LIMIT;  // channel pair not instantiated (reg_network.py uses d_base = 8 only)
+}
+
+// The thin pair whose input rows are 16 channels wide, with the gathered rows read from a bf16 copy (the bf16 training policy,
+// round 6): 64 -> 32 bytes per neighbour row, fp32 weights / accumulation / output.  Measured on the bench lattices
+// (scripts/time_spconv_rows16.py): <16,8> 0.84 -> 0.51, 1.41 -> 0.77, 0.86 -> 0.58 ms; the pairs with 8 input channels gain 5 %
+// (<8,16>) and (16,16) 7 % (it runs on the matrix cores anyway): only (16,8) is dispatched.
+extern "C" int surf_spconv_rows16(const uint16_t* in16, int cin, const int32_t* in_table, int D_in, const int32_t* out_coords,
+                                  int64_t n_out, int mode, const float* weight, int cout, float* out, void* stream) {
+  if (!in16 || !in_table || !out_coords || !weight || !out || n_out <= 0 || D_in < 1 || mode < 0 || mode > 2) return SURF_E_ARG;
+  if (cin != 16 || cout != 8) return SURF_E_LIMIT;
+  SpconvArgs a;
+  a.in = nullptr; a.in16 = in16; a.in_table = in_table; a.Din = D_in; a.out_coords = out_coords; a.n_out = n_out; a.mode = mode;
+  a.weight = weight; a.scale = nullptr; a.shift = nullptr; a.skip = nullptr; a.out = out;
+  if (mode == MODE_SUBM)
+    hipLaunchKernelGGL((spconv_pipe_kernel<16, 8, MODE_SUBM, true>), grid1d(n_out, 256), dim3(256), 0, (hipStream_t)stream, a);
+  else if (mode == MODE_DOWN)
+    hipLaunchKernelGGL((spconv_pipe_kernel<16, 8, MODE_DOWN, true>), grid1d(n_out, 256), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((spconv_pipe_kernel<16, 8, MODE_UP, true>), grid1d(n_out, 256), dim3(256), 0, (hipStream_t)stream, a);
+  return surf_check_launch();
 }
 
 extern "C" int surf_coords_bbox(const int32_t* coords, int64_t n, int32_t* bbox, void* stream) {

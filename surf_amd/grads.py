@@ -25,6 +25,8 @@ class GradSink:
 
 def accumulate(p, g, sink=None):
     g = g.reshape(p.shape).to(device=p.device, dtype=p.dtype)
+    if g.stride() != p.stride():        # e.g. one column of a wider buffer as a 1-element parameter's gradient: DistributedDataParallel
+        g = g.clone(memory_format=torch.contiguous_format)      # wants the parameter's layout in its bucket views (it warns otherwise)
     if sink is not None:
         sink.add(p, g)
     else:

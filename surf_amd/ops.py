@@ -553,6 +553,20 @@ colgram_precision = 0
 # (default: the per-voxel FMA kernels of spconv.hip - both forms wait for the 27 row gathers of a site and the FMA form hides them
 # better: profiles/r06_train_experiments.txt), "bf16" = under the bf16 training policy, "all" = also fp32-equivalent.  A/B switch.
 thin_mfma = os.environ.get("SURF_THIN_MFMA", "none")
+# bf16 ROW STORAGE of the sparse U-Net under the bf16 training policy (round 6): activations with 16 channels get a bf16 shadow
+# (written by the BatchNorm apply / backward kernels in the same pass) that the (16 -> 8) thin convolutions gather from - the one
+# channel pair where halving the row bytes pays (scripts/time_spconv_rows16.py: -35 .. -45 % per launch).  "0" = off (A/B switch).
+bf16_rows = os.environ.get("SURF_BF16_ROWS", "1") != "0"
+bf16_rows_all_modes = os.environ.get("SURF_BF16_ROWS") == "all"      # also the stride-2 / transposed (16 -> 8) layers (measured: no gain)
+
+
+def rows_to_bf16(x):
+    """(n, C) fp32 rows -> their bf16 (round-to-nearest-even) bits as an (n, C) int16 tensor."""
+    _chk(x, torch.float32, "x")
+    out = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+    if x.numel():
+        _lib.check(_lib.lib().surf_rows_to_bf16(_p(x), x.numel(), _p(out), _stream()), "surf_rows_to_bf16")
+    return out
 
 
 def set_train_precision(name):
@@ -1272,6 +1286,15 @@ def spconv(x, in_table, out_coords, mode, weight, bn_scale=None, bn_shift=None, 
                                          _stream())
         _lib.check(rc, "surf_spconv_mfma")
         return out
+    if bf16 and bf16_rows and cin == 16 and cout == 8 and bn_scale is None and skip is None and (mode == SUBM or bf16_rows_all_modes):
+        # the bf16 training policy: gather from the rows' bf16 shadow (attached by bn_train_relu / bn_relu_backward, or made here)
+        r16 = getattr(x, "_rows16", None)
+        if r16 is None:
+            r16 = rows_to_bf16(x)
+        rc = _lib.lib().surf_spconv_rows16(_p(r16), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords), out_coords.shape[0],
+                                           int(mode), _p(weight), cout, _p(out), _stream())
+        _lib.check(rc, "surf_spconv_rows16")
+        return out
     rc = _lib.lib().surf_spconv(_p(x), cin, _p(in_table), int(in_table.shape[0]), _p(out_coords), out_coords.shape[0], int(mode),
                                 _p(weight), cout, _p(bn_scale), _p(bn_shift), _p(skip), _p(out), _stream())
     _lib.check(rc, "surf_spconv")
@@ -1356,7 +1379,7 @@ def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight,
     return dx, dW
 
 
-def bn_train_relu(x, bn, skip=None, saved=None, counters=None):
+def bn_train_relu(x, bn, skip=None, saved=None, counters=None, shadow=False):
     """spnn.BatchNorm in train mode + ReLU (+ skip) on raw convolution outputs x (n, C): batch statistics, running
     statistics updated in place like torch (reg_network.py:14-15,28-29).  bn: the block's nn.BatchNorm1d.
     saved: a dict that receives what bn_relu_backward needs (scale, shift, stats = mean | invstd).
@@ -1385,11 +1408,15 @@ def bn_train_relu(x, bn, skip=None, saved=None, counters=None):
             bn.num_batches_tracked += 1
     if saved is not None:
         saved.update(scale=scale, shift=shift, stats=stats)
-    _lib.check(_lib.lib().surf_bn_relu_apply(_p(x), n, C, _p(scale), _p(shift), _p(skip), _p(out), _stream()), "surf_bn_relu_apply")
+    out16 = torch.empty(n, C, dtype=torch.int16, device=dev) if shadow else None     # shadow: the rows' bf16 copy (ops.bf16_rows)
+    _lib.check(_lib.lib().surf_bn_relu_apply16(_p(x), n, C, _p(scale), _p(shift), _p(skip), _p(out), _p(out16), _stream()),
+               "surf_bn_relu_apply16")
+    if shadow:
+        out._rows16 = out16
     return out
 
 
-def bn_relu_backward(x, dy, scale, shift, stats, train=True):
+def bn_relu_backward(x, dy, scale, shift, stats, train=True, shadow=False):
     """Backward of bn_train_relu (train) / of the folded eval-mode BN + ReLU (train=False): x the raw convolution output
     (n, C), dy the gradient of the block output (which is also the skip's gradient), scale / shift the forward's affine,
     stats = mean | invstd (2C).  Returns (dx (n, C), dgamma (C), dbeta (C))."""
@@ -1404,9 +1431,12 @@ def bn_relu_backward(x, dy, scale, shift, stats, train=True):
     dgamma, dbeta = dgb[0], dgb[1]
     ws = torch.empty(_lib.lib().surf_bn_workspace_bytes(C), dtype=torch.uint8, device=dev)
     mean, invstd = stats[:C], stats[C:]
-    rc = _lib.lib().surf_bn_relu_backward(_p(x), _p(dy), n, C, _p(scale), _p(shift), _p(mean), _p(invstd), int(bool(train)),
-                                          _p(ws), _p(dgamma), _p(dbeta), _p(dx), _stream())
-    _lib.check(rc, "surf_bn_relu_backward")
+    dx16 = torch.empty(n, C, dtype=torch.int16, device=dev) if shadow else None
+    rc = _lib.lib().surf_bn_relu_backward16(_p(x), _p(dy), n, C, _p(scale), _p(shift), _p(mean), _p(invstd), int(bool(train)),
+                                            _p(ws), _p(dgamma), _p(dbeta), _p(dx), _p(dx16), _stream())
+    _lib.check(rc, "surf_bn_relu_backward16")
+    if shadow:
+        dx._rows16 = dx16
     return dx, dgamma, dbeta
 
 

@@ -162,7 +162,9 @@ class SparseCostRegNet(nn.Module):
                              bf16=ops.colgram_precision == 1)
             blk._bn_dirty = True
             saved = {} if tape is not None else None
-            y = ops.bn_train_relu(raw, blk.net[1], skip, saved, counters=counters)
+            # bf16 policy: 16-channel rows get a bf16 shadow in the same pass; the (16 -> 8) convolutions gather from it
+            shadow = ops.colgram_precision == 1 and ops.bf16_rows and raw.shape[1] == 16
+            y = ops.bn_train_relu(raw, blk.net[1], skip, saved, counters=counters, shadow=shadow)
             if tape is not None:
                 tape.append(dict(blk=blk, x=x, raw=raw, y=y, skip=skip, in_site=in_site, out_site=out_site, mode=mode, w=w, **saved))
             return y
@@ -242,7 +244,8 @@ class SparseCostRegNet(nn.Module):
                 add(e["skip"], g)
             if e["raw"].shape[0] == 0:        # an empty level (tiny lattices): nothing flows through this block
                 continue
-            draw, dgamma, dbeta = ops.bn_relu_backward(e["raw"], g.contiguous(), e["scale"], e["shift"], e["stats"], train=True)
+            draw, dgamma, dbeta = ops.bn_relu_backward(e["raw"], g.contiguous(), e["scale"], e["shift"], e["stats"], train=True,
+                                                       shadow=ops.colgram_precision == 1 and ops.bf16_rows and e["raw"].shape[1] == 16)
             bn = e["blk"].net[1]
             acc(bn.weight, dgamma)
             acc(bn.bias, dbeta)

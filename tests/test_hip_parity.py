@@ -1970,3 +1970,44 @@ def test_fpn_mfma_weight_gradient_matches_the_valu_kernel(cb, cs, stride):
     rel_close(out, ref, 1e-5, 2e-6 * scale)
     rel_close(lo, ref, 2e-2, 2e-2 * scale)
     assert float((lo - ref).abs().max()) > 1e-6 * scale
+
+
+def test_bf16_row_shadows_and_the_rows16_convolution():
+    """bf16 ROW STORAGE of the sparse U-Net (round 6, the bf16 training policy): the shadows written by the BatchNorm apply / backward
+    kernels and by surf_rows_to_bf16 are torch's own bf16 rounding of the fp32 rows bit for bit; surf_spconv_rows16 (the (16, 8)
+    pair gathering from the shadow) equals the fp32 kernel on the rounded rows EXACTLY in the three modes (same FMA order) and the
+    unrounded convolution within a bf16 rounding of one operand."""
+    from surf_amd import ops
+    d = dev()
+    g = torch.Generator().manual_seed(31)
+    D = 24
+    occ = torch.rand(D, D, D, generator=g) < 0.3
+    coords = occ.nonzero().to(torch.int32)
+    coords = coords[: coords.shape[0] - (coords.shape[0] % 128) + 53].contiguous().to(d)
+    n = coords.shape[0]
+    table = ops.table_from_coords(coords, D)
+    cd, tcd, D2 = ops.down_sites(coords, D, "dilate")
+    x = torch.randn(n, 16, generator=g).to(d)
+    bits = lambda t: t.to(torch.bfloat16).view(torch.int16)          # noqa: E731
+    assert torch.equal(ops.rows_to_bf16(x), bits(x))
+    bn = torch.nn.BatchNorm1d(16).to(d).train()
+    saved = {}
+    y = ops.bn_train_relu(x, bn, None, saved, shadow=True)
+    y0 = ops.bn_train_relu(x, torch.nn.BatchNorm1d(16).to(d).train(), None, {})
+    assert torch.equal(y, y0) and torch.equal(y._rows16, bits(y))
+    dy = torch.randn(n, 16, generator=g).to(d)
+    dx, dgam, dbet = ops.bn_relu_backward(x, dy, saved["scale"], saved["shift"], saved["stats"], train=True, shadow=True)
+    dx0, _, _ = ops.bn_relu_backward(x, dy, saved["scale"], saved["shift"], saved["stats"], train=True)
+    assert torch.equal(dx, dx0) and torch.equal(dx._rows16, bits(dx))
+    w = (torch.randn(27, 16, 8, generator=g) / (27 * 16) ** 0.5).to(d)
+    x_c = torch.randn(cd.shape[0], 16, generator=g).to(d)
+    xr, xcr = x.to(torch.bfloat16).float(), x_c.to(torch.bfloat16).float()
+    for src, rounded, tab, oc, mode in ((x, xr, table, coords, ops.SUBM), (x, xr, table, cd, ops.DOWN), (x_c, xcr, tcd, coords, ops.UP)):
+        exact = ops.spconv(rounded, tab, oc, mode, w)
+        got = ops.spconv(src, tab, oc, mode, w, bf16=True)                       # converts on the fly: no shadow attached
+        assert torch.equal(got, exact)
+        src._rows16 = ops.rows_to_bf16(src)
+        assert torch.equal(ops.spconv(src, tab, oc, mode, w, bf16=True), exact)  # ... and from an attached shadow
+        full = ops.spconv(src, tab, oc, mode, w)
+        rel_close(got, full, 1e-2, 1e-2 * float(full.abs().max()))
+        assert float((got - full).abs().max()) > 0
