@@ -754,7 +754,7 @@ def parse_args(argv):
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--views", type=int, default=None)
     ap.add_argument("--n-samples", type=str, default=None)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="time budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of the CPU baseline (0 = skip)")
     ap.add_argument("--build", type=int, default=1, help="also time one full volume build (FPN + 4 stages), N=1 only")
     ap.add_argument("--train-step", type=int, default=1, help="also time one full training step (N=1, dtu workload)")
     ap.add_argument("--mesh-grid", type=int, default=512, help="also time the resolution^3 SDF lattice of "

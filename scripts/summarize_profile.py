@@ -26,7 +26,7 @@ def ours(name):
 f = newest(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")))
 rows = list(csv.DictReader(open(f)))
 with open(os.path.join(dst, f"{tag}_bench_kernel_stats.csv"), "w") as w:
-    w.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-seconds 0 --train-step 0   (= the default bench command without its CPU-baseline leg and without the extra training-step timing, whose small launches of the same kernels would dilute the per-kernel averages; MI355X, {tag})\n")
+    w.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --cpu-seconds 0 --train-step 0 --other-configs 0   (= the default bench command without its CPU-baseline leg, without the other BASELINE configs and without the extra training-step timing, whose small launches of the same kernels would dilute the per-kernel averages; MI355X, {tag})\n")
     w.write("# surf_amd kernels verbatim; torch helper kernels (synthetic scene construction) summed in the last row\n")
     w.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev\n")
     other = 0

@@ -755,7 +755,7 @@ __global__ void costvol_bwd_finalize_kernel(const float* __restrict__ replicas, 
 // that merged requests inside a wavefront moved the kernel (see above): the voxels that share a texel are the ones along a
 // viewing ray, far apart in lattice order.  So the adds are sorted COARSELY instead: costvol_bwd_kernel leaves one 32-byte
 // record per (view, voxel) - the feature gradient and the normalised image position - a counting sort (LDS histograms, one
-// reservation per workgroup and bucket) lists the records of every 32 x 32-pixel tile of every view, and one workgroup per
+// reservation per workgroup and bucket) lists the records of every 16 x 16-pixel tile (CVT) of every view, and one workgroup per
 // (view, tile) accumulates its records into LDS images of the tile at the pyramid levels the stage reads and sends each touched
 // texel to memory ONCE.  Requests per step: 200 M 32-byte adds -> ~15 M coalesced ones.
 // The LDS images are 64-bit FIXED POINT: ds_add_f32 costs 81 ns per wave-instruction and CU on gfx950, ds_add_u64 5.5

@@ -2002,12 +2002,18 @@ def test_bf16_row_shadows_and_the_rows16_convolution():
     w = (torch.randn(27, 16, 8, generator=g) / (27 * 16) ** 0.5).to(d)
     x_c = torch.randn(cd.shape[0], 16, generator=g).to(d)
     xr, xcr = x.to(torch.bfloat16).float(), x_c.to(torch.bfloat16).float()
-    for src, rounded, tab, oc, mode in ((x, xr, table, coords, ops.SUBM), (x, xr, table, cd, ops.DOWN), (x_c, xcr, tcd, coords, ops.UP)):
-        exact = ops.spconv(rounded, tab, oc, mode, w)
-        got = ops.spconv(src, tab, oc, mode, w, bf16=True)                       # converts on the fly: no shadow attached
-        assert torch.equal(got, exact)
-        src._rows16 = ops.rows_to_bf16(src)
-        assert torch.equal(ops.spconv(src, tab, oc, mode, w, bf16=True), exact)  # ... and from an attached shadow
-        full = ops.spconv(src, tab, oc, mode, w)
-        rel_close(got, full, 1e-2, 1e-2 * float(full.abs().max()))
-        assert float((got - full).abs().max()) > 0
+    saved_modes, ops.bf16_rows_all_modes = ops.bf16_rows_all_modes, True          # (by default only the submanifold layers are dispatched)
+    try:
+        for src, rounded, tab, oc, mode in ((x, xr, table, coords, ops.SUBM), (x, xr, table, cd, ops.DOWN), (x_c, xcr, tcd, coords, ops.UP)):
+            exact = ops.spconv(rounded, tab, oc, mode, w)
+            got = ops.spconv(src, tab, oc, mode, w, bf16=True)                       # converts on the fly: no shadow attached
+            assert torch.equal(got, exact)
+            src._rows16 = ops.rows_to_bf16(src)
+            assert torch.equal(ops.spconv(src, tab, oc, mode, w, bf16=True), exact)  # ... and from an attached shadow
+            full = ops.spconv(src, tab, oc, mode, w)
+            rel_close(got, full, 1e-2, 1e-2 * float(full.abs().max()))
+            assert float((got - full).abs().max()) > 0
+    finally:
+        ops.bf16_rows_all_modes = saved_modes
+    # default dispatch: a stride-2 / transposed (16 -> 8) layer keeps its fp32 rows even under the policy
+    assert torch.equal(ops.spconv(x, table, cd, ops.DOWN, w, bf16=True), ops.spconv(x, table, cd, ops.DOWN, w))
