@@ -13,6 +13,8 @@
 //   features  dF[row_c] += w_c phibar + (grad w_c . v) phi'bar     (float atomics into the sparse volumes' gradient rows)
 // Plain fp32 FMAs, one wavefront per 4 samples, same lane ownership as sdf_smooth.hip (whose packed weight image it reads);
 // round 6: SURF_TRAIN_WAVES wavefronts per workgroup share the weight stream through LDS (sdf_train_common.h).
+#include <stdlib.h>
+
 #include "sdf_train_common.h"
 
 // weight rows in flight per step of the k / neuron loops (the loops wait for one L2 round trip per unrolled group)
@@ -308,6 +310,12 @@ __global__ __launch_bounds__(surf_train::NT) void sdf_bwd_kernel(BwdArgs a) {
 
 }  // namespace
 
+// sdf_train_mfma.hip (round 6, the default): the same function layer by layer on the bf16 matrix pipe (bf16x3, fp32-equivalent);
+// SURF_SDF_TRAIN_VALU=1 in the environment keeps the monolithic FMA kernel of this file (A/B switch, tests).
+int surf_sdf_backward_layers(const float* pts, const float* ybar, const float* gbar, int64_t n, const float* const* h_vols,
+                             const int32_t* const* h_tables, const int* h_dims, int n_vol, float* const* h_dvols,
+                             const float* packed, float* in_v, float* in_d, float* tb, float* tdb, hipStream_t stream);
+
 // per-sample buffers (floats): in_v / in_d: 7 n 160 each; tb / tdb: 6 n 128 each
 extern "C" int surf_sdf_backward(const float* pts, const float* ybar, const float* gbar, int64_t n, const float* const* h_vols,
                                  const int32_t* const* h_tables, const int* h_dims, int n_vol, float* const* h_dvols,
@@ -324,6 +332,9 @@ extern "C" int surf_sdf_backward(const float* pts, const float* ybar, const floa
     a.dvols[s] = (s < n_vol && h_dvols) ? h_dvols[s] : nullptr;
     if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
   }
+  if (!getenv("SURF_SDF_TRAIN_VALU"))
+    return surf_sdf_backward_layers(pts, ybar, gbar, n, h_vols, h_tables, h_dims, n_vol, h_dvols, packed, in_v, in_d, tb, tdb,
+                                    (hipStream_t)stream);
   const int64_t blocks = (n + S * surf_train::NW - 1) / (S * surf_train::NW);
   if (blocks > 0x7fffffff) return SURF_E_LIMIT;
   hipLaunchKernelGGL(sdf_bwd_kernel, dim3((unsigned)blocks), dim3(surf_train::NT), 0, (hipStream_t)stream, a);

@@ -171,17 +171,23 @@ __global__ __launch_bounds__(surf_train::NT) void sdf_smooth_kernel(SmoothArgs a
 #pragma unroll
   for (int l = 0; l < N_HID; ++l) {
     const float* __restrict__ wt = a.packed + OFF_WT + l * KP * NH;
-    surf_train::V4 acc[2], accd[2];
+    float acc[2][S], accd[2][S];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) { acc[j].zero(); accd[j].zero(); }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int s = 0; s < S; ++s) acc[j][s] = accd[j][s] = 0.f;
     const int K = layer_k(l);
     surf_train::stream_rows<NH>(wt, K, wbuf, [&](int k, const float* __restrict__ wr) {
       const float w0 = wr[lane], w1 = wr[64 + lane];
       const f32x4 xv4 = *reinterpret_cast<const f32x4*>(&xin_t[k * XS]), xd4 = *reinterpret_cast<const f32x4*>(&xin_t[k * XS + S]);
-      acc[0].fma(w0, xv4);
-      acc[1].fma(w1, xv4);
-      accd[0].fma(w0, xd4);
-      accd[1].fma(w1, xd4);
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const float x = xv4[s], xd = xd4[s];
+        acc[0][s] = fmaf(w0, x, acc[0][s]);
+        acc[1][s] = fmaf(w1, x, acc[1][s]);
+        accd[0][s] = fmaf(w0, xd, accd[0][s]);
+        accd[1][s] = fmaf(w1, xd, accd[1][s]);
+      }
     });
     __syncthreads();                                  // every lane has read in_* before the outputs overwrite it
     const int N = layer_n(l);
@@ -224,32 +230,37 @@ __global__ __launch_bounds__(surf_train::NT) void sdf_smooth_kernel(SmoothArgs a
   for (int s = 0; s < S; ++s) gphi[s] = gphid[s] = gev[s] = ged[s] = 0.f;
 #pragma unroll
   for (int l = N_HID; l >= 0; --l) {
-    surf_train::V4 g[3], gd[3];
+    float g[3][S], gd[3][S];
     if (l == N_HID) {                                 // d_6 = e_0: g = row 0 of lin6, g' = 0
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int k = lane + 64 * j;
         const float w = k < KP ? a.packed[OFF_W6 + k] : 0.f;
-        gd[j].zero();
 #pragma unroll
-        for (int s = 0; s < S; ++s) g[j].set(s, w);
+        for (int s = 0; s < S; ++s) { g[j][s] = w; gd[j][s] = 0.f; }
       }
     } else {
       const float* __restrict__ w = a.packed + OFF_W + l * NH * KP;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) { g[j].zero(); gd[j].zero(); }
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int s = 0; s < S; ++s) g[j][s] = gd[j][s] = 0.f;
       const int N = layer_n(l);
       const bool third = lane < KP - 128;
       surf_train::stream_rows<KP>(w, N, wbuf, [&](int nrn, const float* __restrict__ wr) {
         const float w0 = wr[lane], w1 = wr[64 + lane];
         const float w2 = third ? wr[128 + lane] : 0.f;
         const f32x4 dv4 = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS]), dd4 = *reinterpret_cast<const f32x4*>(&dl_t[nrn * XS + S]);
-        g[0].fma(w0, dv4);
-        g[1].fma(w1, dv4);
-        g[2].fma(w2, dv4);
-        gd[0].fma(w0, dd4);
-        gd[1].fma(w1, dd4);
-        gd[2].fma(w2, dd4);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const float d = dv4[s], dd = dd4[s];
+          g[0][s] = fmaf(w0, d, g[0][s]);
+          g[1][s] = fmaf(w1, d, g[1][s]);
+          g[2][s] = fmaf(w2, d, g[2][s]);
+          gd[0][s] = fmaf(w0, dd, gd[0][s]);
+          gd[1][s] = fmaf(w1, dd, gd[1][s]);
+          gd[2][s] = fmaf(w2, dd, gd[2][s]);
+        }
       });
       __syncthreads();                                // dl_* fully consumed
     }

@@ -15,6 +15,8 @@
 //             streams are 4 n contiguous rows, one tall-skinny GEMM per layer)
 //   features  dF[row_c] += w_c pbar + (grad w_c . u) pbar_u + (grad w_c . s) pbar_s + (u^T Hess w_c s) pbar_m
 // Plain fp32 FMAs, one wavefront per 4 samples, same lane ownership and packed weight image as sdf_bwd.hip / sdf_smooth.hip.
+#include <stdlib.h>
+
 #include "common.h"
 
 // weight rows in flight per step of the k / neuron loops (the loops wait for one L2 round trip per unrolled group)
@@ -348,6 +350,12 @@ SURF_TRAIN_UNROLL_PRAGMA
 
 }  // namespace
 
+// sdf_train_mfma.hip (round 6, the default): the same function layer by layer on the bf16 matrix pipe (bf16x3, fp32-equivalent);
+// SURF_SDF_TRAIN_VALU=1 in the environment keeps the monolithic FMA kernel of this file (A/B switch, tests).
+int surf_sdf_smooth_backward_layers(const float* pts, const float* sbar, int64_t n, const float* const* h_vols,
+                                    const int32_t* const* h_tables, const int* h_dims, int n_vol, float* const* h_dvols,
+                                    const float* packed, float* in, float* ab, hipStream_t stream);
+
 // per-sample buffers (floats): in: 7 x 4 x n x 160; ab: 6 x 4 x n x 128 (stream order value | u | s | mixed)
 extern "C" int surf_sdf_smooth_backward(const float* pts, const float* sbar, int64_t n, const float* const* h_vols,
                                         const int32_t* const* h_tables, const int* h_dims, int n_vol, float* const* h_dvols,
@@ -364,6 +372,8 @@ extern "C" int surf_sdf_smooth_backward(const float* pts, const float* sbar, int
     a.dvols[s] = (s < n_vol && h_dvols) ? h_dvols[s] : nullptr;
     if (s < n_vol && (!h_vols[s] || !h_tables[s] || h_dims[s] <= 1)) return SURF_E_ARG;
   }
+  if (!getenv("SURF_SDF_TRAIN_VALU"))
+    return surf_sdf_smooth_backward_layers(pts, sbar, n, h_vols, h_tables, h_dims, n_vol, h_dvols, packed, in, ab, (hipStream_t)stream);
   const int64_t blocks = (n + S - 1) / S;
   if (blocks > 0x7fffffff) return SURF_E_LIMIT;
   hipLaunchKernelGGL(sdf_smooth_bwd_kernel, dim3((unsigned)blocks), dim3(64), 0, (hipStream_t)stream, a);
