@@ -68,11 +68,16 @@ for k, v in V.items():
     print(f"{k:12s} {v}")
 print("split check", oc["split_rays"]["split"]["check"], "| collective_backend", b["collective_backend"])
 if "--fill" in sys.argv:
-    for name in ("DESIGN.md",):
-        s = open(name).read()
+    tm = open("scripts/design_tables.tmpl").read()
+    parts = dict(re.findall(r"=== (\w+)\n(.*?)(?==== |\Z)", tm, re.S))
+    def sub(x):
         for k, v in V.items():
-            s = s.replace(f"@{k}@", v)
-        left = re.findall(r"@[A-Z0-9_]+@", s)
-        assert not left, left
-        open(name, "w").write(s)
-    print("filled")
+            x = x.replace(f"@{k}@", v)
+        assert not re.findall(r"@[A-Z0-9_]+@", x), re.findall(r"@[A-Z0-9_]+@", x)
+        return x
+    d = open("DESIGN.md").read()
+    d = re.sub(r"(<!-- T0[^>]*-->\n).*?(<!-- /T0 -->)", lambda m: m.group(1) + sub(parts["T0"]) + m.group(2), d, flags=re.S)
+    d = re.sub(r"(<!-- T5 -->\n).*?(<!-- /T5 -->)", lambda m: m.group(1) + sub(parts["T5HDR"] + parts["T5"]) + m.group(2), d, flags=re.S)
+    d = re.sub(r"kernel sources `csrc_sha256 [0-9a-f]{16}`", f"kernel sources `csrc_sha256 {V['SHA']}`", d)
+    open("DESIGN.md", "w").write(d)
+    print("filled the T0 / T5 tables of DESIGN.md")

@@ -97,7 +97,7 @@ TRAIN = PRELUDE + textwrap.dedent("""
     stepper = model
     if mode == "ddp":                                           # runner.py:102
         stepper = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
-    losses = []
+    losses, grads1 = [], None
     for it in range(2):
         torch.manual_seed(70 + it)
         if mode == "ddp":                                       # the reference's own sequence, runner.py:152-165
@@ -109,14 +109,14 @@ TRAIN = PRELUDE + textwrap.dedent("""
             losses.append(float(loss.detach()))
         else:                                                   # "group": explicit flat-bucket all-reduce inside train_step
             losses.append(training.train_step(model, ipts, tg, loss_fn, opt, 1.0, 3)["loss"])
+        if it == 0:                                             # step-1 gradients: same parameters in every mode, after the all-reduce
+            grads1 = {n: (p.grad.detach().float().cpu().clone() if p.grad is not None else None) for n, p in model.named_parameters()}
     torch.cuda.synchronize()
     h = hashlib.sha256()
-    sums = {}
     for n, p in model.named_parameters():
-        a = p.detach().cpu().contiguous()
-        h.update(n.encode() + a.numpy().tobytes())
-        sums[n] = [float(a.double().sum()), float(a.double().abs().sum())]
-    print("RESULT " + json.dumps({"sha": h.hexdigest(), "sums": sums, "losses": losses}))
+        h.update(n.encode() + p.detach().cpu().contiguous().numpy().tobytes())
+    torch.save({"grads1": grads1, "params": {n: p.detach().cpu() for n, p in model.named_parameters()}}, sys.argv[2])
+    print("RESULT " + json.dumps({"sha": h.hexdigest(), "losses": losses, "dump": sys.argv[2]}))
     D.shutdown()
 """)
 
@@ -127,10 +127,15 @@ def _env():
     return env
 
 
+_N_DUMPS = [0]
+
+
 def _worker(tmp_path, name, text, mode):
     script = tmp_path / name
     script.write_text(text)
-    res = subprocess.run([sys.executable, str(script), mode], env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    _N_DUMPS[0] += 1
+    dump = str(tmp_path / f"{mode}{_N_DUMPS[0]}.pt")
+    res = subprocess.run([sys.executable, str(script), mode, dump], env=_env(), capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-3000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1]
     return json.loads(line[len("RESULT "):])
@@ -145,11 +150,26 @@ def test_world1_rccl_collectives_are_the_identity(tmp_path):
     assert r["note"].startswith("nccl") and "world 1" in r["note"]
 
 
-def _rel(a, b):
-    worst = 0.0
-    for n, (s, ab) in a["sums"].items():
-        worst = max(worst, abs(s - b["sums"][n][0]) / max(ab, 1e-9))
-    return worst
+def _grad_gap(a, b):
+    """Worst per-parameter max |g_a - g_b| of the FIRST step's gradients (identical parameters in every mode, so the only
+    legitimate difference is the order of the float atomics), each normalised by that gradient's own max plus 1e-4 of the
+    largest gradient of the model: a parameter whose gradient is pure rounding noise cannot decide the test.  (Comparing the
+    parameters after Adam steps cannot: Adam maps a +-1e-12 gradient to a full +-lr update, so rounding noise on a
+    near-zero-gradient parameter becomes an O(1) relative difference - seen as a flake in round 6.)"""
+    ga, gb = torch.load(a["dump"])["grads1"], torch.load(b["dump"])["grads1"]
+    assert ga.keys() == gb.keys()
+    top = max(float(v.abs().max()) for v in ga.values() if v is not None)
+    worst, where = 0.0, None
+    for n, x in ga.items():
+        y = gb[n]
+        assert (x is None) == (y is None), n
+        if x is None:
+            continue
+        assert torch.isfinite(x).all() and torch.isfinite(y).all(), n
+        e = float((x - y).abs().max()) / (float(x.abs().max()) + 1e-4 * top)
+        if e > worst:
+            worst, where = e, n
+    return worst, where
 
 
 def test_world1_rccl_training_step_equals_the_no_group_run(tmp_path):
@@ -160,12 +180,18 @@ def test_world1_rccl_training_step_equals_the_no_group_run(tmp_path):
     g = _worker(tmp_path, "train.py", TRAIN, "group")
     d = _worker(tmp_path, "train.py", TRAIN, "ddp")
     if a["sha"] == b["sha"]:
-        assert g["sha"] == a["sha"], ("explicit all-reduce", _rel(g, a))
-        assert d["sha"] == a["sha"], ("DDP", _rel(d, a))
+        assert g["sha"] == a["sha"], ("explicit all-reduce", _grad_gap(g, a))
+        assert d["sha"] == a["sha"], ("DDP", _grad_gap(d, a))
         assert g["losses"] == a["losses"] and d["losses"] == a["losses"]
     else:                       # the step itself is not run-to-run deterministic here (float atomics): bound by its own spread
-        tol = max(10.0 * _rel(a, b), 1e-6)
-        assert _rel(g, a) <= tol and _rel(d, a) <= tol, (_rel(a, b), _rel(g, a), _rel(d, a))
+        spread = _grad_gap(a, b)
+        tol = max(10.0 * spread[0], 1e-5)
+        assert tol < 1e-2, ("the no-group step itself is not reproducible", spread)
+        gg, gd = _grad_gap(g, a), _grad_gap(d, a)
+        print("step-1 gradient gaps: nogroup/nogroup", spread, "group", gg, "ddp", gd)
+        assert gg[0] <= tol and gd[0] <= tol, (spread, gg, gd)
+        for x in (b, g, d):     # both steps' losses: the second one sees the parameters the first optimiser step wrote
+            assert x["losses"] == pytest.approx(a["losses"], rel=1e-4), (x["losses"], a["losses"])
 
 
 def _bench(args, timeout=1200):
