@@ -615,8 +615,6 @@ def run_rank_train(args):
     sync()
     D.barrier()
     sync()
-    if not dry:
-        ops.kernel_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -625,7 +623,14 @@ def run_rank_train(args):
     sync()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
     events = []
-    if not dry:
+    if not dry and args.kernel_pass:
+        # per-kernel rooflines: the same K steps again, OUTSIDE the timed region, with a HIP event pair around each instrumented
+        # launch - event pairs want in-order launches, so this pass keeps the weight gradients off the side stream
+        # (ops.SideStream.active()); the timed region above runs the step as a user runs it
+        ops.kernel_events = []
+        for _ in range(args.steps):
+            step()
+        sync()
         events, ops.kernel_events = ops.kernel_events, None
     # the gradient all-reduce alone: one flat bucket of the trainable parameters' size (DDP's single 5.6 MB bucket)
     n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
@@ -768,6 +773,9 @@ def parse_args(argv):
                                                     "(reported under other_precisions; '' = none)")
     ap.add_argument("--dry", action="store_true", help="control-flow test: no GPU, no kernels, gloo instead of RCCL")
     ap.add_argument("--rank-timeout", type=float, default=1700.0, help="self-spawned ranks are killed after this many seconds")
+    ap.add_argument("--kernel-pass", type=int, default=1, help="--workload train: after the timed steps, the same steps again "
+                    "with a HIP event pair around every instrumented launch (in-order launches) for the per-kernel rooflines; "
+                    "0 under rocprofv3, whose trace then holds exactly warmup + steps training steps")
     ap.add_argument("--rays", type=int, default=512, help="--workload train: rays per rank and step (confs/surf.conf: 512)")
     ap.add_argument("--train-precision", default="fp32", choices=["fp32", "bf16"],
                     help="training-backward policy (model conf key train_precision): bf16 = weight-gradient reductions on bf16 operands")

@@ -38,7 +38,7 @@ extern "C" {
 
 /* ABI version, bumped whenever a signature below changes.  Defined here once: surf_abi_version() returns it and the
  * host binding (surf_amd/_lib.py ABI_VERSION) refuses a library that reports a different number. */
-#define SURF_ABI_VERSION 38
+#define SURF_ABI_VERSION 39
 int surf_abi_version(void);
 
 /* Repack NCHW fp32 (n, C<=4, H, W) into texel4 NHWC (n, H, W, 4), zero padding channels >= C. */
@@ -323,6 +323,14 @@ int surf_composite_backward(const float* sdf, const float* grad, const float* co
                             const float* pts, const uint8_t* vmask, const float* rays_d, int n_rays, int S, float inv_s,
                             float cos_anneal_ratio, const float* h_rot_ref, const float* g_color, const float* g_depth,
                             float eik_scale, float* d_sdf, float* d_grad, float* d_color, float* d_inv_s, void* stream);
+/* The same with the upstream gradient of gradient_error left ON THE DEVICE: eik_upstream (1 float, may be NULL = 1) multiplies
+ * eik_scale inside the kernel, so a caller holding dL/d gradient_error as a device scalar (autograd) passes
+ * eik_scale = 1 / (sum relax + 1e-5) and never reads the scalar back (a synchronising read at the head of the backward sweep). */
+int surf_composite_backward_s(const float* sdf, const float* grad, const float* color, const float* mid_z, const float* dists,
+                              const float* pts, const uint8_t* vmask, const float* rays_d, int n_rays, int S, float inv_s,
+                              float cos_anneal_ratio, const float* h_rot_ref, const float* g_color, const float* g_depth,
+                              float eik_scale, const float* eik_upstream, float* d_sdf, float* d_grad, float* d_color,
+                              float* d_inv_s, void* stream);
 
 
 /* =====================================================================================================

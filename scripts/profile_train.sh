@@ -5,10 +5,10 @@ REPO="$(pwd)"
 OUT="$REPO/gpurun_out/prof_${1:-r03}_train"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --workload train --steps 5 --warmup 2 > "$OUT/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$REPO/bench.py" --workload train --steps 5 --warmup 2 --kernel-pass 0 > "$OUT/bench_trace.log" 2>&1
 if [[ "${2:-pmc}" == "pmc" ]]; then
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --workload train --steps 1 --warmup 1 > "$OUT/bench_pmc_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --workload train --steps 1 --warmup 1 > "$OUT/bench_pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$REPO/bench.py" --workload train --steps 1 --warmup 1 --kernel-pass 0 > "$OUT/bench_pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$REPO/bench.py" --workload train --steps 1 --warmup 1 --kernel-pass 0 > "$OUT/bench_pmc_write.log" 2>&1
 fi
 cd "$REPO"
 for f in $(find "$OUT/trace" -name "*kernel_stats.csv"); do echo "== $f"; head -45 "$f"; done

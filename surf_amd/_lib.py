@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SURF_HIP_LIB", os.path.join(_HERE, "libsurf_hip.so"))
 
 # must equal SURF_ABI_VERSION of include/surf_hip.h (tests/test_host_modules.py compares the two texts); lib() refuses a
 # library built from another header
-ABI_VERSION = 38
+ABI_VERSION = 39
 
 c_f32p = ctypes.c_void_p
 c_ptr = ctypes.c_void_p
@@ -49,6 +49,8 @@ SIGNATURES = {
     "surf_ptloss_terms": (c_int, [c_ptr, c_int, c_int, c_int, c_ptr, c_ptr, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_composite_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_float, c_float, c_ptr,
                                         c_ptr, c_ptr, c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "surf_composite_backward_s": (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_float, c_float, c_ptr,
+                                          c_ptr, c_ptr, c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_sdf_backward": (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "surf_blend_backward_row_floats": (c_int, []),
     "surf_blend_backward": (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),

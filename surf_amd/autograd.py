@@ -35,8 +35,11 @@ RENDER_KEYS = ("color_fine", "render_depth", "gradient_error", "sparse_sdf", "sm
 
 
 def _scalar(g):
-    """Upstream gradient of a scalar output as a python float (the kernels take it by value)."""
-    return 0.0 if g is None else float(g)
+    """Upstream gradient of a scalar output: a device scalar stays on the device (backward_render multiplies it in inside its
+    kernels / tensor expressions: reading it back would stall the host at the head of the sweep); else a python float."""
+    if g is None:
+        return 0.0
+    return g.detach() if torch.is_tensor(g) and g.is_cuda else float(g)
 
 
 class _Render(torch.autograd.Function):
@@ -97,7 +100,8 @@ class _Build(torch.autograd.Function):
         ctx.precision = ops.colgram_precision
         n = model.num_stage
         ctx.n = n
-        holder.update(tables=tables, mvol=mvol, cams=cams)
+        holder.update(tables=tables, mvol=mvol, cams=cams, tape=tape)
+        ctx.holder = holder
         depths = [outputs[f"depth_stage{s}"] for s in range(n)] + [outputs[f"depth_src_stage{s}"][...] for s in range(n)]
         return tuple(volumes) + tuple(features) + tuple(depths)
 
@@ -109,10 +113,39 @@ class _Build(torch.autograd.Function):
         g_rows, g_feats, g_dep, g_src = g[:n], g[n:2 * n], g[2 * n:3 * n], g[3 * n:4 * n]
         sink = GradSink()
         gfeats = [torch.zeros_like(f) if gf is None else gf.contiguous().clone() for f, gf in zip(tape["feats"], g_feats)]
+        match = ctx.holder.pop("match", None)         # the matching chain, if the depth tap has launched it already
+        ctx.holder["tape"] = None
         with ops.precision_scope(ctx.precision):
-            model.backward_volumes(list(g_rows[::-1]), {s: (g_dep[s], g_src[s]) for s in range(n)}, tape=tape, gfeats=gfeats, sink=sink)
+            model.backward_volumes(list(g_rows[::-1]), {s: (g_dep[s], g_src[s]) for s in range(n)}, tape=tape, gfeats=gfeats, sink=sink,
+                                   match=match)
         ctx.tape = None
         return (None, None, None, None) + tuple(sink.get(p) for p in ctx.params)
+
+
+class _DepthTap(torch.autograd.Function):
+    """Identity on the 2 n depth maps of the volume build, placed in the graph AFTER the render node: autograd runs the younger
+    node first, and the depth terms are the last ones the loss computes (losses/loss.py:47-63), so this backward sees the maps'
+    gradients before the render's backward has started.  It launches the matching chain of the volume backward - which needs
+    nothing but these gradients - on its own stream (SuRF.start_matching_chain), where it runs beside the whole render
+    backward instead of in front of the sparse U-Nets' (-2.8 ms of exposed matching-field backward per step); `_Build.backward`
+    picks the result up from `holder`.  Without side streams (or a loss without depth terms) it is a plain identity."""
+
+    @staticmethod
+    def forward(ctx, model, holder, *depths):
+        ctx.set_materialize_grads(False)
+        ctx.model, ctx.holder = model, holder
+        return tuple(d.view_as(d) for d in depths)
+
+    @staticmethod
+    def backward(ctx, *g):
+        holder = ctx.holder
+        tape = holder.get("tape")
+        if tape is not None and "match" not in holder and any(x is not None for x in g):
+            n = len(g) // 2
+            match = ctx.model.start_matching_chain(tape, {s: (g[s], g[n + s]) for s in range(n)})
+            if match is not None:
+                holder["match"] = match
+        return (None, None) + tuple(g)
 
 
 def differentiable_forward(model, mode, ipts, cos_anneal_ratio=1.0, step=None):
@@ -126,6 +159,8 @@ def differentiable_forward(model, mode, ipts, cos_anneal_ratio=1.0, step=None):
     else:
         holder = {}
         bparams = [p for m in (model.feature_network, model.volume, model.reg_network) for p in m.parameters() if p.requires_grad]
+        with torch.no_grad():
+            match = model.start_match_features(mode, ipts, step)           # on its own stream, beside the volume build
         res = _Build.apply(model, mode, ipts, holder, *bparams)
         n = model.num_stage
         volumes, features = list(res[:n]), list(res[n:2 * n])
@@ -134,9 +169,13 @@ def differentiable_forward(model, mode, ipts, cos_anneal_ratio=1.0, step=None):
             outputs[f"depth_src_stage{s}"] = res[3 * n + s]
         with torch.no_grad():
             scene = model.build_scene(mode, ipts, [v.detach() for v in volumes], holder["tables"], holder["mvol"],
-                                      [f.detach() for f in features], holder["cams"], step)
+                                      [f.detach() for f in features], holder["cams"], step, match=match)
         rows, feats = volumes[::-1], features[::-1]
     outputs.update(_render_node(isurf, lambda: model.run_render(mode, ipts, scene, cos_anneal_ratio, step), rows, feats, "t4"))
+    if not model.has_vol:
+        n = model.num_stage
+        keys = [f"depth_stage{s}" for s in range(n)] + [f"depth_src_stage{s}" for s in range(n)]
+        outputs.update(zip(keys, _DepthTap.apply(model, holder, *[outputs[k] for k in keys])))
     return outputs
 
 

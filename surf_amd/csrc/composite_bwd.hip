@@ -24,6 +24,7 @@ struct CompBwdArgs {
   const float* rays_d;
   int n_rays, S;
   float inv_s, anneal, eik_scale;
+  const float* eik_up;   // device scalar multiplying eik_scale (dL/d gradient_error as autograd holds it) or null
   float rot[9];
   const float* g_color;  // (R,3)
   const float* g_depth;  // (R) or null
@@ -129,11 +130,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompBwdArgs a) {
         gx = t * dx; gy = t * dy; gz = t * dz;
         // eikonal: relax (|g| - 1)^2, relax = |pts| < 1.2 (masked-in samples)
         const float px = a.pts[o * 3 + 0], py = a.pts[o * 3 + 1], pz = a.pts[o * 3 + 2];
-        if (a.eik_scale != 0.f && sqrtf(px * px + py * py + pz * pz) < 1.2f) {
+        const float eik_scale = a.eik_up ? a.eik_scale * *a.eik_up : a.eik_scale;
+        if (eik_scale != 0.f && sqrtf(px * px + py * py + pz * pz) < 1.2f) {
           const float ex = a.grad[o * 3 + 0], ey = a.grad[o * 3 + 1], ez = a.grad[o * 3 + 2];
           const float n = sqrtf(ex * ex + ey * ey + ez * ez);
           if (n > 0.f) {
-            const float f = a.eik_scale * 2.0f * (n - 1.0f) / n;
+            const float f = eik_scale * 2.0f * (n - 1.0f) / n;
             gx += f * ex; gy += f * ey; gz += f * ez;
           }
         }
@@ -150,19 +152,28 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompBwdArgs a) {
 
 }  // namespace
 
-extern "C" int surf_composite_backward(const float* sdf, const float* grad, const float* color, const float* mid_z,
-                                       const float* dists, const float* pts, const uint8_t* vmask, const float* rays_d, int n_rays,
-                                       int S, float inv_s, float cos_anneal_ratio, const float* h_rot_ref, const float* g_color,
-                                       const float* g_depth, float eik_scale, float* d_sdf, float* d_grad, float* d_color,
-                                       float* d_inv_s, void* stream) {
+extern "C" int surf_composite_backward_s(const float* sdf, const float* grad, const float* color, const float* mid_z,
+                                         const float* dists, const float* pts, const uint8_t* vmask, const float* rays_d, int n_rays,
+                                         int S, float inv_s, float cos_anneal_ratio, const float* h_rot_ref, const float* g_color,
+                                         const float* g_depth, float eik_scale, const float* eik_upstream, float* d_sdf,
+                                         float* d_grad, float* d_color, float* d_inv_s, void* stream) {
   if (!sdf || !grad || !color || !mid_z || !dists || !pts || !vmask || !rays_d || !h_rot_ref || !g_color) return SURF_E_ARG;
   if (!d_sdf || !d_grad || !d_color || !d_inv_s || n_rays <= 0 || S < 2) return SURF_E_ARG;
   if (S > SURF_MAX_SAMPLES) return SURF_E_LIMIT;
   CompBwdArgs a;
   a.sdf = sdf; a.grad = grad; a.color = color; a.mid_z = mid_z; a.dists = dists; a.pts = pts; a.vmask = vmask; a.rays_d = rays_d;
-  a.n_rays = n_rays; a.S = S; a.inv_s = inv_s; a.anneal = cos_anneal_ratio; a.eik_scale = eik_scale;
+  a.n_rays = n_rays; a.S = S; a.inv_s = inv_s; a.anneal = cos_anneal_ratio; a.eik_scale = eik_scale; a.eik_up = eik_upstream;
   for (int i = 0; i < 9; ++i) a.rot[i] = h_rot_ref[i];
   a.g_color = g_color; a.g_depth = g_depth; a.d_sdf = d_sdf; a.d_grad = d_grad; a.d_color = d_color; a.d_inv_s = d_inv_s;
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((n_rays + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
   return surf_check_launch();
+}
+
+extern "C" int surf_composite_backward(const float* sdf, const float* grad, const float* color, const float* mid_z,
+                                       const float* dists, const float* pts, const uint8_t* vmask, const float* rays_d, int n_rays,
+                                       int S, float inv_s, float cos_anneal_ratio, const float* h_rot_ref, const float* g_color,
+                                       const float* g_depth, float eik_scale, float* d_sdf, float* d_grad, float* d_color,
+                                       float* d_inv_s, void* stream) {
+  return surf_composite_backward_s(sdf, grad, color, mid_z, dists, pts, vmask, rays_d, n_rays, S, inv_s, cos_anneal_ratio, h_rot_ref,
+                                   g_color, g_depth, eik_scale, nullptr, d_sdf, d_grad, d_color, d_inv_s, stream);
 }

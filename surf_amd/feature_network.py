@@ -115,14 +115,24 @@ class FeatureNetwork(nn.Module):
         t = tape[-1]
         n = self.num_stage
         prec = t.get("prec", 0)                                                 # the policy the forward ran under
+        on_side = ops.side.active("fpn") and g_outs_c2f[0].is_cuda
+        deferred = []
+
+        def wgrad(a, b, stride, finish, w):
+            """The weight gradient of one layer: a leaf of this sweep - on the side stream beside the input-gradient chain
+            (ops.SideStream); `finish` maps the kernel's [ky][kx][.][.] layout to the parameter's, applied after the join."""
+            if on_side:
+                dw = ops.side.run(lambda: ops.conv3x3_wgrad(a, b, stride, prec), keep=(a, b))
+                deferred.append((w, dw, finish))
+            else:
+                acc(w, finish(ops.conv3x3_wgrad(a, b, stride, prec)))
         g_outs = g_outs_c2f[::-1]                                               # index i = level i (0 = finest)
         d_dec = []
         for i in range(n):
             w = self.out_layers[i].weight
             g = g_outs[i].contiguous()
             d_dec.append(ops.conv3x3(g, flipT(w), w.shape[1], 1, prec))
-            dw = ops.conv3x3_wgrad(t["dec_out"][i], g, 1, prec)                 # [ky][kx][ci][co]
-            acc(w, dw.permute(3, 2, 0, 1))
+            wgrad(t["dec_out"][i], g, 1, lambda dw: dw.permute(3, 2, 0, 1), w)  # [ky][kx][ci][co]
         d_enc = [None] * n
         for i in range(n - 1):                                                  # dec[i] = IN(deconv(dec[i+1])) + enc[i]
             r = t["dec"][i]
@@ -132,8 +142,7 @@ class FeatureNetwork(nn.Module):
             d_raw = ops.inorm_relu_backward(r["raw"], g, r["stats"])
             # input gradient of the transposed convolution = stride-2 convolution with [ky][kx][co][ci]
             d_dec[i + 1] = d_dec[i + 1] + ops.conv3x3(d_raw, w.detach().float().permute(2, 3, 1, 0).contiguous(), w.shape[0], 2, prec)
-            dw = ops.conv3x3_wgrad(d_raw, r["x_in"], 2, prec)                   # [ky][kx][co][ci]
-            acc(w, dw.permute(3, 2, 0, 1))
+            wgrad(d_raw, r["x_in"], 2, lambda dw: dw.permute(3, 2, 0, 1), w)    # [ky][kx][co][ci]
         d_enc[n - 1] = d_dec[n - 1]
         g = d_enc[n - 1]
         for k in range(2 * n - 1, -1, -1):                                      # encoder blocks, last to first
@@ -141,8 +150,7 @@ class FeatureNetwork(nn.Module):
             r = t["enc"][k]
             w = r["blk"].conv.weight                                            # (Cout, Cin, 3, 3)
             d_raw = ops.inorm_relu_backward(r["raw"], g.contiguous(), r["stats"])
-            dw = ops.conv3x3_wgrad(r["x_in"], d_raw, r["blk"].stride, prec)     # [ky][kx][ci (padded)][co]
-            acc(w, dw[:, :, :w.shape[1]].permute(3, 2, 0, 1))
+            wgrad(r["x_in"], d_raw, r["blk"].stride, lambda dw, ci=w.shape[1]: dw[:, :, :ci].permute(3, 2, 0, 1), w)  # [ky][kx][ci (padded)][co]
             if k == 0:
                 break
             if r["blk"].stride == 1:
@@ -151,3 +159,7 @@ class FeatureNetwork(nn.Module):
                 g = ops.deconv3x3_s2(d_raw, w.detach().float().permute(2, 3, 0, 1).contiguous(), w.shape[1], prec)
             if j == 0:                                                          # entering stage i - 1's output: add its skip gradient
                 g = g + d_enc[i - 1]
+        if on_side:                                                             # the weight gradients: meet the side stream here
+            ops.side.join(lanes=(0,))
+            for w, dw, finish in deferred:
+                acc(w, finish(dw))

@@ -136,6 +136,9 @@ class SceneVolumes:
         """implicit_surface.py:229-241: FPN levels 0, 1, 2 at the finest level's size (texel4), from `features` or - once
         training is past step 2 - from the frozen `match_features`; built on first use."""
         key = bool(use_match and self.match_feats_t4 is not None)
+        if key and getattr(self, "match_ready", None) is not None:      # launched on a side stream before the volume build
+            ops.side.wait_for(self.match_ready)
+            self.match_ready = None
         if key not in self._warp_maps:
             f = self.match_feats_t4 if key else self.feats_t4
             H, W = f[0].shape[1:3]
@@ -163,6 +166,15 @@ class _LatticeScene:
     def __init__(self, volumes, sparse_idxes):
         self.sv = ops.SparseVolumes([v.detach().float() for v in volumes], list(sparse_idxes))
         self.device = self.sv.vols[0].device
+
+
+def _occupied_list(rec, key):
+    """The indices of the occupied points of a forward record's boolean mask `key`, computed once (a synchronising read: a
+    training forward does it right after the mask, where the host is waiting for the render anyway; see ops.SideStream)."""
+    lst = rec.get(key + "_idx")
+    if lst is None:
+        lst = rec[key + "_idx"] = rec[key].nonzero().squeeze(1)
+    return lst
 
 
 class ImplicitSurface(nn.Module):
@@ -289,6 +301,28 @@ class ImplicitSurface(nn.Module):
                 act = torch.arange(min(10, st["vmask"].numel()), dtype=torch.int32, device=dev)
         else:
             act, n_act = timed("compact", lambda: ops.compact_counted(st["vmask"]))
+        side_fwd = None
+        if patch_warp:
+            # Two branches of a training forward depend on the sample positions alone and meet the rest only in the output
+            # dictionary: smooth_error (:100-103, :172: |H.1| of the SDF averaged over the masked-in samples inside the unit
+            # sphere; 1.3 ms on the step's 65 k samples) and the random points of sparse_sdf (:174-178).  On side streams beside
+            # the SDF / blend / compositing / patch-warp chain (ops.SideStream), joined before the dictionary is filled.
+            def smooth_branch():
+                smooth, _ = ops.sdf_smooth(st["pts"], scene.sv, self.smooth_weights(dev), active_idx=act)
+                inside = ((torch.linalg.norm(st["pts"], ord=2, dim=-1) < 1.0) & st["vmask"].bool()).float()
+                err = (torch.linalg.norm(smooth, ord=2, dim=-1) * inside).sum() / (inside.sum() + 1e-5)
+                return smooth, inside, err
+
+            def sparse_branch():
+                pr = self._random_pts if self._random_pts is not None else torch.rand([1024, 3]) * 2 - 1
+                pr = pr.to(dev, torch.float32).contiguous()
+                occ = scene.occupied_any(pr)
+                sdf_r, _ = ops.sdf_mlp(pr, scene.sv, sdf_w, mask=occ.to(torch.uint8), want_grad=False)
+                return pr, occ, torch.where(occ, sdf_r, torch.zeros_like(sdf_r))
+
+            if ops.side.active("fwd") and dev.type == "cuda" and ev is None:
+                self.smooth_weights(dev)                     # packed on this stream, once per parameter version
+                side_fwd = (ops.side.run(smooth_branch, lane=1), ops.side.run(sparse_branch, lane=0))
         sdf, grad = timed("sdf_mlp", lambda: ops.sdf_mlp(st["pts"], scene.sv, sdf_w, mask=st["vmask"], active_idx=act,
                                                          active_count=n_act))
         col, nvalid = timed("blend", lambda: ops.blend(st["pts"], scene.feats_t4, scene.imgs_t4, scene.cams, blend_w,
@@ -316,20 +350,19 @@ class ImplicitSurface(nn.Module):
             maps = scene.warp_maps(use_match=not (step is None or step < 2))
             out["ref_gray_val"], out["sampled_gray_val"] = ops.patch_warp(pts0, g0, maps, scene.cams)
             out["pts_sdf0"], out["gradients_sdf0"] = pts0, g0
-            # smooth_error (:100-103, :172): |H.1| of the SDF averaged over the masked-in samples inside the unit sphere
-            smooth, _ = ops.sdf_smooth(st["pts"], scene.sv, self.smooth_weights(dev), active_idx=act)
-            inside = ((torch.linalg.norm(st["pts"], ord=2, dim=-1) < 1.0) & st["vmask"].bool()).float()
-            out["smooth_error"] = (torch.linalg.norm(smooth, ord=2, dim=-1) * inside).sum() / (inside.sum() + 1e-5)
+            ops.side.join(lanes=(0, 1, 3))                   # (3: the frozen matching FPN's stream, if it is still open)
+            if side_fwd is not None:
+                (smooth, inside, out["smooth_error"]), (pr, occ, sdf_r0) = side_fwd
+            else:
+                smooth, inside, out["smooth_error"] = smooth_branch()
+                pr, occ, sdf_r0 = sparse_branch()
             # sparse_sdf (:174-178, :255): the SDF at 1024 uniform points (zero where no level is occupied) + at the samples
-            pr = self._random_pts if self._random_pts is not None else torch.rand([1024, 3]) * 2 - 1
-            pr = pr.to(dev, torch.float32).contiguous()
-            occ = scene.occupied_any(pr)
-            sdf_r, _ = ops.sdf_mlp(pr, scene.sv, sdf_w, mask=occ.to(torch.uint8), want_grad=False)
-            out["sparse_sdf"] = torch.cat([torch.where(occ, sdf_r, torch.zeros_like(sdf_r)), sdf]).view(-1, 1)
+            out["sparse_sdf"] = torch.cat([sdf_r0, sdf]).view(-1, 1)
             # what backward_render needs of this forward (row f2: the partial backward of the render)
             self._ctx = dict(st=st, act=act, sdf=sdf, grad=grad, col=col, rays_d=rays_d, anneal=float(cos_anneal_ratio),
                              scene=scene, eik_den=float(eik[1]), random_pts=pr, random_occ=occ, pts0=pts0, g0=g0, maps=maps,
                              smooth=smooth, inside=inside)
+            _occupied_list(self._ctx, "random_occ")
         return out
 
     @torch.no_grad()
@@ -344,7 +377,8 @@ class ImplicitSurface(nn.Module):
         upstream is a tangent direction), surf_blend_backward, and for the NCC term surf_patch_warp_tangent -> surf_lncc_jvp ->
         surf_crossing_backward (d ncc / d z0 as a forward-mode tangent along the ray, then into the two bracketing samples).
         gfeats_t4 (fine -> coarse, like the scene's feature maps): accumulates the colour path's gradient into the FPN maps
-        (generalisation training).  g_smooth_error (scalar): the smooth (H.1) term, through surf_sdf_smooth_backward (reverse
+        (generalisation training).  g_gradient_error / g_smooth_error: python floats or 0-d device tensors (autograd's: they are
+        then never read back).  g_smooth_error: the smooth (H.1) term, through surf_sdf_smooth_backward (reverse
         over a forward with value, two tangents and their mixed tangent).  g_pseudo_sdf (n_pseudo, 1): the pseudo_sdf output
         (`ImplicitSurface.pseudo_sdf` after the training forward).  The volume build's backward is SuRF.backward_volumes.
         g_patches = (d loss / d ref_gray_val, d loss / d sampled_gray_val) - what autograd hands back when the loss consumed
@@ -359,10 +393,13 @@ class ImplicitSurface(nn.Module):
         inv_s = self.deviation_network.inv_s()
         if g_color is None:
             g_color = torch.zeros(c["rays_d"].shape[0], 3, dtype=torch.float32, device=dev)
+        # scalar upstream gradients may arrive as python floats or - from autograd - as device scalars, which stay on the device
+        eik_up = g_gradient_error if torch.is_tensor(g_gradient_error) else None
         d_sdf, d_grad, d_col, d_is = ops.composite_backward(c["sdf"], c["grad"], c["col"], st, c["rays_d"], inv_s, c["anneal"], scene.cams,
                                                         g_color.float().contiguous(),
                                                         None if g_depth is None else g_depth.float().contiguous(),
-                                                        eik_scale=float(g_gradient_error) / (c["eik_den"] + 1e-5))
+                                                        eik_scale=(1.0 if eik_up is not None else float(g_gradient_error)) / (c["eik_den"] + 1e-5),
+                                                        eik_upstream=eik_up)
         if g_ncc is not None or g_patches is not None:
             ref, src, ref_t, src_t = ops.patch_warp_tangent(c["pts0"], c["rays_d"], c["g0"], c["maps"], scene.cams)
             g_z0 = torch.zeros(ref.shape[1], dtype=torch.float32, device=dev)
@@ -375,6 +412,17 @@ class ImplicitSurface(nn.Module):
                 if g_patches[1] is not None:
                     g_z0 += (g_patches[1].float() * src_t).sum(dim=(0, 2, 3))
             ops.crossing_backward(c["sdf"], st["vmask"], st["mid_z"], st["z_vals"].max(), g_z0, d_sdf)
+
+        def blend_branch():
+            cn = dict(self.color_network.named_parameters())     # raw parameter buffer in state_dict order, built on the device
+            raw_w = torch.cat([cn[k].detach().reshape(-1).float() for k in ops.BLEND_KEYS]).contiguous()
+            return ops.blend_backward(st["pts"], act, d_col, scene.feats_t4, scene.imgs_t4, scene.cams, raw_w, gfeats_t4=gfeats_t4)
+
+        # Three branches hang off the compositing backward and meet again only in the parameter gradients / the rows'
+        # atomics: colour (surf_blend_backward + its weight-gradient GEMMs: one-wavefront workgroups), smooth (H.1: its layer
+        # launches + GEMMs) and the SDF value / gradient backward.  Each works on the step's 65 k samples - latency bound, a
+        # fraction of the chip's wave slots - so the first two run on side streams beside the third (ops.SideStream).
+        on_side = ops.side.active("render") and dev.type == "cuda"
         idx = act.long()
         ybar = d_sdf[idx]
         pts = st["pts"][idx]
@@ -382,23 +430,37 @@ class ImplicitSurface(nn.Module):
         if g_sparse_sdf is not None:
             gs = g_sparse_sdf.reshape(-1).float()
             ybar = ybar + gs[1024:][idx]                      # the samples' own share of sparse_sdf (masked-out rows are constants)
-            occ = c["random_occ"]
-            pts = torch.cat([pts, c["random_pts"][occ]])
-            ybar = torch.cat([ybar, gs[:1024][occ]])
-            gbar = torch.cat([gbar, torch.zeros(int(occ.sum()), 3, device=dev)])
+            sel = _occupied_list(c, "random_occ")             # index lists: no synchronising mask reads in the sweep
+            pts = torch.cat([pts, c["random_pts"][sel]])
+            ybar = torch.cat([ybar, gs[:1024][sel]])
+            gbar = torch.cat([gbar, torch.zeros(sel.shape[0], 3, device=dev)])
         if g_pseudo_sdf is not None and "pseudo_pts" in c:        # pseudo_sdf (:425-434): the occupied pseudo points' SDF values
-            occ_p = c["pseudo_occ"]
-            pts = torch.cat([pts, c["pseudo_pts"][occ_p]])
-            ybar = torch.cat([ybar, g_pseudo_sdf.reshape(-1).float()[occ_p]])
-            gbar = torch.cat([gbar, torch.zeros(int(occ_p.sum()), 3, device=dev)])
-        res = ops.sdf_backward(pts.contiguous(), ybar.contiguous(), gbar.contiguous(), scene.sv, self.smooth_weights(dev))
-        if g_smooth_error:
-            # smooth_error = sum_n inside_n |smooth_n| / (sum inside + 1e-5)  ->  sbar_n = g inside_n smooth_n / (|smooth_n| den)
-            sm, ins = c["smooth"][idx], c["inside"][idx]
-            nrm = torch.linalg.norm(sm, ord=2, dim=-1, keepdim=True)
-            sbar = float(g_smooth_error) / (float(c["inside"].sum()) + 1e-5) * ins[:, None] * sm / nrm.clamp_min(1e-30)
-            rs = ops.sdf_smooth_backward(st["pts"][idx].contiguous(), sbar.contiguous(), scene.sv, self.smooth_weights(dev),
-                                         dvols=res["volumes"])           # accumulates into the first backward's rows
+            sel_p = _occupied_list(c, "pseudo_occ")
+            pts = torch.cat([pts, c["pseudo_pts"][sel_p]])
+            ybar = torch.cat([ybar, g_pseudo_sdf.reshape(-1).float()[sel_p]])
+            gbar = torch.cat([gbar, torch.zeros(sel_p.shape[0], 3, device=dev)])
+        if on_side:
+            gb = ops.side.run(blend_branch, lane=0, keep=(d_col,))
+        sw = self.smooth_weights(dev)
+        dvols = [torch.zeros_like(v) for v in scene.sv.vols]      # both SDF branches add into these rows with atomics
+        rs = None
+        if torch.is_tensor(g_smooth_error) or g_smooth_error:
+            def smooth_branch():
+                # smooth_error = sum_n inside_n |smooth_n| / (sum inside + 1e-5)  ->  sbar_n = g inside_n smooth_n / (|smooth_n| den)
+                sm, ins = c["smooth"][idx], c["inside"][idx]
+                nrm = torch.linalg.norm(sm, ord=2, dim=-1, keepdim=True)
+                g_sm = g_smooth_error.detach().float() if torch.is_tensor(g_smooth_error) else float(g_smooth_error)
+                scale = g_sm / (c["inside"].sum() + 1e-5)                         # a device scalar: no host round trip mid-sweep
+                sbar = scale * ins[:, None] * sm / nrm.clamp_min(1e-30)
+                return ops.sdf_smooth_backward(st["pts"][idx].contiguous(), sbar.contiguous(), scene.sv, sw, dvols=dvols)
+
+            rs = ops.side.run(smooth_branch, lane=1, keep=(idx,)) if on_side else smooth_branch()
+        res = ops.sdf_backward(pts.contiguous(), ybar.contiguous(), gbar.contiguous(), scene.sv, sw, dvols=dvols)
+        if on_side:                                            # the three branches meet here
+            ops.side.join(lanes=(0, 1))
+        else:
+            gb = blend_branch()
+        if rs is not None:
             for l in range(7):
                 res["weight"][l] = res["weight"][l] + rs["weight"][l]
                 res["bias"][l] = res["bias"][l] + rs["bias"][l]
@@ -412,14 +474,11 @@ class ImplicitSurface(nn.Module):
             accumulate(lin.weight_g, dgs[l], sink)
             accumulate(lin.weight_v, dvs[l], sink)
             accumulate(lin.bias, res["bias"][l], sink)
-        cn = dict(self.color_network.named_parameters())     # raw parameter buffer in state_dict order, built on the device
-        raw_w = torch.cat([cn[k].detach().reshape(-1).float() for k in ops.BLEND_KEYS]).contiguous()
-        gb = ops.blend_backward(st["pts"], act, d_col, scene.feats_t4, scene.imgs_t4, scene.cams, raw_w, gfeats_t4=gfeats_t4)
         for name, p in self.color_network.named_parameters():
             accumulate(p, gb[name], sink)
         var = self.deviation_network.variance
-        raw = float(torch.exp(var.detach() * 10.0))
-        dvar = d_is * 10.0 * inv_s if 1e-6 < raw < 1e6 else torch.zeros((), device=dev)
+        # inv_s = exp(10 v) clamped to [1e-6, 1e6] (one device read per parameter version): strictly inside = not clamped
+        dvar = d_is * 10.0 * inv_s if 1e-6 < inv_s < 1e6 else torch.zeros((), device=dev)
         accumulate(var, dvar, sink)
         return list(res["volumes"]) if rows8 else [g[:, :7].contiguous() for g in res["volumes"]]
 
@@ -572,6 +631,7 @@ class ImplicitSurface(nn.Module):
         sdf, _ = ops.sdf_mlp(pp, scene.sv, sdf_w, mask=occ.to(torch.uint8), want_grad=False)
         if getattr(self, "_ctx", None) is not None:
             self._ctx["pseudo_pts"], self._ctx["pseudo_occ"] = pp, occ
+            _occupied_list(self._ctx, "pseudo_occ")
         return torch.where(occ, sdf, torch.zeros_like(sdf))[:, None]
 
     def forward(self, mode, ipts, matching_volume, volumes, sparse_idxes, mask_volumes, features, match_features,

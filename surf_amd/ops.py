@@ -45,6 +45,101 @@ class _timed:
         return False
 
 
+class SideStream:
+    """The backward sweep of a training step on several HIP streams.  Its kernels work on the step's 65 k samples or wait on row
+    gathers / an LDS hash: latency bound, a fraction of the chip's wave slots each - so branches that do not depend on one
+    another run side by side (users, each an A/B switch; profiles/r06_side_streams.txt):
+      unet    the sparse U-Nets' kernel gradients (leaves of the sweep) beside their input-gradient chain          lane 0
+      render  the colour branch (lane 0) and the smooth (H.1) branch (lane 1) beside the SDF value / gradient branch
+      match   the matching chain (matching-field backward -> densify backward, fine -> coarse) ahead of the U-Net / cost-volume
+              chain it feeds, one event per stage                                                                 lane 2
+      fpn     the FPN's weight gradients (measured: a loss - those launches fill the chip; off by default)
+      fwd     the forward's smooth / random-point branches and the frozen matching FPN (measured: no gain; off by default)
+    `with side.fork(lane): launch(...)` orders the lane after everything issued so far on the current stream; `run(fn)` does that
+    and marks the results for the current stream; `keep()` holds operands until `join()` (the caching allocator reuses a block
+    for the CURRENT stream as soon as its last reference dies); `join()` makes the current stream wait for every open lane -
+    before the results are read.  Never inside a lane: a synchronising host read (it starves the other streams).
+    SURF_SIDE_STREAM=0: in-order launches."""
+
+    def __init__(self):
+        # "0" none, "1" the users that measured a gain (profiles/r06_side_streams.txt), "all", or a comma list of users
+        env = os.environ.get("SURF_SIDE_STREAM", "1")
+        self.enabled = env != "0"
+        self.users = {"0": set(), "1": {"unet", "render", "match"}, "all": None}.get(env, set(env.split(",")))
+        self._streams = {}
+        self._keep = {}          # (device, lane) -> tensors held until that lane is joined
+        self._open = set()
+
+    def active(self, user=None):
+        # never while a bench is bracketing launches with event pairs (per-kernel times want in-order launches)
+        return (self.enabled and kernel_events is None and torch.cuda.is_available()
+                and (self.users is None or user is None or user in self.users))
+
+    def fork(self, lane=0):
+        cur = torch.cuda.current_stream()
+        key = (cur.device.index, lane)
+        st = self._streams.get(key)
+        if st is None:
+            st = self._streams[key] = torch.cuda.Stream(device=cur.device)
+        st.wait_stream(cur)
+        self._open.add(key)
+        return torch.cuda.stream(st)
+
+    def run(self, fn, lane=0, keep=()):
+        """fn() on side stream `lane`; its result tensors (a tensor, or a list / tuple / dict of them, nested) are allocated in
+        that stream's pool and will be read - and freed - on the current one: marked with record_stream."""
+        main = torch.cuda.current_stream()
+        with self.fork(lane):
+            out = fn()
+
+        def mark(o):
+            if torch.is_tensor(o):
+                if o.is_cuda:
+                    o.record_stream(main)
+            elif isinstance(o, dict):
+                for v in o.values():
+                    mark(v)
+            elif isinstance(o, (list, tuple)):
+                for v in o:
+                    mark(v)
+
+        mark(out)
+        self.keep(*keep, lane=lane)
+        return out
+
+    @staticmethod
+    def mark():
+        """An event on the CURRENT stream (inside `with fork(lane)`: that lane) for `wait_for` on another stream."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    @staticmethod
+    def wait_for(event):
+        torch.cuda.current_stream().wait_event(event)
+
+    def keep(self, *tensors, lane=0):
+        """Hold `tensors` (operands a lane reads, allocated on another stream) until that lane is joined."""
+        if torch.cuda.is_available():
+            key = (torch.cuda.current_device(), lane)
+            self._keep.setdefault(key, []).extend(t for t in tensors if t is not None)
+
+    def join(self, lanes=None):
+        """The current stream waits for the open lanes of its device (all of them, or `lanes`)."""
+        if not self._open:
+            self._keep.clear()
+            return
+        cur = torch.cuda.current_stream()
+        for key in sorted(self._open):
+            if key[0] == cur.device.index and (lanes is None or key[1] in lanes):
+                cur.wait_stream(self._streams[key])
+                self._open.discard(key)
+                self._keep.pop(key, None)
+
+
+side = SideStream()
+
+
 class _ZeroPool:
     """Small zero-initialised buffers carved out of one pre-zeroed block per device: a training step asks for ~100 of them
     (the 27 x C_in x C_out weight-gradient accumulators of the sparse U-Net, 1.2 MB a stage) and each torch.zeros is a ~5 us
@@ -309,6 +404,25 @@ def blend_packed_precision(packed):
 _linspace_cache = {}
 
 
+_nf_cache = {}
+
+
+def _near_fars_host(near_fars):
+    """The (nv, 2) near / far planes as a host array (the kernels take them by value).  A device tensor costs a synchronising
+    copy: paid once per tensor (keyed by storage address + version), not once per stage and direction - and never from inside
+    a side-stream section of the backward sweep, where a host stall starves the other streams (ops.SideStream)."""
+    if not near_fars.is_cuda:
+        return np.ascontiguousarray(near_fars.detach().to(torch.float32).numpy())
+    key = (near_fars.data_ptr(), near_fars._version, tuple(near_fars.shape), near_fars.dtype)
+    hit = _nf_cache.get(key)
+    if hit is None:
+        if len(_nf_cache) >= 16:
+            _nf_cache.clear()
+        # the tensor itself is kept: a live tensor's address cannot be handed to another one
+        hit = _nf_cache[key] = (near_fars, np.ascontiguousarray(near_fars.detach().to("cpu", torch.float32).numpy()))
+    return hit[1]
+
+
 def _linspace_dev(lo, hi, n, dev):
     """torch.linspace computed on the CPU - like the reference, whose sample fractions are CPU linspaces moved to the device
     (implicit_surface.py:271, matching_field.py:31) - and kept on the device: one host-to-device copy per (lo, hi, n), not one
@@ -477,7 +591,7 @@ def sdf_smooth(pts, volumes, packed, active_idx=None, want_grad=False):
     return smooth, grad
 
 
-def sdf_backward(pts, ybar, gbar, volumes, packed, want_dvols=True):
+def sdf_backward(pts, ybar, gbar, volumes, packed, want_dvols=True, dvols=None):
     """Gradients of sum_n (ybar_n sdf_n + gbar_n . grad_n) w.r.t. the EFFECTIVE (weight-normed) matrices / biases of
     lin0..lin6 and the sparse feature rows (surf_sdf_backward; the batch reductions dW = adj^T in are surf_colgram_p: matrix cores).
     packed: sdf_smooth_pack_weights.  Returns {"weight": [7 tensors shaped like W_l], "bias": [7], "volumes": [per level (N_s,8)]}."""
@@ -490,7 +604,10 @@ def sdf_backward(pts, ybar, gbar, volumes, packed, want_dvols=True):
     in_d = torch.empty(7, n, 160, dtype=torch.float32, device=dev)
     tb = torch.empty(6, n, 128, dtype=torch.float32, device=dev)
     tdb = torch.empty(6, n, 128, dtype=torch.float32, device=dev)
-    dvols = [torch.zeros_like(v) for v in volumes.vols] if want_dvols else None
+    if dvols is not None:       # rows to ACCUMULATE into (the kernel adds with atomics either way)
+        assert len(dvols) == volumes.n and all(d.shape == v.shape and d.is_contiguous() for d, v in zip(dvols, volumes.vols))
+    else:
+        dvols = [torch.zeros_like(v) for v in volumes.vols] if want_dvols else None
     with _timed("sdf_bwd", n):
         rc = _lib.lib().surf_sdf_backward(_p(pts), _p(ybar), _p(gbar), n, volumes._vp, volumes._tp, volumes._dp, volumes.n,
                                           _ptr_array(dvols) if dvols is not None else None, _p(packed), _p(in_v), _p(in_d), _p(tb),
@@ -755,7 +872,8 @@ def composite(sdf, grad, color, n_valid, setup, rays_d, inv_s, cos_anneal_ratio,
     return out
 
 
-def composite_backward(sdf, grad, color, setup, rays_d, inv_s, cos_anneal_ratio, cams, g_color, g_depth=None, eik_scale=0.0):
+def composite_backward(sdf, grad, color, setup, rays_d, inv_s, cos_anneal_ratio, cams, g_color, g_depth=None, eik_scale=0.0,
+                       eik_upstream=None):
     """Backward of `composite` w.r.t. (sdf, grad, color, inv_s) for upstream gradients of colour_fine (R,3) and
     render_depth (R) and the eikonal term (eik_scale = dL/d gradient_error / (sum relax + 1e-5)).
     Returns (d_sdf (R*S,), d_grad (R*S,3), d_color (R*S,3), d_inv_s scalar tensor)."""
@@ -766,11 +884,14 @@ def composite_backward(sdf, grad, color, setup, rays_d, inv_s, cos_anneal_ratio,
     d_grad = torch.empty(R * S, 3, dtype=torch.float32, device=dev)
     d_color = torch.empty(R * S, 3, dtype=torch.float32, device=dev)
     d_is = torch.empty(R, dtype=torch.float32, device=dev)
-    rc = _lib.lib().surf_composite_backward(_p(sdf), _p(grad), _p(color), _p(setup["mid_z"]), _p(setup["dists"]), _p(setup["pts"]),
-                                            _p(setup["vmask"]), _p(rays_d), R, S, ctypes.c_float(inv_s),
-                                            ctypes.c_float(cos_anneal_ratio), _np_ptr(cams.rot_ref), _p(g_color), _p(g_depth),
-                                            ctypes.c_float(float(eik_scale)), _p(d_sdf), _p(d_grad), _p(d_color), _p(d_is), _stream())
-    _lib.check(rc, "surf_composite_backward")
+    if eik_upstream is not None:        # dL/d gradient_error as a device scalar: multiplied in inside the kernel, never read back
+        eik_upstream = _chk(eik_upstream.detach().reshape(1).float().contiguous(), torch.float32, "eik_upstream")
+    rc = _lib.lib().surf_composite_backward_s(_p(sdf), _p(grad), _p(color), _p(setup["mid_z"]), _p(setup["dists"]), _p(setup["pts"]),
+                                              _p(setup["vmask"]), _p(rays_d), R, S, ctypes.c_float(inv_s),
+                                              ctypes.c_float(cos_anneal_ratio), _np_ptr(cams.rot_ref), _p(g_color), _p(g_depth),
+                                              ctypes.c_float(float(eik_scale)), _p(eik_upstream), _p(d_sdf), _p(d_grad), _p(d_color),
+                                              _p(d_is), _stream())
+    _lib.check(rc, "surf_composite_backward_s")
     return d_sdf, d_grad, d_color, d_is.sum(dtype=torch.float64).float()
 
 
@@ -1057,7 +1178,7 @@ def matching_depth(mvol, cams, near_fars, H, W, res_level, n, pre_depths=None, r
     lin_x = _linspace_dev(0, W - 1, w, dev)
     lin_y = _linspace_dev(0, H - 1, h, dev)
     lin_n = _linspace_dev(0.0, 1.0, n, dev)
-    nf = np.ascontiguousarray(near_fars.detach().to("cpu", torch.float32).numpy())
+    nf = _near_fars_host(near_fars)
     lr = torch.empty(cams.nv, h, w, dtype=torch.float32, device=dev)
     full = torch.empty(cams.nv, H, W, dtype=torch.float32, device=dev)
     if jitter is not None:
@@ -1088,7 +1209,7 @@ def matching_depth_backward(mvol, cams, near_fars, H, W, res_level, n, g_full, p
     lin_x = _linspace_dev(0, W - 1, w, dev)
     lin_y = _linspace_dev(0, H - 1, h, dev)
     lin_n = _linspace_dev(0.0, 1.0, n, dev)
-    nf = np.ascontiguousarray(near_fars.detach().to("cpu", torch.float32).numpy())
+    nf = _near_fars_host(near_fars)
     g_lr = torch.empty(cams.nv, h, w, dtype=torch.float32, device=dev)
     if stats is not None:
         _chk(stats, torch.float32, "stats")
@@ -1327,14 +1448,15 @@ def dgrad_weights(weight, mode, use_mfma=True, thin=False):
 wgrad_up_from_coarse = True     # False: the transposed layers' weight gradient walks the fine sites (the form until round 5; A/B)
 
 
-def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight, dy, use_mfma=True, dgrad=None):
+def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight, dy, use_mfma=True, dgrad=None, on_side=False):
     """Backward of y = spconv(x, in_table, out_coords, mode, weight) (no BN / ReLU / skip).  Returns (dx (n_in, Cin),
     dW (27, Cin, Cout)).  dx is a sparse convolution of dy over the OUTPUT lattice (`out_table` indexes out_coords):
     submanifold with mirrored offsets, down <-> up, kernel slices transposed.
     use_mfma: the wide layers' input gradient on the matrix cores like their forward (surf_spconv_mfma, bf16x3: both channel
     counts >= 16; the per-voxel kernel sat at 0.02-0.18 of HBM there, round 3); False: every layer on the fp32 per-voxel kernel
     (SparseCostRegNet.use_mfma).  dgrad: a cached dgrad_weights(weight, mode, use_mfma) (SparseCostRegNet keeps one per block
-    and parameter version)."""
+    and parameter version).  on_side: the weight gradient is launched on `side` (SideStream) - the caller calls side.join()
+    before it reads dW."""
     _chk(dy, torch.float32, "dy")
     cin, cout = int(weight.shape[1]), int(weight.shape[2])
     wt, wt_packed = dgrad if dgrad is not None else dgrad_weights(weight, mode, use_mfma)
@@ -1349,11 +1471,14 @@ def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight,
                                    torch.full((27, 8, 8), 0.125, dtype=torch.float32, device=x.device))[:, 0].sum()
     if kernel_events is not None:
         pairs = _pair_counts.get(key, 0)
-    with _timed(f"spconv_dgrad<{cout},{cin}>", {"pairs": pairs, "sites": int(in_coords.shape[0])}):
-        dx = spconv(dy, out_table, in_coords, {SUBM: SUBM, DOWN: UP, UP: DOWN}[mode], wt, packed=wt_packed,
-                    bf16=colgram_precision == 1)
+
+    def dgrad_():
+        with _timed(f"spconv_dgrad<{cout},{cin}>", {"pairs": pairs, "sites": int(in_coords.shape[0])}):
+            return spconv(dy, out_table, in_coords, {SUBM: SUBM, DOWN: UP, UP: DOWN}[mode], wt, packed=wt_packed,
+                          bf16=colgram_precision == 1)
+
     if out_coords.shape[0] == 0 or x.shape[0] == 0:
-        return dx, small_zeros(weight.shape, weight.device)
+        return dgrad_(), small_zeros(weight.shape, weight.device)
     # the weight gradient of a TRANSPOSED layer is computed from the coarse side (round 5): fine site c takes from coarse site q
     # through offset o when c = 2 q + o, which is the stride-2 DOWN relation with the lattices' roles swapped - so
     # dW[k][ci][co] = sum_q x[q][ci] dy[fine(2 q + o_k)][co] is the DOWN-mode weight gradient of (input = dy on the fine lattice,
@@ -1365,15 +1490,26 @@ def spconv_backward(x, in_table, in_coords, out_table, out_coords, mode, weight,
     else:
         wx, wtab, wcoords, wmode, wdy, wci, wco = x, in_table, out_coords, mode, dy, cin, cout
     dW = small_zeros((27, wci, wco), weight.device)       # the kernels accumulate into it
-    with _timed(f"spconv_wgrad<{cin},{cout}>", {"pairs": pairs, "sites": int(out_coords.shape[0])}):
-        if use_mfma and _lib.lib().surf_spconv_wgrad_mfma_supported(wci, wco):
-            # round 5: the channel pairs for which the matrix-core form wins (spconv_wgrad_mfma.hip), fp32-equivalent
-            rc = _lib.lib().surf_spconv_wgrad_mfma(_p(wx), wci, _p(wtab), int(wtab.shape[0]), _p(wcoords), wcoords.shape[0],
-                                                   int(wmode), _p(wdy), wco, _p(dW), _stream())
-        else:
-            rc = _lib.lib().surf_spconv_wgrad(_p(wx), wci, _p(wtab), int(wtab.shape[0]), _p(wcoords), wcoords.shape[0],
-                                              int(wmode), _p(wdy), wco, _p(dW), _stream())
-    _lib.check(rc, "surf_spconv_wgrad")
+
+    def wgrad():
+        with _timed(f"spconv_wgrad<{cin},{cout}>", {"pairs": pairs, "sites": int(out_coords.shape[0])}):
+            if use_mfma and _lib.lib().surf_spconv_wgrad_mfma_supported(wci, wco):
+                # round 5: the channel pairs for which the matrix-core form wins (spconv_wgrad_mfma.hip), fp32-equivalent
+                rc = _lib.lib().surf_spconv_wgrad_mfma(_p(wx), wci, _p(wtab), int(wtab.shape[0]), _p(wcoords), wcoords.shape[0],
+                                                       int(wmode), _p(wdy), wco, _p(dW), _stream())
+            else:
+                rc = _lib.lib().surf_spconv_wgrad(_p(wx), wci, _p(wtab), int(wtab.shape[0]), _p(wcoords), wcoords.shape[0],
+                                                  int(wmode), _p(wdy), wco, _p(dW), _stream())
+        _lib.check(rc, "surf_spconv_wgrad")
+
+    if on_side:     # a leaf of the sweep: on the side stream, forked BEFORE the input gradient is issued so that the two run
+        with side.fork():       # side by side (the caller joins before it reads dW)
+            wgrad()
+        side.keep(wx, wtab, wcoords, wdy, dW, lane=0)
+        dx = dgrad_()
+    else:
+        dx = dgrad_()
+        wgrad()
     if swap:
         dW = dW.transpose(1, 2)
     return dx, dW

@@ -211,13 +211,15 @@ class SparseCostRegNet(nn.Module):
             tape.append(dict(lin=True, x=x, feats=feats))
         return out, x
 
-    def backward(self, tape, d_out, d_mid=None, sink=None):
+    def backward(self, tape, d_out, d_mid=None, sink=None, pending=None):
         """Reverse sweep over a tape recorded by a train-mode forward: gradients of sum(out d_out) + sum(mid d_mid) are
         ACCUMULATED into the `.grad` (or into `sink`, a grads.GradSink) of every convolution kernel, BatchNorm weight / bias and
         out_lin.weight; returns the
         gradient of `feats` (N, d_in).  Each block: BatchNorm(batch statistics) + ReLU + skip backward (surf_bn_relu_backward),
         then the convolution's input gradient as a sparse convolution on the swapped lattices and its kernel gradient
-        (ops.spconv_backward)."""
+        (ops.spconv_backward).  The kernel gradients are leaves of the sweep: launched on the side stream (ops.SideStream) and
+        accumulated after the join - here, or, with `pending` (a list), by the caller: it receives a closure to call after ITS
+        ops.side.join()."""
         def acc(p, g):
             accumulate(p, g, sink)
 
@@ -231,6 +233,8 @@ class SparseCostRegNet(nn.Module):
             k = id(t)
             grads[k] = g if k not in grads else grads[k] + g
 
+        on_side = ops.side.active("unet") and d_out.is_cuda
+        kernel_grads = []
         d_out = d_out.float().contiguous()
         add(x11, ops.row_linear8(d_out, W.t().contiguous()))            # d_out @ W
         if d_mid is not None:
@@ -253,10 +257,22 @@ class SparseCostRegNet(nn.Module):
                                          e["w"], draw, use_mfma=self.use_mfma,
                                          dgrad=e["blk"].prepared_dgrad(e["mode"], self.use_mfma,
                                                                        thin=ops.thin_mfma == "all" or
-                                                                       (ops.thin_mfma == "bf16" and ops.colgram_precision == 1)))
-            idx = e["blk"].slice_index(dW.device)          # back to checkpoint slice order (the permutation is an involution)
-            acc(e["blk"].net[0].kernel, dW if idx is None else dW.index_select(0, idx))
+                                                                       (ops.thin_mfma == "bf16" and ops.colgram_precision == 1)),
+                                         on_side=on_side)
+            kernel_grads.append((e["blk"], dW))
             add(e["x"], dx)
+        # the kernel gradients were launched on the side stream (leaves of this sweep: they overlap its input-gradient chain)
+        def finish():
+            for blk, dW in kernel_grads:
+                idx = blk.slice_index(dW.device)           # back to checkpoint slice order (the permutation is an involution)
+                acc(blk.net[0].kernel, dW if idx is None else dW.index_select(0, idx))
+
+        if on_side and pending is not None:                # the caller joins the side stream later (more to overlap with)
+            pending.append(finish)
+        else:
+            if on_side:
+                ops.side.join(lanes=(0,))
+            finish()
         return grads.pop(id(feats))
 
 

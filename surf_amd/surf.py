@@ -119,15 +119,63 @@ class SuRF(nn.Module):
                 accumulate(p, g)
         return dvols
 
-    def backward_volumes(self, row_grads_f2c, g_depths=None, tape=None, gfeats=None, sink=None):
+    def _match_stage(self, t, s, g_depths, d_mvol):
+        """Stage s's share of the matching chain of `_backward_volumes`: where a depth term reached this stage or a finer one,
+        the matching-field backward into the dense volume gradient, then the densify backward into the rows' logit column and
+        the coarser stage's volume gradient.  Returns (g_logit (N_s, 1) or None, d_mvol of stage s - 1 or None)."""
+        r = t["vol"][s]
+        cams, dev = t["cams"], t["feats"][0].device
+        nv = t["feats"][0].shape[0]
+        H, W = t["hw"]
+        gd = (g_depths or {}).get(s, (None, None))
+        if gd[0] is not None or gd[1] is not None:
+            g_full = torch.zeros(nv, H, W, dtype=torch.float32, device=dev)
+            if gd[0] is not None:
+                g_full[0] += gd[0]
+            if gd[1] is not None:
+                g_full[t["src_idx"]] += gd[1]
+            d_mvol = self.matching_field.backward(cams, t["near_fars"], (H, W), r["mvol"], s, self.range_ratios, g_full,
+                                                  r["pre_depths"], r.get("jitter"), dmvol=d_mvol, src_idx=t["src_idx"],
+                                                  stats=r.get("stats"))
+        g_logit = d_prev = None
+        if d_mvol is not None:
+            g_logit = torch.zeros(r["coords"].shape[0], 1, dtype=torch.float32, device=dev)
+            if s > 0:
+                Dp = r["D"] // 2
+                d_prev = torch.zeros(Dp, Dp, Dp, dtype=torch.float32, device=dev)
+            ops.densify_backward(r["coords"], r["table"], d_mvol, g_logit, d_prev)
+        return g_logit, d_prev
+
+    @torch.no_grad()
+    def start_matching_chain(self, t, g_depths):
+        """The matching chain of the tape `t` for the depth gradients `g_depths` ({stage: (d depth_stage, d depth_src_stage)}) on
+        its own stream (ops.SideStream lane 2), fine -> coarse.  Returns {stage: (g_logit or None, event)} for
+        `_backward_volumes(match=...)`, or None when the side streams are off (the sweep then runs the stages in line)."""
+        dev = t["feats"][0].device
+        if not (ops.side.active("match") and dev.type == "cuda"):
+            return None
+        main = torch.cuda.current_stream()
+        out = {}
+        with ops.side.fork(lane=2):
+            dm = None
+            for s in range(self.num_stage - 1, -1, -1):
+                g_logit, dm = self._match_stage(t, s, g_depths, dm)
+                if g_logit is not None:
+                    g_logit.record_stream(main)          # allocated in the lane's pool, consumed (and freed) on this stream
+                out[s] = (g_logit, ops.side.mark())
+            del dm
+        ops.side.keep(*[g for pair in (g_depths or {}).values() for g in pair], lane=2)
+        return out
+
+    def backward_volumes(self, row_grads_f2c, g_depths=None, tape=None, gfeats=None, sink=None, match=None):
         """See _backward_volumes.  With the module's own tape (tape=None) it runs under the training-precision policy that forward
         was recorded with (a graph node passes its tape AND sets its own scope: surf_amd.autograd._Build)."""
         if tape is not None:
-            return self._backward_volumes(row_grads_f2c, g_depths, tape, gfeats, sink)
+            return self._backward_volumes(row_grads_f2c, g_depths, tape, gfeats, sink, match)
         with ops.precision_scope(getattr(self, "_fwd_precision", None)):
-            return self._backward_volumes(row_grads_f2c, g_depths, tape, gfeats, sink)
+            return self._backward_volumes(row_grads_f2c, g_depths, tape, gfeats, sink, match)
 
-    def _backward_volumes(self, row_grads_f2c, g_depths=None, tape=None, gfeats=None, sink=None):
+    def _backward_volumes(self, row_grads_f2c, g_depths=None, tape=None, gfeats=None, sink=None, match=None):
         """Backward of the volume build + FPN of the last `forward("train", ..., record=True)` (surf.py:80-131 under
         loss.backward()): row_grads_f2c = d loss / d the stages' feature rows, fine -> coarse, (N_s, 7) (what
         ImplicitSurface.backward_render returns) or (N_s, 8) = [logit | 7 features] rows, None = no gradient; g_depths =
@@ -137,7 +185,8 @@ class SuRF(nn.Module):
         -> cost-volume backward (-> FPN maps, agg_mlp) and the parent-feature scatter (-> the coarser stage's `mid` rows);
         then the FPN backward on the maps' total gradient (cost volumes + the colour path's share: `gfeats`, coarse -> fine,
         or what `SuRF.backward` left in the tape).  Not differentiable: the voxel selections, the detached depths.
-        tape: the record to differentiate (default: the module's last one, consumed)."""
+        tape: the record to differentiate (default: the module's last one, consumed).  match: what start_matching_chain(tape,
+        g_depths) returned if the caller has launched the matching chain already."""
         own = tape is None
         t = self._train_tape if own else tape
         if t is None:
@@ -153,6 +202,15 @@ class SuRF(nn.Module):
         g_agg = torch.zeros(49, dtype=torch.float32, device=dev)
         n = self.num_stage
         d_mvol, d_mid = None, None
+        pending = []
+
+        # The matching chain (fine -> coarse: matching-field backward -> densify backward -> the coarser stage's volume gradient)
+        # depends on the other chain (sparse U-Net -> cost volume -> the coarser stage's `mid` rows) nowhere: it only FEEDS it the
+        # logit column of one g_out per stage.  matching_depth_bwd is bound by the probing of its LDS hash (5 ms a step on a
+        # fraction of the chip's wave slots), so the whole chain runs ahead on its own stream (start_matching_chain) - from here,
+        # or already from the graph's depth tap (surf_amd.autograd._DepthTap: before the render's backward), `match`.
+        if match is None:
+            match = self.start_matching_chain(t, g_depths)
         for s in range(n - 1, -1, -1):
             r = t["vol"][s]
             rg = row_grads_f2c[n - 1 - s]
@@ -162,28 +220,22 @@ class SuRF(nn.Module):
                 g_out = rg.float().clone()                                  # written into below: never the caller's tensor
             else:
                 g_out = torch.cat([rg.new_zeros(rg.shape[0], 1), rg], dim=1).float()
-            gd = (g_depths or {}).get(s, (None, None))
-            if gd[0] is not None or gd[1] is not None:
-                g_full = torch.zeros(nv, H, W, dtype=torch.float32, device=dev)
-                if gd[0] is not None:
-                    g_full[0] += gd[0]
-                if gd[1] is not None:
-                    g_full[t["src_idx"]] += gd[1]
-                d_mvol = self.matching_field.backward(cams, t["near_fars"], (H, W), r["mvol"], s, self.range_ratios, g_full,
-                                                      r["pre_depths"], r.get("jitter"), dmvol=d_mvol, src_idx=t["src_idx"],
-                                                      stats=r.get("stats"))
-            d_prev = None
-            if d_mvol is not None:
-                if s > 0:
-                    Dp = r["D"] // 2
-                    d_prev = torch.zeros(Dp, Dp, Dp, dtype=torch.float32, device=dev)
-                ops.densify_backward(r["coords"], r["table"], d_mvol, g_out, d_prev)
-            d_reg_in = self.reg_network.nets[s].backward(r["reg_tape"], g_out, d_mid, sink=sink)
+            if match is not None:
+                g_logit, ev = match[s]
+                if ev is not None:
+                    ops.side.wait_for(ev)
+            else:
+                g_logit, d_mvol = self._match_stage(t, s, g_depths, d_mvol)
+            if g_logit is not None:
+                g_out[:, 0] += g_logit.view(-1)
+            d_reg_in = self.reg_network.nets[s].backward(r["reg_tape"], g_out, d_mid, sink=sink, pending=pending)
             d_mid = self.volume.stage_backward(s, r["D"], feats, gfeats, cams, r["coords"], d_reg_in, g_agg, r.get("pidx"),
                                                r["n_parents"])
-            d_mvol = d_prev
         self.volume.assign_agg_grad(g_agg, sink=sink)
         self.feature_network.backward(t["fpn"], gfeats, sink=sink)
+        ops.side.join()                              # the U-Nets' kernel gradients ran on the side stream beside all of the above
+        for finish in pending:
+            finish()
         self.last_voxels_per_stage = [int(r["coords"].shape[0]) for r in t["vol"]]
         if own:
             self._train_tape = None                 # the tapes hold every stage's activations (GBs at full size): one backward each
@@ -277,18 +329,38 @@ class SuRF(nn.Module):
         return outputs, volumes, tables, mvol, features, cams, tape
 
     @torch.no_grad()
-    def build_scene(self, mode, ipts, volumes, tables, mvol, features, cams, step=None):
+    def start_match_features(self, mode, ipts, step=None):
+        """The frozen matching FPN's maps of a training forward (surf.py:141-148: loss-only inputs, read by the patch warp at the
+        end of the render).  They depend on the images alone, so the forward launches them FIRST, on their own stream beside the
+        whole volume build (ops.SideStream lane 3).  Returns (maps fine -> coarse, event or None) or None in `val`."""
+        if mode == "val":
+            return None
+        imgs = ipts["imgs"]
+        if step is not None and step % 2 == 0:                              # refresh the frozen matching FPN
+            self.match_feature_network.load_state_dict(self.feature_network.state_dict(), strict=True)
+            for p in self.match_feature_network.parameters():
+                p.requires_grad = False
+        if ops.side.active("fwd") and imgs.is_cuda:
+            main = torch.cuda.current_stream()
+            with ops.side.fork(lane=3):
+                feats = self.match_feature_network(imgs)[::-1]
+                ev = ops.side.mark()
+            for f in feats:
+                f.record_stream(main)
+            return feats, ev
+        return self.match_feature_network(imgs)[::-1], None
+
+    @torch.no_grad()
+    def build_scene(self, mode, ipts, volumes, tables, mvol, features, cams, step=None, match=None):
         """SceneVolumes of a freshly built pyramid (kernel layouts, no re-packing) + the frozen matching FPN's maps of a
-        training forward (surf.py:141-148)."""
+        training forward (`match`: what start_match_features returned before the build; None: computed here)."""
         imgs = ipts["imgs"]
         scene = SceneVolumes.from_device_layouts(mvol, [v[:, 1:] for v in volumes[::-1]], tables[::-1], features[::-1],
                                                  ops.pack_texel4(imgs.detach().float().contiguous()), cams)
-        if mode != "val":                                                   # surf.py:141-148 (loss-only inputs)
-            if step is not None and step % 2 == 0:                          # refresh the frozen matching FPN
-                self.match_feature_network.load_state_dict(self.feature_network.state_dict(), strict=True)
-                for p in self.match_feature_network.parameters():
-                    p.requires_grad = False
-            scene.match_feats_t4 = self.match_feature_network(imgs)[::-1]
+        if mode != "val":
+            if match is None:
+                match = self.start_match_features(mode, ipts, step)
+            scene.match_feats_t4, scene.match_ready = match
         return scene
 
     @torch.no_grad()
@@ -333,8 +405,9 @@ class SuRF(nn.Module):
             if self.has_vol:                                                    # surf.py:149-156
                 outputs, scene = {}, self._frozen_scene(ipts)
             else:
+                match = self.start_match_features(mode, ipts, step)
                 outputs, volumes, tables, mvol, features, cams, tape = self.run_build(mode, ipts, record=record)
                 self._train_tape = tape
-                scene = self.build_scene(mode, ipts, volumes, tables, mvol, features, cams, step)
+                scene = self.build_scene(mode, ipts, volumes, tables, mvol, features, cams, step, match=match)
             outputs.update(self.run_render(mode, ipts, scene, cos_anneal_ratio, step))
             return outputs

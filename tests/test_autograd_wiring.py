@@ -42,7 +42,7 @@ FAKE = textwrap.dedent("""
             tape = {"feats": feats} if record else None
             return outs, vols, [None] * 4, None, feats, None, tape
 
-        def build_scene(mode, ipts, volumes, tables, mvol, features, cams, step=None):
+        def build_scene(mode, ipts, volumes, tables, mvol, features, cams, step=None, match=None):
             return "scene"
 
         def run_render(mode, ipts, scene, cos_anneal_ratio=1.0, step=None):
@@ -73,7 +73,7 @@ FAKE = textwrap.dedent("""
                 return [torch.cat([torch.full((n, 7), 3.0), torch.zeros(n, 1)], dim=1) for n in N[::-1]]
             return [torch.full((n, 7), 3.0) for n in N[::-1]]
 
-        def backward_volumes(row_grads_f2c, g_depths=None, tape=None, gfeats=None, sink=None):
+        def backward_volumes(row_grads_f2c, g_depths=None, tape=None, gfeats=None, sink=None, match=None):
             calls.append("build_bwd")
             seen.update(rows=row_grads_f2c, g_depths=g_depths, gfeats=gfeats, tape=tape)
             k = sum(float(g[0].sum()) for g in g_depths.values() if g[0] is not None)
@@ -83,6 +83,7 @@ FAKE = textwrap.dedent("""
             return gfeats
 
         model.run_build, model.build_scene, model.run_render = run_build, build_scene, run_render
+        model.start_match_features = lambda mode, ipts, step=None: None        # the frozen matching FPN's launch (kernels)
         model.backward_volumes = backward_volumes
         model.implicit_surface.backward_render = backward_render
         return model, calls, seen
