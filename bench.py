@@ -299,7 +299,7 @@ def training_step_timing(args, dev, steps=5):
     for precision in ("fp32", "bf16"):
         model, ipts, targets, loss_fn, opt = training_step_setup(dev, args.height, args.width, args.views, args.base_dim,
                                                                  precision=precision)
-        def timed(stepper, sync):
+        def timed(stepper, sync, opt=opt):
             for _ in range(2):
                 out = training.train_step(stepper, ipts, targets, loss_fn, opt, 1.0, 3, sync=sync)
             torch.cuda.synchronize()
@@ -320,6 +320,19 @@ def training_step_timing(args, dev, steps=5):
             res[precision]["ddp_ms_per_step"] = ms_d
             res[precision]["ddp_steps_ms"] = [round(v, 2) for v in per_d]
             del ddp
+        if precision == "fp32":
+            # context, not the headline: the reference constructs torch.optim.Adam(optim_param) (runner.py:94: the foreach form,
+            # ~25 launches with the host in between at the very end of a step); one keyword there - fused=True - is one launch a group
+            opt_f = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}), fused=True)
+            ms_f, per_f, _ = timed(model, False, opt_f)
+            res[precision]["fused_adam_ms_per_step"] = ms_f
+            res[precision]["fused_adam_steps_ms"] = [round(v, 2) for v in per_f]
+            # the same step with every launch in order on one stream (SURF_SIDE_STREAM=0): what the side streams buy
+            was, ops.side.enabled = ops.side.enabled, False
+            ms_o, per_o, _ = timed(model, False)
+            ops.side.enabled = was
+            res[precision]["in_order_ms_per_step"] = ms_o
+            del opt_f
         voxels = model.last_voxels_per_stage
         rays = int(ipts["rays_o"].shape[0])
         del model, opt
@@ -327,6 +340,12 @@ def training_step_timing(args, dev, steps=5):
     return {"ms_per_step": res["fp32"]["ms_per_step"], "rays": rays, "samples_per_ray": 128, "voxels_per_stage": voxels,
             "loss": res["fp32"]["loss"], "steps_ms": res["fp32"]["steps_ms"], "train_precision_bf16": res["bf16"],
             "ddp_ms_per_step": res["fp32"].get("ddp_ms_per_step"),
+            "ddp_steps_ms": res["fp32"].get("ddp_steps_ms"),
+            "in_order_ms_per_step": res["fp32"].get("in_order_ms_per_step"),
+            "fused_adam_ms_per_step": res["fp32"].get("fused_adam_ms_per_step"),
+            "streams": "backward sweep on 4 HIP streams (surf_amd.ops.SideStream: U-Net kernel gradients, render branches, matching chain); "
+                       "in_order_ms_per_step = SURF_SIDE_STREAM=0; fused_adam_ms_per_step = the same step with "
+                       "torch.optim.Adam(..., fused=True) instead of runner.py:94's default (foreach) form",
             "data_parallel": ("ddp_ms_per_step: the same step with the model wrapped in DistributedDataParallel over " + D.backend_note()
                               + " (bucket hooks, buffer broadcast, the 5.6 MB all-reduce with one peer)") if D._active() else None,
             "what": "median of 5 steps of: forward (FPN, volume build, render) + loss + loss.backward() (HIP backward of all of it) + Adam; every term of "

@@ -185,7 +185,7 @@ def test_world1_rccl_training_step_equals_the_no_group_run(tmp_path):
         assert g["losses"] == a["losses"] and d["losses"] == a["losses"]
     else:                       # the step itself is not run-to-run deterministic here (float atomics): bound by its own spread
         spread = _grad_gap(a, b)
-        tol = max(10.0 * spread[0], 1e-5)
+        tol = max(10.0 * spread[0], 1e-4)      # fp32 atomics in another order: 1e-6 .. 3e-5 observed; a wrong gradient is >> 1e-3
         assert tol < 1e-2, ("the no-group step itself is not reproducible", spread)
         gg, gd = _grad_gap(g, a), _grad_gap(d, a)
         print("step-1 gradient gaps: nogroup/nogroup", spread, "group", gg, "ddp", gd)
