@@ -245,6 +245,51 @@ def photometric_loss(depth, imgs_t4, mask, cams, ref_idx=0, topk=2):
     return _Photometric.apply(depth, imgs_t4, mask, cams, ref_idx, topk)
 
 
+class _PhotometricMulti(torch.autograd.Function):
+    """compute_ptloss of SEVERAL depth maps (the 2 n per-stage maps of losses/loss.py:47-55) as one graph node: the terms are
+    independent of one another and each launch is bound by L2 reads and channel-planar atomics on a fraction of the chip, so
+    both directions CAN deal them out over side streams (ops.SideStream lanes 4..7, user "loss": measured slower by 1.5 ms a
+    step - the launches are bound by the memory system - and off by default; in line the node still saves autograd 2 n - 1
+    node visits each way)."""
+    LANES = (4, 5, 6, 7)
+
+    @staticmethod
+    def forward(ctx, imgs_t4, cams, specs, *depths):
+        ctx.set_materialize_grads(False)
+        depths = [d.float().contiguous() for d in depths]
+        on_side = ops.side.active("loss") and imgs_t4.is_cuda
+        res = []
+        for i, (d, (mask, ref_idx, topk)) in enumerate(zip(depths, specs)):
+            fn = lambda d=d, mask=mask, ref_idx=ref_idx, topk=topk: ops.photometric_loss(d, imgs_t4, mask, cams, ref_idx=ref_idx,   # noqa: E731
+                                                                                      topk=topk, return_state=True)
+            res.append(ops.side.run(fn, lane=_PhotometricMulti.LANES[i % 4], keep=(d,)) if on_side else fn())
+        if on_side:
+            ops.side.join(lanes=_PhotometricMulti.LANES)
+        ctx.depths, ctx.states, ctx.imgs_t4, ctx.cams, ctx.specs = depths, [st for _, st in res], imgs_t4, cams, specs
+        return tuple(loss for loss, _ in res)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        on_side = ops.side.active("loss") and ctx.imgs_t4.is_cuda
+        out = []
+        for i, (g, d, st, (mask, ref_idx, topk)) in enumerate(zip(gs, ctx.depths, ctx.states, ctx.specs)):
+            if g is None:
+                out.append(None)
+                continue
+            fn = lambda g=g, d=d, st=st, mask=mask, ref_idx=ref_idx, topk=topk: ops.photometric_loss_backward(          # noqa: E731
+                d, ctx.imgs_t4, mask, ctx.cams, ref_idx, topk, upstream=g, state=st)
+            out.append(ops.side.run(fn, lane=_PhotometricMulti.LANES[i % 4], keep=(g,)) if on_side else fn())
+        if on_side:
+            ops.side.join(lanes=_PhotometricMulti.LANES)
+        ctx.states = None
+        return (None, None, None) + tuple(out)
+
+
+def photometric_losses(depths, imgs_t4, cams, specs):
+    """[compute_ptloss(depth_i) for i] with specs[i] = (mask (H,W) fp32, ref_idx, topk): one graph node, the launches side by side."""
+    return _PhotometricMulti.apply(imgs_t4, cams, list(specs), *depths)
+
+
 class _MaskedL1(torch.autograd.Function):
     """sum(|pred - target| mask) / (sum(mask) + 1e-8) (losses/loss.py:71-93) = surf_masked_l1, backward surf_masked_l1_backward:
     two launches instead of ~13 small torch kernels per term."""

@@ -57,9 +57,12 @@ class Loss(nn.Module):
             cams = ops.Cameras(targets["intrs"], targets["c2ws"])
             src_idx = int(targets["src_idx"])
             mask_ref, mask_src = targets["mask_ref"].float().contiguous(), targets["mask_src"].float().contiguous()
+            # the 2 n photometric terms are independent: one graph node, the launches dealt out over side streams both ways
+            photos = autograd.photometric_losses(
+                [preds[f"depth_stage{i}"] for i in range(n)] + [preds[f"depth_src_stage{i}"] for i in range(n)], imgs_t4, cams,
+                [(mask_ref, 0, 2)] * n + [(mask_src, src_idx, 1)] * n)
             for i in range(n):
-                ref_photo = autograd.photometric_loss(preds[f"depth_stage{i}"], imgs_t4, mask_ref, cams)
-                src_photo = autograd.photometric_loss(preds[f"depth_src_stage{i}"], imgs_t4, mask_src, cams, ref_idx=src_idx, topk=1)
+                ref_photo, src_photo = photos[i], photos[n + i]
                 photo_loss = photo_loss + (ref_photo + src_photo) * self.stage_weights[i]
                 pa = self._masked_l1(preds[f"depth_stage{i}"], targets["pseudo_depth_ref"], "target>0")
                 spa = self._masked_l1(preds[f"depth_src_stage{i}"], targets["pseudo_depth_src"], "target>0")

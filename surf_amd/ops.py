@@ -53,6 +53,8 @@ class SideStream:
       render  the colour branch (lane 0) and the smooth (H.1) branch (lane 1) beside the SDF value / gradient branch
       match   the matching chain (matching-field backward -> densify backward, fine -> coarse) ahead of the U-Net / cost-volume
               chain it feeds, one event per stage                                                                 lane 2
+      loss    the 2 n photometric terms of the loss, both directions (autograd._PhotometricMulti; lanes 4..7; measured: a loss of
+              1.5 ms - the launches are bound by the memory system, not by latency; off by default)
       fpn     the FPN's weight gradients (measured: a loss - those launches fill the chip; off by default)
       fwd     the forward's smooth / random-point branches and the frozen matching FPN (measured: no gain; off by default)
     `with side.fork(lane): launch(...)` orders the lane after everything issued so far on the current stream; `run(fn)` does that

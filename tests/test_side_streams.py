@@ -36,7 +36,7 @@ def test_side_stream_switch_and_lanes():
     """The switch's users and the lane bookkeeping (fork / keep / join) on the device."""
     from surf_amd import ops
     s = ops.SideStream()
-    assert s.enabled and s.users == {"unet", "render", "match"} or "SURF_SIDE_STREAM" in os.environ
+    assert (s.enabled and {"unet", "render", "match"} <= s.users) or "SURF_SIDE_STREAM" in os.environ
     dev = torch.device("cuda", 0)
     x = torch.ones(1 << 20, device=dev)
     out = s.run(lambda: x * 2.0, lane=1, keep=(x,))
@@ -53,3 +53,34 @@ def test_side_stream_switch_and_lanes():
     s.wait_for(ev)
     assert float(z.sum()) == 3.0 * (1 << 20)
     s.join()
+
+
+def test_photometric_terms_as_one_node_equal_the_single_nodes():
+    """autograd.photometric_losses (one graph node, the 2 n launches dealt out over side streams both ways) against
+    autograd.photometric_loss per map: values bit-equal, gradients equal up to the order of the backward's float atomics."""
+    from surf_amd import autograd, ops
+    from tests.conftest import load_npz
+    scene = load_npz("scene.npz")
+    d = torch.device("cuda", 0)
+    imgs_t4 = ops.pack_texel4(scene["imgs"].to(d).contiguous())
+    cams = ops.Cameras(scene["intrs"], scene["c2ws"])
+    H, W = imgs_t4.shape[1:3]
+    g = torch.Generator().manual_seed(3)
+    masks = [(torch.rand(H, W, generator=g) < 0.9).float().to(d) for _ in range(2)]
+    specs, depths_a, depths_b = [], [], []
+    for i in range(6):
+        base = (2.0 + 0.3 * torch.rand(H, W, generator=g)).to(d)
+        depths_a.append(base.clone().requires_grad_(True))
+        depths_b.append(base.clone().requires_grad_(True))
+        specs.append((masks[i % 2], 0, 2) if i < 3 else (masks[i % 2], 1, 1))
+    w = [0.3 + 0.1 * i for i in range(6)]
+    multi = autograd.photometric_losses(depths_a, imgs_t4, cams, specs)
+    single = [autograd.photometric_loss(x, imgs_t4, m, cams, ref_idx=r, topk=k) for x, (m, r, k) in zip(depths_b, specs)]
+    for a, b in zip(multi, single):
+        assert float(a) == float(b)
+    sum(wi * a for wi, a in zip(w, multi[:5])).backward()          # the sixth map gets no gradient: None, not zeros
+    sum(wi * b for wi, b in zip(w, single[:5])).backward()
+    assert depths_a[5].grad is None and depths_b[5].grad is None
+    for xa, xb in zip(depths_a[:5], depths_b[:5]):
+        assert float(xb.grad.abs().max()) > 0
+        assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * float(xb.grad.abs().max())
