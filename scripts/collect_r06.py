@@ -18,6 +18,16 @@ med = lambda xs: sorted(xs, key=lambda t: t["ms_per_step"])[len(xs) // 2]
 json.dump(med(tr), open("profiles/r06_bench_train.json", "w"))
 json.dump(med(tb), open("profiles/r06_bench_train_bf16.json", "w"))
 shutil.copy(f"{O}/scene_parts.log", "profiles/r06_scene_parts.txt")
+tl = "gpurun_out/prof_r06_train"
+if os.path.exists(f"{tl}/timeline_streams.txt"):
+    with open("profiles/r06_train_timeline.txt", "w") as f:
+        f.write("# scripts/trace_timeline.py on rocprofv3 --kernel-trace of `bench.py --workload train` (scripts/profile_train.sh; the profiler slows\n"
+                "# the host: walls are larger than unprofiled).  First the default multi-stream backward sweep, then SURF_SIDE_STREAM=0.\n")
+        f.write("## backward sweep on several HIP streams (default)\n" + open(f"{tl}/timeline_streams.txt").read())
+        f.write("## in-order launches (SURF_SIDE_STREAM=0)\n" + open(f"{tl}/timeline_inorder.txt").read())
+for name in ("phases.txt", "phases_inorder.txt"):
+    if os.path.exists(f"{O}/{name}"):
+        shutil.copy(f"{O}/{name}", f"profiles/r06_train_{name}")
 shutil.copy(f"{O}/sdf_sq_bf16x3.txt", "profiles/r06_sdf_sq_bf16x3.txt")
 with open("profiles/r06_gpu_tests.txt", "w") as f:
     f.write("# python -m pytest tests -m gpu -q ; smoke()   (scripts/final_r06.sh on the GPU box)\n")

@@ -15,5 +15,7 @@ for i in 1 2 3; do
   python bench.py --workload train --train-precision bf16 > $O/train_bf16_$i.json 2> $O/train_bf16_$i.err
 done
 python bench.py --workload train --force-group 0 --cpu-seconds 0 > $O/train_nogroup.json 2> $O/train_nogroup.err
+python scripts/step_phases.py > $O/phases.txt 2>&1
+SURF_SIDE_STREAM=0 python scripts/step_phases.py > $O/phases_inorder.txt 2>&1
 python scripts/time_scene_parts.py > $O/scene_parts.log 2>&1
 ls -la $O

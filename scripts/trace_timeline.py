@@ -13,21 +13,15 @@ rows = []
 for r in csv.DictReader(open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")))
 rows.sort()
-# step boundaries: the first Adam launch (multi_tensor_apply) after a gap of other kernels
-marks = []
-last_adam = -10**18
+# step boundaries: the optimiser's addcmul / addcdiv launches form one cluster per step (clusters are > 20 ms apart)
+clusters = []
 for i, (s, e, n, q) in enumerate(rows):
-    if "multi_tensor_apply" in n:
-        if s - last_adam > 5_000_000:      # a new optimiser step (its launches are microseconds apart)
-            marks.append(i)
-        last_adam = s
-# a step = from the end of the previous optimiser's last launch to the end of this one's
-ends = []
-for m in marks:
-    j = m
-    while j + 1 < len(rows) and ("multi_tensor_apply" in rows[j + 1][2] or rows[j + 1][0] - rows[j][1] < 200_000 and "multi_tensor" in rows[j + 1][2]):
-        j += 1
-    ends.append(j)
+    if "multi_tensor_apply" in n and "PointwiseOp" in n:      # Adam's addcmul / addcdiv (the U-Nets' counter bump is a foreach too)
+        if not clusters or s - rows[clusters[-1][-1]][0] > 20_000_000:
+            clusters.append([i])
+        else:
+            clusters[-1].append(i)
+ends = [c[-1] for c in clusters]        # a step = after the previous optimiser's last launch .. this optimiser's last launch
 short = lambda n: n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60]
 print(f"{len(rows)} launches, {len(ends)} optimiser steps found")
 for k in range(max(1, len(ends) - nsteps), len(ends)):

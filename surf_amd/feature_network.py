@@ -24,18 +24,33 @@ class _Deconv(nn.Module):
         self.conv = nn.ConvTranspose2d(cin, cout, 3, stride=2, padding=1, output_padding=1, bias=False)
 
 
+def _layout(w, tag, build):
+    """A re-laid-out copy of the convolution weight `w`, cached on the parameter per version: built once per optimiser step (the
+    frozen matching FPN: once per refresh) instead of once per forward AND backward call - ~60 small launches a training step,
+    the backward's share of them on its device-bound main chain."""
+    cache = w.__dict__.setdefault("_surf_layouts", {})
+    key = (w._version, w.data_ptr())
+    hit = cache.get(tag)
+    if hit is None or hit[0] != key or not ops.layout_cache:
+        with torch.no_grad():
+            hit = cache[tag] = (key, build(w.detach().float()))
+    return hit[1]
+
+
 def _pack_conv(w):
     """(Cout, Cin, 3, 3) -> [ky][kx][Cin (padded to a multiple of 4)][Cout]."""
-    w = w.detach().float().permute(2, 3, 1, 0)
-    cin = w.shape[2]
-    if cin % 4:
-        w = torch.cat([w, torch.zeros(3, 3, 4 - cin % 4, w.shape[3], device=w.device)], dim=2)
-    return w.contiguous()
+    def build(v):
+        v = v.permute(2, 3, 1, 0)
+        cin = v.shape[2]
+        if cin % 4:
+            v = torch.cat([v, torch.zeros(3, 3, 4 - cin % 4, v.shape[3], device=v.device)], dim=2)
+        return v.contiguous()
+    return _layout(w, "conv", build)
 
 
 def _pack_deconv(w):
     """(Cin, Cout, 3, 3) -> [ky][kx][Cin][Cout]."""
-    return w.detach().float().permute(2, 3, 0, 1).contiguous()
+    return _layout(w, "deconv", lambda v: v.permute(2, 3, 0, 1).contiguous())
 
 
 class FeatureNetwork(nn.Module):
@@ -110,7 +125,7 @@ class FeatureNetwork(nn.Module):
 
         def flipT(w):
             """Conv2d weight (Cout, Cin, 3, 3) -> the packed kernel [ky][kx][Cout][Cin] of its input gradient (stride 1)."""
-            return w.detach().float().flip(2, 3).permute(2, 3, 0, 1).contiguous()
+            return _layout(w, "flipT", lambda v: v.flip(2, 3).permute(2, 3, 0, 1).contiguous())
 
         t = tape[-1]
         n = self.num_stage
@@ -141,7 +156,7 @@ class FeatureNetwork(nn.Module):
             d_enc[i] = g
             d_raw = ops.inorm_relu_backward(r["raw"], g, r["stats"])
             # input gradient of the transposed convolution = stride-2 convolution with [ky][kx][co][ci]
-            d_dec[i + 1] = d_dec[i + 1] + ops.conv3x3(d_raw, w.detach().float().permute(2, 3, 1, 0).contiguous(), w.shape[0], 2, prec)
+            d_dec[i + 1] = d_dec[i + 1] + ops.conv3x3(d_raw, _layout(w, "deconv_dgrad", lambda v: v.permute(2, 3, 1, 0).contiguous()), w.shape[0], 2, prec)
             wgrad(d_raw, r["x_in"], 2, lambda dw: dw.permute(3, 2, 0, 1), w)    # [ky][kx][co][ci]
         d_enc[n - 1] = d_dec[n - 1]
         g = d_enc[n - 1]
@@ -156,7 +171,7 @@ class FeatureNetwork(nn.Module):
             if r["blk"].stride == 1:
                 g = ops.conv3x3(d_raw, flipT(w), w.shape[1], 1, prec)
             else:                                                               # stride-2 conv <- transposed conv, [ky][kx][co][ci]
-                g = ops.deconv3x3_s2(d_raw, w.detach().float().permute(2, 3, 0, 1).contiguous(), w.shape[1], prec)
+                g = ops.deconv3x3_s2(d_raw, _layout(w, "conv_s2_dgrad", lambda v: v.permute(2, 3, 0, 1).contiguous()), w.shape[1], prec)
             if j == 0:                                                          # entering stage i - 1's output: add its skip gradient
                 g = g + d_enc[i - 1]
         if on_side:                                                             # the weight gradients: meet the side stream here

@@ -68,6 +68,7 @@ class SideStream:
         env = os.environ.get("SURF_SIDE_STREAM", "1")
         self.enabled = env != "0"
         self.users = {"0": set(), "1": {"unet", "render", "match"}, "all": None}.get(env, set(env.split(",")))
+        self.priority = int(os.environ.get("SURF_SIDE_PRIORITY", "0"))      # of the lanes' streams (0 = as the current stream's)
         self._streams = {}
         self._keep = {}          # (device, lane) -> tensors held until that lane is joined
         self._open = set()
@@ -82,7 +83,7 @@ class SideStream:
         key = (cur.device.index, lane)
         st = self._streams.get(key)
         if st is None:
-            st = self._streams[key] = torch.cuda.Stream(device=cur.device)
+            st = self._streams[key] = torch.cuda.Stream(device=cur.device, priority=self.priority)
         st.wait_stream(cur)
         self._open.add(key)
         return torch.cuda.stream(st)
@@ -675,6 +676,7 @@ thin_mfma = os.environ.get("SURF_THIN_MFMA", "none")
 # bf16 ROW STORAGE of the sparse U-Net under the bf16 training policy (round 6): activations with 16 channels get a bf16 shadow
 # (written by the BatchNorm apply / backward kernels in the same pass) that the (16 -> 8) thin convolutions gather from - the one
 # channel pair where halving the row bytes pays (scripts/time_spconv_rows16.py: -35 .. -45 % per launch).  "0" = off (A/B switch).
+layout_cache = os.environ.get("SURF_LAYOUT_CACHE", "1") != "0"   # FPN weight layouts cached per parameter version + the U-Nets' dgrad kernels built in the forward (A/B)
 bf16_rows = os.environ.get("SURF_BF16_ROWS", "1") != "0"
 bf16_rows_all_modes = os.environ.get("SURF_BF16_ROWS") == "all"      # also the stride-2 / transposed (16 -> 8) layers (measured: no gain)
 

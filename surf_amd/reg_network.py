@@ -167,6 +167,11 @@ class SparseCostRegNet(nn.Module):
             y = ops.bn_train_relu(raw, blk.net[1], skip, saved, counters=counters, shadow=shadow)
             if tape is not None:
                 tape.append(dict(blk=blk, x=x, raw=raw, y=y, skip=skip, in_site=in_site, out_site=out_site, mode=mode, w=w, **saved))
+                # the backward's re-laid-out kernel (cached per parameter version) is built HERE: the forward has idle bubbles
+                # behind its voxel-count reads, the backward sweep is device bound and would pay these launches on its main chain
+                if ops.layout_cache:
+                    blk.prepared_dgrad(mode, self.use_mfma, thin=ops.thin_mfma == "all" or
+                                       (ops.thin_mfma == "bf16" and ops.colgram_precision == 1))
             return y
         if tape is not None:
             raise RuntimeError("SparseCostRegNet: the backward tape is recorded in train mode only")
