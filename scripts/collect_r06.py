@@ -66,6 +66,7 @@ V = {
     "LAT_MS": f"{b['mesh_grid']['sdf_kernel_ms']:.1f}", "LAT_FRAC": f"{lat['frac']:.3f}", "MC_MS": f"{b['mesh_grid']['marching_cubes_ms']:.1f}",
     "SCENE_MS": f"{b['scene']['scene_ms']:.0f}", "BUILD_MS": f"{b['volume_build']['total_ms']:.1f}",
     "TRAIN_FP32": f"{f32:.1f}", "TRAIN_BF16": f"{b16:.1f}", "BF16_PCT": f"{100 * (f32 - b16) / f32:.1f}",
+    "TRAIN_INORDER": f"{ts['in_order_ms_per_step']:.1f}", "TRAIN_FUSED": f"{ts['fused_adam_ms_per_step']:.1f}",
     "TRAIN_DDP": f"{ts['ddp_ms_per_step']:.1f}", "TRAIN_KERNEL": f"{tkern:.1f}", "FPN_MS": f"{fpn:.1f}",
     "TRAINW_FP32": " / ".join(f"{t['ms_per_step']:.1f}" for t in tr), "TRAINW_BF16": " / ".join(f"{t['ms_per_step']:.1f}" for t in tb),
     "AR_MS": f"{b['collectives']['gradient_bucket_allreduce_ms']:.3f}", "AG_MS": f"{b['collectives']['gather_rows_ms']:.2f}",

@@ -30,7 +30,7 @@ f = newest(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")))
 rows = list(csv.DictReader(open(f)))
 total = sum(int(r["TotalDurationNs"]) for r in rows)
 with open(os.path.join(dst, f"{tag}_train_kernel_stats.csv"), "w") as w:
-    w.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload train --steps 5 --warmup 2   (MI355X, {tag}: {STEPS} training "
+    w.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload train --steps 5 --warmup 2 --kernel-pass 0 with SURF_SIDE_STREAM=0 (in-order launches: overlapped kernels lengthen one another)   (MI355X, {tag}: {STEPS} training "
             f"steps = forward + Loss + loss.backward() + Adam at 5 views 576x800, 512 rays x 128 samples, 88^3 -> 704^3 pyramid)\n")
     w.write(f"# kernel time per step: {total / STEPS / 1e6:.2f} ms (all kernels, incl. torch's fill / copy / reduce helpers, summed in the last row)\n")
     w.write(f"# csrc_sha256: {csrc_digest()}\n")
