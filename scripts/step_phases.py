@@ -1,6 +1,6 @@
 """Where a training step's wall time goes, phase by phase, on the host clock and on the device clock (events on the main stream):
 forward (model), loss, loss.backward(), optimizer.step().  A phase whose device time exceeds the sum of its kernels is waiting for
-the host.    python scripts/step_phases.py [fused]"""
+the host.    python scripts/step_phases.py [fused] [ddp [nobuf]]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,6 +10,12 @@ dev = torch.device("cuda:0")
 model, ipts, targets, loss_fn, opt = training_step_setup(dev, 576, 800, 5, 88, 512)
 if "fused" in sys.argv:
     opt = torch.optim.Adam(model.get_optim_params({"mlp_lr": 5e-4, "feat_lr": 1e-3}), fused=True)
+stepper = model
+if "ddp" in sys.argv:
+    from surf_amd import dist as D
+    D.init_from_env("nccl", dev, force=True, timeout_s=300)
+    kw = {"broadcast_buffers": False} if "nobuf" in sys.argv else {}
+    stepper = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True, **kw)
 inputs = {**targets, **ipts}
 names = ["forward", "loss", "backward", "optimizer"]
 
@@ -18,7 +24,7 @@ def step(rec=None):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     th = [time.perf_counter()]
     ev[0].record()
-    out = model("train", inputs, cos_anneal_ratio=1.0, step=3.0)
+    out = stepper("train", inputs, cos_anneal_ratio=1.0, step=3.0)
     ev[1].record(); th.append(time.perf_counter())
     loss = loss_fn(out, inputs, 3.0)["loss"]
     ev[2].record(); th.append(time.perf_counter())

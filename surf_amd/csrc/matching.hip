@@ -5,6 +5,8 @@
 // which keeps the trilinear gathers in L2); the softmax expectation over the n (or 2n) samples is
 // accumulated online, so nothing is stored per sample and the reference's sort of the two bands is not
 // needed (a softmax-weighted mean does not depend on sample order).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -113,6 +115,107 @@ __global__ __launch_bounds__(256) void matching_depth_kernel(MatchArgs a) {
     }
   }
   if (j == 0) {
+    a.out[i] = (num / den) * cosz;
+    if (a.stats) reinterpret_cast<f32x4*>(a.stats)[i] = f32x4{m, den, num / den, 0.f};
+  }
+}
+
+// Round 6: SAMPLE-per-lane form.  L = 32 or 64 lanes = one ray, lane l = samples l, l + L, ... of the ray's nb n samples: the position
+// arithmetic of a sample is done once (the corner-per-lane forms above repeat it in every lane of the ray: they are bound by VALU
+// issue, 240 instructions per ray-sample-octet), its eight corners are four 8-byte loads (the z-neighbours of a cell are adjacent
+// floats), and the softmax expectation is a segmented wave reduction of per-lane (max, denominator, numerator) triples instead of
+// a serial online chain over the samples.  Same sums in another order: results agree with the forms above to rounding.
+// Measured per stage (bench scene, same box, three alternations): 0.196 / 0.70 / 0.60 / 1.20 ms (best of the forms above) ->
+// 0.164 / 0.73 / 0.525 / 0.96 ms: -12 % in all - less than the instruction count promised, because what remains is the texture
+// path's cache-line rate (a wave's 64 samples touch ~256 distinct lines of the z-fastest volume per step either way).
+struct __attribute__((packed, aligned(4))) F2u { float a, b; };      // an 8-byte load from a 4-byte aligned address
+
+template <int L>
+__global__ __launch_bounds__(256) void matching_depth_spl_kernel(MatchArgs a) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per_view = (int64_t)a.h * a.w;
+  const int l = (int)(t % L);
+  const int64_t ray = t / L;
+  const bool live = ray < per_view * a.nv;        // uniform over the ray's lanes; dead rays walk ray 0 (the shuffles want every lane)
+  const int64_t i = live ? ray : 0;
+  const int v = (int)(i / per_view);
+  const int p = (int)(i % per_view);
+  const float px = a.lin_x[p % a.w], py = a.lin_y[p / a.w];
+  const float* Ki = a.Kinv[v];
+  float cx = Ki[0] * px + Ki[1] * py + Ki[2];
+  float cy = Ki[3] * px + Ki[4] * py + Ki[5];
+  float cz_ = Ki[6] * px + Ki[7] * py + Ki[8];
+  const float nrm = sqrtf(cx * cx + cy * cy + cz_ * cz_);
+  cx /= nrm; cy /= nrm; cz_ /= nrm;
+  const float* R = a.R[v];
+  const float dx = R[0] * cx + R[1] * cy + R[2] * cz_;
+  const float dy = R[3] * cx + R[4] * cy + R[5] * cz_;
+  const float dz = R[6] * cx + R[7] * cy + R[8] * cz_;
+  const float* Ri = a.Rinv[v];
+  const float cosz = Ri[6] * dx + Ri[7] * dy + Ri[8] * dz;
+  const float ox = a.t[v][0], oy = a.t[v][1], oz = a.t[v][2];
+  const float n0 = a.nearv[v], f0 = a.farv[v];
+  float lo[2], hi[2];
+  int nb = 1;
+  lo[0] = n0; hi[0] = f0; lo[1] = n0; hi[1] = f0;
+  if (a.pre) {
+    const float pre = a.pre[((int64_t)v * a.H + (int)py) * a.W + (int)px];
+    const float zc = pre / cosz;
+    band(zc, ((f0 - n0) * a.ratio_cur) / 2.0f, n0, f0, lo[0], hi[0]);
+    band(zc, ((f0 - n0) * a.ratio_prev) / 2.0f, n0, f0, lo[1], hi[1]);
+    nb = 2;
+  }
+  const int D = a.D, S = nb * a.n;
+  const float* __restrict__ mvol = a.mvol;
+  float m = -INFINITY, den = 0.f, num = 0.f;
+  for (int s = l; s < S; s += L) {
+    const int b = s >= a.n ? 1 : 0, k = s - b * a.n;
+    const float rng = hi[b] - lo[b];
+    float z = lo[b] + rng * a.lin_n[k];
+    if (a.jitter) z = z + a.jitter[i * 2 + b] * rng / (float)a.n;
+    const float qx = unnorm_acf(ox + dx * z, D), qy = unnorm_acf(oy + dy * z, D), qz = unnorm_acf(oz + dz * z, D);
+    const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
+    const float tx = qx - fx, ty = qy - fy, tz = qz - fz;
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const bool zlo = (z0 >= 0) & (z0 < D), zhi = (z0 + 1 >= 0) & (z0 + 1 < D);
+    float rho = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int cdx = c >> 1, cdy = c & 1;
+      const int xi = x0 + cdx, yi = y0 + cdy;
+      if ((xi >= 0) & (xi < D) & (yi >= 0) & (yi < D)) {
+        const float wxy = (cdx ? tx : 1.0f - tx) * (cdy ? ty : 1.0f - ty);
+        const float* __restrict__ row = mvol + ((int64_t)xi * D + yi) * D;
+        float v0 = 0.f, v1 = 0.f;
+        if (zlo & zhi) {
+          const F2u pr = *reinterpret_cast<const F2u*>(row + z0);
+          v0 = pr.a; v1 = pr.b;
+        } else {
+          if (zlo) v0 = row[z0];
+          if (zhi) v1 = row[z0 + 1];
+        }
+        // (corner weight = the product in the order of the forms above: x, y, z)
+        if (zlo) rho += v0 * (wxy * (1.0f - tz));
+        if (zhi) rho += v1 * (wxy * tz);
+      }
+    }
+    const float mn = fmaxf(m, rho);
+    const float sc = expf(m - mn), e = expf(rho - mn);
+    den = den * sc + e;
+    num = num * sc + e * z;
+    m = mn;
+  }
+  // merge the L lanes' (max, denominator, numerator) triples; a lane without samples carries (-inf, 0, 0)
+#pragma unroll
+  for (int o = 1; o < L; o <<= 1) {
+    const float m2 = __shfl_xor(m, o), den2 = __shfl_xor(den, o), num2 = __shfl_xor(num, o);
+    const float mn = fmaxf(m, m2);
+    const float s1 = m == -INFINITY ? 0.f : expf(m - mn), s2 = m2 == -INFINITY ? 0.f : expf(m2 - mn);
+    den = den * s1 + den2 * s2;
+    num = num * s1 + num2 * s2;
+    m = mn;
+  }
+  if (l == 0 && live) {
     a.out[i] = (num / den) * cosz;
     if (a.stats) reinterpret_cast<f32x4*>(a.stats)[i] = f32x4{m, den, num / den, 0.f};
   }
@@ -351,7 +454,13 @@ extern "C" int surf_matching_depth(const float* mvol, int D, int nv, const float
   fill_match_args(a, nv, h_kinv, h_c2w, h_rinv, h_near_fars);
   hipStream_t st = (hipStream_t)stream;
   const int64_t n_lr = (int64_t)nv * h * w, n_full = (int64_t)nv * H * W;
-  if ((pre_depths ? 2 : 1) * n <= 64)
+  static const int form = [] { const char* e = getenv("SURF_MD_FORM"); return e ? atoi(e) : 1; }();   // 0: the corner-per-lane forms (A/B)
+  const int S = (pre_depths ? 2 : 1) * n;
+  if (form == 1 && S <= 32)
+    hipLaunchKernelGGL(matching_depth_spl_kernel<32>, dim3((unsigned)((n_lr * 32 + 255) / 256)), dim3(256), 0, st, a);
+  else if (form == 1)
+    hipLaunchKernelGGL(matching_depth_spl_kernel<64>, dim3((unsigned)((n_lr * 64 + 255) / 256)), dim3(256), 0, st, a);
+  else if (S <= 64)
     hipLaunchKernelGGL(matching_depth_kernel<8>, dim3((unsigned)((n_lr * 8 + 255) / 256)), dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL(matching_depth_kernel<2>, dim3((unsigned)((n_lr * 2 + 255) / 256)), dim3(256), 0, st, a);
