@@ -101,6 +101,10 @@ __global__ __launch_bounds__(256) void spconv_kernel(SpconvArgs a) {
 // R16 (round 6, the bf16 training policy): the gathered rows are read from a bf16 copy (half the bytes per neighbour row) and
 // widened in registers; weights, accumulation and output stay fp32.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) I3u { int a, b, c; };      // a 12-byte load from a 4-byte aligned address
+#ifndef SURF_SPCONV_TRIPLE
+#define SURF_SPCONV_TRIPLE 1
+#endif
 template <int CIN, int COUT, int MODE, bool R16 = false>
 __global__ __launch_bounds__(256) void spconv_pipe_kernel(SpconvArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -108,6 +112,28 @@ __global__ __launch_bounds__(256) void spconv_pipe_kernel(SpconvArgs a) {
   const int cx = a.out_coords[i * 3 + 0], cy = a.out_coords[i * 3 + 1], cz = a.out_coords[i * 3 + 2];
   const int D = a.Din;
   int rows[27];
+  // Round 6: the three z-neighbours of an (x, y) column are adjacent entries of the z-fastest table: for the submanifold and
+  // stride-2 windows (z - 1, z, z + 1 around bz) they come as ONE 12-byte load per column - 9 requests instead of 27 for the
+  // table (the texture path serves distinct cache lines one at a time: the table was half of this kernel's line requests).
+  // Same entries, same order of the offsets below: bit-identical results.  (Sites on the lattice's z border take the single loads.)
+  // Measured (same box): sparse U-Net of a volume build 7.82 -> 7.57 ms; training step -0.3 ms (ABBA x 2), -0.5 ms with in-order launches.
+  bool triple = false;
+  if constexpr ((MODE == MODE_SUBM || MODE == MODE_DOWN) && SURF_SPCONV_TRIPLE) {
+    const int bx = MODE == MODE_SUBM ? cx : 2 * cx, by = MODE == MODE_SUBM ? cy : 2 * cy, bz = MODE == MODE_SUBM ? cz : 2 * cz;
+    triple = bz - 1 >= 0 && bz + 1 < D;
+    if (triple) {
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const int x = bx + j % 3 - 1, y = by + j / 3 - 1;
+        const bool ok = x >= 0 && x < D && y >= 0 && y < D;
+        const I3u t3 = *reinterpret_cast<const I3u*>(a.in_table + (ok ? ((int64_t)x * D + y) * D + (bz - 1) : 0));
+        rows[j] = ok ? t3.a : -1;
+        rows[9 + j] = ok ? t3.b : -1;
+        rows[18 + j] = ok ? t3.c : -1;
+      }
+    }
+  }
+  if (!triple)
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
     const int ox = k % 3 - 1, oy = (k / 3) % 3 - 1, oz = k / 9 - 1;
