@@ -74,6 +74,20 @@ __device__ __forceinline__ int wave_min_i(int v) {
   return v;
 }
 
+// The three z-neighbours (bz - 1, bz, bz + 1) of a column (x, y) of a z-fastest D^3 index table as ONE 12-byte load (round 6: the
+// sparse-convolution kernels' submanifold and stride-2 windows walk 9 such columns instead of 27 single entries; the texture path
+// serves distinct cache lines one at a time, and the table was half of those kernels' line requests).  The caller guarantees
+// bz - 1 >= 0 and bz + 1 < D; a column outside the lattice yields (-1, -1, -1).
+#ifndef SURF_SPCONV_TRIPLE
+#define SURF_SPCONV_TRIPLE 1
+#endif
+struct __attribute__((packed, aligned(4))) I3u { int a, b, c; };      // a 12-byte load from a 4-byte aligned address
+__device__ __forceinline__ I3u surf_table_column3(const int32_t* __restrict__ table, int D, int x, int y, int bz) {
+  const bool ok = x >= 0 && x < D && y >= 0 && y < D;
+  const I3u t = *reinterpret_cast<const I3u*>(table + (ok ? ((int64_t)x * D + y) * D + (bz - 1) : 0));
+  return ok ? t : I3u{-1, -1, -1};
+}
+
 // grid_sample's normalised->index rule for align_corners=False applied to a world coordinate in
 // [-1,1]: ((p + 1) * D - 1) / 2   (projector.py:406,415 use the default align_corners=False).
 __device__ __forceinline__ float unnorm_acf(float p, int D) { return ((p + 1.0f) * (float)D - 1.0f) / 2.0f; }

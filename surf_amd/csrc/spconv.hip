@@ -101,10 +101,6 @@ __global__ __launch_bounds__(256) void spconv_kernel(SpconvArgs a) {
 // R16 (round 6, the bf16 training policy): the gathered rows are read from a bf16 copy (half the bytes per neighbour row) and
 // widened in registers; weights, accumulation and output stay fp32.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-struct __attribute__((packed, aligned(4))) I3u { int a, b, c; };      // a 12-byte load from a 4-byte aligned address
-#ifndef SURF_SPCONV_TRIPLE
-#define SURF_SPCONV_TRIPLE 1
-#endif
 template <int CIN, int COUT, int MODE, bool R16 = false>
 __global__ __launch_bounds__(256) void spconv_pipe_kernel(SpconvArgs a) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -124,12 +120,10 @@ __global__ __launch_bounds__(256) void spconv_pipe_kernel(SpconvArgs a) {
     if (triple) {
 #pragma unroll
       for (int j = 0; j < 9; ++j) {
-        const int x = bx + j % 3 - 1, y = by + j / 3 - 1;
-        const bool ok = x >= 0 && x < D && y >= 0 && y < D;
-        const I3u t3 = *reinterpret_cast<const I3u*>(a.in_table + (ok ? ((int64_t)x * D + y) * D + (bz - 1) : 0));
-        rows[j] = ok ? t3.a : -1;
-        rows[9 + j] = ok ? t3.b : -1;
-        rows[18 + j] = ok ? t3.c : -1;
+        const I3u t3 = surf_table_column3(a.in_table, D, bx + j % 3 - 1, by + j / 3 - 1, bz);
+        rows[j] = t3.a;
+        rows[9 + j] = t3.b;
+        rows[18 + j] = t3.c;
       }
     }
   }

@@ -217,13 +217,38 @@ __global__ __launch_bounds__(256) void spconv_wgrad_thin_kernel(WgArgs a) {
     __syncthreads();
     // ---- B1: reference q = p + 256 j = (offset q / TS, site q % TS): table lookup, row id into the hash set
     int my_row[NJ], my_slot[NJ];
+    // Round 6 (submanifold / stride-2 windows): the three z-neighbours of a column come as one 12-byte table load
+    // (common.h surf_table_column3) - 9 TS requests instead of 27 TS - staged through the row cache's LDS (free until phase C);
+    // -2 marks the columns of a site on the lattice's z border: those entries are looked up one by one as before.
+    const bool columns = SURF_SPCONV_TRIPLE && a.mode != MODE_UP;
+    int* __restrict__ stage = reinterpret_cast<int*>(xs);         // 27 TS ints < CAP XS: the zero row at CAP XS stays untouched
+    static_assert(27 * TS <= CAP * XS, "the staged table entries fit below the row cache's zero row");
+    if (columns) {
+      for (int q = p; q < 9 * TS; q += 256) {
+        const int jc = q / TS, st = q % TS;
+        const int64_t si = tile * TS + st;
+        I3u t3 = {-1, -1, -1};
+        if (si < a.n_out) {
+          const int f = a.mode == MODE_DOWN ? 2 : 1;
+          const int bx = f * a.out_coords[si * 3 + 0], by = f * a.out_coords[si * 3 + 1], bz = f * a.out_coords[si * 3 + 2];
+          if (bz - 1 >= 0 && bz + 1 < D) t3 = surf_table_column3(a.in_table, D, bx + jc % 3 - 1, by + jc / 3 - 1, bz);
+          else t3 = I3u{-2, -2, -2};
+        }
+        stage[jc * TS + st] = t3.a;
+        stage[(9 + jc) * TS + st] = t3.b;
+        stage[(18 + jc) * TS + st] = t3.c;
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {                                // all table lookups first: independent loads in flight together
       const int q = p + 256 * j;
       const int k = q / TS, st = q % TS;
       const int64_t si = tile * TS + st;
       int row = -1;
-      if (k < 27 && si < a.n_out) {
+      const int staged = (columns && k < 27) ? stage[q] : -2;
+      if (staged != -2) row = staged;
+      else if (k < 27 && si < a.n_out) {
         const int cx = a.out_coords[si * 3 + 0], cy = a.out_coords[si * 3 + 1], cz = a.out_coords[si * 3 + 2];
         const int ox = k % 3 - 1, oy = (k / 3) % 3 - 1, oz = k / 9 - 1;
         int x, y, z;

@@ -68,8 +68,28 @@ __global__ __launch_bounds__(256) void spconv_wgrad_mfma_kernel(WgmArgs a) {
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     __syncthreads();                                              // the previous tile's LDS is consumed
     // ---- neighbour rows of the tile's 27 x 64 (offset, site) references, one table lookup each
+    // (submanifold / stride-2 windows: the three z-neighbours of a column as one 12-byte load, common.h surf_table_column3; sites
+    // on the lattice's z border and the transposed mode take the single lookups below)
+    const bool columns = SURF_SPCONV_TRIPLE && a.mode != MODE_UP;
+    if (columns)
+      for (int q = threadIdx.x; q < 9 * TS; q += 256) {
+        const int j = q / TS, st = q % TS;
+        const int64_t si = tile * TS + st;
+        I3u t3 = {-1, -1, -1};
+        if (si < a.n_out) {
+          const int f = a.mode == MODE_DOWN ? 2 : 1;
+          const int bx = f * a.out_coords[si * 3 + 0], by = f * a.out_coords[si * 3 + 1], bz = f * a.out_coords[si * 3 + 2];
+          if (bz - 1 >= 0 && bz + 1 < D) t3 = surf_table_column3(a.in_table, D, bx + j % 3 - 1, by + j / 3 - 1, bz);
+          else t3 = I3u{-2, -2, -2};                             // -2: looked up entry by entry below
+        }
+        nbr[j * TS + st] = t3.a;
+        nbr[(9 + j) * TS + st] = t3.b;
+        nbr[(18 + j) * TS + st] = t3.c;
+      }
+    if (columns) __syncthreads();
     for (int q = threadIdx.x; q < 27 * TS; q += 256) {
       const int k = q / TS, st = q % TS;
+      if (columns && nbr[q] != -2) continue;
       const int64_t si = tile * TS + st;
       int row = -1;
       if (si < a.n_out) {
