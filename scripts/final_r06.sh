@@ -6,8 +6,9 @@ set -u
 O=gpurun_out/r06final; mkdir -p $O
 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log; tail -3 $O/pytest.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-python bench.py > $O/bench.json 2> $O/bench.err; head -c 400 $O/bench.json; echo; wc -l $O/bench.json
 bash scripts/profile_bench.sh r06 > $O/profile_bench.log 2>&1
+python scripts/summarize_profile.py r06 > /dev/null 2>&1      # profiles/r06_bench_pmc.csv of THESE sources, so that the line below carries roofline.traffic
+python bench.py > $O/bench.json 2> $O/bench.err; head -c 400 $O/bench.json; echo; wc -l $O/bench.json
 SURF_PREC=bf16x3 TSDF_ARGS=576 bash scripts/pmc_time_sdf.sh > $O/sdf_sq_bf16x3.txt 2>&1
 bash scripts/profile_train.sh r06 pmc > $O/profile_train.log 2>&1
 for i in 1 2 3; do
