@@ -454,7 +454,8 @@ extern "C" int surf_matching_depth(const float* mvol, int D, int nv, const float
   fill_match_args(a, nv, h_kinv, h_c2w, h_rinv, h_near_fars);
   hipStream_t st = (hipStream_t)stream;
   const int64_t n_lr = (int64_t)nv * h * w, n_full = (int64_t)nv * H * W;
-  static const int form = [] { const char* e = getenv("SURF_MD_FORM"); return e ? atoi(e) : 1; }();   // 0: the corner-per-lane forms (A/B)
+  const char* form_env = getenv("SURF_MD_FORM");                 // 0: the corner-per-lane forms (A/B, tests); read per call
+  const int form = form_env ? atoi(form_env) : 1;
   const int S = (pre_depths ? 2 : 1) * n;
   if (form == 1 && S <= 32)
     hipLaunchKernelGGL(matching_depth_spl_kernel<32>, dim3((unsigned)((n_lr * 32 + 255) / 256)), dim3(256), 0, st, a);

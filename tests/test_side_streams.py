@@ -77,10 +77,50 @@ def test_photometric_terms_as_one_node_equal_the_single_nodes():
     multi = autograd.photometric_losses(depths_a, imgs_t4, cams, specs)
     single = [autograd.photometric_loss(x, imgs_t4, m, cams, ref_idx=r, topk=k) for x, (m, r, k) in zip(depths_b, specs)]
     for a, b in zip(multi, single):
-        assert float(a) == float(b)
+        assert float(a.detach()) == float(b.detach())
     sum(wi * a for wi, a in zip(w, multi[:5])).backward()          # the sixth map gets no gradient: None, not zeros
     sum(wi * b for wi, b in zip(w, single[:5])).backward()
     assert depths_a[5].grad is None and depths_b[5].grad is None
     for xa, xb in zip(depths_a[:5], depths_b[:5]):
         assert float(xb.grad.abs().max()) > 0
         assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * float(xb.grad.abs().max())
+
+
+def test_matching_depth_sample_per_lane_form_equals_the_corner_per_lane_forms(monkeypatch):
+    """Round 6: matching_depth_spl_kernel (one lane = one sample, segmented wave reduction of the softmax triples) against the
+    corner-per-lane kernels it replaced (SURF_MD_FORM=0), on the golden pipeline's four stage shapes (128 / 2x64 / 2x32 / 2x16
+    samples per ray: both lane counts, one and two passes per lane), with and without the train-mode jitter; the per-ray
+    statistics handed to the backward agree too.  Same sums in another order: 1e-5 of the depth range."""
+    from surf_amd import ops
+    from tests.conftest import load_npz
+    from tests.golden.make_golden import MODEL_CONF as CFG
+    scene = load_npz("scene.npz")
+    gp = load_npz("pipeline.npz")
+    d = torch.device("cuda", 0)
+    cams = ops._cams_ext(ops.Cameras(scene["intrs"], scene["c2ws"]), scene["intrs"], scene["c2ws"])
+    H, W = scene["imgs"].shape[-2:]
+    mf = CFG["matching_field"]
+    nv = scene["imgs"].shape[0]
+    g = torch.Generator().manual_seed(11)
+    for s in range(4):
+        mvol = gp[f"s{s}_mvol"].to(d).contiguous()
+        pre = gp[f"s{s - 1}_depths"].to(d).contiguous() if s > 0 else None
+        lvl, n = mf["depth_res_levels"][s], mf["n_samples_depths"][s]
+        h, w = H // lvl, W // lvl
+        for jit in (None, (torch.rand(nv, h * w, 2, generator=g) - 0.5).to(d).contiguous()):
+            res = {}
+            for form in ("0", "1"):
+                monkeypatch.setenv("SURF_MD_FORM", form)
+                saved = {}
+                full, lr = ops.matching_depth(mvol, cams, scene["near_fars"], H, W, lvl, n, pre, CFG["range_ratios"][s],
+                                              CFG["range_ratios"][s - 1] if s > 0 else 1.0, return_lr=True, jitter=jit, saved=saved)
+                res[form] = (full, lr, saved["stats"])
+            span = float(res["0"][1].max() - res["0"][1].min()) + 1e-6
+            for a, b in zip(res["0"][:2], res["1"][:2]):
+                assert torch.isfinite(b).all()
+                assert float((a - b).abs().max()) <= 1e-5 * max(span, 1.0), (s, jit is not None)
+            sa, sb = res["0"][2], res["1"][2]
+            assert float((sa[..., 2] - sb[..., 2]).abs().max()) <= 1e-5 * max(span, 1.0)        # expected z
+            # max logit (the corner sums of a sample are formed in another order) and softmax denominator: relative
+            assert float(((sa[..., 0] - sb[..., 0]).abs() / sb[..., 0].abs().clamp_min(1.0)).max()) <= 1e-5
+            assert float(((sa[..., 1] - sb[..., 1]).abs() / sb[..., 1]).max()) <= 1e-4
