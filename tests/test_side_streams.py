@@ -124,3 +124,61 @@ def test_matching_depth_sample_per_lane_form_equals_the_corner_per_lane_forms(mo
             # max logit (the corner sums of a sample are formed in another order) and softmax denominator: relative
             assert float(((sa[..., 0] - sb[..., 0]).abs() / sb[..., 0].abs().clamp_min(1.0)).max()) <= 1e-5
             assert float(((sa[..., 1] - sb[..., 1]).abs() / sb[..., 1]).max()) <= 1e-4
+
+
+def _small_training_setup():
+    from surf_amd import conf
+    from surf_amd.surf import SuRF
+    from tests.conftest import load_npz
+    from tests.golden.make_golden import MODEL_CONF
+    dev = torch.device("cuda", 0)
+    scene = load_npz("scene.npz")
+    cfg = dict(MODEL_CONF)
+    cfg["reg_network"] = {"d_in": [8, 16, 16, 16], "d_base": [8] * 4, "d_out": [8] * 4}
+    torch.manual_seed(4)
+    model = SuRF(conf.from_dict(cfg))
+    with torch.no_grad():
+        model.implicit_surface.deviation_network.variance.fill_(0.3)
+        for net in model.reg_network.nets:
+            net.out_lin.weight.mul_(4.0)
+    model = model.to(dev).train()
+    ipts = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in scene.items()}
+    ipts["src_idx"] = 1
+    return model, ipts
+
+
+@pytest.mark.parametrize("which", ["colour", "depth"])
+def test_partial_losses_on_the_multi_stream_sweep(which, monkeypatch):
+    """A loss that reaches only ONE of the two graph nodes: colour alone (the depth tap sees no gradient: the matching chain has
+    nothing to do, the render backward's three branches still fork and join) or the depth maps alone (the tap launches the
+    matching chain, the render node never runs, the volume backward gets no row gradients).  Multi-stream == in-order, and the
+    parameters the loss cannot reach get no gradient either way."""
+    from surf_amd import ops
+    grads = {}
+    for side in (False, True):
+        monkeypatch.setattr(ops.side, "enabled", side)
+        model, ipts = _small_training_setup()
+        torch.manual_seed(70)
+        out = model("train", ipts, cos_anneal_ratio=1.0, step=3)
+        if which == "colour":
+            loss = (out["color_fine"] * torch.linspace(0.5, 1.5, 3, device=out["color_fine"].device)).sum()
+        else:
+            loss = sum((0.3 + 0.1 * s) * out[f"depth_stage{s}"].mean() + 0.2 * out[f"depth_src_stage{s}"].mean() for s in range(4))
+        loss.backward()
+        torch.cuda.synchronize()
+        grads[side] = {n: (None if p.grad is None else p.grad.detach().clone()) for n, p in model.named_parameters()}
+    a, b = grads[False], grads[True]
+    top = max(float(g.abs().max()) for g in a.values() if g is not None)
+    assert top > 0
+    reached = 0
+    for n in a:
+        assert (a[n] is None) == (b[n] is None), n
+        if a[n] is None:
+            continue
+        assert torch.isfinite(b[n]).all(), n
+        reached += int(float(a[n].abs().max()) > 0)
+        # (volume.agg_mlp.2.bias shifts every softmax logit alike: its gradient is rounding noise, 1e-9 of the largest one)
+        assert float((a[n] - b[n]).abs().max()) <= 1e-4 * float(a[n].abs().max()) + 1e-6 * top, n
+    assert reached > 10
+    if which == "depth":        # the implicit surface is not on the path of the depth maps
+        assert all(g is None or float(g.abs().max()) == 0.0 for n, g in b.items() if n.startswith("implicit_surface."))
