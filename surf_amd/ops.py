@@ -53,6 +53,7 @@ class SideStream:
       render  the colour branch (lane 0) and the smooth (H.1) branch (lane 1) beside the SDF value / gradient branch
       match   the matching chain (matching-field backward -> densify backward, fine -> coarse) ahead of the U-Net / cost-volume
               chain it feeds, one event per stage                                                                 lane 2
+      costvol the stages' cost-volume backward (a leaf: only the parent-feature scatter feeds the next stage)           lane 4
       loss    the 2 n photometric terms of the loss, both directions (autograd._PhotometricMulti; lanes 4..7; measured: a loss of
               1.5 ms - the launches are bound by the memory system, not by latency; off by default)
       fpn     the FPN's weight gradients (measured: a loss - those launches fill the chip; off by default)
@@ -67,7 +68,7 @@ class SideStream:
         # "0" none, "1" the users that measured a gain (profiles/r06_side_streams.txt), "all", or a comma list of users
         env = os.environ.get("SURF_SIDE_STREAM", "1")
         self.enabled = env != "0"
-        self.users = {"0": set(), "1": {"unet", "render", "match"}, "all": None}.get(env, set(env.split(",")))
+        self.users = {"0": set(), "1": {"unet", "render", "match", "costvol"}, "all": None}.get(env, set(env.split(",")))
         self.priority = int(os.environ.get("SURF_SIDE_PRIORITY", "0"))      # of the lanes' streams (0 = as the current stream's)
         self._streams = {}
         self._keep = {}          # (device, lane) -> tensors held until that lane is joined

@@ -244,7 +244,11 @@ class SparseCostRegNet(nn.Module):
         add(x11, ops.row_linear8(d_out, W.t().contiguous()))            # d_out @ W
         if d_mid is not None:
             add(x11, d_mid.float().contiguous())
-        acc(self.out_lin.weight, ops.colgram(d_out, x11))                # d_out^T x11
+        if on_side:                                                      # d_out^T x11: a leaf too (side stream, accumulated after the join)
+            g_lin = ops.side.run(lambda: ops.colgram(d_out, x11), lane=0, keep=(d_out, x11))
+        else:
+            g_lin = None
+            acc(self.out_lin.weight, ops.colgram(d_out, x11))
         for e in reversed(tape[:-1]):
             g = grads.pop(id(e["y"]), None)
             if g is None:
@@ -268,6 +272,8 @@ class SparseCostRegNet(nn.Module):
             add(e["x"], dx)
         # the kernel gradients were launched on the side stream (leaves of this sweep: they overlap its input-gradient chain)
         def finish():
+            if g_lin is not None:
+                acc(self.out_lin.weight, g_lin)
             for blk, dW in kernel_grads:
                 idx = blk.slice_index(dW.device)           # back to checkpoint slice order (the permutation is an involution)
                 acc(blk.net[0].kernel, dW if idx is None else dW.index_select(0, idx))

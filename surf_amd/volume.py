@@ -62,7 +62,15 @@ class Volume(nn.Module):
         gfeats_c2f), agg_mlp's (accumulated into g_agg, 49 floats) and, for stage > 0, the gradient of the previous stage's
         `mid` rows (returned, (n_parents, 8)).  The voxel selection (depth filter, visibility) is not differentiable."""
         g_cv = d_reg_in[:, :8].contiguous()
-        ops.costvol_backward(feats_c2f, gfeats_c2f, stage, D, cams, self.agg_host(), coords, g_cv, g_agg)
+        agg = self.agg_host()
+        if ops.side.active("costvol") and d_reg_in.is_cuda:
+            # a LEAF of the sweep: its results (the FPN maps' gradients, agg_mlp's 49 floats: float atomics) are read by the FPN
+            # backward at the very end; only the parent-feature scatter below feeds the next stage - so the cost-volume backward
+            # (4.4 ms a step) leaves the main chain for a side stream (ops.SideStream lane 4; SuRF._backward_volumes joins it)
+            ops.side.run(lambda: ops.costvol_backward(feats_c2f, gfeats_c2f, stage, D, cams, agg, coords, g_cv, g_agg), lane=4,
+                         keep=(g_cv, coords))
+        else:
+            ops.costvol_backward(feats_c2f, gfeats_c2f, stage, D, cams, agg, coords, g_cv, g_agg)
         if stage == 0:
             return None
         d_mid = torch.zeros(n_parents, 8, dtype=torch.float32, device=d_reg_in.device)
