@@ -53,7 +53,7 @@ class SideStream:
       render  the colour branch (lane 0) and the smooth (H.1) branch (lane 1) beside the SDF value / gradient branch
       match   the matching chain (matching-field backward -> densify backward, fine -> coarse) ahead of the U-Net / cost-volume
               chain it feeds, one event per stage                                                                 lane 2
-      costvol the stages' cost-volume backward (a leaf: only the parent-feature scatter feeds the next stage)           lane 4
+      costvol the stages' cost-volume backward (a leaf: only the parent-feature scatter feeds the next stage)           lane 2 (reused)
       loss    the 2 n photometric terms of the loss, both directions (autograd._PhotometricMulti; lanes 4..7; measured: a loss of
               1.5 ms - the launches are bound by the memory system, not by latency; off by default)
       fpn     the FPN's weight gradients (measured: a loss - those launches fill the chip; off by default)
@@ -142,6 +142,12 @@ class SideStream:
 
 
 side = SideStream()
+# The runtime multiplexes HIP streams onto a handful of hardware queues (4 by default): which streams share one decides how much really
+# overlaps, and a fifth stream (or RCCL's own) reshuffles the assignment.  The cost-volume backward therefore REUSES the matching
+# chain's lane (which ran ahead and is idle by then) instead of opening another stream: main + three lanes in all.  Measured on the
+# default line's step (ms, group present / absent, two runs each): own lane 67.3 65.1 / 65.3 64.3, smooth lane 67.2 64.5 / 66.1 66.0,
+# matching lane 65.5 63.5 / 64.5 64.5; under DistributedDataParallel 69.9 70.9 | 70.6 66.2 | 65.2 66.3.
+COSTVOL_LANE = int(os.environ.get("SURF_COSTVOL_LANE", "2"))
 
 
 class _ZeroPool:

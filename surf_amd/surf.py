@@ -231,7 +231,7 @@ class SuRF(nn.Module):
             d_reg_in = self.reg_network.nets[s].backward(r["reg_tape"], g_out, d_mid, sink=sink, pending=pending)
             d_mid = self.volume.stage_backward(s, r["D"], feats, gfeats, cams, r["coords"], d_reg_in, g_agg, r.get("pidx"),
                                                r["n_parents"])
-        ops.side.join(lanes=(4,))                    # the stages' cost-volume backward launches (gfeats, g_agg are complete now)
+        ops.side.join(lanes=(ops.COSTVOL_LANE,))     # the stages' cost-volume backward launches (gfeats, g_agg are complete now)
         self.volume.assign_agg_grad(g_agg, sink=sink)
         self.feature_network.backward(t["fpn"], gfeats, sink=sink)
         ops.side.join()                              # the U-Nets' kernel gradients ran on the side stream beside all of the above

@@ -66,8 +66,8 @@ class Volume(nn.Module):
         if ops.side.active("costvol") and d_reg_in.is_cuda:
             # a LEAF of the sweep: its results (the FPN maps' gradients, agg_mlp's 49 floats: float atomics) are read by the FPN
             # backward at the very end; only the parent-feature scatter below feeds the next stage - so the cost-volume backward
-            # (4.4 ms a step) leaves the main chain for a side stream (ops.SideStream lane 4; SuRF._backward_volumes joins it)
-            ops.side.run(lambda: ops.costvol_backward(feats_c2f, gfeats_c2f, stage, D, cams, agg, coords, g_cv, g_agg), lane=4,
+            # (4.4 ms a step) leaves the main chain for a side stream (ops.SideStream lane COSTVOL_LANE; SuRF._backward_volumes joins it)
+            ops.side.run(lambda: ops.costvol_backward(feats_c2f, gfeats_c2f, stage, D, cams, agg, coords, g_cv, g_agg), lane=ops.COSTVOL_LANE,
                          keep=(g_cv, coords))
         else:
             ops.costvol_backward(feats_c2f, gfeats_c2f, stage, D, cams, agg, coords, g_cv, g_agg)
