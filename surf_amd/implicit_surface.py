@@ -454,10 +454,10 @@ class ImplicitSurface(nn.Module):
                 sbar = scale * ins[:, None] * sm / nrm.clamp_min(1e-30)
                 return ops.sdf_smooth_backward(st["pts"][idx].contiguous(), sbar.contiguous(), scene.sv, sw, dvols=dvols)
 
-            rs = ops.side.run(smooth_branch, lane=1, keep=(idx,)) if on_side else smooth_branch()
+            rs = ops.side.run(smooth_branch, lane=ops.SMOOTH_LANE, keep=(idx,)) if on_side else smooth_branch()
         res = ops.sdf_backward(pts.contiguous(), ybar.contiguous(), gbar.contiguous(), scene.sv, sw, dvols=dvols)
         if on_side:                                            # the three branches meet here
-            ops.side.join(lanes=(0, 1))
+            ops.side.join(lanes=(0, ops.SMOOTH_LANE))
         else:
             gb = blend_branch()
         if rs is not None:

@@ -148,6 +148,7 @@ side = SideStream()
 # default line's step (ms, group present / absent, two runs each): own lane 67.3 65.1 / 65.3 64.3, smooth lane 67.2 64.5 / 66.1 66.0,
 # matching lane 65.5 63.5 / 64.5 64.5; under DistributedDataParallel 69.9 70.9 | 70.6 66.2 | 65.2 66.3.
 COSTVOL_LANE = int(os.environ.get("SURF_COSTVOL_LANE", "2"))
+SMOOTH_LANE = int(os.environ.get("SURF_SMOOTH_LANE", "1"))       # the render backward's smooth branch (A/B: 0 = behind the colour branch)
 
 
 class _ZeroPool:
