@@ -184,9 +184,11 @@ def all_reduce_gradients(params, bucket_bytes=25 << 20):
         flat /= world
         off = 0
         for p in bucket:
-            g = flat[off:off + p.numel()].view_as(p).to(p.dtype)
+            g = flat[off:off + p.numel()].view_as(p)
             off += p.numel()
-            p.grad = g.clone() if p.grad is None else p.grad.copy_(g)
+            # fp32 parameters take their slice of the reduced bucket AS their gradient (a view, like DDP's gradient_as_bucket_view:
+            # no copy back - 150 small launches at the end of a step); other dtypes get a converted copy
+            p.grad = g if p.dtype == torch.float32 else g.to(p.dtype)
     return len(buckets)
 
 
