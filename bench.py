@@ -315,7 +315,7 @@ def training_step_timing(args, dev, steps=5):
         ms, per_step, out = timed(model, False)
         res[precision] = {"ms_per_step": ms, "loss": out["loss"], "steps_ms": [round(v, 2) for v in per_step]}
         if D._active():                   # the same step as runner.py:102 runs it on N GPUs: wrapped in DDP over the (world-1) RCCL group
-            ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], gradient_as_bucket_view=True)
+            ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index])      # runner.py:102, argument for argument
             ms_d, per_d, _ = timed(ddp, True)
             res[precision]["ddp_ms_per_step"] = ms_d
             res[precision]["ddp_steps_ms"] = [round(v, 2) for v in per_d]
@@ -614,7 +614,7 @@ def run_rank_train(args):
                                                                  precision=args.train_precision)
         inputs = {**targets, **ipts}                                    # the runner hands ONE dictionary to model and loss
         loss_of = lambda outputs: loss_fn(outputs, inputs, 3.0)["loss"]  # noqa: E731
-        ddp = (DistributedDataParallel(model, device_ids=[local_rank], gradient_as_bucket_view=True)   # runner.py:102
+        ddp = (DistributedDataParallel(model, device_ids=[local_rank])                                 # runner.py:102, argument for argument
                if grouped else model)
 
     def step():                                                        # runner.py:155-164
