@@ -1,6 +1,6 @@
 """Where a training step's wall time goes, phase by phase, on the host clock and on the device clock (events on the main stream):
 forward (model), loss, loss.backward(), optimizer.step().  A phase whose device time exceeds the sum of its kernels is waiting for
-the host.    python scripts/step_phases.py [fused] [ddp [nobuf]]"""
+the host.    python scripts/step_phases.py [fused] [ddp [nobuf] [bucketview]]"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +15,9 @@ if "ddp" in sys.argv:
     from surf_amd import dist as D
     D.init_from_env("nccl", dev, force=True, timeout_s=300)
     kw = {"broadcast_buffers": False} if "nobuf" in sys.argv else {}
-    stepper = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True, **kw)
+    if "bucketview" in sys.argv:
+        kw["gradient_as_bucket_view"] = True
+    stepper = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], **kw)             # runner.py:102
 inputs = {**targets, **ipts}
 names = ["forward", "loss", "backward", "optimizer"]
 
