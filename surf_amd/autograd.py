@@ -101,6 +101,8 @@ class _Build(torch.autograd.Function):
         n = model.num_stage
         ctx.n = n
         holder.update(tables=tables, mvol=mvol, cams=cams, tape=tape)
+        if features and features[0].is_cuda:
+            holder["stream"] = torch.cuda.current_stream()       # where this node's backward will run (autograd's stream rule)
         ctx.holder = holder
         depths = [outputs[f"depth_stage{s}"] for s in range(n)] + [outputs[f"depth_src_stage{s}"][...] for s in range(n)]
         return tuple(volumes) + tuple(features) + tuple(depths)
@@ -142,7 +144,7 @@ class _DepthTap(torch.autograd.Function):
         tape = holder.get("tape")
         if tape is not None and "match" not in holder and any(x is not None for x in g):
             n = len(g) // 2
-            match = ctx.model.start_matching_chain(tape, {s: (g[s], g[n + s]) for s in range(n)})
+            match = ctx.model.start_matching_chain(tape, {s: (g[s], g[n + s]) for s in range(n)}, consumer=holder.get("stream"))
             if match is not None:
                 holder["match"] = match
         return (None, None) + tuple(g)
@@ -175,7 +177,18 @@ def differentiable_forward(model, mode, ipts, cos_anneal_ratio=1.0, step=None):
     if not model.has_vol:
         n = model.num_stage
         keys = [f"depth_stage{s}" for s in range(n)] + [f"depth_src_stage{s}" for s in range(n)]
-        outputs.update(zip(keys, _DepthTap.apply(model, holder, *[outputs[k] for k in keys])))
+        depths = [outputs[k] for k in keys]
+        if ops.side.active("match") and ops.lane_nodes and depths[0].is_cuda:
+            # the tap LIVES on the matching lane: autograd runs a node's backward on the stream of its forward and orders the
+            # gradients that cross streams, so the tap's backward - and the matching chain it launches - need no fork of their own,
+            # and whatever feeds it from another lane (the photometric terms, surf_amd.losses) never touches the main stream
+            lane = ops.side.lane_stream(2, depths[0].device)
+            lane.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(lane):
+                taps = _DepthTap.apply(model, holder, *depths)           # views: no kernel runs here
+        else:
+            taps = _DepthTap.apply(model, holder, *depths)
+        outputs.update(zip(keys, taps))
     return outputs
 
 

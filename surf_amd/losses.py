@@ -36,6 +36,28 @@ class Loss(nn.Module):
         return ((pred - target).abs() * mask).sum() / (mask.sum() + 1e-8)
 
     def forward(self, preds, targets, step=None, mode="train"):
+        # The 2 n photometric terms (5 ms of a step, both directions) depend on the depth maps and the images alone.  Their graph node
+        # is created FIRST and on the matching chain's stream (ops.SideStream lane 2): forward, its launches run beside the other
+        # terms below; backward, autograd runs the node on that same stream (its stream rule) and orders the gradients that cross
+        # streams - so the photometric backward and the matching chain it feeds (through autograd._DepthTap, which lives on the
+        # lane too) never occupy the main stream, where the render backward starts at once.
+        photos, lane = None, None
+        if mode == "train":
+            n = len(self.stage_weights)
+            imgs_t4 = ops.pack_texel4(targets["imgs"].float().contiguous())
+            cams = ops.Cameras(targets["intrs"], targets["c2ws"])
+            src_idx = int(targets["src_idx"])
+            mask_ref, mask_src = targets["mask_ref"].float().contiguous(), targets["mask_src"].float().contiguous()
+            depth_maps = [preds[f"depth_stage{i}"] for i in range(n)] + [preds[f"depth_src_stage{i}"] for i in range(n)]
+            specs = [(mask_ref, 0, 2)] * n + [(mask_src, src_idx, 1)] * n
+            if imgs_t4.is_cuda and ops.side.active("match") and ops.lane_nodes:
+                cur = torch.cuda.current_stream()
+                lane = ops.side.lane_stream(2, imgs_t4.device)
+                lane.wait_stream(cur)
+                with torch.cuda.stream(lane):
+                    photos = autograd.photometric_losses(depth_maps, imgs_t4, cams, specs)
+            else:
+                photos = autograd.photometric_losses(depth_maps, imgs_t4, cams, specs)
         valid_mask = preds["valid_mask"]
         if "mask" in targets:
             valid_mask = valid_mask * targets["mask"].reshape(-1, 1)
@@ -52,15 +74,11 @@ class Loss(nn.Module):
         zero = 0.0
         photo_loss = pseudo_auxi = auxi = auxi0 = src_auxi = src_auxi0 = zero
         if mode == "train":
-            n = len(self.stage_weights)
-            imgs_t4 = ops.pack_texel4(targets["imgs"].float().contiguous())
-            cams = ops.Cameras(targets["intrs"], targets["c2ws"])
-            src_idx = int(targets["src_idx"])
-            mask_ref, mask_src = targets["mask_ref"].float().contiguous(), targets["mask_src"].float().contiguous()
-            # the 2 n photometric terms are independent: one graph node, the launches dealt out over side streams both ways
-            photos = autograd.photometric_losses(
-                [preds[f"depth_stage{i}"] for i in range(n)] + [preds[f"depth_src_stage{i}"] for i in range(n)], imgs_t4, cams,
-                [(mask_ref, 0, 2)] * n + [(mask_src, src_idx, 1)] * n)
+            if lane is not None:                       # the photometric values are read on this stream from here on
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(lane)
+                for ph in photos:
+                    ph.record_stream(cur)
             for i in range(n):
                 ref_photo, src_photo = photos[i], photos[n + i]
                 photo_loss = photo_loss + (ref_photo + src_photo) * self.stage_weights[i]

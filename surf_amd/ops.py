@@ -89,6 +89,22 @@ class SideStream:
         self._open.add(key)
         return torch.cuda.stream(st)
 
+    def lane_stream(self, lane, device=None):
+        """The stream object of `lane` on `device` (default: the current one), created on first use, NOT ordered after anything:
+        for graph nodes that LIVE on a lane - autograd runs a node's backward on the stream its forward ran on and orders the
+        gradients that cross streams itself."""
+        idx = torch.cuda.current_device() if device is None else torch.device(device).index
+        key = (idx, lane)
+        st = self._streams.get(key)
+        if st is None:
+            st = self._streams[key] = torch.cuda.Stream(device=torch.device("cuda", idx), priority=self.priority)
+        return st
+
+    def on_lane(self, lane):
+        """True when the current stream is the stream of `lane`."""
+        st = self._streams.get((torch.cuda.current_device(), lane))
+        return st is not None and torch.cuda.current_stream() == st
+
     def run(self, fn, lane=0, keep=()):
         """fn() on side stream `lane`; its result tensors (a tensor, or a list / tuple / dict of them, nested) are allocated in
         that stream's pool and will be read - and freed - on the current one: marked with record_stream."""
@@ -147,6 +163,9 @@ side = SideStream()
 # chain's lane (which ran ahead and is idle by then) instead of opening another stream: main + three lanes in all.  Measured on the
 # default line's step (ms, group present / absent, two runs each): own lane 67.3 65.1 / 65.3 64.3, smooth lane 67.2 64.5 / 66.1 66.0,
 # matching lane 65.5 63.5 / 64.5 64.5; under DistributedDataParallel 69.9 70.9 | 70.6 66.2 | 65.2 66.3.
+# graph nodes that live on the matching lane (the depth tap, the loss's photometric node): autograd runs their backward there (A/B: 0 =
+# the tap on the main stream forks the lane itself, the photometric terms run on the main stream)
+lane_nodes = os.environ.get("SURF_LANE_NODES", "1") != "0"
 COSTVOL_LANE = int(os.environ.get("SURF_COSTVOL_LANE", "2"))
 SMOOTH_LANE = int(os.environ.get("SURF_SMOOTH_LANE", "1"))       # the render backward's smooth branch (A/B: 0 = behind the colour branch)
 

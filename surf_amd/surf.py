@@ -147,24 +147,32 @@ class SuRF(nn.Module):
         return g_logit, d_prev
 
     @torch.no_grad()
-    def start_matching_chain(self, t, g_depths):
+    def start_matching_chain(self, t, g_depths, consumer=None):
         """The matching chain of the tape `t` for the depth gradients `g_depths` ({stage: (d depth_stage, d depth_src_stage)}) on
-        its own stream (ops.SideStream lane 2), fine -> coarse.  Returns {stage: (g_logit or None, event)} for
+        its own stream (ops.SideStream lane 2; `consumer`: the stream that will read the results when the caller already runs on
+        the lane), fine -> coarse.  Returns {stage: (g_logit or None, event)} for
         `_backward_volumes(match=...)`, or None when the side streams are off (the sweep then runs the stages in line)."""
         dev = t["feats"][0].device
         if not (ops.side.active("match") and dev.type == "cuda"):
             return None
-        main = torch.cuda.current_stream()
+        inline = ops.side.on_lane(2)     # called from a graph node that lives on the lane (autograd._DepthTap): already there
+        main = consumer if (inline and consumer is not None) else torch.cuda.current_stream()
         out = {}
-        with ops.side.fork(lane=2):
+
+        def chain():
             dm = None
             for s in range(self.num_stage - 1, -1, -1):
                 g_logit, dm = self._match_stage(t, s, g_depths, dm)
                 if g_logit is not None:
-                    g_logit.record_stream(main)          # allocated in the lane's pool, consumed (and freed) on this stream
+                    g_logit.record_stream(main)          # allocated in the lane's pool, consumed (and freed) on the sweep's stream
                 out[s] = (g_logit, ops.side.mark())
-            del dm
-        ops.side.keep(*[g for pair in (g_depths or {}).values() for g in pair], lane=2)
+
+        if inline:
+            chain()
+        else:
+            with ops.side.fork(lane=2):
+                chain()
+            ops.side.keep(*[g for pair in (g_depths or {}).values() for g in pair], lane=2)
         return out
 
     def backward_volumes(self, row_grads_f2c, g_depths=None, tape=None, gfeats=None, sink=None, match=None):
