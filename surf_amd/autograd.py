@@ -278,23 +278,29 @@ class _PhotometricMulti(torch.autograd.Function):
             res.append(ops.side.run(fn, lane=_PhotometricMulti.LANES[i % 4], keep=(d,)) if on_side else fn())
         if on_side:
             ops.side.join(lanes=_PhotometricMulti.LANES)
-        ctx.depths, ctx.states, ctx.imgs_t4, ctx.cams, ctx.specs = depths, [st for _, st in res], imgs_t4, cams, specs
+        n = len(depths)
+        masks = [m for m, _, _ in specs]
+        # tensors through save_for_backward (autograd's in-place modification check covers them), the rest on ctx
+        ctx.save_for_backward(imgs_t4, *depths, *masks, *[st[0] for _, st in res], *[st[1] for _, st in res])
+        ctx.n, ctx.cams, ctx.views = n, cams, [(r, k) for _, r, k in specs]
         return tuple(loss for loss, _ in res)
 
     @staticmethod
     def backward(ctx, *gs):
-        on_side = ops.side.active("loss") and ctx.imgs_t4.is_cuda
+        saved, n = ctx.saved_tensors, ctx.n
+        imgs_t4 = saved[0]
+        depths, masks, warps, sums = (saved[1 + k * n:1 + (k + 1) * n] for k in range(4))
+        on_side = ops.side.active("loss") and imgs_t4.is_cuda
         out = []
-        for i, (g, d, st, (mask, ref_idx, topk)) in enumerate(zip(gs, ctx.depths, ctx.states, ctx.specs)):
+        for i, (g, d, mask, (ref_idx, topk)) in enumerate(zip(gs, depths, masks, ctx.views)):
             if g is None:
                 out.append(None)
                 continue
-            fn = lambda g=g, d=d, st=st, mask=mask, ref_idx=ref_idx, topk=topk: ops.photometric_loss_backward(          # noqa: E731
-                d, ctx.imgs_t4, mask, ctx.cams, ref_idx, topk, upstream=g, state=st)
+            fn = lambda g=g, d=d, mask=mask, st=(warps[i], sums[i]), ref_idx=ref_idx, topk=topk: ops.photometric_loss_backward(  # noqa: E731
+                d, imgs_t4, mask, ctx.cams, ref_idx, topk, upstream=g, state=st)
             out.append(ops.side.run(fn, lane=_PhotometricMulti.LANES[i % 4], keep=(g,)) if on_side else fn())
         if on_side:
             ops.side.join(lanes=_PhotometricMulti.LANES)
-        ctx.states = None
         return (None, None, None) + tuple(out)
 
 
