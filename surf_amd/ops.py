@@ -112,18 +112,18 @@ class SideStream:
         with self.fork(lane):
             out = fn()
 
-        def mark(o):
+        def claim(o):
             if torch.is_tensor(o):
                 if o.is_cuda:
                     o.record_stream(main)
             elif isinstance(o, dict):
                 for v in o.values():
-                    mark(v)
+                    claim(v)
             elif isinstance(o, (list, tuple)):
                 for v in o:
-                    mark(v)
+                    claim(v)
 
-        mark(out)
+        claim(out)
         self.keep(*keep, lane=lane)
         return out
 
